@@ -1,0 +1,1 @@
+from . import registration  # noqa: F401

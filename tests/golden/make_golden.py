@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ENV in the build container.
+
+Run once, here (needs /root/reference; the GPU box never sees it):
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/make_golden.py
+
+What it does
+  * puts tests/golden/_refstubs (a ~40-line stand-in for the absent gym / skimage packages) and
+    /root/reference/envs/gym-track2d on sys.path and imports gym_track2d.envs.track_1v1.Track1v1Env;
+  * neutralises the argument-less np.random.seed() calls inside generators.py:41,56 (they make the
+    reference non-deterministic) so that one np.random.seed(s) fixes the whole trajectory;
+  * records, per case, the map, spawns, goals, the action streams as consumed by _next_state, and
+    per-step obs / rewards / done / far counter / positions.
+
+The outputs are DATA (inputs + expected outputs) — no reference source text is stored.
+gym's TimeLimit (gym==0.12.5, not vendored) is restated as `done |= elapsed >= 500` when
+`time_limit` is set for a case.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.path.insert(0, os.path.join(HERE, "_refstubs"))
+sys.path.insert(0, os.path.join(REF, "envs", "gym-track2d"))
+
+import numpy as np  # noqa: E402
+
+from gym_track2d.envs.track_1v1 import Track1v1Env  # noqa: E402
+from gym_track2d.envs.Astar_solver import AstarSolver  # noqa: E402
+import gym_track2d  # noqa: E402,F401  (fills the registry stub)
+from gym.envs.registration import REGISTRY  # noqa: E402
+
+_real_seed = np.random.seed
+
+
+def patched_seed(*a, **k):
+    if a or k:
+        return _real_seed(*a, **k)
+    return None  # argument-less re-seed neutralised
+
+
+np.random.seed = patched_seed
+
+
+def pack_maze(m):
+    m = np.asarray(m)
+    return np.packbits((m != 0).astype(np.uint8).reshape(-1)), m.shape[0]
+
+
+def chase_action(env, rs):
+    (r0, c0), (r1, c1) = [list(map(int, s)) for s in env.state]
+    cands = []
+    if r1 < r0: cands.append(0)
+    if r1 > r0: cands.append(1)
+    if c1 < c0: cands.append(2)
+    if c1 > c0: cands.append(3)
+    if not cands or rs.rand() < 0.15:
+        return int(rs.randint(0, 4))
+    return int(cands[rs.randint(0, len(cands))])
+
+
+def run_case(map_type, mode, level, seed, n_episodes, max_steps, policy="random", time_limit=500):
+    env = Track1v1Env(map_type=map_type, target_mode=mode, level=level)
+    emitted = []
+    if env.Target:
+        tgt = env.Target[0]
+        orig_step = tgt.step
+
+        def rec_step(*a, **k):
+            out = orig_step(*a, **k)
+            act = out[0] if isinstance(out, tuple) else out
+            emitted.append(int(np.asarray(act).reshape(-1)[0]))
+            return out
+
+        tgt.step = rec_step
+    rs = np.random.RandomState(10_000 + seed)  # private action stream (not the global RNG)
+    np.random.seed(seed)                       # seeds the reference's global stream
+    eps = []
+    for ep in range(n_episodes):
+        obs0 = env.reset()
+        rec = dict(maze=np.array(env.maze), init=np.array(env.init_states, np.int32).copy(),
+                   goals=np.array(env.goal_states, np.int32).copy(), obs0=np.asarray(obs0).astype(np.uint8),
+                   act_in=[], act_applied=[], obs=[], rew=[], done=[], cfar=[], pos=[])
+        if mode == "Ram":
+            rec["plan0"] = np.array(env.Target[0].plan_actions, np.int32).copy()
+        if mode == "Nav":
+            rec["plan0"] = np.array(env.Target[0].plan_actions, np.int32).copy()
+            rec["navgoal0"] = np.array(env.Target[0].goal_states, np.int32).copy()
+        t = 0
+        while True:
+            a0 = chase_action(env, rs) if policy == "chase" else int(rs.randint(0, 4))
+            a1 = int(rs.randint(0, 4))
+            n_em = len(emitted)
+            obs, rew, done, info = env.step([a0, a1])
+            t += 1
+            applied1 = emitted[n_em] if len(emitted) > n_em else a1
+            if time_limit and t >= time_limit:
+                done = True
+            rec["act_in"].append([a0, a1]); rec["act_applied"].append([a0, applied1])
+            rec["obs"].append(np.asarray(obs).astype(np.uint8).reshape(2, 13, 13))
+            rec["rew"].append(np.asarray(rew, np.float64).copy()); rec["done"].append(bool(done))
+            rec["cfar"].append(int(env.C_far))
+            rec["pos"].append(np.array(env.state, np.int32).copy())
+            assert set(np.unique(rec["obs"][-1])) <= {0, 1, 2, 4}
+            if done or t >= max_steps:
+                break
+        eps.append(rec)
+    return eps
+
+
+def flatten(prefix, eps, out):
+    out[prefix + "n_eps"] = np.int32(len(eps))
+    for i, r in enumerate(eps):
+        p = "%sep%d_" % (prefix, i)
+        bits, side = pack_maze(r["maze"])
+        out[p + "maze"] = bits; out[p + "side"] = np.int32(side)
+        out[p + "init"] = r["init"]; out[p + "goals"] = r["goals"]; out[p + "obs0"] = r["obs0"].reshape(2, 13, 13)
+        out[p + "act_in"] = np.array(r["act_in"], np.uint8); out[p + "act_applied"] = np.array(r["act_applied"], np.uint8)
+        out[p + "obs"] = np.array(r["obs"], np.uint8); out[p + "rew"] = np.array(r["rew"], np.float64)
+        out[p + "done"] = np.array(r["done"], np.uint8); out[p + "cfar"] = np.array(r["cfar"], np.int32)
+        out[p + "pos"] = np.array(r["pos"], np.int32)
+        for k in ("plan0", "navgoal0"):
+            if k in r:
+                out[p + k] = r[k]
+
+
+def episodes():
+    out = {}
+    cases = []
+    # (map, mode, level, seed, n_episodes, max_steps, policy)
+    for mode in ("PZR", "Adv", "Far", "Ram"):
+        cases.append(("Block", mode, 0, 11, 3, 120, "random"))
+        cases.append(("Maze", mode, 0, 12, 3, 120, "random"))
+    cases.append(("Block", "PZR", 1, 13, 2, 80, "random"))
+    cases.append(("Maze", "PZR", 1, 14, 2, 80, "random"))
+    cases.append(("Empty", "PZR", 0, 15, 2, 60, "random"))
+    cases.append(("Block", "PZR", 0, 16, 1, 520, "chase"))   # runs into the 500-step TimeLimit
+    cases.append(("Block", "Ram", 0, 17, 2, 300, "chase"))
+    cases.append(("Block", "Nav", 0, 18, 2, 150, "chase"))
+    cases.append(("Maze", "Nav", 0, 19, 2, 150, "chase"))
+    cases.append(("Maze", "Ram", 1, 20, 2, 100, "chase"))
+    names = []
+    for (mp, mode, lvl, seed, n_ep, mx, pol) in cases:
+        name = "%s_%s_l%d_s%d" % (mp, mode, lvl, seed)
+        eps = run_case(mp, mode, lvl, seed, n_ep, mx, pol)
+        flatten(name + "/", eps, out)
+        out[name + "/meta"] = np.array([mp, mode, str(lvl), str(seed), pol])
+        names.append(name)
+        print(name, [len(e["obs"]) for e in eps], [bool(e["done"][-1]) for e in eps])
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "episodes.npz"), **out)
+
+
+def edge_cases():
+    """Hand-placed situations driven through the reference env's own step()."""
+    out = {}
+    names = []
+
+    def drive(name, maze, pos, actions, mode="PZR"):
+        env = Track1v1Env(map_type="Block", target_mode="Adv" if mode == "Adv" else mode, level=1)
+        np.random.seed(5)
+        env.reset()
+        env.maze = np.array(maze, dtype=float)
+        env.state = [list(pos[0]), list(pos[1])]
+        env.init_states = env.state
+        env.C_far = 0
+        obs0 = np.asarray(env._get_obs()).astype(np.uint8).reshape(2, 13, 13)
+        obs, rew, done, cfar, posl = [], [], [], [], []
+        for a in actions:
+            o, r, d, _ = env.step(list(a))
+            obs.append(np.asarray(o).astype(np.uint8).reshape(2, 13, 13)); rew.append(np.asarray(r, np.float64).copy())
+            done.append(bool(d)); cfar.append(int(env.C_far)); posl.append(np.array(env.state, np.int32).copy())
+        bits, side = pack_maze(maze)
+        p = name + "/"
+        out[p + "maze"] = bits; out[p + "side"] = np.int32(side); out[p + "pos0"] = np.array(pos, np.int32)
+        out[p + "obs0"] = obs0; out[p + "actions"] = np.array(actions, np.uint8)
+        out[p + "obs"] = np.array(obs, np.uint8); out[p + "rew"] = np.array(rew, np.float64)
+        out[p + "done"] = np.array(done, np.uint8); out[p + "cfar"] = np.array(cfar, np.int32)
+        out[p + "pos"] = np.array(posl, np.int32); out[p + "mode"] = np.array(mode)
+        names.append(name)
+
+    def empty(S=82):
+        m = np.zeros((S, S), np.uint8)
+        m[0, :] = m[-1, :] = 1; m[:, 0] = m[:, -1] = 1
+        return m
+
+    rs = np.random.RandomState(77)
+    m = empty()
+    # co-located agents, then separate
+    drive("colocated", m, [[10, 10], [10, 10]], [[0, 0], [0, 1], [2, 3], [3, 2], [1, 1]])
+    # corners: maximum padding (6 out-of-bounds rows/cols) and wall bumps
+    drive("corner_tl", m, [[1, 1], [1, 2]], [[0, 0], [2, 2], [0, 2], [3, 3], [1, 1]])
+    drive("corner_br", m, [[80, 80], [80, 79]], [[1, 1], [3, 3], [1, 3], [2, 2], [0, 0]])
+    drive("corner_tr_bl", m, [[1, 80], [80, 1]], [[0, 1], [3, 2], [2, 3], [1, 0]], mode="Far")
+    # other agent exactly at Chebyshev distance 6 / 7 (window edge) and d2 = 36 vs 37
+    drive("cheb6", m, [[40, 40], [34, 46]], [[0, 0], [1, 1], [1, 1], [2, 3], [3, 2]])
+    drive("d2_36_37", m, [[40, 40], [40, 46]], [[2, 3], [3, 2], [0, 1], [1, 0], [2, 2], [2, 3]])
+    drive("d2_37_diag", m, [[40, 40], [41, 46]], [[0, 0], [0, 1], [1, 1], [2, 3]])
+    # 11-step far run -> done on the 11th consecutive far step; re-entry resets the counter
+    drive("far_run", m, [[10, 10], [10, 30]], [[2, 3]] * 5 + [[3, 2]] * 30 + [[2, 3]] * 40, mode="Adv")
+    drive("far_run_pzr", m, [[10, 10], [30, 30]], [[0, 1]] * 14)
+    drive("far_run_farmode", m, [[10, 10], [10, 20]], [[2, 3]] * 14, mode="Far")
+    # dense random obstacles: K = 959 (max level-0 density) and K = 0
+    dm = empty()
+    idx = rs.permutation(6400)[:959]
+    dm[1 + idx // 80, 1 + idx % 80] = 1
+    free = np.argwhere(dm == 0)
+    p0 = free[rs.randint(len(free))]
+    acts = rs.randint(0, 4, size=(60, 2)).tolist()
+    drive("dense959", dm, [list(map(int, p0)), list(map(int, p0))], acts)
+    drive("dense959_far", dm, [list(map(int, free[5])), list(map(int, free[-5]))], acts[:20], mode="Far")
+    # maze-sized (81x81) empty map = Maze with density 0
+    drive("maze81_empty", empty(81), [[79, 79], [78, 79]], rs.randint(0, 4, size=(30, 2)).tolist())
+    drive("maze81_tl", empty(81), [[1, 1], [2, 1]], rs.randint(0, 4, size=(30, 2)).tolist(), mode="Adv")
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "edges.npz"), **out)
+    print("edges:", names)
+
+
+def astar_cases():
+    out = {}
+    rs = np.random.RandomState(123)
+    n = 0
+    for map_type in ("Block", "Maze"):
+        for level in (0, 1):
+            for k in range(4):
+                env = Track1v1Env(map_type=map_type, target_mode="PZR", level=level)
+                np.random.seed(200 + n)
+                env.reset()
+                maze = np.array(env.maze)
+                free = np.argwhere(maze == 0)
+                for q in range(3):
+                    s = free[rs.randint(len(free))]; g = free[rs.randint(len(free))]
+                    if q == 2:
+                        g = s.copy()  # start == goal -> empty plan
+                    sol = AstarSolver([int(s[0]), int(s[1])], [0, 1, 2, 3], maze, [int(g[0]), int(g[1])])
+                    p = "a%d/" % n
+                    bits, side = pack_maze(maze)
+                    out[p + "maze"] = bits; out[p + "side"] = np.int32(side)
+                    out[p + "start"] = np.array(s, np.int32); out[p + "goal"] = np.array(g, np.int32)
+                    out[p + "solvable"] = np.bool_(sol.solvable())
+                    out[p + "actions"] = np.array(sol.get_actions() if sol.solvable() else [], np.int32)
+                    n += 1
+    # walled-off goal -> unsolvable
+    m = np.zeros((82, 82), np.uint8); m[0, :] = m[-1, :] = 1; m[:, 0] = m[:, -1] = 1
+    m[9, 9:12] = 1; m[11, 9:12] = 1; m[10, 9] = 1; m[10, 11] = 1
+    sol = AstarSolver([3, 3], [0, 1, 2, 3], m.astype(float), [10, 10])
+    p = "a%d/" % n
+    bits, side = pack_maze(m)
+    out[p + "maze"] = bits; out[p + "side"] = np.int32(side); out[p + "start"] = np.array([3, 3], np.int32)
+    out[p + "goal"] = np.array([10, 10], np.int32); out[p + "solvable"] = np.bool_(sol.solvable())
+    out[p + "actions"] = np.array([], np.int32)
+    n += 1
+    out["count"] = np.int32(n)
+    np.savez_compressed(os.path.join(HERE, "astar.npz"), **out)
+    print("astar cases:", n)
+
+
+def registry():
+    ids = sorted(REGISTRY)
+    rows = [[i, REGISTRY[i]["kwargs"]["map_type"], REGISTRY[i]["kwargs"]["obs_type"], str(REGISTRY[i]["kwargs"]["level"]),
+             REGISTRY[i]["kwargs"]["target_mode"], str(REGISTRY[i]["max_episode_steps"])] for i in ids]
+    np.savez_compressed(os.path.join(HERE, "registry.npz"), rows=np.array(rows))
+    print("registry ids:", len(ids))
+
+
+if __name__ == "__main__":
+    episodes()
+    edge_cases()
+    astar_cases()
+    registry()

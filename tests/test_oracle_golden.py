@@ -1,0 +1,94 @@
+"""Pins the CPU oracle (oracle/track2d_oracle.c, numpy-legacy RNG mode) to the golden vectors captured
+from the reference env (tests/golden/make_golden.py): maps, spawns, goals, scripted-target actions,
+per-step obs / rewards / done — all bit-exact, over several consecutive episodes of one RNG stream."""
+import numpy as np
+import pytest
+
+from conftest import unpack_maze
+from oracle import oracle as orc
+
+
+def _names(npz):
+    return [str(n) for n in npz["names"]]
+
+
+def test_episode_cases_bit_exact(golden_episodes):
+    g = golden_episodes
+    checked_steps = 0
+    for name in _names(g):
+        mp, mode, lvl, seed, _pol = [str(x) for x in g[name + "/meta"]]
+        env = orc.OracleEnv(mp, mode, int(lvl), 500, orc.RNG_NP, int(seed))
+        env.seed_np(int(seed))
+        for ep in range(int(g[name + "/n_eps"])):
+            p = "%s/ep%d_" % (name, ep)
+            obs0 = env.reset()
+            maze = unpack_maze(g[p + "maze"], g[p + "side"])
+            assert env.side == int(g[p + "side"]), name
+            np.testing.assert_array_equal(env.maze, maze, err_msg=name + " maze")
+            st = env.state()
+            np.testing.assert_array_equal(st["pos"], g[p + "init"], err_msg=name + " init")
+            np.testing.assert_array_equal(st["goals"], g[p + "goals"], err_msg=name + " goals")
+            np.testing.assert_array_equal(obs0, g[p + "obs0"], err_msg=name + " obs0")
+            if p + "plan0" in g.files:
+                plan, cur = env.plan()
+                np.testing.assert_array_equal(plan, g[p + "plan0"], err_msg=name + " plan0")
+                assert cur == 0
+            acts = g[p + "act_in"]
+            for t in range(len(acts)):
+                obs, rew, done, applied = env.step(acts[t])
+                assert np.array_equal(obs, g[p + "obs"][t]), (name, ep, t)
+                assert rew[0] == g[p + "rew"][t][0] and rew[1] == g[p + "rew"][t][1], (name, ep, t, rew)
+                assert done == bool(g[p + "done"][t]), (name, ep, t)
+                assert np.array_equal(applied, g[p + "act_applied"][t]), (name, ep, t)
+                s = env.state()
+                assert s["c_far"] == g[p + "cfar"][t]
+                assert np.array_equal(s["pos"], g[p + "pos"][t])
+                checked_steps += 1
+    assert checked_steps > 2500
+
+
+def test_edge_cases_bit_exact(golden_edges):
+    g = golden_edges
+    for name in _names(g):
+        mode = str(g[name + "/mode"])
+        maze = unpack_maze(g[name + "/maze"], g[name + "/side"])
+        env = orc.OracleEnv("Block", mode, 1, 0, orc.RNG_NP, 0)
+        env.inject(maze, g[name + "/pos0"])
+        np.testing.assert_array_equal(env.obs(), g[name + "/obs0"], err_msg=name)
+        for t, a in enumerate(g[name + "/actions"]):
+            obs, rew, done, _ = env.step(a)
+            assert np.array_equal(obs, g[name + "/obs"][t]), (name, t)
+            assert tuple(rew) == tuple(g[name + "/rew"][t]), (name, t)
+            assert done == bool(g[name + "/done"][t]), (name, t)
+            s = env.state()
+            assert s["c_far"] == g[name + "/cfar"][t], (name, t)
+            assert np.array_equal(s["pos"], g[name + "/pos"][t]), (name, t)
+
+
+def test_far_run_terminates_on_eleventh_far_step(golden_edges):
+    g = golden_edges
+    d = g["far_run_pzr/done"]
+    assert d.argmax() == 10 and d[10] == 1  # done exactly on the 11th consecutive far step
+
+
+def test_astar_matches_reference(golden_astar):
+    g = golden_astar
+    n = int(g["count"])
+    solv = 0
+    for i in range(n):
+        p = "a%d/" % i
+        maze = unpack_maze(g[p + "maze"], g[p + "side"])
+        got = orc.astar(maze, g[p + "start"], g[p + "goal"])
+        if bool(g[p + "solvable"]):
+            assert got is not None
+            np.testing.assert_array_equal(got, g[p + "actions"], err_msg=p)
+            solv += 1
+        else:
+            assert got is None
+    assert solv >= 40
+
+
+def test_time_limit_episode(golden_episodes):
+    g = golden_episodes
+    d = g["Block_PZR_l0_s16/ep0_done"]
+    assert len(d) == 500 and d[-1] == 1 and d[:-1].sum() == 0
