@@ -1,0 +1,312 @@
+// t2d_device.h — device-side building blocks of the batched Track2D environment (gfx950 / CDNA4 only).
+//
+// Execution model: ONE WAVEFRONT (64 lanes) PER ENV. An env's 82x82 0/1 map is a 1 KiB bit-packed tile
+// (row r = words 3r..3r+2, bit c&31 of word c>>5): 64 lanes x 16 B = the whole tile in one coalesced
+// global_load_dwordx4, staged in LDS for the wall tests, the 13x13 crops and (on reset) in-place
+// generation. All scalar per-env state is wave-uniform; lane 0 commits it.
+//
+// Random numbers: Philox4x32-10 counter streams keyed (seed) / (block, episode, global env id, stream) —
+// the spec is the PHILOX mode of oracle/track2d_oracle.c, which these functions match bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace t2d {
+
+constexpr int kTileWords = 256;   // 1 KiB per env (246 used)
+constexpr int kRowWords = 3;
+constexpr int kWavesPerBlock = 4; // 256-thread workgroups: 4 envs per block
+constexpr int kObsPerEnv = 338;   // 2 agents x 13 x 13
+
+enum : int { MAP_BLOCK = 0, MAP_MAZE = 1, MAP_EMPTY = 2 };
+enum : int { TGT_ADV = 0, TGT_PZR = 1, TGT_FAR = 2, TGT_NAV = 3, TGT_RAM = 4 };
+enum : uint32_t { STREAM_MAP = 0, STREAM_SPAWN = 1, STREAM_TARGET = 2, STREAM_ACTION = 7 };
+
+// ---- wave-level helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // DS operations of one wave execute in order; this only stops the compiler from moving LDS
+    // accesses across the point and lets other lanes' writes be re-read.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int uni(int v) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)v); }
+
+// ---- Philox4x32-10 ----------------------------------------------------------------------------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                                               uint32_t c2, uint32_t c3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+// Sequential word reader over one stream (wave-uniform use).
+struct Stream {
+    uint32_t k0, k1, episode, env, stream;
+    uint32_t ctr;      // next word index
+    uint32_t blk;      // cached block index (0xffffffff = none)
+    u32x4 w;
+    __device__ __forceinline__ void init(uint32_t k0_, uint32_t k1_, uint32_t ep, uint32_t env_, uint32_t s,
+                                         uint32_t ctr_)
+    {
+        k0 = k0_; k1 = k1_; episode = ep; env = env_; stream = s; ctr = ctr_; blk = 0xffffffffu;
+        w = u32x4{0, 0, 0, 0};
+    }
+    __device__ __forceinline__ uint32_t next()
+    {
+        uint32_t i = ctr++;
+        uint32_t b = i >> 2;
+        if (b != blk) { w = philox4x32_10(k0, k1, b, episode, env, stream); blk = b; }
+        uint32_t j = i & 3u;
+        return j == 0 ? w.x : (j == 1 ? w.y : (j == 2 ? w.z : w.w));
+    }
+    // numpy-legacy random_sample layout: 53 bits from two words
+    __device__ __forceinline__ double next_double()
+    {
+        uint32_t a = next() >> 5, b = next() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    // uniform integer in [0, max]: masked rejection, one word per attempt; max == 0 draws nothing
+    __device__ __forceinline__ uint32_t bounded(uint32_t max)
+    {
+        if (max == 0) return 0;
+        uint32_t mask = 0xffffffffu >> __builtin_clz(max);
+        uint32_t v;
+        do { v = next() & mask; } while (v > max);
+        return v;
+    }
+};
+
+// ---- keyed permutation of [0, 6400) (oracle: orc_perm6400) --------------------------------------------
+__device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t perm6400(const uint32_t (&rk)[8], uint32_t i)
+{
+    uint32_t a = i / 80u, b = i - a * 80u;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint32_t f = __umulhi(fmix32(b * 0x9E3779B1u + rk[r]), 80u);
+        uint32_t t = a + f;
+        if (t >= 80u) t -= 80u;
+        a = b; b = t;
+    }
+    return a * 80u + b;
+}
+
+// ---- map tile access (LDS) ------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t tile_bit(const uint32_t *tile, int r, int c)
+{
+    return (tile[r * kRowWords + (c >> 5)] >> (c & 31)) & 1u;
+}
+__device__ __forceinline__ uint32_t valid_mask_w2(int side) { return (1u << (side - 64)) - 1u; }
+
+// Number of free (0) cells per row for rows lane and lane+64, exclusive prefix sums over the wave and
+// the total; used to select the k-th free cell in np.where(maze == 0) row-major order
+// (G/envs/generators.py:42-43,57-58).
+struct FreeIndex {
+    int z0, z1;       // zeros in row lane / lane+64
+    int ex0, ex1;     // exclusive prefix of z0 over lanes / of z1 over lanes
+    int total0, total; // sum z0 / sum z0+z1
+};
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ FreeIndex build_free_index(const uint32_t *tile, int side, int lane)
+{
+    FreeIndex f;
+    uint32_t m2 = valid_mask_w2(side);
+    auto zeros = [&](int row) -> int {
+        if (row >= side) return 0;
+        const uint32_t *w = tile + row * kRowWords;
+        return side - (__popc(w[0]) + __popc(w[1]) + __popc(w[2] & m2));
+    };
+    f.z0 = zeros(lane);
+    f.z1 = zeros(lane + 64);
+    int in0 = wave_incl_scan(f.z0, lane), in1 = wave_incl_scan(f.z1, lane);
+    f.ex0 = in0 - f.z0; f.ex1 = in1 - f.z1;
+    f.total0 = __shfl(in0, 63, 64);
+    f.total = f.total0 + __shfl(in1, 63, 64);
+    return f;
+}
+// k-th free cell (row-major). Wave-uniform k in [0, total). Returns r | c << 8.
+__device__ __forceinline__ uint32_t select_free(const uint32_t *tile, int side, const FreeIndex &f, int k, int lane)
+{
+    int row, kk;
+    if (k < f.total0) {
+        bool mine = (k >= f.ex0) && (k < f.ex0 + f.z0);
+        int src = __ffsll((unsigned long long)__ballot(mine)) - 1;
+        row = src; kk = k - __shfl(f.ex0, src, 64);
+    } else {
+        int k2 = k - f.total0;
+        bool mine = (k2 >= f.ex1) && (k2 < f.ex1 + f.z1);
+        int src = __ffsll((unsigned long long)__ballot(mine)) - 1;
+        row = src + 64; kk = k2 - __shfl(f.ex1, src, 64);
+    }
+    row = uni(row); kk = uni(kk);
+    const uint32_t *w = tile + row * kRowWords;
+    uint32_t fr[3] = {~w[0], ~w[1], ~w[2] & valid_mask_w2(side)};
+    int col = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        int n = __popc(fr[j]);
+        if (kk >= 0 && kk < n) {
+            uint32_t m = fr[j];
+            for (int q = 0; q < kk; q++) m &= m - 1u;
+            col = j * 32 + (__ffs(m) - 1);
+            kk = -1;
+        } else if (kk >= 0) {
+            kk -= n;
+        }
+    }
+    return (uint32_t)row | ((uint32_t)col << 8);
+}
+
+// ---- generators (write the LDS tile in place) -----------------------------------------------------------
+__device__ __forceinline__ void tile_clear(uint32_t *tile, int lane)
+{
+    reinterpret_cast<uint4 *>(tile)[lane] = make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ void tile_border(uint32_t *tile, int side, int lane)
+{
+    uint32_t last = 1u << (side - 1 - 64);
+    for (int row = lane; row < side; row += 64) {
+        uint32_t *w = tile + row * kRowWords;
+        if (row == 0 || row == side - 1) { w[0] = 0xffffffffu; w[1] = 0xffffffffu; w[2] = (last << 1) - 1u; }
+        else { w[0] |= 1u; w[2] |= last; }
+    }
+}
+
+// RandomBlockMazeGenerator._generate_maze — G/envs/generators.py:157-176: exactly K = int(ratio * 6400)
+// distinct interior cells, here the first K images of a keyed permutation; then the wall border.
+__device__ __forceinline__ void gen_block(uint32_t *tile, int lane, Stream &ms, double ratio)
+{
+    tile_clear(tile, lane);
+    int K = (int)(ratio * 6400.0);
+    ms.ctr = 4; // round keys = MAP words 4..11
+    uint32_t rk[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rk[i] = ms.next();
+    wave_lds_sync();
+    for (int i = lane; i < K; i += 64) {
+        uint32_t c = perm6400(rk, (uint32_t)i);
+        uint32_t row = c / 80u + 1u, col = c - (c / 80u) * 80u + 1u;
+        atomicOr(&tile[row * kRowWords + (col >> 5)], 1u << (col & 31u));
+    }
+    wave_lds_sync();
+    tile_border(tile, 82, lane);
+    wave_lds_sync();
+}
+
+// RandomMazeGenerator._generate_maze — G/envs/generators.py:115-145 (81x81). Inherently sequential:
+// every lane runs the same wave-uniform loop, lane 0 commits the writes.
+__device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, Stream &ms, double ratio)
+{
+    const int S = 81;
+    tile_clear(tile, lane);
+    wave_lds_sync();
+    tile_border(tile, S, lane);
+    wave_lds_sync();
+    int complexity = (int)(ratio * 810.0);
+    int density = (int)(ratio * 1600.0);
+    auto set = [&](int y, int x) {
+        if (lane == 0) tile[y * kRowWords + (x >> 5)] |= 1u << (x & 31);
+    };
+    for (int i = 0; i < density; i++) {
+        int x = (int)ms.bounded(40u) * 2;
+        int y = (int)ms.bounded(40u) * 2;
+        set(y, x);
+        wave_lds_sync();
+        for (int j = 0; j < complexity; j++) {
+            // neighbour list order of generators.py:135-138; k-th present candidate, no local arrays
+            const bool c0 = x > 1, c1 = x < S - 2, c2 = y > 1, c3 = y < S - 2;
+            const int n = (int)c0 + (int)c1 + (int)c2 + (int)c3;
+            int k = (int)ms.bounded((uint32_t)(n - 1));
+            int y_ = y, x_ = x, seen = 0;
+            if (c0) { if (seen == k) { y_ = y;     x_ = x - 2; } seen++; }
+            if (c1) { if (seen == k) { y_ = y;     x_ = x + 2; } seen++; }
+            if (c2) { if (seen == k) { y_ = y - 2; x_ = x;     } seen++; }
+            if (c3) { if (seen == k) { y_ = y + 2; x_ = x;     } seen++; }
+            if (tile_bit(tile, y_, x_) == 0u) {
+                set(y_, x_);
+                set(y_ + (y - y_) / 2, x_ + (x - x_) / 2);
+                x = x_; y = y_;
+                wave_lds_sync();
+            }
+        }
+    }
+    wave_lds_sync();
+}
+
+// ---- scripted Ram target (G/envs/navigator.py:73-93) ----------------------------------------------------
+// plan word: bits 0..19 ten 2-bit actions, 20..23 length, 24..27 cursor, 28 Nav plan-B flag.
+__device__ __forceinline__ uint32_t plan_len(uint32_t p) { return (p >> 20) & 15u; }
+__device__ __forceinline__ uint32_t plan_cur(uint32_t p) { return (p >> 24) & 15u; }
+__device__ __forceinline__ uint32_t plan_act(uint32_t p, uint32_t i) { return (p >> (2u * i)) & 3u; }
+__device__ __forceinline__ uint32_t plan_random(Stream &ts, uint32_t n)
+{
+    uint32_t p = 0;
+    for (uint32_t i = 0; i < n; i++) p |= ts.bounded(3u) << (2u * i);
+    return p | (n << 20);
+}
+__device__ __forceinline__ uint32_t ram_reset(Stream &ts)
+{
+    uint32_t n = 1u + ts.bounded(8u); // randint(1,10) is evaluated before choice(4, n)  (navigator.py:91)
+    return plan_random(ts, n);
+}
+__device__ __forceinline__ uint32_t ram_step(uint32_t &plan, Stream &ts)
+{
+    uint32_t cur = plan_cur(plan), len = plan_len(plan);
+    uint32_t action = plan_act(plan, cur);
+    cur++;
+    if (cur >= len) {
+        if (ts.bounded(1u) == 0u) {                   // np.random.choice([0,1],1) == 0  (navigator.py:81)
+            action = ts.bounded(3u);
+            uint32_t n = 1u + ts.bounded(8u);
+            plan = (action * 0x55555u & ((1u << (2u * n)) - 1u)) | (n << 20);
+        } else {
+            uint32_t n = 1u + ts.bounded(8u);
+            plan = plan_random(ts, n);
+        }
+    } else {
+        plan = (plan & 0xf0ffffffu) | (cur << 24);
+    }
+    return action;
+}
+
+// ---- rewards (G/envs/track_1v1.py:94-104), float64 in the reference's operation order ---------------------
+__device__ __forceinline__ void reward_f64(uint32_t d2, double w_p, double &r_track, double &r_target)
+{
+    const double max_distance = 6.0;
+    double distance = __dsqrt_rn((double)d2);
+    double rt = 1.0 - __ddiv_rn(2.0 * distance, max_distance);
+    rt = rt > -1.0 ? rt : -1.0;
+    double over = distance - max_distance;
+    over = over > 0.0 ? over : 0.0;
+    double rg = -rt - __ddiv_rn(w_p * over, max_distance);
+    rg = rg > -1.0 ? rg : -1.0;
+    r_track = rt; r_target = rg;
+}
+
+} // namespace t2d

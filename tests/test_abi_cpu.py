@@ -1,0 +1,63 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every symbol that
+include/track2d.h declares; the env-id table equals the reference registry (golden registry.npz); the product
+path refuses to run without the GPU instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "track2d.h")).read()
+    return sorted(set(re.findall(r"\b(t2d_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from active_tracking_rl_amd import build, vec_env
+    build.build()
+    lib = ctypes.CDLL(vec_env.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(vec_env.ABI_SYMBOLS) == syms
+    lib.t2d_abi_version.restype = ctypes.c_int
+    assert lib.t2d_abi_version() == vec_env.ABI_VERSION
+
+
+def test_registry_matches_reference():
+    from active_tracking_rl_amd import registry
+    rows = np.load(os.path.join(GOLDEN, "registry.npz"))["rows"]
+    assert len(rows) == 72 == len(registry.REGISTRY)
+    for env_id, mp, ob, lvl, tgt, mx in rows:
+        r = registry.REGISTRY[str(env_id)]
+        assert (r["map_type"], r["obs_type"], str(r["level"]), r["target_mode"], str(r["max_episode_steps"])) == \
+            (str(mp), str(ob), str(lvl), str(tgt), str(mx))
+    assert registry.spec("Track2D-BlockPartialPZR-v0")["target_mode"] == "PZR"
+    with pytest.raises(NotImplementedError):
+        registry.spec("Track2D-BlockFullPZR-v0")
+    with pytest.raises(KeyError):
+        registry.spec("Track2D-Nope-v0")
+
+
+def test_no_cpu_fallback():
+    import torch
+    from active_tracking_rl_amd import vec_env
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(vec_env.T2DError):
+        vec_env.VecTrack2D("Track2D-BlockPartialPZR-v0", num_envs=4)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "active_tracking_rl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "libtrack2d_oracle" not in txt, f

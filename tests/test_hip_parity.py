@@ -1,0 +1,271 @@
+"""-m gpu parity tests proper: the HIP path (through the C ABI, via active_tracking_rl_amd.vec_env) against
+ (a) the golden vectors captured from the reference env — injected maps/spawns/actions, bit-exact obs, done,
+     far counter, positions; rewards exactly float32(reference float64);
+ (b) the CPU oracle in its PHILOX (device-spec) mode — generated maps, spawns, goals, Ram plans and whole
+     auto-reset trajectories, bit-exact;
+ (c) size-independent invariants at the BASELINE sizes (4096 / 16384 envs).
+Tolerance: none — integer/byte work is bit-exact; rewards are float64 arithmetic rounded once to f32 and are
+compared for equality (north_star allows 1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import unpack_maze
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+MODE_CODE = {"Adv": 0, "PZR": 1, "Far": 2, "Nav": 3, "Ram": 4}
+
+
+@pytest.fixture(scope="module")
+def vec():
+    from active_tracking_rl_amd import vec_env
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return vec_env
+
+
+def _pad82(m):
+    out = np.zeros((82, 82), np.uint8)
+    out[: m.shape[0], : m.shape[1]] = m
+    return out
+
+
+def _run_injected(vec, items):
+    """items: list of dict(maze, pos0, actions[T,2], obs[T,2,13,13], rew[T,2] f64, done[T], cfar[T], pos[T,2,2],
+    mode, obs0). Each item becomes one env of a batch (81- and 82-sided maps in separate batches)."""
+    for side in (81, 82):
+        sel = [it for it in items if it["maze"].shape[0] == side]
+        if not sel:
+            continue
+        n = len(sel)
+        modes = np.array([MODE_CODE[it["mode"]] for it in sel], np.uint8)
+        env = vec.VecTrack2D(num_envs=n, map_type="Block", target_mode="Adv", level=1, auto_reset=False,
+                             max_episode_steps=500, target_mode_per_env=modes)
+        env.inject(np.stack([it["maze"] for it in sel]), np.stack([it["pos0"].reshape(4) for it in sel]))
+        obs0 = env.observe().cpu().numpy()
+        for i, it in enumerate(sel):
+            assert np.array_equal(obs0[i].astype(np.uint8), it["obs0"]), ("obs0", it["name"])
+            assert np.array_equal(obs0[i], it["obs0"].astype(np.float32))
+        T = max(len(it["actions"]) for it in sel)
+        acts = np.zeros((T, n, 2), np.int64)
+        for i, it in enumerate(sel):
+            acts[: len(it["actions"]), i] = it["actions"]
+        acts_d = torch.from_numpy(acts).cuda()
+        for t in range(T):
+            obs, rew, done = env.step(acts_d[t, :, 0].contiguous(), acts_d[t, :, 1].contiguous())
+            obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+            st = env.get_state()
+            for i, it in enumerate(sel):
+                if t >= len(it["actions"]):
+                    continue
+                tag = (it["name"], t)
+                assert np.array_equal(obs[i], it["obs"][t].astype(np.float32)), tag
+                assert np.array_equal(rew[i], it["rew"][t].astype(np.float32)), (tag, rew[i], it["rew"][t])
+                assert bool(done[i]) == bool(it["done"][t]), tag
+                assert st["c_far"][i] == it["cfar"][t], tag
+                assert np.array_equal(st["pos"][i], it["pos"][t]), tag
+        assert env.faults() == 0
+        env.close()
+
+
+def test_golden_episodes_injected(vec, golden_episodes):
+    g = golden_episodes
+    items = []
+    for name in [str(n) for n in g["names"]]:
+        mp, mode, lvl, seed, _ = [str(x) for x in g[name + "/meta"]]
+        for ep in range(int(g[name + "/n_eps"])):
+            p = "%s/ep%d_" % (name, ep)
+            items.append(dict(name=p, maze=unpack_maze(g[p + "maze"], g[p + "side"]), pos0=g[p + "init"],
+                              actions=g[p + "act_applied"], obs=g[p + "obs"], rew=g[p + "rew"], done=g[p + "done"],
+                              cfar=g[p + "cfar"], pos=g[p + "pos"], obs0=g[p + "obs0"],
+                              mode=mode if mode in ("PZR", "Far") else "Adv"))
+    assert len(items) >= 30
+    _run_injected(vec, items)
+
+
+def test_golden_edges_injected(vec, golden_edges):
+    g = golden_edges
+    items = []
+    for name in [str(n) for n in g["names"]]:
+        items.append(dict(name=name, maze=unpack_maze(g[name + "/maze"], g[name + "/side"]), pos0=g[name + "/pos0"],
+                          actions=g[name + "/actions"], obs=g[name + "/obs"], rew=g[name + "/rew"],
+                          done=g[name + "/done"], cfar=g[name + "/cfar"], pos=g[name + "/pos"],
+                          obs0=g[name + "/obs0"], mode=str(g[name + "/mode"])))
+    _run_injected(vec, items)
+
+
+def test_reward_table_exhaustive_bit_exact(vec):
+    env = vec.VecTrack2D(num_envs=1, map_type="Block", target_mode="PZR")
+    d2 = torch.arange(0, 2 * 81 * 81 + 1, dtype=torch.int32)
+    for w_p in (1.0, -0.5, 0.0):
+        rt, rg = env.reward_table(d2, w_p)
+        rt, rg = rt.cpu().numpy(), rg.cpu().numpy()
+        want = np.array([orc.reward(int(v), w_p) for v in d2.numpy()], np.float64).astype(np.float32)
+        assert np.array_equal(rt, want[:, 0]) and np.array_equal(rg, want[:, 1]), w_p
+    env.close()
+
+
+def _oracle_batch(n, map_types, modes, levels, seed, base=0):
+    return [orc.OracleEnv(map_types[i], modes[i], int(levels[i]), 500, orc.RNG_PHILOX, seed, base + i)
+            for i in range(n)]
+
+
+def _check_generated(vec, n, map_type, mode, level, seed, steps, per_env=None, base=0):
+    if per_env is None:
+        mts, mds, lvs = [map_type] * n, [mode] * n, [level] * n
+        env = vec.VecTrack2D(num_envs=n, map_type=map_type, target_mode=mode, level=level, seed=seed,
+                             env_id_base=base, auto_reset=True)
+    else:
+        mts, mds, lvs = per_env
+        from active_tracking_rl_amd import registry
+        env = vec.VecTrack2D(num_envs=n, map_type="Block", target_mode="Adv", level=0, seed=seed, env_id_base=base,
+                             auto_reset=True,
+                             map_type_per_env=np.array([registry.MAP_CODE[m] for m in mts], np.uint8),
+                             target_mode_per_env=np.array([registry.TARGET_CODE[m] for m in mds], np.uint8),
+                             level_per_env=np.array(lvs, np.uint8))
+    oracles = _oracle_batch(n, mts, mds, lvs, seed, base)
+    obs = env.reset().cpu().numpy()
+    want0 = np.stack([o.reset() for o in oracles])
+    maps = env.get_maps()
+    st = env.get_state()
+    for i, o in enumerate(oracles):
+        assert st["side"][i] == o.side
+        assert np.array_equal(maps[i], _pad82(o.maze)), ("map", i)
+        s = o.state()
+        assert np.array_equal(st["pos"][i], s["pos"]), ("spawn", i, st["pos"][i], s["pos"])
+        assert np.array_equal(st["goals"][i], s["goals"]), ("goals", i)
+    assert np.array_equal(obs, want0.astype(np.float32))
+    rs = np.random.RandomState(seed)
+    n_done = 0
+    for t in range(steps):
+        acts = rs.randint(0, 4, size=(n, 2))
+        a = torch.from_numpy(acts).cuda()
+        obs, rew, done = env.step(a[:, 0].contiguous(), a[:, 1].contiguous())
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        for i, o in enumerate(oracles):
+            wo, wr, wd, _ = o.step(acts[i])
+            if wd:
+                wo = o.reset()  # auto-reset: first observation of the next episode
+                n_done += 1
+            assert bool(done[i]) == wd, (t, i)
+            assert np.array_equal(rew[i], wr.astype(np.float32)), (t, i, rew[i], wr)
+            assert np.array_equal(obs[i], wo.astype(np.float32)), (t, i)
+    st = env.get_state()
+    for i, o in enumerate(oracles):
+        s = o.state()
+        assert np.array_equal(st["pos"][i], s["pos"]) and st["c_far"][i] == s["c_far"] and st["t"][i] == s["t"]
+        assert st["episode"][i] == o.L.orc_episode(o.h)
+    assert env.faults() == 0
+    env.close()
+    return n_done
+
+
+def test_generated_block_pzr_matches_oracle(vec):
+    assert _check_generated(vec, 96, "Block", "PZR", 0, seed=7, steps=90) > 50
+
+
+def test_generated_block_ram_matches_oracle(vec):
+    assert _check_generated(vec, 64, "Block", "Ram", 0, seed=11, steps=120) > 30
+
+
+def test_generated_maze_far_and_levels_match_oracle(vec):
+    _check_generated(vec, 48, "Maze", "Far", 0, seed=3, steps=60)
+    _check_generated(vec, 16, "Maze", "Adv", 1, seed=4, steps=40)
+    _check_generated(vec, 16, "Block", "Adv", 1, seed=5, steps=40)
+    _check_generated(vec, 16, "Empty", "PZR", 0, seed=6, steps=40)
+
+
+def test_generated_mixed_batch_and_sharding(vec):
+    n = 40
+    rs = np.random.RandomState(0)
+    mts = [("Block", "Maze")[k] for k in rs.randint(0, 2, n)]
+    mds = [("Adv", "PZR", "Far", "Ram")[k] for k in rs.randint(0, 4, n)]
+    lvs = rs.randint(0, 2, n).tolist()
+    _check_generated(vec, n, None, None, None, seed=21, steps=50, per_env=(mts, mds, lvs))
+    # a shard [base, base+n) of a larger job is keyed by GLOBAL env ids
+    _check_generated(vec, 24, "Block", "PZR", 0, seed=7, steps=30, base=1000)
+
+
+def test_odd_batch_sizes_and_tail_blocks(vec):
+    for n in (1, 2, 3, 5, 7):
+        _check_generated(vec, n, "Block", "PZR", 0, seed=100 + n, steps=25)
+
+
+def test_gym_protocol_masked_reset(vec):
+    n = 12
+    env = vec.VecTrack2D(num_envs=n, map_type="Block", target_mode="PZR", seed=9, auto_reset=False)
+    oracles = _oracle_batch(n, ["Block"] * n, ["PZR"] * n, [0] * n, 9)
+    env.reset()
+    for o in oracles:
+        o.reset()
+    rs = np.random.RandomState(1)
+    for t in range(60):
+        acts = rs.randint(0, 4, size=(n, 2))
+        a = torch.from_numpy(acts).cuda()
+        obs, rew, done = env.step(a[:, 0].contiguous(), a[:, 1].contiguous())
+        want = []
+        dn = []
+        for i, o in enumerate(oracles):
+            wo, _, wd, _ = o.step(acts[i])
+            want.append(wo); dn.append(wd)
+        assert np.array_equal(done.cpu().numpy().astype(bool), np.array(dn))
+        assert np.array_equal(obs.cpu().numpy(), np.stack(want).astype(np.float32))  # terminal obs kept
+        if any(dn):
+            obs = env.reset(mask=done)
+            for i, o in enumerate(oracles):
+                if dn[i]:
+                    want[i] = o.reset()
+            assert np.array_equal(obs.cpu().numpy(), np.stack(want).astype(np.float32))
+    env.close()
+
+
+def test_invalid_action_sets_fault(vec):
+    env = vec.VecTrack2D(num_envs=4, map_type="Block", target_mode="PZR", seed=2)
+    env.reset()
+    a = torch.tensor([0, 1, 7, 3], dtype=torch.int64, device="cuda")
+    env.step(a, a.clone())
+    assert env.faults() & 1
+    env.close()
+
+
+@pytest.mark.parametrize("n,map_type,mode", [(4096, "Block", "PZR"), (16384, "Block", "Adv"), (8192, "Maze", "Ram")])
+def test_invariants_at_baseline_sizes(vec, n, map_type, mode):
+    """SURVEY.md §8c property list, checked on the full batch without the oracle."""
+    env = vec.VecTrack2D(num_envs=n, map_type=map_type, target_mode=mode, seed=1, auto_reset=True)
+    obs = env.reset()
+    S = 81 if map_type == "Maze" else 82
+    maps = env.get_maps()
+    st = env.get_state()
+    assert (maps[:, 0, :S] == 1).all() and (maps[:, S - 1, :S] == 1).all()
+    assert (maps[:, :S, 0] == 1).all() and (maps[:, :S, S - 1] == 1).all()
+    if map_type == "Block":
+        k = maps[:, 1:81, 1:81].reshape(n, -1).sum(1)
+        assert k.min() >= 0 and k.max() <= 959
+        assert len(np.unique(k)) > 300          # K = int(0.15 * u * 6400) varies per episode
+    idx = np.arange(n)
+    p = st["pos"]
+    assert (maps[idx, p[:, 0, 0], p[:, 0, 1]] == 0).all() and (maps[idx, p[:, 1, 0], p[:, 1, 1]] == 0).all()
+    d = p[:, 0] - p[:, 1]                        # target spawns in the 2x2 block up-left of the tracker
+    assert ((d >= 0) & (d <= 1)).all()
+    o = obs.cpu().numpy()
+    assert set(np.unique(o)) <= {0.0, 1.0, 2.0, 4.0}
+    assert (o[:, 0, 6, 6] == 2).all() and (o[:, 1, 6, 6] == 4).all()
+    ep_before = st["episode"].copy()
+    steps_done = np.zeros(n, np.int64)
+    total_done = 0
+    for t in range(40):
+        obs, rew, done = env.step_random(1, action_seed=5)
+        dn = done.cpu().numpy().astype(bool)
+        total_done += int(dn.sum())
+        r = rew.cpu().numpy()
+        assert (r >= -1).all() and (r[:, 0] <= 1).all()
+        steps_done += 1
+        assert not dn[steps_done < 11].any()     # done needs 11 consecutive far steps
+        steps_done[dn] = 0
+    st2 = env.get_state()
+    assert (st2["episode"] - ep_before).sum() == total_done
+    o = obs.cpu().numpy()
+    assert (o[:, 0, 6, 6] == 2).all() and (o[:, 1, 6, 6] == 4).all()
+    assert set(np.unique(o)) <= {0.0, 1.0, 2.0, 4.0}
+    env.close()
