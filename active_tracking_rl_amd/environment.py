@@ -1,0 +1,147 @@
+"""create_env and the env-side protocol objects — the drop-in seam of environment.py:11-32,128-175.
+
+Two adapters sit on the same C ABI (vec_env.VecTrack2D -> libtrack2d_hip.so):
+
+  VecEnv       the batched protocol the MI355X rollout driver uses: device tensors in, device tensors out,
+               `observation_space` / `action_space` are per-agent LISTS exactly like the reference's
+               (len(env.observation_space) is how Agent learns num_agents, player_util.py:13).
+  Track2DEnv   a single env that speaks the reference's gym protocol verbatim (numpy float32 obs
+               [A, stack, 1, 13, 13], float64 rewards [A], bool done, info['distance']) so reference-style
+               loops (gym_eval.py:97-121, random_agent_multi.py:17-53) run unchanged on top of the HIP path.
+
+frame_stack (environment.py:128-156) is folded in: obs are float32, `stack_frames` most recent frames per
+agent, the deque filled with the first frame on reset. Rescale / listspace / UnrealPreprocess belong to the
+image envs and are not built.
+"""
+import numpy as np
+import torch
+
+from . import registry
+from .vec_env import VecTrack2D
+
+
+class Discrete(object):
+    """gym.spaces.Discrete stand-in (gym is not a dependency of this package)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def sample(self):
+        return int(np.random.randint(self.n))
+
+
+class Box(object):
+    """gym.spaces.Box stand-in: Box(low=0, high=6, shape=(1,13,13)) — track_1v1.py:257-259."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+
+def _spaces():
+    obs = [Box(0, 6, (1, 13, 13), np.float32) for _ in range(2)]
+    act = [Discrete(4) for _ in range(2)]
+    return obs, act
+
+
+class VecEnv(object):
+    """Batched env: reset() -> obs [N, A, stack, 1, 13, 13] f32 (device);
+    step([a_tracker [N], a_target [N]]) -> (obs, rewards [N, A] f32, done [N] uint8, info)."""
+
+    def __init__(self, env_id, num_envs, device="cuda:0", seed=1, stack_frames=1, env_id_base=0, auto_reset=True,
+                 **overrides):
+        self.env_id = env_id
+        self.num_envs = num_envs
+        self.stack_frames = int(stack_frames)
+        self.observation_space, self.action_space = _spaces()
+        self.core = VecTrack2D(env_id, num_envs=num_envs, device=device, seed=seed, env_id_base=env_id_base,
+                               auto_reset=auto_reset, **overrides)
+        self.device = self.core.device
+        self._frames = None
+        self._seed = seed
+
+    def seed(self, seed=None):
+        """Accepted for protocol compatibility. In the reference env.seed() has no effect on trajectories
+        (track_1v1.py:129-132 sets an RNG that is never read); here the Philox key is fixed at construction."""
+        return [seed]
+
+    def _stack(self, obs, done=None, fill=False):
+        # obs [N, A, 13, 13] -> [N, A, stack, 1, 13, 13]
+        cur = obs.unsqueeze(2).unsqueeze(3)
+        if self.stack_frames == 1:
+            return cur
+        if fill or self._frames is None:
+            self._frames = cur.expand(-1, -1, self.stack_frames, -1, -1, -1).clone()
+        else:
+            nxt = torch.cat([self._frames[:, :, 1:], cur], dim=2)
+            if done is not None:  # auto-reset envs restart their stack from the first frame of the new episode
+                d = done.bool().view(-1, 1, 1, 1, 1, 1)
+                nxt = torch.where(d, cur.expand_as(nxt), nxt)
+            self._frames = nxt
+        return self._frames
+
+    def reset(self):
+        return self._stack(self.core.reset(), fill=True)
+
+    def step(self, actions):
+        a0 = actions[0]
+        a1 = actions[1] if len(actions) > 1 else None
+        obs, rew, done = self.core.step(a0, a1)
+        return self._stack(obs, done), rew, done, {}
+
+    def close(self):
+        self.core.close()
+
+    def render(self, *a, **k):
+        raise NotImplementedError("matplotlib rendering (track_1v1.py:170-216) is out of scope")
+
+
+class Track2DEnv(object):
+    """One env behind the reference's exact gym protocol (TimeLimit + frame_stack included)."""
+
+    def __init__(self, env_id, device="cuda:0", seed=1, stack_frames=1):
+        self.vec = VecEnv(env_id, 1, device=device, seed=seed, stack_frames=stack_frames, auto_reset=False)
+        self.observation_space, self.action_space = self.vec.observation_space, self.vec.action_space
+
+    def seed(self, seed=None):
+        return self.vec.seed(seed)
+
+    def reset(self):
+        return self.vec.reset()[0].cpu().numpy()
+
+    def step(self, action):
+        a = [torch.tensor([int(np.asarray(x).reshape(-1)[0])], dtype=torch.int64, device=self.vec.device)
+             for x in list(action)[:2]]
+        if len(a) == 1:
+            a.append(torch.zeros_like(a[0]))
+        obs, rew, done, _ = self.vec.step(a)
+        d2 = int(self.vec.core.get_state()["d2"][0])
+        info = {"distance": float(np.sqrt(float(d2)))}           # track_1v1.py:118
+        return obs[0].cpu().numpy(), rew[0].double().cpu().numpy(), bool(done[0].item()), info
+
+    def close(self):
+        self.vec.close()
+
+    def render(self, *a, **k):
+        return self.vec.render()
+
+
+def create_env(env_id, args, num_envs=None, device=None, env_id_base=0):
+    """environment.create_env (environment.py:11-32) for the Track2D ids.
+
+    args carries the reference's flags (stack_frames, seed, ...) plus optionally `num_envs` and `gpu_ids`.
+    Returns a VecEnv when num_envs (argument or args.num_envs) > 1, else a gym-protocol Track2DEnv."""
+    if '2D' not in env_id:
+        raise NotImplementedError("only the Track2D-* ids are in scope (Unreal envs need UE4 binaries)")
+    registry.spec(env_id)
+    if getattr(args, "single", False) or getattr(args, "rescale", False):
+        raise NotImplementedError("--single / --rescale wrappers belong to the image envs")
+    n = num_envs if num_envs is not None else getattr(args, "num_envs", 1)
+    if device is None:
+        gpu_ids = getattr(args, "gpu_ids", [0])
+        gid = gpu_ids[0] if isinstance(gpu_ids, (list, tuple)) else gpu_ids
+        device = "cuda:%d" % max(int(gid), 0)
+    stack = getattr(args, "stack_frames", 1)
+    seed = getattr(args, "seed", 1)
+    if n > 1:
+        return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base)
+    return Track2DEnv(env_id, device=device, seed=seed, stack_frames=stack)

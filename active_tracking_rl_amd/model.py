@@ -1,0 +1,265 @@
+"""Batched restatement of the reference policy networks (stays PyTorch-ROCm, per the north star).
+
+Mirrors model.py:12-265 and perception.py:68-92 of the reference with IDENTICAL module / parameter names and
+shapes (state-dict contract), so checkpoints move both ways:
+  player{0,1}.encoder.conv1/conv2/fc, .lstm (LSTMCell 256->128), .actor.actor_linear, .critic.critic_linear,
+  and for `tat` heads player1.fc_action_tracker, player1.reward_aux.
+
+The reference networks are structurally batch-1 (`x.view(1, -1)`, perception.py:89). Here every env is a row:
+  states  [N, A=2, stack, C=1, 13, 13]   (or the reference layout [A, stack, C, 13, 13] for one env)
+  hx, cx  [N, A, rnn_out]                 (or [A, rnn_out])
+and `view(N, -1)` keeps the per-env feature order of the reference, including the
+[tracker frame, target frame] concatenation the TAT target uses (model.py:255).
+Only the discrete maze heads are built ('maze' encoders, 'lstm' core); the continuous / Unreal image heads
+(CNN_simple, ICML, GRU) are outside the hot-path scope.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ---- initialisers (utils.py:30-33,47-72) ---------------------------------------------------------------
+def norm_col_init(weights, std=1.0):
+    x = torch.randn(weights.size())
+    x *= std / torch.sqrt((x ** 2).sum(1, keepdim=True))
+    return x
+
+
+def weights_init(m):
+    classname = m.__class__.__name__
+    if classname.find('Conv') != -1:
+        weight_shape = list(m.weight.data.size())
+        fan_in = np.prod(weight_shape[1:4])
+        fan_out = np.prod(weight_shape[2:4]) * weight_shape[0]
+        w_bound = np.sqrt(6. / (fan_in + fan_out))
+        m.weight.data.uniform_(-w_bound, w_bound)
+        m.bias.data.fill_(0)
+    elif classname.find('Linear') != -1:
+        weight_shape = list(m.weight.data.size())
+        w_bound = np.sqrt(6. / (weight_shape[1] + weight_shape[0]))
+        m.weight.data.uniform_(-w_bound, w_bound)
+        m.bias.data.fill_(0)
+
+
+def weights_init_mlp(m):
+    if m.__class__.__name__.find('Linear') != -1:
+        m.weight.data.normal_(0, 1)
+        m.weight.data *= 1 / torch.sqrt(m.weight.data.pow(2).sum(1, keepdim=True))
+        if m.bias is not None:
+            m.bias.data.fill_(0)
+
+
+def build_model(obs_space, action_space, args, device):
+    """Same signature as the reference build_model (model.py:12-15)."""
+    model = A3C_Dueling(obs_space, action_space, args, device)
+    model.train()
+    return model
+
+
+def sample_action(logit, test=False):
+    """Discrete branch of sample_action (model.py:41-50), batched: logit [N, n_actions].
+    Returns action int64 [N] (stays on the device), entropy [N,1], log_prob [N,1] (train) or [N,n] (test)."""
+    prob = F.softmax(logit, dim=1)
+    log_prob = F.log_softmax(logit, dim=1)
+    entropy = -(log_prob * prob).sum(1, keepdim=True)
+    if test:
+        action = prob.max(1)[1]
+    else:
+        action = prob.multinomial(1).squeeze(1)
+        log_prob = log_prob.gather(1, action.unsqueeze(1))
+    return action, entropy, log_prob
+
+
+class ValueNet(nn.Module):
+    def __init__(self, input_dim):
+        super(ValueNet, self).__init__()
+        self.critic_linear = nn.Linear(input_dim, 1)
+        self.critic_linear.weight.data = norm_col_init(self.critic_linear.weight.data, 0.01)
+        self.critic_linear.bias.data.fill_(0)
+
+    def forward(self, x):
+        return self.critic_linear(x)
+
+
+class PolicyNet(nn.Module):
+    def __init__(self, input_dim, action_space, head_name, device):
+        super(PolicyNet, self).__init__()
+        if 'continuous' in head_name:
+            raise NotImplementedError("continuous heads belong to the Unreal envs (out of scope)")
+        self.actor_linear = nn.Linear(input_dim, action_space.n)
+        self.actor_linear.weight.data = norm_col_init(self.actor_linear.weight.data, 0.01)
+        self.actor_linear.bias.data.fill_(0)
+
+    def forward(self, x, test=False):
+        return sample_action(self.actor_linear(x), test)
+
+
+class CNN_maze(nn.Module):
+    """perception.py:68-92. `stack_frames` frames per env are folded into the conv batch and unfolded into the
+    feature axis, exactly what the reference's view(1, -1) does for one env."""
+
+    def __init__(self, obs_shape, stack_frames):
+        super(CNN_maze, self).__init__()
+        self.conv1 = nn.Conv2d(obs_shape[0], 16, 3, stride=2, padding=1)
+        self.conv2 = nn.Conv2d(16, 32, 3, stride=2, padding=1)
+        relu_gain = nn.init.calculate_gain('relu')
+        self.conv1.weight.data.mul_(relu_gain)
+        self.conv2.weight.data.mul_(relu_gain)
+        with torch.no_grad():
+            dummy = torch.rand(1, stack_frames, obs_shape[0], obs_shape[1], obs_shape[2])
+            cnn_dim = self.forward(dummy, fc=False).size(-1)
+        self.fc = nn.Linear(cnn_dim, 256)
+        self.outdim = 256
+        self.apply(weights_init)
+        self.train()
+
+    def forward(self, x, fc=True):
+        n, f = x.shape[0], x.shape[1]
+        x = x.reshape(n * f, x.shape[2], x.shape[3], x.shape[4])
+        x = F.relu(self.conv1(x))
+        x = F.relu(self.conv2(x))
+        x = x.reshape(n, -1)
+        if fc:
+            x = F.relu(self.fc(x))
+        return x
+
+
+def _make_encoder(head_name, obs_space, stack_frames):
+    if 'maze' not in head_name:
+        raise NotImplementedError("only the 'maze' encoders (maze-lstm, tat-maze-lstm) are in scope; got %r" % head_name)
+    return CNN_maze(obs_space, stack_frames)
+
+
+class A3C(nn.Module):
+    """Tracker network, model.py:102-145."""
+
+    def __init__(self, obs_space, action_space, rnn_out=128, head_name='cnn_lstm', stack_frames=1, sub_task=False,
+                 device=None):
+        super(A3C, self).__init__()
+        self.sub_task = sub_task
+        self.head_name = head_name
+        self.encoder = _make_encoder(head_name, obs_space, stack_frames)
+        feature_dim = self.encoder.outdim
+        if 'lstm' not in head_name:
+            raise NotImplementedError("only LSTM cores are in scope")
+        self.lstm = nn.LSTMCell(feature_dim, rnn_out)
+        self.lstm.bias_ih.data.fill_(0)
+        self.lstm.bias_hh.data.fill_(0)
+        feature_dim = rnn_out
+        self.actor = PolicyNet(feature_dim, action_space, head_name, device)
+        self.critic = ValueNet(feature_dim)
+        self.apply(weights_init)
+        self.train()
+
+    def forward(self, inputs, test=False):
+        x, (hx, cx) = inputs
+        feature = self.encoder(x)
+        hx, cx = self.lstm(feature, (hx, cx))
+        value = self.critic(hx)
+        action, entropy, log_prob = self.actor(hx, test)
+        return value, action, entropy, log_prob, (hx, cx)
+
+
+class TAT(nn.Module):
+    """Tracker-aware target, model.py:148-209."""
+
+    def __init__(self, obs_space, action_space, rnn_out=128, head_name='cnn_lstm', stack_frames=1,
+                 dim_action_tracker=-1, device=None):
+        super(TAT, self).__init__()
+        self.sub_task = dim_action_tracker > 0
+        self.head_name = head_name
+        self.encoder = _make_encoder(head_name, obs_space, stack_frames)
+        feature_dim = self.encoder.outdim
+        if 'lstm' not in head_name:
+            raise NotImplementedError("only LSTM cores are in scope")
+        self.lstm = nn.LSTMCell(feature_dim, rnn_out)
+        self.lstm.bias_ih.data.fill_(0)
+        self.lstm.bias_hh.data.fill_(0)
+        feature_dim = rnn_out
+        self.actor = PolicyNet(feature_dim, action_space, head_name, device)
+        self.critic = ValueNet(feature_dim)
+        self.fc_action_tracker = nn.Linear(dim_action_tracker, self.encoder.outdim)
+        weights_init_mlp(self.fc_action_tracker)
+        if self.sub_task:
+            self.reward_aux = nn.Linear(feature_dim, 1)
+            self.reward_aux.weight.data = norm_col_init(self.reward_aux.weight.data, 0.01)
+            self.reward_aux.bias.data.fill_(0)
+        self.apply(weights_init)
+        self.train()
+
+    def forward(self, inputs, test=False):
+        x, (hx, cx), action_tracker = inputs
+        feature = self.encoder(x) + self.fc_action_tracker(action_tracker)
+        hx, cx = self.lstm(feature, (hx, cx))
+        value = self.critic(hx)
+        action, entropy, log_prob = self.actor(hx, test)
+        R_pred = self.reward_aux(hx) if self.sub_task else None
+        return value, action, entropy, log_prob, (hx, cx), R_pred
+
+
+class A3C_Dueling(nn.Module):
+    """Two-player wrapper, model.py:212-265.
+
+    Batched call:   states [N,2,stack,C,13,13], hx/cx [N,2,R]  ->
+        values [N,2,1], [a_tracker [N], a_target [N]] (int64, on device), entropies [N,2,1],
+        log_probs [N,2,1] (test: [N,2,n_actions]), (hx, cx) [N,2,R], R_pred [N,1] (int 0 when not tat)
+    Reference-layout call (one env): states [2,stack,C,13,13], hx/cx [2,R] -> the reference's shapes:
+        values [2,1], [0-d numpy ints], entropies [2,1], log_probs [2,1], (hx,cx) [2,R], R_pred [1,1].
+    """
+
+    def __init__(self, obs_space, action_space, args, device=None):
+        super(A3C_Dueling, self).__init__()
+        self.num_agents = len(obs_space)
+        obs_shapes = [obs_space[i].shape for i in range(self.num_agents)]
+        stack_frames = args.stack_frames
+        rnn_out = args.rnn_out
+        head_name = args.network
+        self.single = args.single
+        self.device = device
+        if 'continuous' in head_name:
+            raise NotImplementedError("continuous heads belong to the Unreal envs (out of scope)")
+        self.continuous = False
+        self.action_dim_tracker = action_space[0].n
+        self.player0 = A3C(obs_shapes[0], action_space[0], rnn_out, head_name, stack_frames, device=device)
+        if not self.single:
+            if 'tat' in head_name:
+                self.tat = True
+                self.player1 = TAT(obs_shapes[1], action_space[1], rnn_out, head_name, stack_frames * 2,
+                                   self.action_dim_tracker, device=device)
+            else:
+                self.tat = False
+                self.player1 = A3C(obs_shapes[1], action_space[1], rnn_out, head_name, stack_frames, device=device)
+
+    def forward(self, inputs, test=False):
+        states, (hx, cx) = inputs
+        ref_layout = states.dim() == 5
+        if ref_layout:
+            states, hx, cx = states.unsqueeze(0), hx.unsqueeze(0), cx.unsqueeze(0)
+        n = states.shape[0]
+        value0, action_0, entropy_0, log_prob_0, (hx_0, cx_0) = self.player0(
+            (states[:, 0], (hx[:, 0], cx[:, 0])), test)
+        if self.single or states.shape[1] == 1:
+            out = (value0.unsqueeze(1), [action_0], entropy_0.unsqueeze(1), log_prob_0.unsqueeze(1),
+                   (hx_0.unsqueeze(1), cx_0.unsqueeze(1)), 0)
+            return self._to_ref(out) if ref_layout else out
+        R_pred = 0
+        if self.tat:
+            action2target = F.one_hot(action_0, self.action_dim_tracker).to(states.dtype)   # model.py:253-254
+            state_target = states.reshape(n, -1, states.shape[3], states.shape[4], states.shape[5])  # :255
+            value1, action_1, entropy_1, log_prob_1, (hx1, cx1), R_pred = self.player1(
+                (state_target, (hx[:, 1], cx[:, 1]), action2target), test)
+        else:
+            value1, action_1, entropy_1, log_prob_1, (hx1, cx1) = self.player1(
+                (states[:, 1], (hx[:, 1], cx[:, 1])), test)
+        out = (torch.stack([value0, value1], 1), [action_0, action_1], torch.stack([entropy_0, entropy_1], 1),
+               torch.stack([log_prob_0, log_prob_1], 1), (torch.stack([hx_0, hx1], 1), torch.stack([cx_0, cx1], 1)),
+               R_pred)
+        return self._to_ref(out) if ref_layout else out
+
+    @staticmethod
+    def _to_ref(out):
+        values, actions, entropies, log_probs, (hx, cx), R_pred = out
+        actions = [np.squeeze(a.cpu().numpy()) for a in actions]            # model.py:50
+        R_pred = R_pred if isinstance(R_pred, int) else R_pred              # [1,1] already
+        return values[0], actions, entropies[0], log_probs[0], (hx[0], cx[0]), R_pred

@@ -1,0 +1,171 @@
+"""Agent — the rollout buffer + n-step A3C/GAE loss of player_util.py:9-161, batched over N envs.
+
+Same constructor, method and attribute names as the reference so train/test/eval-style callers read the same:
+    Agent(model, env, args, state, device); action_train(); action_test(); reset(); optimize(params, optimizer,
+    shared_model, training_mode, device_share); .done .reward .reward_org .eps_len .n_steps .num_agents ...
+
+What changes under vectorisation (SURVEY.md §7 hard part 5):
+  * env is a VecEnv (environment.py): N envs advance per call; finished envs auto-reset inside the step launch,
+    so the rollout never breaks early — per-env episode boundaries are carried as `done` masks instead:
+      - LSTM state of a finished env is zeroed before its next step (reset_rnn_hiden, player_util.py:98-102);
+      - n-step return and GAE are cut at the boundary (R = r, no bootstrap — the `done` branch of :109-117);
+  * the loss is the mean over envs of the reference's per-env loss (:128-154);
+  * ensure_shared_grads + lock-free SharedAdam (utils.py:36-44) become an all-reduce(mean) of the flat gradient
+    bucket over RCCL followed by an identical optimizer step on every replica.
+Reference quirk kept on purpose: clip_grad_norm_(params, 50) at :157 is a no-op in the reference (the generator
+is exhausted after the first call, which itself sees grad=None), so no clipping is applied
+unless args.max_grad_norm is set.
+"""
+import torch
+import torch.distributed as dist
+
+
+class Agent(object):
+    def __init__(self, model, env, args, state, device):
+        self.model = model
+        self.env = env
+        self.num_agents = len(env.observation_space)
+        self.num_envs = getattr(env, "num_envs", 1)
+        if 'continuous' in args.network:
+            raise NotImplementedError("continuous actions belong to the Unreal envs (out of scope)")
+        self.dim_action = 1
+        self.args = args
+        self.device = device
+        self.rnn_out = args.rnn_out
+        self.values, self.log_probs, self.rewards, self.entropies, self.preds, self.dones = [], [], [], [], [], []
+        self.done = torch.ones(self.num_envs, dtype=torch.uint8, device=device)
+        self.info = None
+        self.reward = 0
+        self.reward_org = 0
+        self.num_steps = 0
+        self.n_steps = 0
+        self.state = state
+        self.eps_len = torch.zeros(self.num_envs, dtype=torch.int32, device=device)
+        self.hxs = torch.zeros(self.num_envs, self.num_agents, self.rnn_out, device=device)
+        self.cxs = torch.zeros(self.num_envs, self.num_agents, self.rnn_out, device=device)
+        self.w_entropy_target = getattr(args, "entropy_target", 0.2)
+        self.gpu_id = device.index if isinstance(device, torch.device) and device.index is not None else -1
+
+    # -- acting ------------------------------------------------------------------------------------------
+    def action_train(self):
+        self.n_steps += 1
+        value_multi, action_env_multi, entropy, log_prob, (self.hxs, self.cxs), R_pred = self.model(
+            (self.state, (self.hxs, self.cxs)))
+        state_multi, reward_multi, done, self.info = self.env.step(action_env_multi)
+        self.reward_org = reward_multi
+        self.reward = reward_multi
+        self.state = state_multi
+        self.done = done
+        keep = (done == 0)
+        self.eps_len = (self.eps_len + 1) * keep.to(self.eps_len.dtype)
+        # a finished env starts its next episode with a zero hidden state (train.py:73-74 -> reset())
+        k = keep.to(self.hxs.dtype).view(-1, 1, 1)
+        self.hxs = self.hxs * k
+        self.cxs = self.cxs * k
+        self.values.append(value_multi)
+        self.entropies.append(entropy)
+        self.log_probs.append(log_prob)
+        self.rewards.append(reward_multi.unsqueeze(2))
+        self.preds.append(R_pred)
+        self.dones.append(done)
+        return self
+
+    def action_test(self):
+        with torch.no_grad():
+            value_multi, action_env_multi, entropy, log_prob, (self.hxs, self.cxs), R_pred = self.model(
+                (self.state, (self.hxs, self.cxs)), True)
+        state_multi, self.reward, done, self.info = self.env.step(action_env_multi)
+        self.state = state_multi
+        self.done = done
+        keep = (done == 0)
+        self.eps_len = (self.eps_len + 1) * keep.to(self.eps_len.dtype)
+        k = keep.to(self.hxs.dtype).view(-1, 1, 1)
+        self.hxs = self.hxs * k
+        self.cxs = self.cxs * k
+        return self
+
+    def reset(self):
+        self.state = self.env.reset()
+        self.num_agents = self.state.shape[1]
+        self.eps_len = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        self.done = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+        self.reset_rnn_hiden()
+
+    def clear_actions(self):
+        self.values, self.log_probs, self.rewards, self.entropies, self.preds, self.dones = [], [], [], [], [], []
+        return self
+
+    def reset_rnn_hiden(self):
+        self.cxs = torch.zeros(self.num_envs, self.num_agents, self.rnn_out, device=self.device)
+        self.hxs = torch.zeros(self.num_envs, self.num_agents, self.rnn_out, device=self.device)
+
+    def update_rnn_hiden(self):
+        self.cxs = self.cxs.detach()
+        self.hxs = self.hxs.detach()
+
+    # -- learning ----------------------------------------------------------------------------------------
+    def loss(self, training_mode):
+        """The loss of player_util.py:108-154 per env, averaged over envs. Returns (loss, policy_loss [N,A,1],
+        value_loss [N,A,1], entropies [N,A,1], pred_loss [N,1])."""
+        args = self.args
+        N, A = self.num_envs, self.num_agents
+        with torch.no_grad():  # bootstrap value V(s_T) (:109-117); finished envs are masked step by step below
+            value_multi, _, _, _, _, _ = self.model((self.state, (self.hxs, self.cxs)))
+        R = value_multi.detach()
+        self.values.append(R)
+        policy_loss = torch.zeros(N, A, 1, device=self.device)
+        value_loss = torch.zeros(N, A, 1, device=self.device)
+        pred_loss = torch.zeros(N, 1, device=self.device)
+        entropies = torch.zeros(N, A, self.dim_action, device=self.device)
+        w_entropies = float(args.entropy) * torch.ones(1, A, self.dim_action, device=self.device)
+        if A > 1:
+            w_entropies[:, 1:] = float(self.w_entropy_target)
+        gae = torch.zeros(N, A, 1, device=self.device)
+        use_aux = 'reward' in args.aux
+        for i in reversed(range(len(self.rewards))):
+            nd = (self.dones[i] == 0).to(R.dtype).view(N, 1, 1)
+            if use_aux:
+                pred_loss = pred_loss + (self.preds[i] - self.rewards[i][:, 0]).abs()   # L1Loss (:129-130)
+            R = args.gamma * R * nd + self.rewards[i]
+            advantage = R - self.values[i]
+            value_loss = value_loss + 0.5 * advantage.pow(2)
+            delta_t = self.rewards[i] + args.gamma * self.values[i + 1].detach() * nd - self.values[i].detach()
+            gae = gae * args.gamma * args.tau * nd + delta_t
+            policy_loss = policy_loss - (self.log_probs[i] * gae.detach()) - (w_entropies * self.entropies[i])
+            entropies = entropies + self.entropies[i].detach()
+        loss_tracker = (policy_loss[:, 0] + 0.5 * value_loss[:, 0]).mean()
+        loss_target = (policy_loss[:, 1] + 0.5 * value_loss[:, 1]).mean() if A > 1 else 0
+        if training_mode == 0:
+            loss = loss_tracker
+        elif training_mode == 1:
+            loss = loss_target
+        else:
+            loss = loss_tracker + loss_target
+        if use_aux and training_mode != 0:
+            loss = loss + pred_loss.mean()
+        return loss, policy_loss, value_loss, entropies, pred_loss
+
+    def optimize(self, params, optimizer, shared_model, training_mode, device_share):
+        """One synchronous data-parallel update. `params`, `shared_model`, `device_share` are accepted for
+        signature compatibility with player_util.py:108; the replica IS the shared model."""
+        loss, policy_loss, value_loss, entropies, pred_loss = self.loss(training_mode)
+        optimizer.zero_grad()
+        loss.backward()
+        max_norm = getattr(self.args, "max_grad_norm", None)
+        bucket = getattr(optimizer, "bucket", None)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # the ONE collective of the path: flat fp32 gradient bucket, mean over ranks (RCCL over xGMI)
+            if bucket is not None:
+                dist.all_reduce(bucket.grad, op=dist.ReduceOp.SUM)
+                bucket.grad.div_(dist.get_world_size())
+            else:
+                for p in self.model.parameters():
+                    if p.grad is not None:
+                        dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                        p.grad.div_(dist.get_world_size())
+        if max_norm:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm)
+        optimizer.step()
+        self.clear_actions()
+        return (policy_loss.detach().mean(0), value_loss.detach().mean(0), entropies.mean(0),
+                pred_loss.detach().mean(0, keepdim=True))

@@ -1,0 +1,92 @@
+"""SharedAdam numerics on one flat fp32 parameter bucket (replaces shared_optim.py:90-175 + utils.py:36-44).
+
+The reference keeps Adam state in OS shared memory and lets 16 Hogwild workers race on it. The MI355X design
+is synchronous data parallel: every rank holds a bit-identical replica whose parameters AND gradients are
+views into two flat buffers, so the only exchange is ONE RCCL all-reduce of the flat gradient bucket
+(801 291 fp32 for tat-maze-lstm) followed by an identical update on every replica.
+
+Update rule = SharedAdam.step (shared_optim.py:122-175) with its non-standard details kept:
+  amsgrad, eps = 1e-3 added AFTER sqrt(max second moment), bias corrections folded into
+  step_size = lr * sqrt(1 - b2^t) / (1 - b1^t), no weight decay by default.
+The step counter and the two bias-correction powers live on the device, so the whole update is
+hipGraph-capturable (no host sync, no Python-side scalar math per step).
+"""
+import torch
+
+
+class FlatParams(object):
+    """Re-homes a module's parameters (and their .grad) as views of two contiguous fp32 buffers."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        total = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(total, dtype=torch.float32, device=ref.device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=ref.device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view_as(p.data)
+            p.grad = self.grad[off:off + n].view_as(p.data)
+            off += n
+        self.numel = total
+
+    def zero_grad(self):
+        self.grad.zero_()
+        off = 0
+        for p in self.params:  # re-attach in case autograd replaced .grad
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.grad[off:off + n].data_ptr():
+                p.grad = self.grad[off:off + n].view_as(p.data)
+            off += n
+
+
+class SharedAdam(torch.optim.Optimizer):
+    """Adam+AMSGrad with the reference's SharedAdam numerics over a FlatParams bucket."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-3, weight_decay=0, amsgrad=True):
+        params = list(params)
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+        super(SharedAdam, self).__init__(params, defaults)
+        self.bucket = FlatParams(params)
+        dev = self.bucket.flat.device
+        z = lambda: torch.zeros_like(self.bucket.flat)
+        self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq = z(), z(), z()
+        # float64 scalars on the device: step, beta1^t, beta2^t
+        self.step_t = torch.zeros((), dtype=torch.float64, device=dev)
+        self.b1_pow = torch.ones((), dtype=torch.float64, device=dev)
+        self.b2_pow = torch.ones((), dtype=torch.float64, device=dev)
+
+    def share_memory(self):
+        """API compatibility with main.py:93 — there is no shared-memory state in the data-parallel design."""
+        return self
+
+    def zero_grad(self, set_to_none=False):
+        self.bucket.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        beta1, beta2 = g['betas']
+        grad, p = self.bucket.grad, self.bucket.flat
+        if g['weight_decay'] != 0:
+            grad = grad.add(p, alpha=g['weight_decay'])
+        self.step_t += 1
+        self.b1_pow *= beta1
+        self.b2_pow *= beta2
+        self.exp_avg.mul_(beta1).add_(grad, alpha=1 - beta1)
+        self.exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        if g['amsgrad']:
+            torch.max(self.max_exp_avg_sq, self.exp_avg_sq, out=self.max_exp_avg_sq)
+            denom = self.max_exp_avg_sq.sqrt().add_(g['eps'])
+        else:
+            denom = self.exp_avg_sq.sqrt().add_(g['eps'])
+        step_size = (g['lr'] * torch.sqrt(1 - self.b2_pow) / (1 - self.b1_pow)).to(torch.float32)
+        p.sub_(self.exp_avg / denom * step_size)
+        return loss
+
+    def state_dict_flat(self):
+        return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, max_exp_avg_sq=self.max_exp_avg_sq,
+                    step=self.step_t, b1_pow=self.b1_pow, b2_pow=self.b2_pow)

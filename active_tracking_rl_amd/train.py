@@ -1,0 +1,115 @@
+"""train — the worker loop of train.py:15-113, one process per GPU instead of 16 Hogwild CPU workers.
+
+    train(rank, args, shared_model, optimizer, train_modes, n_iters, env=None)
+
+keeps the reference signature. Semantics per iteration are the reference's (sync weights -> <= num_steps env
+steps -> optimize -> log), with these MI355X-first substitutions:
+  * each rank owns `args.num_envs` envs (a shard of the global batch; Philox streams are keyed by the global env
+    id so the union of shards equals the unsharded batch) stepped by the HIP kernels;
+  * `shared_model` is this rank's replica (weights stay bit-identical across ranks because every rank applies
+    the same all-reduced gradient), so `load_state_dict(shared_model.state_dict())` (train.py:71) is a no-op
+    and is skipped;
+  * the rollout is always `num_steps` long — finished envs auto-reset in the step launch (see player_util).
+`train_modes` / `n_iters` may be plain lists (single process) or mp.Manager lists as in main.py:103-105.
+"""
+import os
+import time
+
+import torch
+
+from .environment import create_env
+from .model import build_model
+from .player_util import Agent
+from .shared_optim import SharedAdam
+
+
+def default_args(**over):
+    """The flag defaults of main.py:16-50 as a namespace (plus num_envs / max_grad_norm)."""
+    import argparse
+    d = dict(lr=0.001, gamma=0.9, tau=1.00, entropy=0.01, entropy_target=0.2, seed=1, workers=1, num_steps=20,
+             test_eps=100, env='Track2D-BlockPartialPZR-v0', env_base='Track2D-BlockPartialNav-v0', optimizer='Adam',
+             amsgrad=True, load_model_dir=None, log_dir='logs/', network='tat-maze-lstm', aux='reward', gpu_ids=[0],
+             obs='img', single=False, gray=False, crop=False, inv=False, rescale=False, render=False,
+             shared_optimizer=True, split=False, train_mode=-1, stack_frames=1, input_size=80, rnn_out=128,
+             sleep_time=0, max_step=150000, init_step=-1, num_envs=4096, max_grad_norm=None)
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+def select_params(model, train_mode):
+    """train.py:39-44: which half of the two-player model the optimizer owns."""
+    if train_mode == 0:
+        return list(model.player0.parameters())
+    if train_mode == 1:
+        return list(model.player1.parameters())
+    return list(model.parameters())
+
+
+def make_player(args, device, rank=0, world_size=1, env=None, model=None, optimizer=None):
+    """Build env shard + replica + optimizer + Agent for one rank."""
+    torch.manual_seed(args.seed)          # same init on every rank (replicas must start identical)
+    if env is None:
+        env = create_env(args.env, args, num_envs=args.num_envs, device=str(device),
+                         env_id_base=rank * args.num_envs)
+    if model is None:
+        model = build_model(env.observation_space, env.action_space, args, device).to(device)
+    model.train()
+    if optimizer is None:
+        optimizer = SharedAdam(select_params(model, args.train_mode), lr=args.lr, amsgrad=args.amsgrad)
+    torch.manual_seed(args.seed + rank)   # per-rank action sampling (train.py:20)
+    if device.type == 'cuda':
+        torch.cuda.manual_seed(args.seed + rank)
+    player = Agent(model, env, args, None, device)
+    player.w_entropy_target = args.entropy_target
+    player.reset()
+    return player, optimizer
+
+
+def rollout(player, num_steps):
+    """train.py:79-88 without the early break (done is a per-env mask)."""
+    player.update_rnn_hiden()
+    for _ in range(num_steps):
+        player.action_train()
+
+
+def train(rank, args, shared_model, optimizer, train_modes, n_iters, env=None):
+    gpu_id = args.gpu_ids[rank % len(args.gpu_ids)]
+    device = torch.device('cuda:%d' % gpu_id)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    training_mode = args.train_mode
+    while len(train_modes) <= rank:
+        train_modes.append(training_mode)
+        n_iters.append(0)
+    player, optimizer = make_player(args, device, rank, world, env=env, model=shared_model, optimizer=optimizer)
+    writer = None
+    try:
+        from tensorboardX import SummaryWriter  # optional, as in the reference (train.py:9,17)
+        writer = SummaryWriter(os.path.join(args.log_dir, 'Agent:{}'.format(rank)))
+    except Exception:
+        pass
+    n_iter = 0
+    try:
+        while True:
+            t0 = time.time()
+            rollout(player, args.num_steps)
+            training_mode = train_modes[rank]
+            policy_loss, value_loss, entropies, pred_loss = player.optimize(
+                None, optimizer, shared_model, training_mode, device)
+            n_iter += 1
+            n_iters[rank] = n_iter
+            if writer is not None and n_iter % 10 == 0:
+                torch.cuda.synchronize(device)
+                fps = args.num_steps * player.num_envs / (time.time() - t0)
+                for i in range(min(player.num_agents, 3)):
+                    writer.add_scalar('train/policy_loss_' + str(i), policy_loss[i].mean().item(), player.n_steps)
+                    writer.add_scalar('train/value_loss_' + str(i), value_loss[i].item(), player.n_steps)
+                    writer.add_scalar('train/entropies' + str(i), entropies[i].mean().item(), player.n_steps)
+                writer.add_scalar('train/pred_R_loss', pred_loss.item(), player.n_steps)
+                writer.add_scalar('train/mode', training_mode, player.n_steps)
+                writer.add_scalar('train/fps', fps, player.n_steps)
+            if train_modes[rank] == -100 or n_iter * world > args.max_step:   # test.py:129-134 stop rule
+                break
+        player.env.close()
+    except KeyboardInterrupt:
+        player.env.close()
+    return player

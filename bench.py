@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""bench.py — env steps/sec of the Track2D hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE config 3 — Track2D-BlockPartialPZR-v0 (AD-VAT dueling), 4096 envs per GPU,
+tat-maze-lstm tracker + target, train-mode -1, 20-step rollouts. A "step" is ONE batched env step of the full
+A3C path: policy forward for both players (PyTorch-ROCm) -> HIP step/observe kernel for all envs (in-launch
+auto-reset) -> every 20th step the n-step/GAE loss, backward, ONE all-reduce of the flat gradient bucket (RCCL)
+and the SharedAdam update. value = (K x envs over all ranks) / max-over-ranks wall time. Weak scaling: 4096 envs
+per GPU, independent shards keyed by global env id.
+
+Extra objects on the same JSON line:
+  roofline     the step/observe kernel (k_env<OP_STEP>): algorithmic bytes (1723 B x envs per launch)
+               / average launch duration, measured with HIP events on the launch stream over back-to-back
+               launches; peak 8 TB/s (HBM3E). `traffic` comes from a separate rocprofv3 --pmc pass (see
+               profiles/), so it is null in the line.
+  env_only     the same kernel driven with on-device random actions (no policy): launches/s -> env steps/s.
+  cpu_baseline reference-shaped 16-worker CPU A3C on the oracle (oracle/cpu_a3c.py), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_STEP = 1723          # algorithmic bytes per env-step
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--env", default="Track2D-BlockPartialPZR-v0")
+    ap.add_argument("--network", default="tat-maze-lstm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from active_tracking_rl_amd import build
+    if rank == 0:
+        build.build()
+    if world > 1:
+        dist.barrier()
+    from active_tracking_rl_amd.train import default_args, make_player, rollout
+
+    T = 20
+    steps = max(T, (a.steps + T - 1) // T * T)
+    warm = (a.warmup + T - 1) // T * T
+    args = default_args(env=a.env, network=a.network, num_envs=a.envs_per_gpu, num_steps=T, gpu_ids=[local_rank],
+                        aux="reward" if "tat" in a.network else "none", train_mode=-1)
+    player, optimizer = make_player(args, device, rank, world)
+
+    def iteration():
+        rollout(player, T)
+        player.optimize(None, optimizer, player.model, args.train_mode, device)
+
+    for _ in range(max(1, warm // T)):
+        iteration()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps // T):
+        iteration()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_total = a.envs_per_gpu * world
+    value = steps * n_total / dt
+
+    # ---- roofline of the step/observe kernel: HIP events on the launch stream --------------------------
+    core = player.env.core
+    n = a.envs_per_gpu
+    M = 300
+    acts = torch.randint(0, 4, (M, 2, n), device=device)
+    out = (torch.empty((n, 2, 13, 13), device=device), torch.empty((n, 2), device=device),
+           torch.empty((n,), dtype=torch.uint8, device=device))
+    for i in range(20):
+        core.step(acts[i, 0], acts[i, 1], out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    e0.record()
+    for i in range(M):
+        core.step(acts[i, 0], acts[i, 1], out)
+    e1.record()
+    torch.cuda.synchronize(device)
+    k_us = e0.elapsed_time(e1) * 1e3 / M
+    achieved = B_STEP * n / (k_us * 1e-6) / 1e9
+    # env-only loop with on-device random actions
+    core.step_random(50, 7, out)
+    torch.cuda.synchronize(device)
+    e0.record()
+    core.step_random(1000, 7, out)
+    e1.record()
+    torch.cuda.synchronize(device)
+    eo_us = e0.elapsed_time(e1) * 1e3 / 1000
+
+    line = {
+        "metric": "env steps/sec, Track2D-BlockPartialPZR-v0 @4096 envs, 1/2/4/8 GPU",
+        "value": value, "unit": "env steps/s", "n_gpus": world, "steps": steps, "warmup": warm,
+        "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8 map bits / f64 reward -> f32 obs+reward; policy fp32", "data": "synthetic",
+        "config": {"workload": "%s, %d envs/GPU x %d GPU, %s tracker+target, train-mode -1, 20-step A3C rollouts "
+                               "(policy fwd + HIP env step + loss/backward + grad all-reduce + SharedAdam)"
+                               % (a.env, n, world, a.network),
+                   "global_envs": n_total, "rollout": T, "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},
+        "roofline": {"bound": "hbm", "kernel": "t2d::k_env<OP_STEP> (step+observe, in-launch auto-reset)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "bytes_per_launch": B_STEP * n, "avg_launch_us": k_us},
+        "env_only": {"value": n * world / (eo_us * 1e-6), "unit": "env steps/s", "us_per_launch": eo_us,
+                     "note": "same kernel, on-device random actions, one launch per batched step, per-rank x ranks"},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            from oracle import cpu_a3c
+            cb = cpu_a3c.run(env_id=a.env, workers=16, seconds=a.cpu_seconds, network=a.network,
+                             aux=args.aux, train_mode=-1)
+            line["cpu_baseline"] = {
+                "value": cb["value"], "unit": "env steps/s", "cores": cb["cores"], "kind": "port",
+                "sample": "%d Hogwild workers x %.0f s of reference-shaped A3C (1 oracle env + batch-1 %s on torch-CPU "
+                          "per worker, <=20-step rollouts, SharedAdam), host has %d logical CPUs; oracle env alone "
+                          "%.0f steps/s on 1 core" % (cb["cores"], cb["seconds"], a.network, cb["host_cpus"],
+                                                       cpu_a3c.env_only(a.env, 2.0))}
+        except Exception as ex:  # the GPU numbers must still be printed
+            line["cpu_baseline"] = {"value": None, "error": repr(ex)}
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,30 @@
+"""Env-only throughput probe: random-policy steps with on-device actions (one launch per step)."""
+import argparse
+import time
+
+import torch
+
+from active_tracking_rl_amd.vec_env import VecTrack2D
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--env", default="Track2D-BlockPartialPZR-v0")
+ap.add_argument("--n", type=int, default=4096)
+ap.add_argument("--steps", type=int, default=2000)
+ap.add_argument("--warmup", type=int, default=200)
+ap.add_argument("--no-auto-reset", action="store_true")
+args = ap.parse_args()
+env = VecTrack2D(args.env, num_envs=args.n, seed=1, auto_reset=not args.no_auto_reset)
+out = (env.reset(), torch.empty((args.n, 2), device="cuda"), torch.empty((args.n,), dtype=torch.uint8, device="cuda"))
+env.step_random(args.warmup, 1, out)
+torch.cuda.synchronize()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.time()
+ev0.record()
+env.step_random(args.steps, 1, out)
+ev1.record()
+torch.cuda.synchronize()
+dt = time.time() - t0
+gpu_ms = ev0.elapsed_time(ev1)
+print("env=%s N=%d auto_reset=%s steps=%d wall=%.3fs gpu=%.3fms  %.1f us/step  %.3e env-steps/s  (%.1f GB/s algorithmic)" % (
+    args.env, args.n, not args.no_auto_reset, args.steps, dt, gpu_ms, 1e3 * gpu_ms / args.steps,
+    args.n * args.steps / (gpu_ms * 1e-3), 1723.0 * args.n * args.steps / (gpu_ms * 1e-3) / 1e9))
