@@ -95,9 +95,37 @@ class PolicyNet(nn.Module):
         return sample_action(self.actor_linear(x), test)
 
 
+def _toeplitz_index(c_in, c_out, h_in, k, stride, pad):
+    """Index table that expands a conv kernel [c_out, c_in, k, k] into the dense matrix of the same linear map
+    on a fixed h_in x h_in input: rows (co, oh, ow), columns (ci, ih, iw); entries point into the flattened
+    kernel, or to an appended zero slot where the tap falls outside the (zero-padded) input."""
+    h_out = (h_in + 2 * pad - k) // stride + 1
+    zero_slot = c_out * c_in * k * k
+    idx = torch.full((c_out * h_out * h_out, c_in * h_in * h_in), zero_slot, dtype=torch.long)
+    co = torch.arange(c_out).view(-1, 1, 1, 1, 1, 1)
+    oh = torch.arange(h_out).view(1, -1, 1, 1, 1, 1)
+    ow = torch.arange(h_out).view(1, 1, -1, 1, 1, 1)
+    ci = torch.arange(c_in).view(1, 1, 1, -1, 1, 1)
+    kh = torch.arange(k).view(1, 1, 1, 1, -1, 1)
+    kw = torch.arange(k).view(1, 1, 1, 1, 1, -1)
+    ih, iw = oh * stride - pad + kh, ow * stride - pad + kw
+    ok = ((ih >= 0) & (ih < h_in) & (iw >= 0) & (iw < h_in)).expand(c_out, h_out, h_out, c_in, k, k)
+    row = ((co * h_out + oh) * h_out + ow).expand_as(ok)
+    col = ((ci * h_in + ih) * h_in + iw).expand_as(ok)
+    src = (((co * c_in + ci) * k + kh) * k + kw).expand_as(ok)
+    idx[row[ok], col[ok]] = src[ok]
+    return idx, h_out
+
+
 class CNN_maze(nn.Module):
-    """perception.py:68-92. `stack_frames` frames per env are folded into the conv batch and unfolded into the
-    feature axis, exactly what the reference's view(1, -1) does for one env."""
+    """perception.py:68-92: conv(C->16,k3,s2,p1) 13->7, conv(16->32,k3,s2,p1) 7->4, fc 512*F->256, ReLUs.
+
+    `stack_frames` frames per env are folded into the batch and unfolded into the feature axis, exactly what the
+    reference's view(1, -1) does for one env. MI355X-first evaluation: on a fixed 13x13 input each conv is a small
+    fixed linear map, so the two convs run as two plain fp32 GEMMs against Toeplitz-expanded weights (built from
+    conv{1,2}.weight by one gather, differentiable) — no im2col, no per-sample MIOpen launches (MIOpen's GEMM path
+    issues one Im2Col kernel PER SAMPLE: 393 216 launches for 100 steps of 4096 envs). Parameters keep the
+    reference's names and shapes; outputs equal F.conv2d's up to fp32 summation order."""
 
     def __init__(self, obs_shape, stack_frames):
         super(CNN_maze, self).__init__()
@@ -106,15 +134,46 @@ class CNN_maze(nn.Module):
         relu_gain = nn.init.calculate_gain('relu')
         self.conv1.weight.data.mul_(relu_gain)
         self.conv2.weight.data.mul_(relu_gain)
-        with torch.no_grad():
-            dummy = torch.rand(1, stack_frames, obs_shape[0], obs_shape[1], obs_shape[2])
-            cnn_dim = self.forward(dummy, fc=False).size(-1)
+        assert obs_shape[1] == obs_shape[2], "square observations"
+        idx1, h1 = _toeplitz_index(obs_shape[0], 16, obs_shape[1], 3, 2, 1)
+        idx2, h2 = _toeplitz_index(16, 32, h1, 3, 2, 1)
+        self.register_buffer("_idx1", idx1, persistent=False)
+        self.register_buffer("_idx2", idx2, persistent=False)
+        self._hw1, self._hw2 = h1 * h1, h2 * h2
+        cnn_dim = 32 * self._hw2 * stack_frames
         self.fc = nn.Linear(cnn_dim, 256)
         self.outdim = 256
+        self._dense = None
         self.apply(weights_init)
         self.train()
 
+    def dense_weights(self):
+        """(W1 [16*49, C*169], b1, W2 [32*16, 16*49], b2) — differentiable w.r.t. conv1/conv2 parameters."""
+        def expand(conv, idx, hw):
+            w = torch.cat([conv.weight.reshape(-1), conv.weight.new_zeros(1)])
+            return w[idx], conv.bias.repeat_interleave(hw)
+        W1, b1 = expand(self.conv1, self._idx1, self._hw1)
+        W2, b2 = expand(self.conv2, self._idx2, self._hw2)
+        return W1, b1, W2, b2
+
+    def cache_dense(self, on=True):
+        """Build the expanded weights once and reuse them for every forward until cache_dense(False): the rollout
+        driver brackets the 20-step rollout + backward with it (weights only change at optimizer.step)."""
+        self._dense = self.dense_weights() if on else None
+
     def forward(self, x, fc=True):
+        n, f = x.shape[0], x.shape[1]
+        W1, b1, W2, b2 = self._dense if self._dense is not None else self.dense_weights()
+        x = x.reshape(n * f, -1)
+        x = F.relu(F.linear(x, W1, b1))
+        x = F.relu(F.linear(x, W2, b2))
+        x = x.reshape(n, -1)
+        if fc:
+            x = F.relu(self.fc(x))
+        return x
+
+    def forward_conv2d(self, x, fc=True):
+        """The same network through F.conv2d — the plain PyTorch fp32 reference used by the numerics tests."""
         n, f = x.shape[0], x.shape[1]
         x = x.reshape(n * f, x.shape[2], x.shape[3], x.shape[4])
         x = F.relu(self.conv1(x))
@@ -230,6 +289,12 @@ class A3C_Dueling(nn.Module):
             else:
                 self.tat = False
                 self.player1 = A3C(obs_shapes[1], action_space[1], rnn_out, head_name, stack_frames, device=device)
+
+    def cache_dense(self, on=True):
+        """Expand the conv weights once per rollout (see CNN_maze.cache_dense)."""
+        for m in self.modules():
+            if isinstance(m, CNN_maze):
+                m.cache_dense(on)
 
     def forward(self, inputs, test=False):
         states, (hx, cx) = inputs

@@ -145,27 +145,40 @@ class Agent(object):
             loss = loss + pred_loss.mean()
         return loss, policy_loss, value_loss, entropies, pred_loss
 
-    def optimize(self, params, optimizer, shared_model, training_mode, device_share):
-        """One synchronous data-parallel update. `params`, `shared_model`, `device_share` are accepted for
-        signature compatibility with player_util.py:108; the replica IS the shared model."""
+    def compute_grads(self, optimizer, training_mode):
+        """loss -> backward into the flat gradient bucket (hipGraph-capturable: no host sync)."""
         loss, policy_loss, value_loss, entropies, pred_loss = self.loss(training_mode)
         optimizer.zero_grad()
         loss.backward()
-        max_norm = getattr(self.args, "max_grad_norm", None)
+        self.clear_actions()
+        if hasattr(self.model, "cache_dense"):
+            self.model.cache_dense(False)
+        return (policy_loss.detach().mean(0), value_loss.detach().mean(0), entropies.mean(0),
+                pred_loss.detach().mean(0, keepdim=True))
+
+    def allreduce_grads(self, optimizer):
+        """The ONE collective of the path: flat fp32 gradient bucket, mean over ranks (RCCL over xGMI). Replaces
+        ensure_shared_grads + the shared-memory model (utils.py:36-44)."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        world = dist.get_world_size()
         bucket = getattr(optimizer, "bucket", None)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # the ONE collective of the path: flat fp32 gradient bucket, mean over ranks (RCCL over xGMI)
-            if bucket is not None:
-                dist.all_reduce(bucket.grad, op=dist.ReduceOp.SUM)
-                bucket.grad.div_(dist.get_world_size())
-            else:
-                for p in self.model.parameters():
-                    if p.grad is not None:
-                        dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-                        p.grad.div_(dist.get_world_size())
+        if bucket is not None:
+            dist.all_reduce(bucket.grad, op=dist.ReduceOp.SUM)
+            bucket.grad.div_(world)
+        else:
+            for p in self.model.parameters():
+                if p.grad is not None:
+                    dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                    p.grad.div_(world)
+
+    def optimize(self, params, optimizer, shared_model, training_mode, device_share):
+        """One synchronous data-parallel update. `params`, `shared_model`, `device_share` are accepted for
+        signature compatibility with player_util.py:108; the replica IS the shared model."""
+        stats = self.compute_grads(optimizer, training_mode)
+        self.allreduce_grads(optimizer)
+        max_norm = getattr(self.args, "max_grad_norm", None)
         if max_norm:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm)
         optimizer.step()
-        self.clear_actions()
-        return (policy_loss.detach().mean(0), value_loss.detach().mean(0), entropies.mean(0),
-                pred_loss.detach().mean(0, keepdim=True))
+        return stats

@@ -68,8 +68,59 @@ def make_player(args, device, rank=0, world_size=1, env=None, model=None, optimi
 def rollout(player, num_steps):
     """train.py:79-88 without the early break (done is a per-env mask)."""
     player.update_rnn_hiden()
+    if hasattr(player.model, "cache_dense"):
+        player.model.cache_dense(True)   # expand conv weights once per rollout (released in compute_grads)
     for _ in range(num_steps):
         player.action_train()
+
+
+class GraphedIteration(object):
+    """One A3C iteration (20-step rollout -> loss -> backward | all-reduce | SharedAdam) replayed as two hipGraphs.
+
+    The rollout is launch-bound in eager mode (~60 small kernels per env step); capturing it removes the host
+    from the loop. The gradient all-reduce stays an eager RCCL call between the two graphs, so the captured
+    regions contain no collective. State carried between iterations (obs, LSTM state, done, episode lengths) lives
+    in static tensors that the captured region reads first and writes last; the env state itself is device-resident
+    inside the HIP library."""
+
+    def __init__(self, player, optimizer, args, warmup=2):
+        self.player, self.optimizer, self.args = player, optimizer, args
+        dev = player.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.carry = dict(state=player.state.clone(), hxs=player.hxs.detach().clone(),
+                          cxs=player.cxs.detach().clone(), done=player.done.clone(), eps_len=player.eps_len.clone())
+        self.g_roll, self.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_roll):
+            player.state, player.hxs, player.cxs = self.carry["state"], self.carry["hxs"], self.carry["cxs"]
+            player.done, player.eps_len = self.carry["done"], self.carry["eps_len"]
+            rollout(player, args.num_steps)
+            self.stats = player.compute_grads(optimizer, args.train_mode)
+            self.carry["state"].copy_(player.state)
+            self.carry["hxs"].copy_(player.hxs.detach())
+            self.carry["cxs"].copy_(player.cxs.detach())
+            self.carry["done"].copy_(player.done)
+            self.carry["eps_len"].copy_(player.eps_len)
+        with torch.cuda.graph(self.g_opt):
+            optimizer.step()
+        player.state, player.hxs, player.cxs = self.carry["state"], self.carry["hxs"], self.carry["cxs"]
+        player.done, player.eps_len = self.carry["done"], self.carry["eps_len"]
+
+    def _eager(self):
+        rollout(self.player, self.args.num_steps)
+        self.player.optimize(None, self.optimizer, self.player.model, self.args.train_mode, self.player.device)
+
+    def run(self):
+        self.g_roll.replay()
+        self.player.allreduce_grads(self.optimizer)
+        self.g_opt.replay()
+        self.player.n_steps += self.args.num_steps
+        return self.stats
 
 
 def train(rank, args, shared_model, optimizer, train_modes, n_iters, env=None):

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--env", default="Track2D-BlockPartialPZR-v0")
     ap.add_argument("--network", default="tat-maze-lstm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run the iteration eagerly instead of as hipGraphs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
 
@@ -65,7 +66,7 @@ def main():
         build.build()
     if world > 1:
         dist.barrier()
-    from active_tracking_rl_amd.train import default_args, make_player, rollout
+    from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player, rollout
 
     T = 20
     steps = max(T, (a.steps + T - 1) // T * T)
@@ -74,10 +75,18 @@ def main():
                         aux="reward" if "tat" in a.network else "none", train_mode=-1)
     player, optimizer = make_player(args, device, rank, world)
 
-    def iteration():
+    def eager_iteration():
         rollout(player, T)
         player.optimize(None, optimizer, player.model, args.train_mode, device)
 
+    iteration, graphed = eager_iteration, False
+    if not a.no_graph:
+        try:
+            iteration = GraphedIteration(player, optimizer, args).run
+            graphed = True
+        except Exception as ex:  # fall back to eager, and say so in the JSON line
+            print("hipGraph capture failed, running eagerly: %r" % (ex,), file=sys.stderr)
+            torch.cuda.synchronize(device)
     for _ in range(max(1, warm // T)):
         iteration()
 
@@ -134,7 +143,7 @@ def main():
         "config": {"workload": "%s, %d envs/GPU x %d GPU, %s tracker+target, train-mode -1, 20-step A3C rollouts "
                                "(policy fwd + HIP env step + loss/backward + grad all-reduce + SharedAdam)"
                                % (a.env, n, world, a.network),
-                   "global_envs": n_total, "rollout": T, "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},
+                   "global_envs": n_total, "rollout": T, "hipgraph": graphed, "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},
         "roofline": {"bound": "hbm", "kernel": "t2d::k_env<OP_STEP> (step+observe, in-launch auto-reset)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "bytes_per_launch": B_STEP * n, "avg_launch_us": k_us},
@@ -143,15 +152,19 @@ def main():
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            from oracle import cpu_a3c
-            cb = cpu_a3c.run(env_id=a.env, workers=16, seconds=a.cpu_seconds, network=a.network,
-                             aux=args.aux, train_mode=-1)
+            # separate process: the baseline forks Hogwild workers, which must not inherit autograd/HIP state
+            import subprocess
+            r = subprocess.run([sys.executable, "-m", "oracle.cpu_a3c", "--json", "--env", a.env, "--network", a.network,
+                                "--aux", args.aux, "--workers", "16", "--seconds", str(a.cpu_seconds)],
+                               cwd=ROOT, capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES=""))
+            cb = json.loads(r.stdout.strip().splitlines()[-1])
             line["cpu_baseline"] = {
                 "value": cb["value"], "unit": "env steps/s", "cores": cb["cores"], "kind": "port",
                 "sample": "%d Hogwild workers x %.0f s of reference-shaped A3C (1 oracle env + batch-1 %s on torch-CPU "
                           "per worker, <=20-step rollouts, SharedAdam), host has %d logical CPUs; oracle env alone "
                           "%.0f steps/s on 1 core" % (cb["cores"], cb["seconds"], a.network, cb["host_cpus"],
-                                                       cpu_a3c.env_only(a.env, 2.0))}
+                                                       cb["env_only"])}
         except Exception as ex:  # the GPU numbers must still be printed
             line["cpu_baseline"] = {"value": None, "error": repr(ex)}
     if rank == 0:

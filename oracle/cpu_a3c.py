@@ -50,9 +50,10 @@ def _worker(rank, args, shared_model, opt_state, seconds, counter, barrier):
         os.sched_setaffinity(0, {rank % (os.cpu_count() or 1)})
     except Exception:
         pass
-    from active_tracking_rl_amd.model import build_model
+    from active_tracking_rl_amd.model import CNN_maze, build_model
     from active_tracking_rl_amd.player_util import Agent
     from active_tracking_rl_amd.train import select_params
+    CNN_maze.forward = CNN_maze.forward_conv2d   # the reference's F.conv2d stem (perception.py:86-92) on CPU
     torch.manual_seed(args.seed + rank)
     device = torch.device("cpu")
     env = OracleVecEnv(args.env, args.seed + rank)
@@ -144,5 +145,17 @@ def env_only(env_id="Track2D-BlockPartialPZR-v0", seconds=3.0, seed=1):
 
 
 if __name__ == "__main__":
-    print(run(workers=int(os.environ.get("W", "8")), seconds=float(os.environ.get("S", "6"))))
-    print("env-only steps/s (1 core):", env_only())
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--env", default="Track2D-BlockPartialPZR-v0")
+    ap.add_argument("--network", default="tat-maze-lstm")
+    ap.add_argument("--aux", default="reward")
+    ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--seconds", type=float, default=12.0)
+    ap.add_argument("--train-mode", type=int, default=-1)
+    ap.add_argument("--json", action="store_true")
+    a = ap.parse_args()
+    res = run(a.env, a.workers, a.seconds, a.network, a.aux, a.train_mode)
+    res["env_only"] = env_only(a.env, 2.0)
+    print(json.dumps(res) if a.json else res)
