@@ -268,8 +268,120 @@ def registry():
     print("registry ids:", len(ids))
 
 
+def det_weights(shape, k):
+    """Deterministic pseudo-weights shared with tests/test_model.py (no checkpoint needs to be stored)."""
+    n = int(np.prod(shape))
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
+    w = np.sin(np.arange(n, dtype=np.float64) * 0.7391 + 0.1 * k) / np.sqrt(max(fan_in, 1))
+    return w.astype(np.float32).reshape(shape)
+
+
+def model_fixture():
+    """Reference A3C_Dueling.forward(test=True) (model.py:238-265) on deterministic weights and inputs."""
+    import argparse
+    import torch
+    sys.path.insert(0, REF)
+    import model as ref_model  # the reference's model.py (needs the cv2 stub for utils.py)
+    from gym import spaces
+    out = {}
+    rs = np.random.RandomState(5)
+    for net in ("tat-maze-lstm", "maze-lstm"):
+        args = argparse.Namespace(stack_frames=1, rnn_out=128, network=net, single=False)
+        obs_space = [spaces.Box(0, 6, (1, 13, 13), np.float32) for _ in range(2)]
+        act_space = [spaces.Discrete(4) for _ in range(2)]
+        torch.manual_seed(0)
+        m = ref_model.build_model(obs_space, act_space, args, torch.device("cpu"))
+        sd = m.state_dict()
+        keys = sorted(sd.keys())
+        for k, name in enumerate(keys):
+            sd[name].copy_(torch.from_numpy(det_weights(tuple(sd[name].shape), k)))
+        m.eval()
+        B = 6
+        states = rs.choice([0, 1, 2, 4], size=(B, 2, 1, 1, 13, 13)).astype(np.float32)
+        hx = rs.randn(B, 2, 128).astype(np.float32) * 0.3
+        cx = rs.randn(B, 2, 128).astype(np.float32) * 0.3
+        vals, acts, ents, lps, hxo, cxo, rp = [], [], [], [], [], [], []
+        for b in range(B):
+            with torch.no_grad():
+                v, a, e, lp, (h, c), r = m((torch.from_numpy(states[b]), (torch.from_numpy(hx[b]), torch.from_numpy(cx[b]))), True)
+            vals.append(v.numpy()); acts.append([int(x) for x in a]); ents.append(e.numpy()); lps.append(lp.numpy())
+            hxo.append(h.numpy()); cxo.append(c.numpy()); rp.append(np.asarray(r.numpy() if hasattr(r, "numpy") else r, np.float32).reshape(-1))
+        p = net + "/"
+        out[p + "keys"] = np.array(keys); out[p + "shapes"] = np.array([str(tuple(sd[k].shape)) for k in keys])
+        out[p + "states"] = states; out[p + "hx"] = hx; out[p + "cx"] = cx
+        out[p + "values"] = np.array(vals); out[p + "actions"] = np.array(acts); out[p + "entropies"] = np.array(ents)
+        out[p + "log_probs"] = np.array(lps); out[p + "hx_out"] = np.array(hxo); out[p + "cx_out"] = np.array(cxo)
+        out[p + "r_pred"] = np.array(rp)
+        out[p + "n_params"] = np.int64(sum(v.numel() for v in sd.values()))
+        print(net, "params", int(out[p + "n_params"]), "values", np.array(vals).shape)
+    np.savez_compressed(os.path.join(HERE, "model.npz"), **out)
+
+
+def loss_fixture():
+    """Reference Agent.optimize (player_util.py:108-161) on synthetic rollout buffers: pins the n-step return /
+    GAE / entropy / aux-reward loss arithmetic for done and not-done rollouts and the three training modes."""
+    import argparse
+    import torch
+    sys.path.insert(0, REF)
+    import player_util as ref_pu
+    from gym import spaces
+    out = {}
+    rs = np.random.RandomState(9)
+
+    class FakeEnv(object):
+        observation_space = [spaces.Box(0, 6, (1, 13, 13), np.float32)] * 2
+        action_space = [spaces.Discrete(4)] * 2
+
+    case = 0
+    for aux in ("reward", "none"):
+        for done in (True, False):
+            for mode in (-1, 0, 1):
+                T = int(rs.randint(3, 9))
+                args = argparse.Namespace(network="tat-maze-lstm", rnn_out=128, gamma=0.9, tau=1.0, entropy=0.01, aux=aux)
+                ag = ref_pu.Agent(None, FakeEnv(), args, None, torch.device("cpu"))
+                ag.w_entropy_target = 0.2
+                boot = torch.tensor(rs.randn(2, 1), dtype=torch.float32)
+                lin = torch.nn.Linear(1, 1)  # stands in for shared_model (only .parameters() is used)
+
+                class StubModel(torch.nn.Module):   # returns the bootstrap value; no parameters of its own
+                    def forward(self, inp, test=False, b=boot):
+                        return b.clone(), None, None, None, None, None
+
+                ag.model = StubModel()
+                ag.state = torch.zeros(2, 1, 1, 13, 13)
+                ag.done = done
+                vals = rs.randn(T, 2, 1).astype(np.float32); lps = -np.abs(rs.randn(T, 2, 1)).astype(np.float32)
+                ents = np.abs(rs.randn(T, 2, 1)).astype(np.float32); rews = rs.uniform(-1, 1, (T, 2, 1)).astype(np.float32)
+                preds = rs.randn(T, 1, 1).astype(np.float32)
+                leaf = torch.ones(1, requires_grad=True)
+                ag.values = [torch.from_numpy(v) * leaf for v in vals]
+                ag.log_probs = [torch.from_numpy(v) * leaf for v in lps]
+                ag.entropies = [torch.from_numpy(v) * leaf for v in ents]
+                ag.rewards = [torch.from_numpy(v) for v in rews]
+                ag.preds = [torch.from_numpy(v) * leaf for v in preds]
+                opt = torch.optim.SGD([leaf], lr=0.0)
+                pl, vl, en, pr = ag.optimize([leaf], opt, lin, mode, torch.device("cpu"))
+                p = "c%d/" % case
+                out[p + "aux"] = np.array(aux); out[p + "done"] = np.bool_(done); out[p + "mode"] = np.int32(mode)
+                out[p + "boot"] = boot.numpy(); out[p + "values"] = vals; out[p + "log_probs"] = lps
+                out[p + "entropies"] = ents; out[p + "rewards"] = rews; out[p + "preds"] = preds
+                out[p + "policy_loss"] = pl.detach().numpy(); out[p + "value_loss"] = vl.detach().numpy()
+                out[p + "entropy_sum"] = en.detach().numpy(); out[p + "pred_loss"] = pr.detach().numpy()
+                out[p + "dloss_dleaf"] = leaf.grad.numpy().copy()   # scalar summary of the total loss gradient
+                case += 1
+    out["count"] = np.int32(case)
+    np.savez_compressed(os.path.join(HERE, "loss.npz"), **out)
+    print("loss cases:", case)
+
+
 if __name__ == "__main__":
+    if "--model-only" in sys.argv:
+        model_fixture()
+        loss_fixture()
+        sys.exit(0)
     episodes()
     edge_cases()
     astar_cases()
     registry()
+    model_fixture()
+    loss_fixture()
