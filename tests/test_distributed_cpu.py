@@ -1,0 +1,136 @@
+"""N>1 path on CPU: world_size-2 gloo run of the data-parallel update (Agent.allreduce_grads + SharedAdam on the
+flat bucket). Checks that (a) the all-reduced gradient is the mean of the per-rank gradients, (b) replicas stay
+bit-identical after updates although every rank sees different envs, (c) the sharded update equals the single-
+process update over the union of the shards."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from active_tracking_rl_amd.environment import _spaces
+from active_tracking_rl_amd.model import build_model
+from active_tracking_rl_amd.player_util import Agent
+from active_tracking_rl_amd.shared_optim import SharedAdam
+from active_tracking_rl_amd.train import default_args, rollout, select_params
+
+
+class FakeVecEnv(object):
+    """Action-independent synthetic env on CPU: obs/reward/done streams are a function of (global env id, t)."""
+
+    def __init__(self, ids):
+        self.ids = list(ids)
+        self.num_envs = len(self.ids)
+        self.observation_space, self.action_space = _spaces()
+        self.t = 0
+
+    def _gen(self):
+        obs, rew, done = [], [], []
+        for g in self.ids:
+            rs = np.random.RandomState(1000 * g + self.t)
+            obs.append(rs.choice([0, 1, 2, 4], size=(2, 1, 1, 13, 13)).astype(np.float32))
+            rew.append(rs.uniform(-1, 1, 2).astype(np.float32))
+            done.append(1 if rs.rand() < 0.1 else 0)
+        return (torch.from_numpy(np.stack(obs)), torch.from_numpy(np.stack(rew)),
+                torch.tensor(done, dtype=torch.uint8))
+
+    def reset(self):
+        self.t = 0
+        return self._gen()[0]
+
+    def step(self, actions):
+        self.t += 1
+        o, r, d = self._gen()
+        return o, r, d, {}
+
+
+def _player(ids, seed=3):
+    args = default_args(num_envs=len(ids), num_steps=5)
+    dev = torch.device("cpu")
+    torch.manual_seed(seed)
+    env = FakeVecEnv(ids)
+    model = build_model(env.observation_space, env.action_space, args, dev)
+    opt = SharedAdam(select_params(model, args.train_mode), lr=args.lr)
+    player = Agent(model, env, args, None, dev)
+    player.reset()
+    return player, opt, args
+
+
+def _deterministic_sampling():
+    # make action sampling a pure function of the logits so that sharded and unsharded runs agree
+    torch.Tensor.multinomial = lambda self, n, *a, **k: self.argmax(1, keepdim=True)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _deterministic_sampling()
+    torch.set_num_threads(1)
+    ids = [rank * 3 + i for i in range(3)]          # env_id_base = rank * num_envs
+    player, opt, args = _player(ids)
+    for it in range(2):
+        rollout(player, args.num_steps)
+        player.compute_grads(opt, args.train_mode)
+        local = opt.bucket.grad.clone()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        player.allreduce_grads(opt)
+        assert torch.allclose(opt.bucket.grad, sum(gathered) / world, rtol=1e-6, atol=1e-8)
+        assert not torch.equal(gathered[0], gathered[1])           # ranks really saw different envs
+        opt.step()
+        flats = [torch.zeros_like(opt.bucket.flat) for _ in range(world)]
+        dist.all_gather(flats, opt.bucket.flat)
+        assert torch.equal(flats[0], flats[1]), "replicas diverged"
+    if rank == 0:
+        torch.save(opt.bucket.flat, os.path.join(out_dir, "flat.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_update_matches_single_process():
+    out_dir = tempfile.mkdtemp()
+    mp.spawn(_worker, args=(2, _free_port(), out_dir), nprocs=2, join=True)
+    sharded = torch.load(os.path.join(out_dir, "flat.pt"))
+    saved = torch.Tensor.multinomial
+    try:
+        _deterministic_sampling()
+        player, opt, args = _player(list(range(6)))
+        for it in range(2):
+            rollout(player, args.num_steps)
+            player.optimize(None, opt, player.model, args.train_mode, torch.device("cpu"))
+    finally:
+        torch.Tensor.multinomial = saved
+    np.testing.assert_allclose(opt.bucket.flat.numpy(), sharded.numpy(), rtol=2e-4, atol=2e-6)
+
+
+def test_flat_bucket_views_and_sharedadam_numerics():
+    """SharedAdam over the flat bucket == the reference update rule (shared_optim.py:149-173) in float64."""
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(7, 5)
+    opt = SharedAdam(lin.parameters(), lr=1e-3)
+    assert lin.weight.data_ptr() == opt.bucket.flat.data_ptr()           # params are views of the bucket
+    p = opt.bucket.flat.double().clone()
+    m = torch.zeros_like(p); v = torch.zeros_like(p); vmax = torch.zeros_like(p)
+    for t in range(1, 6):
+        opt.zero_grad()
+        (lin(torch.randn(4, 7)) ** 2).sum().backward()
+        assert lin.weight.grad.data_ptr() == opt.bucket.grad.data_ptr()   # grads accumulate into the bucket
+        g = opt.bucket.grad.double().clone()
+        opt.step()
+        m = m * 0.9 + 0.1 * g; v = v * 0.999 + 0.001 * g * g; vmax = torch.maximum(vmax, v)
+        step_size = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        p = p - step_size * m / (vmax.sqrt() + 1e-3)
+        np.testing.assert_allclose(opt.bucket.flat.numpy(), p.float().numpy(), rtol=1e-5, atol=1e-7)
