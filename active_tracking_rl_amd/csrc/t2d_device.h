@@ -295,6 +295,134 @@ __device__ __forceinline__ uint32_t ram_step(uint32_t &plan, Stream &ts)
     return action;
 }
 
+// ---- Nav target: goal-rooted BFS direction field (device form of Navigator + AstarSolver) -----------------
+// The reference plans with heap A* (G/envs/Astar_solver.py:121-149) and follows the plan open-loop
+// (G/envs/navigator.py:11-41). A* returns A shortest path; its tie-breaks depend on Python heap/list
+// comparison order and are not reproduced on the device. Instead (spec = oracle PHILOX mode, orc_bfs_field):
+// dist-to-goal by 4-connected BFS over free cells, dir[cell] = first action in order up, down, left, right whose
+// neighbour is one step closer. Following dir from any reachable cell is a shortest path (same length as A*).
+//
+// Wave-parallel bit BFS held entirely in registers: lane l owns row l (set A) and, for l < 18, row l+64 (set B),
+// 3 words per row. One BFS level = OR of the frontier shifted up/down (neighbour lanes) and left/right (96-bit
+// shifts), masked by free & ~visited. Direction planes: d0 = (code & 1), d1 = (code >> 1).
+struct RowBits { uint32_t w[3]; };
+
+__device__ __forceinline__ RowBits row_shl1(const RowBits &a) // cell c takes the value of cell c-1
+{
+    RowBits r;
+    r.w[0] = a.w[0] << 1;
+    r.w[1] = (a.w[1] << 1) | (a.w[0] >> 31);
+    r.w[2] = (a.w[2] << 1) | (a.w[1] >> 31);
+    return r;
+}
+__device__ __forceinline__ RowBits row_shr1(const RowBits &a) // cell c takes the value of cell c+1
+{
+    RowBits r;
+    r.w[0] = (a.w[0] >> 1) | (a.w[1] << 31);
+    r.w[1] = (a.w[1] >> 1) | (a.w[2] << 31);
+    r.w[2] = a.w[2] >> 1;
+    return r;
+}
+
+struct NavField {
+    RowBits visA, visB;    // reachable cells
+    RowBits d0A, d0B, d1A, d1B;
+};
+
+__device__ __forceinline__ uint32_t rowbits_get(const RowBits &a, const RowBits &b, int r, int c)
+{
+    // wave-uniform (r, c): fetch the bit from the owning lane
+    const int j = c >> 5;
+    const bool setb = r >= 64;
+    const int owner = setb ? r - 64 : r;
+    uint32_t va = j == 0 ? a.w[0] : (j == 1 ? a.w[1] : a.w[2]);
+    uint32_t vb = j == 0 ? b.w[0] : (j == 1 ? b.w[1] : b.w[2]);
+    uint32_t word = __shfl(setb ? vb : va, owner, 64);
+    return (word >> (c & 31)) & 1u;
+}
+
+__device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, int lane, int gr, int gc, NavField &f)
+{
+    RowBits freeA, freeB, frA, frB;
+    const uint32_t m2 = valid_mask_w2(side);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint32_t vm = j == 2 ? m2 : 0xffffffffu;
+        freeA.w[j] = (lane < side) ? (~tile[lane * kRowWords + j] & vm) : 0u;
+        freeB.w[j] = (lane + 64 < side) ? (~tile[(lane + 64) * kRowWords + j] & vm) : 0u;
+        frA.w[j] = 0u; frB.w[j] = 0u;
+        f.d0A.w[j] = f.d0B.w[j] = f.d1A.w[j] = f.d1B.w[j] = 0u;
+    }
+    {   // seed the frontier with the goal cell
+        const uint32_t bit = 1u << (gc & 31);
+        const int j = gc >> 5;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            if (q == j && gr < 64 && lane == gr) frA.w[q] = bit;
+            if (q == j && gr >= 64 && lane == gr - 64) frB.w[q] = bit;
+        }
+    }
+    f.visA = frA; f.visB = frB;
+    for (;;) {
+        RowBits upA, dnA, upB, dnB;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t a_prev = __shfl_up(frA.w[j], 1, 64);     // row lane-1 (set A)
+            const uint32_t a_next = __shfl_down(frA.w[j], 1, 64);   // row lane+1 (set A)
+            const uint32_t b_prev = __shfl_up(frB.w[j], 1, 64);
+            const uint32_t b_next = __shfl_down(frB.w[j], 1, 64);
+            const uint32_t a_last = __shfl(frA.w[j], 63, 64);       // row 63
+            const uint32_t b_first = __shfl(frB.w[j], 0, 64);       // row 64
+            upA.w[j] = lane == 0 ? 0u : a_prev;                     // frontier cell above  -> action 0 (up)
+            dnA.w[j] = lane == 63 ? b_first : a_next;               // frontier cell below  -> action 1 (down)
+            upB.w[j] = lane == 0 ? a_last : b_prev;
+            dnB.w[j] = lane == 63 ? 0u : b_next;
+        }
+        const RowBits lfA = row_shl1(frA), rtA = row_shr1(frA);     // frontier cell to the left / right
+        const RowBits lfB = row_shl1(frB), rtB = row_shr1(frB);
+        uint32_t any = 0u;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            {
+                const uint32_t open = freeA.w[j] & ~f.visA.w[j];
+                const uint32_t u = upA.w[j] & open, d = dnA.w[j] & open & ~u;
+                const uint32_t l = lfA.w[j] & open & ~(u | d), r = rtA.w[j] & open & ~(u | d | l);
+                const uint32_t nw = u | d | l | r;
+                f.d0A.w[j] |= d | r; f.d1A.w[j] |= l | r;
+                f.visA.w[j] |= nw; frA.w[j] = nw; any |= nw;
+            }
+            {
+                const uint32_t open = freeB.w[j] & ~f.visB.w[j];
+                const uint32_t u = upB.w[j] & open, d = dnB.w[j] & open & ~u;
+                const uint32_t l = lfB.w[j] & open & ~(u | d), r = rtB.w[j] & open & ~(u | d | l);
+                const uint32_t nw = u | d | l | r;
+                f.d0B.w[j] |= d | r; f.d1B.w[j] |= l | r;
+                f.visB.w[j] |= nw; frB.w[j] = nw; any |= nw;
+            }
+        }
+        if (__ballot(any != 0u) == 0ull) break;
+    }
+}
+
+// direction-plane tile in HBM: plane 0 = words 0..245, plane 1 = words 256..501 (same row layout as the map)
+constexpr int kDirWords = 512;
+__device__ __forceinline__ void store_dir_field(uint32_t *gdir, const NavField &f, int side, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        if (lane < side) { gdir[lane * kRowWords + j] = f.d0A.w[j]; gdir[256 + lane * kRowWords + j] = f.d1A.w[j]; }
+        if (lane + 64 < side) {
+            gdir[(lane + 64) * kRowWords + j] = f.d0B.w[j];
+            gdir[256 + (lane + 64) * kRowWords + j] = f.d1B.w[j];
+        }
+    }
+}
+__device__ __forceinline__ uint32_t load_dir(const uint32_t *gdir, int r, int c)
+{
+    const int w = r * kRowWords + (c >> 5);
+    return ((gdir[w] >> (c & 31)) & 1u) | (((gdir[256 + w] >> (c & 31)) & 1u) << 1);
+}
+
 // ---- rewards (G/envs/track_1v1.py:94-104), float64 in the reference's operation order ---------------------
 __device__ __forceinline__ void reward_f64(uint32_t d2, double w_p, double &r_track, double &r_target)
 {

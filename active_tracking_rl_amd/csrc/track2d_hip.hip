@@ -33,6 +33,7 @@ struct DevState {
     uint32_t *tctr;     // [N] TARGET stream word counter
     uint32_t *navgoal;  // [N] r | c<<8
     uint32_t *d2;       // [N] last squared distance
+    uint32_t *dirf;     // [N][512] Nav direction planes (allocated only if some env has a Nav target)
     uint32_t *faults;   // [1]
     int n;
     uint32_t env_base, k0, k1;
@@ -49,6 +50,28 @@ __device__ __forceinline__ int load_action(const void *p, int dtype, int e, uint
     else v = reinterpret_cast<const long long *>(p)[e];
     if (v < 0 || v > 3) { atomicOr(faults, 1u); v &= 3; }
     return (int)v;
+}
+
+// Navigator.reset / the re-plan branch of Navigator.step (navigator.py:43-63, :15-38): plan from (fr, fc) to navgoal;
+// unreachable or empty plan -> resample the goal, the 6th failure -> plan B (10 random actions).
+__device__ __forceinline__ void nav_plan(const uint32_t *tile, int side, int lane, int fr, int fc, const FreeIndex &fi,
+                                         uint32_t &navgoal, Stream &ts, uint32_t &plan, NavField &f)
+{
+    int count_res = 0;
+    bool planb = false;
+    for (;;) {
+        const int gr = (int)(navgoal & 0xffu), gc = (int)(navgoal >> 8);
+        bfs_dir_field(tile, side, lane, gr, gc, f);
+        const bool ok = rowbits_get(f.visA, f.visB, fr, fc) != 0u && !(fr == gr && fc == gc);
+        if (ok) break;
+        if (++count_res > 5) { planb = true; break; }
+        navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+    }
+    plan = planb ? (plan_random(ts, 10u) | (1u << 28)) : 0u;
+}
+__device__ __forceinline__ uint32_t nav_dir_from_regs(const NavField &f, int r, int c)
+{
+    return rowbits_get(f.d0A, f.d0B, r, c) | (rowbits_get(f.d1A, f.d1B, r, c) << 1);
 }
 
 // Track1v1Env.reset -> init_maze (track_1v1.py:134-168,218-240) for one env, executed by one wave on its
@@ -109,6 +132,11 @@ __device__ __forceinline__ void reset_env(const DevState &s, int e, uint32_t *ti
     plan = 0;
     navgoal = g1;
     if (mode == TGT_RAM) plan = ram_reset(ts);
+    if (mode == TGT_NAV) { // Navigator.reset (navigator.py:43-63): plan from the target spawn to goal_states[1]
+        NavField nf;
+        nav_plan(tile, side, lane, (int)(tg & 0xffu), (int)(tg >> 8), fi, navgoal, ts, plan, nf);
+        if (((plan >> 28) & 1u) == 0u) store_dir_field(s.dirf + (size_t)e * kDirWords, nf, side, lane);
+    }
     tctr = ts.ctr;
     cnt = (uint32_t)side << 24;
     const int dr = (int)(tg & 0xffu) - r, dc = (int)(tg >> 8) - c;
@@ -136,7 +164,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         const uint32_t cfg = s.cfg[e];
         uint32_t goals = 0, episode = 0, plan = 0, tctr = 0, navgoal = 0, d2 = 0;
         const int mode = (int)((cfg >> 2) & 7u);
-        bool do_reset = false, dirty = false;
+        bool do_reset = false, dirty = false, s_navgoal_dirty = false;
         wave_lds_sync();
 
         if (OP == OP_RESET) do_reset = (mask == nullptr) || (mask[e] != 0);
@@ -160,9 +188,39 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
                 tctr = ts.ctr;
                 dirty = true;
             }
-            // _next_state (track_1v1.py:271-285): stay put iff the destination cell is a wall
             int r0 = (int)(pos & 0xffu), c0 = (int)((pos >> 8) & 0xffu);
             int r1 = (int)((pos >> 16) & 0xffu), c1 = (int)(pos >> 24);
+            if (mode == TGT_NAV) { // track_1v1.py:83-84 -> Navigator.step(old_state[1], ...) (navigator.py:11-41)
+                plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; navgoal = s.navgoal[e];
+                uint32_t *gdir = s.dirf + (size_t)e * kDirWords;
+                Stream ts;
+                ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, tctr);
+                bool planb = ((plan >> 28) & 1u) != 0u;
+                const bool exhausted = planb ? (plan_cur(plan) >= plan_len(plan))
+                                             : (r1 == (int)(navgoal & 0xffu) && c1 == (int)(navgoal >> 8));
+                uint32_t dir = 0;
+                if (exhausted) {
+                    const FreeIndex fi = build_free_index(tile, side, lane);
+                    navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+                    NavField nf;
+                    nav_plan(tile, side, lane, r1, c1, fi, navgoal, ts, plan, nf);
+                    planb = ((plan >> 28) & 1u) != 0u;
+                    if (!planb) { store_dir_field(gdir, nf, side, lane); dir = nav_dir_from_regs(nf, r1, c1); }
+                    s_navgoal_dirty = true;
+                } else if (!planb) {
+                    dir = load_dir(gdir, r1, c1);
+                }
+                if (planb) {
+                    const uint32_t cur = plan_cur(plan);
+                    a_tg = (int)plan_act(plan, cur);
+                    plan = (plan & 0xf0ffffffu) | ((cur + 1u) << 24);
+                } else {
+                    a_tg = (int)dir;
+                }
+                tctr = ts.ctr;
+                dirty = true;
+            }
+            // _next_state (track_1v1.py:271-285): stay put iff the destination cell is a wall
             {
                 int nr = r0 + (a_tr == 0 ? -1 : (a_tr == 1 ? 1 : 0)), nc = c0 + (a_tr == 2 ? -1 : (a_tr == 3 ? 1 : 0));
                 if (tile_bit(tile, nr, nc) == 0u) { r0 = nr; c0 = nc; }
@@ -197,6 +255,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
             if (OP == OP_STEP || do_reset) { s.pos[e] = pos; s.cnt[e] = cnt; s.d2[e] = d2; }
             if (do_reset) { s.goals[e] = goals; s.episode[e] = episode; s.navgoal[e] = navgoal; }
             if (do_reset || dirty) { s.plan[e] = plan; s.tctr[e] = tctr; }
+            if (s_navgoal_dirty && !do_reset) s.navgoal[e] = navgoal;
         }
         if (lane == 0) { s_pos[wave] = pos; s_side[wave] = (int)(cnt >> 24); }
     }
@@ -313,13 +372,14 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         return fail(T2D_ERR_INVALID, "t2d_create: device %d out of range (%d visible)", cfg->device, ndev);
     const int n = cfg->num_envs;
     std::vector<uint32_t> hcfg((size_t)n);
+    bool has_nav = false;
     for (int i = 0; i < n; i++) {
         uint32_t mt = cfg->map_type_per_env ? cfg->map_type_per_env[i] : cfg->map_type;
         uint32_t tm = cfg->target_mode_per_env ? cfg->target_mode_per_env[i] : cfg->target_mode;
         uint32_t lv = cfg->level_per_env ? cfg->level_per_env[i] : cfg->level;
         if (mt > T2D_MAP_EMPTY) return fail(T2D_ERR_INVALID, "t2d_create: map_type %u (env %d)", mt, i);
         if (tm > T2D_TGT_RAM) return fail(T2D_ERR_INVALID, "t2d_create: target_mode %u (env %d)", tm, i);
-        if (tm == T2D_TGT_NAV) return fail(T2D_ERR_INVALID, "t2d_create: Nav target not built yet (env %d)", i);
+        has_nav = has_nav || tm == T2D_TGT_NAV;
         if (lv > 15) return fail(T2D_ERR_INVALID, "t2d_create: level %u (env %d)", lv, i);
         hcfg[(size_t)i] = mt | (tm << 2) | (lv << 5);
     }
@@ -342,6 +402,10 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         if (err == hipSuccess) err = hipMalloc((void **)a, nb);
         if (err == hipSuccess) err = hipMemset(*a, 0, nb);
     }
+    if (has_nav) {
+        if (err == hipSuccess) err = hipMalloc((void **)&s.dirf, (size_t)n * kDirWords * sizeof(uint32_t));
+        if (err == hipSuccess) err = hipMemset(s.dirf, 0, (size_t)n * kDirWords * sizeof(uint32_t));
+    }
     if (err == hipSuccess) err = hipMalloc((void **)&s.faults, sizeof(uint32_t));
     if (err == hipSuccess) err = hipMemset(s.faults, 0, sizeof(uint32_t));
     if (err == hipSuccess) err = hipMemcpy(s.cfg, hcfg.data(), nb, hipMemcpyHostToDevice);
@@ -358,7 +422,7 @@ extern "C" int t2d_destroy(t2d_handle *h)
     if (!h) return T2D_OK;
     DeviceGuard guard(h->device);
     DevState &s = h->s;
-    void *ptrs[] = {s.maps, s.pos, s.goals, s.cnt, s.cfg, s.episode, s.plan, s.tctr, s.navgoal, s.d2, s.faults};
+    void *ptrs[] = {s.maps, s.pos, s.goals, s.cnt, s.cfg, s.episode, s.plan, s.tctr, s.navgoal, s.d2, s.dirf, s.faults};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -436,7 +500,7 @@ extern "C" int t2d_inject(t2d_handle *h, int first, int count, int side, const u
     if (count == 0) return T2D_OK;
     DeviceGuard guard(h->device);
     std::vector<uint32_t> tiles((size_t)count * kTileWords, 0u), pos((size_t)count), goals((size_t)count, 0u),
-        cnt((size_t)count), zero((size_t)count, 0u), d2((size_t)count);
+        cnt((size_t)count), zero((size_t)count, 0u), d2((size_t)count), navgoal((size_t)count);
     for (int i = 0; i < count; i++) {
         const uint8_t *m = maze_host + (size_t)i * side * side;
         uint32_t *t = tiles.data() + (size_t)i * kTileWords;
@@ -454,6 +518,7 @@ extern "C" int t2d_inject(t2d_handle *h, int first, int count, int side, const u
             goals[(size_t)i] = ((uint32_t)g[0] & 0xff) | (((uint32_t)g[1] & 0xff) << 8) | (((uint32_t)g[2] & 0xff) << 16) | (((uint32_t)g[3] & 0xff) << 24);
         }
         cnt[(size_t)i] = (uint32_t)side << 24;
+        navgoal[(size_t)i] = (uint32_t)p[2] | ((uint32_t)p[3] << 8); // Nav: "standing on the goal" -> re-plan at the next step
         const int dr = p[2] - p[0], dc = p[3] - p[1];
         d2[(size_t)i] = (uint32_t)(dr * dr + dc * dc);
     }
@@ -465,6 +530,8 @@ extern "C" int t2d_inject(t2d_handle *h, int first, int count, int side, const u
     HIP_TRY(hipMemcpyAsync(s.goals + first, goals.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s.cnt + first, cnt.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s.d2 + first, d2.data(), nb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s.navgoal + first, navgoal.data(), nb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s.plan + first, zero.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (first == 0 && count == s.n) h->reset_done = true;
     return T2D_OK;

@@ -97,7 +97,8 @@ int t2d_observe(t2d_handle *h, float *obs_dev, void *stream);
 
 /* Parity/test mode: overwrite envs [first, first+count) with host-supplied maps (u8 side*side each, 0 free
  * / 1 wall, side 81 or 82), positions pos[count][4] = {tracker r,c, target r,c} and goals (may be NULL);
- * counters are zeroed. Synchronises the stream. */
+ * counters are zeroed; the scripted-target plan is cleared (a Nav target re-plans at its next step, a Ram target
+ * needs t2d_inject_plan). Synchronises the stream. */
 int t2d_inject(t2d_handle *h, int first, int count, int side, const uint8_t *maze_host,
                const int32_t *pos_host, const int32_t *goals_host, void *stream);
 /* Ram target plan injection for one env: len in [1,10], actions 0..3. Synchronises. */

@@ -714,6 +714,9 @@ int orc_inject(orc_env *e, int side, const uint8_t *maze, const int *pos, const 
         }
     set_wp(e);
     e->c_far = 0; e->t = 0;
+    /* scripted-target plan cleared: a Nav target re-plans at its next step */
+    e->plan_len = 0; e->plan_cur = 0; e->nav_planb = 0;
+    e->nav_goal[0] = e->pos[1][0]; e->nav_goal[1] = e->pos[1][1];
     int dr = e->pos[1][0] - e->pos[0][0], dc = e->pos[1][1] - e->pos[0][1];
     e->d2 = (int64_t)dr * dr + (int64_t)dc * dc;
     return 0;

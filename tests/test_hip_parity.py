@@ -176,11 +176,49 @@ def test_generated_maze_far_and_levels_match_oracle(vec):
     _check_generated(vec, 16, "Empty", "PZR", 0, seed=6, steps=40)
 
 
+def test_generated_nav_matches_oracle(vec):
+    """Nav target: goal sampling, BFS direction field, closed-loop descent, re-planning at the goal."""
+    _check_generated(vec, 40, "Block", "Nav", 0, seed=13, steps=150)
+    _check_generated(vec, 24, "Maze", "Nav", 0, seed=14, steps=120)
+    _check_generated(vec, 8, "Block", "Nav", 1, seed=15, steps=60)
+
+
+def test_nav_plan_b_when_target_is_walled_in(vec):
+    """Unreachable goals: six failed plans -> plan B = 10 random actions (navigator.py:22-36), repeatedly."""
+    m = np.zeros((82, 82), np.uint8)
+    m[0, :] = m[-1, :] = 1; m[:, 0] = m[:, -1] = 1
+    m[9, 9:12] = 1; m[11, 9:12] = 1; m[10, 9] = 1; m[10, 11] = 1     # the target sits in a 1-cell pocket
+    pos = np.array([[[20, 20], [10, 10]], [[12, 10], [10, 10]]], np.int32)
+    n = 2
+    env = vec.VecTrack2D(num_envs=n, map_type="Block", target_mode="Nav", level=1, seed=5, auto_reset=False)
+    oracles = _oracle_batch(n, ["Block"] * n, ["Nav"] * n, [1] * n, 5)
+    env.reset()
+    for o in oracles:
+        o.reset()
+    env.inject(np.stack([m, m]), pos.reshape(n, 4))
+    for i, o in enumerate(oracles):
+        o.inject(m, pos[i])
+    rs = np.random.RandomState(3)
+    for t in range(35):
+        acts = rs.randint(0, 4, size=(n, 2))
+        a = torch.from_numpy(acts).cuda()
+        obs, rew, done = env.step(a[:, 0].contiguous())
+        tg = env.get_target()
+        for i, o in enumerate(oracles):
+            wo, wr, wd, applied = o.step(acts[i])
+            assert np.array_equal(obs[i].cpu().numpy(), wo.astype(np.float32)), (t, i)
+            assert np.array_equal(rew[i].cpu().numpy(), wr.astype(np.float32))
+            assert o.state()["pos"][1].tolist() == [10, 10]          # never leaves the pocket
+            plan, cur = o.plan()
+            assert tg["len"][i] == 10 and tg["cursor"][i] == cur and np.array_equal(tg["plan"][i], plan)
+    env.close()
+
+
 def test_generated_mixed_batch_and_sharding(vec):
     n = 40
     rs = np.random.RandomState(0)
     mts = [("Block", "Maze")[k] for k in rs.randint(0, 2, n)]
-    mds = [("Adv", "PZR", "Far", "Ram")[k] for k in rs.randint(0, 4, n)]
+    mds = [("Adv", "PZR", "Far", "Ram", "Nav")[k] for k in rs.randint(0, 5, n)]
     lvs = rs.randint(0, 2, n).tolist()
     _check_generated(vec, n, None, None, None, seed=21, steps=50, per_env=(mts, mds, lvs))
     # a shard [base, base+n) of a larger job is keyed by GLOBAL env ids
@@ -229,7 +267,8 @@ def test_invalid_action_sets_fault(vec):
     env.close()
 
 
-@pytest.mark.parametrize("n,map_type,mode", [(4096, "Block", "PZR"), (16384, "Block", "Adv"), (8192, "Maze", "Ram")])
+@pytest.mark.parametrize("n,map_type,mode", [(4096, "Block", "PZR"), (16384, "Block", "Adv"), (8192, "Maze", "Ram"),
+                                             (8192, "Maze", "Nav")])
 def test_invariants_at_baseline_sizes(vec, n, map_type, mode):
     """SURVEY.md §8c property list, checked on the full batch without the oracle."""
     env = vec.VecTrack2D(num_envs=n, map_type=map_type, target_mode=mode, seed=1, auto_reset=True)
