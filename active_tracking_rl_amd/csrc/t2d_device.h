@@ -88,6 +88,49 @@ struct Stream {
     }
 };
 
+// The same word sequence served 64 WORDS at a time: lane l holds word `base + l` (the four lanes of a quad compute
+// the same Philox block and keep one component each), so a draw is a single v_readlane with a uniform lane index
+// and no branch. Used by the generators, whose long sequential loops (maze growth, spawn picks) would otherwise
+// pay a full 10-round Philox on the one active wave every fourth draw.
+struct VStream {
+    uint32_t k0, k1, episode, env, stream;
+    uint32_t ctr;       // next word index (wave-uniform)
+    uint32_t base;      // first word held in the lanes (multiple of 64), 0xffffffff = nothing loaded
+    uint32_t wv;        // per-lane word `base + lane`
+    int lane;
+    __device__ __forceinline__ void init(uint32_t k0_, uint32_t k1_, uint32_t ep, uint32_t env_, uint32_t s,
+                                         uint32_t ctr_, int lane_)
+    {
+        k0 = k0_; k1 = k1_; episode = ep; env = env_; stream = s; ctr = ctr_; base = 0xffffffffu; lane = lane_;
+        wv = 0u;
+    }
+    __device__ __forceinline__ uint32_t next()
+    {
+        const uint32_t i = uni(ctr);
+        ctr = i + 1u;
+        if ((i & ~63u) != base) {
+            base = i & ~63u;
+            const u32x4 w = philox4x32_10(k0, k1, (base >> 2) + (uint32_t)(lane >> 2), episode, env, stream);
+            const int j = lane & 3;
+            wv = j == 0 ? w.x : (j == 1 ? w.y : (j == 2 ? w.z : w.w));
+        }
+        return __builtin_amdgcn_readlane(wv, (int)(i & 63u));
+    }
+    __device__ __forceinline__ double next_double()
+    {
+        uint32_t a = next() >> 5, b = next() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    __device__ __forceinline__ uint32_t bounded(uint32_t max)
+    {
+        if (max == 0) return 0;
+        uint32_t mask = 0xffffffffu >> __builtin_clz(max);
+        uint32_t v;
+        do { v = next() & mask; } while (v > max);
+        return v;
+    }
+};
+
 // ---- keyed permutation of [0, 6400) (oracle: orc_perm6400) --------------------------------------------
 __device__ __forceinline__ uint32_t fmix32(uint32_t h)
 {
@@ -200,7 +243,8 @@ __device__ __forceinline__ void tile_border(uint32_t *tile, int side, int lane)
 
 // RandomBlockMazeGenerator._generate_maze — G/envs/generators.py:157-176: exactly K = int(ratio * 6400)
 // distinct interior cells, here the first K images of a keyed permutation; then the wall border.
-__device__ __forceinline__ void gen_block(uint32_t *tile, int lane, Stream &ms, double ratio)
+template <class S>
+__device__ __forceinline__ void gen_block(uint32_t *tile, int lane, S &ms, double ratio)
 {
     tile_clear(tile, lane);
     int K = (int)(ratio * 6400.0);
@@ -219,40 +263,68 @@ __device__ __forceinline__ void gen_block(uint32_t *tile, int lane, Stream &ms, 
     wave_lds_sync();
 }
 
-// RandomMazeGenerator._generate_maze — G/envs/generators.py:115-145 (81x81). Inherently sequential:
-// every lane runs the same wave-uniform loop, lane 0 commits the writes.
-__device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, Stream &ms, double ratio)
+// RandomMazeGenerator._generate_maze — G/envs/generators.py:115-145 (81x81). Inherently sequential (every step
+// depends on the walls laid so far), so it is one wave-uniform loop made as short as possible:
+//   * the algorithm only ever READS cells at even coordinates ("nodes", a 41x41 grid); their occupancy lives in
+//     registers — lane y holds node row y as 41 bits — and is read/updated with readlane/writelane, no LDS round trip;
+//   * the full-resolution tile (nodes + the carved midpoints) is write-only here: lane 0 fires LDS stores;
+//   * random words come from the 64-block VStream (one readlane per draw).
+template <class S>
+__device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double ratio)
 {
-    const int S = 81;
+    const int SZ = 81;
     tile_clear(tile, lane);
     wave_lds_sync();
-    tile_border(tile, S, lane);
+    tile_border(tile, SZ, lane);
     wave_lds_sync();
-    int complexity = (int)(ratio * 810.0);
-    int density = (int)(ratio * 1600.0);
-    auto set = [&](int y, int x) {
-        if (lane == 0) tile[y * kRowWords + (x >> 5)] |= 1u << (x & 31);
+    const int complexity = (int)(ratio * 810.0);
+    const int density = (int)(ratio * 1600.0);
+    // node rows: bit x/2 of row y/2; border nodes are walls
+    uint32_t nlo = 0u, nhi = 0u;
+    if (lane == 0 || lane == 40) { nlo = 0xffffffffu; nhi = 0x1ffu; }
+    else if (lane < 40) { nlo = 1u; nhi = 0x100u; }
+    auto node_get = [&](int ny, int nx) -> uint32_t {
+        const uint32_t lo = __builtin_amdgcn_readlane(nlo, ny), hi = __builtin_amdgcn_readlane(nhi, ny);
+        return nx < 32 ? (lo >> nx) & 1u : (hi >> (nx - 32)) & 1u;
     };
+    auto node_set = [&](int ny, int nx) {
+        if (lane == ny) { if (nx < 32) nlo |= 1u << nx; else nhi |= 1u << (nx - 32); }
+    };
+    auto set = [&](int y, int x) { // fire-and-forget ds_or_b32: the loop never reads the tile back
+        if (lane == 0) atomicOr(&tile[y * kRowWords + (x >> 5)], 1u << (x & 31));
+    };
+    // k-th present candidate of the neighbour list [(y,x-2) if x>1, (y,x+2) if x<S-2, (y-2,x) if y>1, (y+2,x) if
+    // y<S-2] (generators.py:135-138) as a table: entry (mask, k) = direction 0..3, 2 bits each.
+    unsigned long long tbl_lo = 0ull, tbl_hi = 0ull;
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        int seen = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            if (m & (1 << d)) {
+                const int e = (m * 4 + seen) * 2;
+                if (e < 64) tbl_lo |= (unsigned long long)d << e; else tbl_hi |= (unsigned long long)d << (e - 64);
+                seen++;
+            }
+    }
     for (int i = 0; i < density; i++) {
         int x = (int)ms.bounded(40u) * 2;
         int y = (int)ms.bounded(40u) * 2;
         set(y, x);
-        wave_lds_sync();
+        node_set(y >> 1, x >> 1);
         for (int j = 0; j < complexity; j++) {
-            // neighbour list order of generators.py:135-138; k-th present candidate, no local arrays
-            const bool c0 = x > 1, c1 = x < S - 2, c2 = y > 1, c3 = y < S - 2;
-            const int n = (int)c0 + (int)c1 + (int)c2 + (int)c3;
-            int k = (int)ms.bounded((uint32_t)(n - 1));
-            int y_ = y, x_ = x, seen = 0;
-            if (c0) { if (seen == k) { y_ = y;     x_ = x - 2; } seen++; }
-            if (c1) { if (seen == k) { y_ = y;     x_ = x + 2; } seen++; }
-            if (c2) { if (seen == k) { y_ = y - 2; x_ = x;     } seen++; }
-            if (c3) { if (seen == k) { y_ = y + 2; x_ = x;     } seen++; }
-            if (tile_bit(tile, y_, x_) == 0u) {
+            const int m = (int)(x > 1) | ((int)(x < SZ - 2) << 1) | ((int)(y > 1) << 2) | ((int)(y < SZ - 2) << 3);
+            const int n = __popc((unsigned)m);
+            const int k = (int)ms.bounded((uint32_t)(n - 1));
+            const int e = (m * 4 + k) * 2;
+            const int d = (int)((e < 64 ? tbl_lo >> e : tbl_hi >> (e - 64)) & 3ull);
+            const int step = (d & 1) * 4 - 2;                    // -2 for directions 0/2, +2 for 1/3
+            const int x_ = x + ((d & 2) ? 0 : step), y_ = y + ((d & 2) ? step : 0);
+            if (node_get(y_ >> 1, x_ >> 1) == 0u) {
                 set(y_, x_);
                 set(y_ + (y - y_) / 2, x_ + (x - x_) / 2);
+                node_set(y_ >> 1, x_ >> 1);
                 x = x_; y = y_;
-                wave_lds_sync();
             }
         }
     }
@@ -264,13 +336,15 @@ __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, Stream &ms, d
 __device__ __forceinline__ uint32_t plan_len(uint32_t p) { return (p >> 20) & 15u; }
 __device__ __forceinline__ uint32_t plan_cur(uint32_t p) { return (p >> 24) & 15u; }
 __device__ __forceinline__ uint32_t plan_act(uint32_t p, uint32_t i) { return (p >> (2u * i)) & 3u; }
-__device__ __forceinline__ uint32_t plan_random(Stream &ts, uint32_t n)
+template <class S>
+__device__ __forceinline__ uint32_t plan_random(S &ts, uint32_t n)
 {
     uint32_t p = 0;
     for (uint32_t i = 0; i < n; i++) p |= ts.bounded(3u) << (2u * i);
     return p | (n << 20);
 }
-__device__ __forceinline__ uint32_t ram_reset(Stream &ts)
+template <class S>
+__device__ __forceinline__ uint32_t ram_reset(S &ts)
 {
     uint32_t n = 1u + ts.bounded(8u); // randint(1,10) is evaluated before choice(4, n)  (navigator.py:91)
     return plan_random(ts, n);
@@ -306,6 +380,17 @@ __device__ __forceinline__ uint32_t ram_step(uint32_t &plan, Stream &ts)
 // 3 words per row. One BFS level = OR of the frontier shifted up/down (neighbour lanes) and left/right (96-bit
 // shifts), masked by free & ~visited. Direction planes: d0 = (code & 1), d1 = (code >> 1).
 struct RowBits { uint32_t w[3]; };
+
+// Neighbour-lane moves on the DPP crossbar (GFX9 wave_shr:1 / wave_shl:1): lane l reads lane l-1 / l+1; the edge
+// lane gets 0. One VALU op each instead of a ds_bpermute round trip (the BFS needs 12 of them per level).
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
 
 __device__ __forceinline__ RowBits row_shl1(const RowBits &a) // cell c takes the value of cell c-1
 {
@@ -367,12 +452,12 @@ __device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, in
         RowBits upA, dnA, upB, dnB;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            const uint32_t a_prev = __shfl_up(frA.w[j], 1, 64);     // row lane-1 (set A)
-            const uint32_t a_next = __shfl_down(frA.w[j], 1, 64);   // row lane+1 (set A)
-            const uint32_t b_prev = __shfl_up(frB.w[j], 1, 64);
-            const uint32_t b_next = __shfl_down(frB.w[j], 1, 64);
-            const uint32_t a_last = __shfl(frA.w[j], 63, 64);       // row 63
-            const uint32_t b_first = __shfl(frB.w[j], 0, 64);       // row 64
+            const uint32_t a_prev = from_prev_lane(frA.w[j]);       // row lane-1 (set A)
+            const uint32_t a_next = from_next_lane(frA.w[j]);       // row lane+1 (set A)
+            const uint32_t b_prev = from_prev_lane(frB.w[j]);
+            const uint32_t b_next = from_next_lane(frB.w[j]);
+            const uint32_t a_last = __builtin_amdgcn_readlane(frA.w[j], 63);  // row 63
+            const uint32_t b_first = __builtin_amdgcn_readlane(frB.w[j], 0);  // row 64
             upA.w[j] = lane == 0 ? 0u : a_prev;                     // frontier cell above  -> action 0 (up)
             dnA.w[j] = lane == 63 ? b_first : a_next;               // frontier cell below  -> action 1 (down)
             upB.w[j] = lane == 0 ? a_last : b_prev;

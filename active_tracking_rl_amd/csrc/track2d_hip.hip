@@ -23,6 +23,7 @@
 namespace t2d {
 
 struct DevState {
+    // ---- current episode (read/written by the step kernel) ----
     uint32_t *maps;     // [N][256] bit-packed tiles
     uint32_t *pos;      // [N] tracker r | c<<8 | target r<<16 | c<<24
     uint32_t *goals;    // [N] goal0 r | c<<8 | goal1 r<<16 | c<<24
@@ -33,7 +34,10 @@ struct DevState {
     uint32_t *tctr;     // [N] TARGET stream word counter
     uint32_t *navgoal;  // [N] r | c<<8
     uint32_t *d2;       // [N] last squared distance
-    uint32_t *dirf;     // [N][512] Nav direction planes (allocated only if some env has a Nav target)
+    uint32_t *dirf;     // [N][512] Nav direction planes (only if some env has a Nav target)
+    // ---- next episode, generated ahead of time by k_gen (episode[e] + 1) ----
+    uint32_t *n_maps, *n_pos, *n_goals, *n_plan, *n_tctr, *n_navgoal, *n_d2, *n_dirf;
+    uint32_t *gen_req;  // [N] 0 = next slot valid; s > 0 = consumed at step stamp s, to be regenerated
     uint32_t *faults;   // [1]
     int n;
     uint32_t env_base, k0, k1;
@@ -54,8 +58,9 @@ __device__ __forceinline__ int load_action(const void *p, int dtype, int e, uint
 
 // Navigator.reset / the re-plan branch of Navigator.step (navigator.py:43-63, :15-38): plan from (fr, fc) to navgoal;
 // unreachable or empty plan -> resample the goal, the 6th failure -> plan B (10 random actions).
+template <class S>
 __device__ __forceinline__ void nav_plan(const uint32_t *tile, int side, int lane, int fr, int fc, const FreeIndex &fi,
-                                         uint32_t &navgoal, Stream &ts, uint32_t &plan, NavField &f)
+                                         uint32_t &navgoal, S &ts, uint32_t &plan, NavField &f)
 {
     int count_res = 0;
     bool planb = false;
@@ -74,22 +79,23 @@ __device__ __forceinline__ uint32_t nav_dir_from_regs(const NavField &f, int r, 
     return rowbits_get(f.d0A, f.d0B, r, c) | (rowbits_get(f.d1A, f.d1B, r, c) << 1);
 }
 
-// Track1v1Env.reset -> init_maze (track_1v1.py:134-168,218-240) for one env, executed by one wave on its
-// LDS tile. All arguments are wave-uniform.
-__device__ __forceinline__ void reset_env(const DevState &s, int e, uint32_t *tile, int lane, uint32_t cfg,
-                                          uint32_t &pos, uint32_t &goals, uint32_t &cnt, uint32_t &episode,
-                                          uint32_t &plan, uint32_t &tctr, uint32_t &navgoal, uint32_t &d2)
+__device__ __forceinline__ int side_of_cfg(uint32_t cfg) { return (cfg & 3u) == (uint32_t)MAP_MAZE ? 81 : 82; }
+
+// Track1v1Env.reset -> init_maze (track_1v1.py:134-168,218-240) for one env and one episode number, executed by
+// one wave on an LDS tile. All arguments are wave-uniform. `gdir` receives the Nav direction planes.
+template <bool NAV>
+__device__ __forceinline__ void generate_episode(const DevState &s, int e, uint32_t *tile, int lane, uint32_t cfg,
+                                                 uint32_t episode, uint32_t *gdir, uint32_t &pos, uint32_t &goals,
+                                                 uint32_t &plan, uint32_t &tctr, uint32_t &navgoal, uint32_t &d2)
 {
     const int map_type = cfg & 3, mode = (cfg >> 2) & 7, level = (cfg >> 5) & 15;
     const uint32_t genv = s.env_base + (uint32_t)e;
-    episode += 1u;
-    Stream ms;
-    ms.init(s.k0, s.k1, episode, genv, STREAM_MAP, 0);
-    int side = 82;
+    VStream ms;
+    ms.init(s.k0, s.k1, episode, genv, STREAM_MAP, 0, lane);
+    const int side = side_of_cfg(cfg);
     if (map_type == MAP_MAZE) {
         double r = level > 0 ? (double)level * 0.02 : .03 * ms.next_double();
         gen_maze(tile, lane, ms, r);
-        side = 81;
     } else if (map_type == MAP_BLOCK) {
         double r = level > 0 ? (double)level * 0.05 : 0.15 * ms.next_double();
         gen_block(tile, lane, ms, r);
@@ -98,8 +104,8 @@ __device__ __forceinline__ void reset_env(const DevState &s, int e, uint32_t *ti
     }
     const FreeIndex fi = build_free_index(tile, side, lane);
     const int n = fi.total;
-    Stream ss;
-    ss.init(s.k0, s.k1, episode, genv, STREAM_SPAWN, 0);
+    VStream ss;
+    ss.init(s.k0, s.k1, episode, genv, STREAM_SPAWN, 0, lane);
     uint32_t g0, g1;
     auto sample_goal2 = [&]() { // MazeGenerator.sample_goal(2), generators.py:38-51
         int i0 = (int)ss.bounded((uint32_t)(n - 1));
@@ -127,176 +133,222 @@ __device__ __forceinline__ void reset_env(const DevState &s, int e, uint32_t *ti
     while (tr == g0 || tr == g1) sample_goal2(); // goal_test loop, track_1v1.py:239-240
     pos = tr | (tg << 16);
     goals = g0 | (g1 << 16);
-    Stream ts;
-    ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, 0);
+    VStream ts;
+    ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, 0, lane);
     plan = 0;
     navgoal = g1;
     if (mode == TGT_RAM) plan = ram_reset(ts);
-    if (mode == TGT_NAV) { // Navigator.reset (navigator.py:43-63): plan from the target spawn to goal_states[1]
+    if (NAV && mode == TGT_NAV) { // Navigator.reset (navigator.py:43-63): plan from the target spawn to goal_states[1]
         NavField nf;
         nav_plan(tile, side, lane, (int)(tg & 0xffu), (int)(tg >> 8), fi, navgoal, ts, plan, nf);
-        if (((plan >> 28) & 1u) == 0u) store_dir_field(s.dirf + (size_t)e * kDirWords, nf, side, lane);
+        if (((plan >> 28) & 1u) == 0u) store_dir_field(gdir, nf, side, lane);
     }
     tctr = ts.ctr;
-    cnt = (uint32_t)side << 24;
     const int dr = (int)(tg & 0xffu) - r, dc = (int)(tg >> 8) - c;
     d2 = (uint32_t)(dr * dr + dc * dc);
 }
 
-template <int OP, bool RANDOM>
-__global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const void *act1, int act_dtype,
-                                             const uint8_t *mask, float *obs, float *rew, uint8_t *done_out,
-                                             uint32_t aseed_lo, uint32_t aseed_hi, uint32_t step_idx)
+// Generator kernel: fills the "next episode" slot (episode[e] + 1) of every env whose slot was consumed at a step
+// stamp <= upto (or of every env when force != 0). Launched by the host every `gen_every` steps (<= 10): a
+// consumed slot cannot be needed again for 11 steps (done needs 11 consecutive far steps, track_1v1.py:106-111),
+// so generation is off the step kernel's critical path and its cost is amortised over the period.
+template <bool NAV>
+__global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t upto, int force)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tiles[kWavesPerBlock][kTileWords];
-    __shared__ uint32_t s_pos[kWavesPerBlock];
-    __shared__ int s_side[kWavesPerBlock];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int e = (int)blockIdx.x * kWavesPerBlock + wave;
+    if (e >= s.n) return;
+    const uint32_t req = s.gen_req[e];
+    if (!force && (req == 0u || req > upto)) return;
+    uint32_t *tile = tiles[wave];
+    const uint32_t cfg = s.cfg[e];
+    uint32_t pos, goals, plan, tctr, navgoal, d2;
+    uint32_t *gdir = NAV ? s.n_dirf + (size_t)e * kDirWords : nullptr;
+    generate_episode<NAV>(s, e, tile, lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2);
+    wave_lds_sync();
+    reinterpret_cast<uint4 *>(s.n_maps + (size_t)e * kTileWords)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
+    if (lane == 0) {
+        s.n_pos[e] = pos; s.n_goals[e] = goals; s.n_plan[e] = plan; s.n_tctr[e] = tctr;
+        s.n_navgoal[e] = navgoal; s.n_d2[e] = d2; s.gen_req[e] = 0u;
+    }
+}
+
+// _get_obs / _get_partial_obs (track_1v1.py:287-326) for ONE env by ONE wave. Lanes 0..51 each expand one half
+// row (7 + 6 cells) of the 2 x 13 crop rows from the LDS tile into an LDS staging row (bits -> bytes by a
+// multiply spread, agent marks, v_cvt_f32_ubyteN); then all 64 lanes stream the 338 floats out as coalesced
+// 8 B/lane stores (1352 B per env is 8-byte, not 16-byte, aligned).
+__device__ __forceinline__ void emit_obs(const uint32_t *tile, float *stage, uint32_t pos, int side, int lane,
+                                         float *gobs)
+{
+    if (lane < 52) {
+        const int row = lane >> 1, h = lane & 1;
+        const int ag = row >= T2D_WIN ? 1 : 0;
+        const int y = row - ag * T2D_WIN;
+        const int tr_r = (int)(pos & 0xffu), tr_c = (int)((pos >> 8) & 0xffu);
+        const int tg_r = (int)((pos >> 16) & 0xffu), tg_c = (int)(pos >> 24);
+        const int rr = (ag ? tg_r : tr_r) - T2D_POB + y;
+        const int c0 = (ag ? tg_c : tr_c) - T2D_POB + h * 7;   // first column of this half row, in [-5, 81]
+        uint32_t bits = 0x7fu;                                   // np.pad(..., 1): rows outside the map
+        if ((unsigned)rr < (unsigned)side) {
+            const uint32_t *w = tile + rr * kRowWords;
+            const uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+            const uint64_t hi = (uint64_t)w[2] | (~0ull << (side - 64));   // columns >= side read as 1
+            uint64_t v;
+            if (c0 < 0) v = (lo << (-c0)) | ((1ull << (-c0)) - 1ull);      // columns < 0 read as 1
+            else if (c0 == 0) v = lo;
+            else if (c0 < 64) v = (lo >> c0) | (hi << (64 - c0));
+            else v = hi >> (c0 - 64);
+            bits = (uint32_t)v & 0x7fu;
+        }
+        // bit k -> byte k (0/1)
+        uint64_t bytes = ((uint64_t)bits * 0x0002040810204081ull) & 0x0101010101010101ull;
+        if (rr == tr_r) { const int k = tr_c - c0; if (k >= 0 && k < 7) bytes = (bytes & ~(0xffull << (8 * k))) | (2ull << (8 * k)); }
+        if (rr == tg_r) { const int k = tg_c - c0; if (k >= 0 && k < 7) bytes = (bytes & ~(0xffull << (8 * k))) | (4ull << (8 * k)); }
+        if (y == T2D_POB && h == 0) bytes = (bytes & ~(0xffull << 48)) | ((ag ? 4ull : 2ull) << 48);  // own cell (:313)
+        float *dst = stage + row * T2D_WIN + h * 7;
+        const uint32_t b0 = (uint32_t)bytes, b1 = (uint32_t)(bytes >> 32);
+        dst[0] = (float)(b0 & 0xffu); dst[1] = (float)((b0 >> 8) & 0xffu); dst[2] = (float)((b0 >> 16) & 0xffu);
+        dst[3] = (float)(b0 >> 24); dst[4] = (float)(b1 & 0xffu); dst[5] = (float)((b1 >> 8) & 0xffu);
+        if (h == 0) dst[6] = (float)((b1 >> 16) & 0xffu);
+    }
+    wave_lds_sync();
+    const float2 *src = reinterpret_cast<const float2 *>(stage);
+    float2 *out = reinterpret_cast<float2 *>(gobs);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int q = lane + 64 * i;
+        if (q < kObsPerEnv / 2) out[q] = src[q];
+    }
+}
+
+template <int OP, bool RANDOM, bool NAV>
+__global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const void *act1, int act_dtype,
+                                             const uint8_t *mask, float *obs, float *rew, uint8_t *done_out,
+                                             uint32_t aseed_lo, uint32_t aseed_hi, uint32_t step_idx, uint32_t stamp)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kWavesPerBlock][kTileWords];
+    __shared__ __attribute__((aligned(16))) float stages[kWavesPerBlock][kObsPerEnv + 2];
 
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = uni((int)(threadIdx.x >> 6));
     const int e = (int)blockIdx.x * kWavesPerBlock + wave;
+    if (e >= s.n) return;
 
-    if (e < s.n) {
-        uint32_t *tile = tiles[wave];
-        uint32_t *gtile = s.maps + (size_t)e * kTileWords;
-        reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(gtile)[lane];
-        uint32_t pos = s.pos[e], cnt = s.cnt[e];
-        const uint32_t cfg = s.cfg[e];
-        uint32_t goals = 0, episode = 0, plan = 0, tctr = 0, navgoal = 0, d2 = 0;
-        const int mode = (int)((cfg >> 2) & 7u);
-        bool do_reset = false, dirty = false, s_navgoal_dirty = false;
-        wave_lds_sync();
+    uint32_t *tile = tiles[wave];
+    uint32_t *gtile = s.maps + (size_t)e * kTileWords;
+    reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(gtile)[lane];
+    uint32_t pos = s.pos[e], cnt = s.cnt[e];
+    const uint32_t cfg = s.cfg[e];
+    uint32_t plan = 0, tctr = 0, navgoal = 0, d2 = 0;
+    const int mode = (int)((cfg >> 2) & 7u);
+    bool consume = false, dirty = false, navgoal_dirty = false;
+    wave_lds_sync();
 
-        if (OP == OP_RESET) do_reset = (mask == nullptr) || (mask[e] != 0);
+    if (OP == OP_RESET) consume = (mask == nullptr) || (mask[e] != 0);
 
-        if (OP == OP_STEP) {
-            const uint32_t genv = s.env_base + (uint32_t)e;
-            int side = (int)(cnt >> 24), c_far = (int)(cnt & 0xffu), t = (int)((cnt >> 8) & 0xffffu);
-            int a_tr, a_tg;
-            if (RANDOM) {
-                u32x4 w = philox4x32_10(aseed_lo, aseed_hi, step_idx, 0u, genv, STREAM_ACTION);
-                a_tr = (int)(w.x & 3u); a_tg = (int)(w.y & 3u);
+    if (OP == OP_STEP) {
+        const uint32_t genv = s.env_base + (uint32_t)e;
+        const int side = (int)(cnt >> 24);
+        int c_far = (int)(cnt & 0xffu), t = (int)((cnt >> 8) & 0xffffu);
+        int a_tr, a_tg;
+        if (RANDOM) {
+            u32x4 w = philox4x32_10(aseed_lo, aseed_hi, step_idx, 0u, genv, STREAM_ACTION);
+            a_tr = (int)(w.x & 3u); a_tg = (int)(w.y & 3u);
+        } else {
+            a_tr = load_action(act0, act_dtype, e, s.faults);
+            a_tg = act1 ? load_action(act1, act_dtype, e, s.faults) : 0;
+        }
+        if (mode == TGT_RAM) { // track_1v1.py:81-82
+            plan = s.plan[e]; tctr = s.tctr[e];
+            Stream ts;
+            ts.init(s.k0, s.k1, s.episode[e], genv, STREAM_TARGET, tctr);
+            a_tg = (int)ram_step(plan, ts);
+            tctr = ts.ctr;
+            dirty = true;
+        }
+        int r0 = (int)(pos & 0xffu), c0 = (int)((pos >> 8) & 0xffu);
+        int r1 = (int)((pos >> 16) & 0xffu), c1 = (int)(pos >> 24);
+        if (NAV && mode == TGT_NAV) { // track_1v1.py:83-84 -> Navigator.step(old_state[1], ...) (navigator.py:11-41)
+            plan = s.plan[e]; tctr = s.tctr[e]; navgoal = s.navgoal[e];
+            uint32_t *gdir = s.dirf + (size_t)e * kDirWords;
+            Stream ts;
+            ts.init(s.k0, s.k1, s.episode[e], genv, STREAM_TARGET, tctr);
+            bool planb = ((plan >> 28) & 1u) != 0u;
+            const bool exhausted = planb ? (plan_cur(plan) >= plan_len(plan))
+                                         : (r1 == (int)(navgoal & 0xffu) && c1 == (int)(navgoal >> 8));
+            uint32_t dir = 0;
+            if (exhausted) {
+                const FreeIndex fi = build_free_index(tile, side, lane);
+                navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+                NavField nf;
+                nav_plan(tile, side, lane, r1, c1, fi, navgoal, ts, plan, nf);
+                planb = ((plan >> 28) & 1u) != 0u;
+                if (!planb) { store_dir_field(gdir, nf, side, lane); dir = nav_dir_from_regs(nf, r1, c1); }
+                navgoal_dirty = true;
+            } else if (!planb) {
+                dir = load_dir(gdir, r1, c1);
+            }
+            if (planb) {
+                const uint32_t cur = plan_cur(plan);
+                a_tg = (int)plan_act(plan, cur);
+                plan = (plan & 0xf0ffffffu) | ((cur + 1u) << 24);
             } else {
-                a_tr = load_action(act0, act_dtype, e, s.faults);
-                a_tg = act1 ? load_action(act1, act_dtype, e, s.faults) : 0;
+                a_tg = (int)dir;
             }
-            if (mode == TGT_RAM) { // track_1v1.py:81-82
-                plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e];
-                Stream ts;
-                ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, tctr);
-                a_tg = (int)ram_step(plan, ts);
-                tctr = ts.ctr;
-                dirty = true;
-            }
-            int r0 = (int)(pos & 0xffu), c0 = (int)((pos >> 8) & 0xffu);
-            int r1 = (int)((pos >> 16) & 0xffu), c1 = (int)(pos >> 24);
-            if (mode == TGT_NAV) { // track_1v1.py:83-84 -> Navigator.step(old_state[1], ...) (navigator.py:11-41)
-                plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; navgoal = s.navgoal[e];
-                uint32_t *gdir = s.dirf + (size_t)e * kDirWords;
-                Stream ts;
-                ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, tctr);
-                bool planb = ((plan >> 28) & 1u) != 0u;
-                const bool exhausted = planb ? (plan_cur(plan) >= plan_len(plan))
-                                             : (r1 == (int)(navgoal & 0xffu) && c1 == (int)(navgoal >> 8));
-                uint32_t dir = 0;
-                if (exhausted) {
-                    const FreeIndex fi = build_free_index(tile, side, lane);
-                    navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
-                    NavField nf;
-                    nav_plan(tile, side, lane, r1, c1, fi, navgoal, ts, plan, nf);
-                    planb = ((plan >> 28) & 1u) != 0u;
-                    if (!planb) { store_dir_field(gdir, nf, side, lane); dir = nav_dir_from_regs(nf, r1, c1); }
-                    s_navgoal_dirty = true;
-                } else if (!planb) {
-                    dir = load_dir(gdir, r1, c1);
-                }
-                if (planb) {
-                    const uint32_t cur = plan_cur(plan);
-                    a_tg = (int)plan_act(plan, cur);
-                    plan = (plan & 0xf0ffffffu) | ((cur + 1u) << 24);
-                } else {
-                    a_tg = (int)dir;
-                }
-                tctr = ts.ctr;
-                dirty = true;
-            }
-            // _next_state (track_1v1.py:271-285): stay put iff the destination cell is a wall
-            {
-                int nr = r0 + (a_tr == 0 ? -1 : (a_tr == 1 ? 1 : 0)), nc = c0 + (a_tr == 2 ? -1 : (a_tr == 3 ? 1 : 0));
-                if (tile_bit(tile, nr, nc) == 0u) { r0 = nr; c0 = nc; }
-                nr = r1 + (a_tg == 0 ? -1 : (a_tg == 1 ? 1 : 0)); nc = c1 + (a_tg == 2 ? -1 : (a_tg == 3 ? 1 : 0));
-                if (tile_bit(tile, nr, nc) == 0u) { r1 = nr; c1 = nc; }
-            }
-            pos = (uint32_t)r0 | ((uint32_t)c0 << 8) | ((uint32_t)r1 << 16) | ((uint32_t)c1 << 24);
-            const int dr = r1 - r0, dc = c1 - c0;
-            d2 = (uint32_t)(dr * dr + dc * dc);
-            const double w_p = mode == TGT_PZR ? 1.0 : (mode == TGT_FAR ? -0.5 : 0.0); // track_1v1.py:147-152
-            double rt, rg;
-            reward_f64(d2, w_p, rt, rg);
-            c_far = d2 <= 36u ? 0 : min(c_far + 1, 255);  // distance <= 6 (track_1v1.py:106-109)
-            int dn = c_far > 10;
-            t = min(t + 1, 65535);
-            if (s.max_steps > 0 && t >= s.max_steps) dn = 1; // gym TimeLimit
-            cnt = (uint32_t)c_far | ((uint32_t)t << 8) | ((uint32_t)side << 24);
-            if (lane == 0) {
-                reinterpret_cast<float2 *>(rew)[e] = make_float2((float)rt, (float)rg);
-                done_out[e] = (uint8_t)dn;
-            }
-            do_reset = dn && s.auto_reset;
+            tctr = ts.ctr;
+            dirty = true;
         }
-
-        if (do_reset) {
-            episode = s.episode[e];
-            reset_env(s, e, tile, lane, cfg, pos, goals, cnt, episode, plan, tctr, navgoal, d2);
-            wave_lds_sync();
-            reinterpret_cast<uint4 *>(gtile)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
+        // _next_state (track_1v1.py:271-285): stay put iff the destination cell is a wall
+        {
+            int nr = r0 + (a_tr == 0 ? -1 : (a_tr == 1 ? 1 : 0)), nc = c0 + (a_tr == 2 ? -1 : (a_tr == 3 ? 1 : 0));
+            if (tile_bit(tile, nr, nc) == 0u) { r0 = nr; c0 = nc; }
+            nr = r1 + (a_tg == 0 ? -1 : (a_tg == 1 ? 1 : 0)); nc = c1 + (a_tg == 2 ? -1 : (a_tg == 3 ? 1 : 0));
+            if (tile_bit(tile, nr, nc) == 0u) { r1 = nr; c1 = nc; }
         }
-        if (lane == 0 && OP != OP_OBSERVE) {
-            if (OP == OP_STEP || do_reset) { s.pos[e] = pos; s.cnt[e] = cnt; s.d2[e] = d2; }
-            if (do_reset) { s.goals[e] = goals; s.episode[e] = episode; s.navgoal[e] = navgoal; }
-            if (do_reset || dirty) { s.plan[e] = plan; s.tctr[e] = tctr; }
-            if (s_navgoal_dirty && !do_reset) s.navgoal[e] = navgoal;
+        pos = (uint32_t)r0 | ((uint32_t)c0 << 8) | ((uint32_t)r1 << 16) | ((uint32_t)c1 << 24);
+        const int dr = r1 - r0, dc = c1 - c0;
+        d2 = (uint32_t)(dr * dr + dc * dc);
+        const double w_p = mode == TGT_PZR ? 1.0 : (mode == TGT_FAR ? -0.5 : 0.0); // track_1v1.py:147-152
+        double rt, rg;
+        reward_f64(d2, w_p, rt, rg);
+        c_far = d2 <= 36u ? 0 : min(c_far + 1, 255);  // distance <= 6 (track_1v1.py:106-109)
+        int dn = c_far > 10;
+        t = min(t + 1, 65535);
+        if (s.max_steps > 0 && t >= s.max_steps) dn = 1; // gym TimeLimit
+        cnt = (uint32_t)c_far | ((uint32_t)t << 8) | ((uint32_t)side << 24);
+        if (lane == 0) {
+            reinterpret_cast<float2 *>(rew)[e] = make_float2((float)rt, (float)rg);
+            done_out[e] = (uint8_t)dn;
         }
-        if (lane == 0) { s_pos[wave] = pos; s_side[wave] = (int)(cnt >> 24); }
+        consume = dn && s.auto_reset;
     }
-    __syncthreads();
 
-    // ---- phase B: _get_obs (track_1v1.py:287-326) for the block's envs, 16 B per lane per store ----------
-    if (obs == nullptr) return;
-    const int first = (int)blockIdx.x * kWavesPerBlock;
-    const int nloc = min(kWavesPerBlock, s.n - first);
-    const int nflt = nloc * kObsPerEnv;
-    float *out = obs + (size_t)first * kObsPerEnv;
-    for (int q = (int)threadIdx.x; q * 4 < nflt; q += (int)blockDim.x) {
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int f = q * 4 + j;
-            const int el = f / kObsPerEnv;
-            const int rem = f - el * kObsPerEnv;
-            const int ag = rem >= 169 ? 1 : 0;
-            const int ci = rem - ag * 169;
-            const int y = ci / 13, x = ci - y * 13;
-            const int eli = min(el, nloc - 1);
-            const uint32_t p = s_pos[eli];
-            const int side = s_side[eli];
-            const int tr_r = (int)(p & 0xffu), tr_c = (int)((p >> 8) & 0xffu);
-            const int tg_r = (int)((p >> 16) & 0xffu), tg_c = (int)(p >> 24);
-            const int rr = (ag ? tg_r : tr_r) - T2D_POB + y, cc = (ag ? tg_c : tr_c) - T2D_POB + x;
-            float val = 1.0f; // np.pad(..., constant_values=1) outside the map (track_1v1.py:321)
-            if ((unsigned)rr < (unsigned)side && (unsigned)cc < (unsigned)side) {
-                val = (float)tile_bit(tiles[eli], rr, cc);
-                if (rr == tr_r && cc == tr_c) val = 2.0f;          // tracker, track_1v1.py:300-305
-                if (rr == tg_r && cc == tg_c) val = 4.0f;          // target painted last
-                if (ci == 84) val = ag ? 4.0f : 2.0f;              // own cell re-painted, :313
-            }
-            v[j] = val;
+    if (OP != OP_OBSERVE && consume) {
+        // Track1v1Env.reset(): switch to the pre-generated next episode (k_gen) — one 1 KiB tile copy + scalars
+        const uint4 nt = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)e * kTileWords)[lane];
+        reinterpret_cast<uint4 *>(tile)[lane] = nt;
+        reinterpret_cast<uint4 *>(gtile)[lane] = nt;
+        if (NAV && mode == TGT_NAV) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(s.n_dirf + (size_t)e * kDirWords);
+            uint4 *dst = reinterpret_cast<uint4 *>(s.dirf + (size_t)e * kDirWords);
+            dst[lane] = src[lane]; dst[lane + 64] = src[lane + 64];
         }
-        if (q * 4 + 3 < nflt) reinterpret_cast<float4 *>(out)[q] = make_float4(v[0], v[1], v[2], v[3]);
-        else
-            for (int j = 0; j < 4; j++)
-                if (q * 4 + j < nflt) out[q * 4 + j] = v[j];
+        pos = s.n_pos[e]; plan = s.n_plan[e]; tctr = s.n_tctr[e]; navgoal = s.n_navgoal[e]; d2 = s.n_d2[e];
+        cnt = (uint32_t)side_of_cfg(cfg) << 24;
+        if (lane == 0) {
+            s.goals[e] = s.n_goals[e]; s.episode[e] = s.episode[e] + 1u; s.navgoal[e] = navgoal;
+            s.gen_req[e] = stamp;
+        }
+        wave_lds_sync();
     }
+    if (lane == 0 && OP != OP_OBSERVE) {
+        if (OP == OP_STEP || consume) { s.pos[e] = pos; s.cnt[e] = cnt; s.d2[e] = d2; }
+        if (consume || dirty) { s.plan[e] = plan; s.tctr[e] = tctr; }
+        if (navgoal_dirty && !consume) s.navgoal[e] = navgoal;
+    }
+    if (obs != nullptr) emit_obs(tile, stages[wave], pos, (int)(cnt >> 24), lane, obs + (size_t)e * kObsPerEnv);
 }
 
 __global__ void k_reward_table(const uint32_t *d2, int n, double w_p, float *r_track, float *r_target)
@@ -318,8 +370,12 @@ using namespace t2d;
 struct t2d_handle {
     DevState s;
     int device;
-    bool reset_done;
+    bool reset_done;   // every env has a current episode
+    bool primed;       // every env has a valid next slot
+    bool has_nav;
     uint32_t random_step;
+    uint32_t gen_every; // generator launch period in steps (see step_impl)
+    uint32_t phase;     // steps since the last generator launch = stamp of the last step launch
 };
 
 static thread_local char g_err[512] = "";
@@ -388,26 +444,30 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     if (!h) return fail(T2D_ERR_INVALID, "t2d_create: out of host memory");
     std::memset(&h->s, 0, sizeof(h->s));
     h->device = cfg->device;
-    h->reset_done = false;
-    h->random_step = 0;
+    h->reset_done = false; h->primed = false; h->has_nav = has_nav;
+    h->random_step = 0; h->phase = 0;
+    // A slot consumed at step q cannot be needed again before step q + min(11, max_episode_steps): done needs 11
+    // consecutive far steps (track_1v1.py:106-111) or the TimeLimit. Launching the generator every G <= that many
+    // steps, in order on the caller's stream, therefore always refills a slot before its next use.
+    h->gen_every = 10u;
+    if (cfg->max_episode_steps > 0 && (uint32_t)cfg->max_episode_steps < h->gen_every) h->gen_every = (uint32_t)cfg->max_episode_steps;
     DevState &s = h->s;
     s.n = n; s.env_base = cfg->env_id_base;
     s.k0 = (uint32_t)cfg->seed; s.k1 = (uint32_t)(cfg->seed >> 32);
     s.max_steps = cfg->max_episode_steps; s.auto_reset = cfg->auto_reset ? 1 : 0;
-    const size_t nb = (size_t)n * sizeof(uint32_t);
-    uint32_t **arrs[] = {&s.pos, &s.goals, &s.cnt, &s.cfg, &s.episode, &s.plan, &s.tctr, &s.navgoal, &s.d2};
-    hipError_t err = hipMalloc((void **)&s.maps, (size_t)n * kTileWords * sizeof(uint32_t));
-    if (err == hipSuccess) err = hipMemset(s.maps, 0, (size_t)n * kTileWords * sizeof(uint32_t));
-    for (auto a : arrs) {
-        if (err == hipSuccess) err = hipMalloc((void **)a, nb);
-        if (err == hipSuccess) err = hipMemset(*a, 0, nb);
-    }
-    if (has_nav) {
-        if (err == hipSuccess) err = hipMalloc((void **)&s.dirf, (size_t)n * kDirWords * sizeof(uint32_t));
-        if (err == hipSuccess) err = hipMemset(s.dirf, 0, (size_t)n * kDirWords * sizeof(uint32_t));
-    }
-    if (err == hipSuccess) err = hipMalloc((void **)&s.faults, sizeof(uint32_t));
-    if (err == hipSuccess) err = hipMemset(s.faults, 0, sizeof(uint32_t));
+    const size_t nb = (size_t)n * sizeof(uint32_t), tb = (size_t)n * kTileWords * sizeof(uint32_t),
+                 db = (size_t)n * kDirWords * sizeof(uint32_t);
+    hipError_t err = hipSuccess;
+    auto alloc = [&](uint32_t **p, size_t bytes) {
+        if (err == hipSuccess) err = hipMalloc((void **)p, bytes);
+        if (err == hipSuccess) err = hipMemset(*p, 0, bytes);
+    };
+    alloc(&s.maps, tb); alloc(&s.n_maps, tb);
+    uint32_t **arrs[] = {&s.pos, &s.goals, &s.cnt, &s.cfg, &s.episode, &s.plan, &s.tctr, &s.navgoal, &s.d2,
+                         &s.n_pos, &s.n_goals, &s.n_plan, &s.n_tctr, &s.n_navgoal, &s.n_d2, &s.gen_req};
+    for (auto a : arrs) alloc(a, nb);
+    if (has_nav) { alloc(&s.dirf, db); alloc(&s.n_dirf, db); }
+    alloc(&s.faults, sizeof(uint32_t));
     if (err == hipSuccess) err = hipMemcpy(s.cfg, hcfg.data(), nb, hipMemcpyHostToDevice);
     if (err != hipSuccess) {
         t2d_destroy(h);
@@ -422,7 +482,8 @@ extern "C" int t2d_destroy(t2d_handle *h)
     if (!h) return T2D_OK;
     DeviceGuard guard(h->device);
     DevState &s = h->s;
-    void *ptrs[] = {s.maps, s.pos, s.goals, s.cnt, s.cfg, s.episode, s.plan, s.tctr, s.navgoal, s.d2, s.dirf, s.faults};
+    void *ptrs[] = {s.maps, s.n_maps, s.pos, s.goals, s.cnt, s.cfg, s.episode, s.plan, s.tctr, s.navgoal, s.d2,
+                    s.n_pos, s.n_goals, s.n_plan, s.n_tctr, s.n_navgoal, s.n_d2, s.gen_req, s.dirf, s.n_dirf, s.faults};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -431,12 +492,68 @@ extern "C" int t2d_destroy(t2d_handle *h)
 
 static inline dim3 env_grid(int n) { return dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)); }
 
+static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t upto, int force)
+{
+    if (h->has_nav) hipLaunchKernelGGL((k_gen<true>), env_grid(h->s.n), dim3(256), 0, st, h->s, upto, force);
+    else hipLaunchKernelGGL((k_gen<false>), env_grid(h->s.n), dim3(256), 0, st, h->s, upto, force);
+}
+
+template <int OP, bool RANDOM>
+static void launch_env(t2d_handle *h, hipStream_t st, const void *a0, const void *a1, int adt, const uint8_t *mask,
+                       float *obs, float *rew, uint8_t *done, uint32_t slo, uint32_t shi, uint32_t sidx, uint32_t stamp)
+{
+    if (h->has_nav)
+        hipLaunchKernelGGL((k_env<OP, RANDOM, true>), env_grid(h->s.n), dim3(256), 0, st, h->s, a0, a1, adt, mask, obs,
+                           rew, done, slo, shi, sidx, stamp);
+    else
+        hipLaunchKernelGGL((k_env<OP, RANDOM, false>), env_grid(h->s.n), dim3(256), 0, st, h->s, a0, a1, adt, mask, obs,
+                           rew, done, slo, shi, sidx, stamp);
+}
+
+// Regenerate every consumed next-episode slot, in order on `st`, and restart the stamps.
+static int flush_impl(t2d_handle *h, hipStream_t st)
+{
+    if (h->s.auto_reset && h->phase != 0u) {
+        launch_gen(h, st, h->phase, 0);
+        HIP_TRY(hipGetLastError());
+    }
+    h->phase = 0;
+    return T2D_OK;
+}
+
+extern "C" int t2d_flush(t2d_handle *h, void *stream)
+{
+    if (!h) return fail(T2D_ERR_INVALID, "t2d_flush: null handle");
+    DeviceGuard guard(h->device);
+    return flush_impl(h, (hipStream_t)stream);
+}
+
+template <bool RANDOM>
+static int step_impl(t2d_handle *h, hipStream_t st, const void *a0, const void *a1, int adt, float *obs, float *rew,
+                     uint8_t *done, uint32_t slo, uint32_t shi, uint32_t sidx)
+{
+    if (h->s.auto_reset) h->phase++;
+    launch_env<OP_STEP, RANDOM>(h, st, a0, a1, adt, nullptr, obs, rew, done, slo, shi, sidx, h->phase);
+    HIP_TRY(hipGetLastError());
+    if (h->s.auto_reset && h->phase >= h->gen_every) return flush_impl(h, st);
+    return T2D_OK;
+}
+
 extern "C" int t2d_reset(t2d_handle *h, const uint8_t *mask_dev, float *obs_dev, void *stream)
 {
     if (!h) return fail(T2D_ERR_INVALID, "t2d_reset: null handle");
     DeviceGuard guard(h->device);
-    hipLaunchKernelGGL((k_env<OP_RESET, false>), env_grid(h->s.n), dim3(256), 0, (hipStream_t)stream, h->s,
-                       nullptr, nullptr, 0, mask_dev, obs_dev, nullptr, nullptr, 0u, 0u, 0u);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = flush_impl(h, st);
+    if (rc) return rc;
+    if (!h->primed) { // first use: generate episode 1 into every next slot
+        launch_gen(h, st, 0u, 1);
+        h->primed = true;
+    }
+    if (mask_dev != nullptr && !h->reset_done)
+        return fail(T2D_ERR_STATE, "t2d_reset: the first reset must cover every env (mask == NULL)");
+    launch_env<OP_RESET, false>(h, st, nullptr, nullptr, 0, mask_dev, obs_dev, nullptr, nullptr, 0u, 0u, 0u, 1u);
+    launch_gen(h, st, 1u, 0); // refill the consumed next slots, in order on the caller's stream
     HIP_TRY(hipGetLastError());
     if (mask_dev == nullptr) h->reset_done = true;
     return T2D_OK;
@@ -449,11 +566,10 @@ extern "C" int t2d_step(t2d_handle *h, const void *act_tracker_dev, const void *
     if (!act_tracker_dev || !rew_dev || !done_dev) return fail(T2D_ERR_INVALID, "t2d_step: null buffer");
     if (act_dtype < T2D_ACT_U8 || act_dtype > T2D_ACT_I64) return fail(T2D_ERR_INVALID, "t2d_step: act_dtype %d", act_dtype);
     if (!h->reset_done) return fail(T2D_ERR_STATE, "t2d_step: call t2d_reset (all envs) or t2d_inject first");
+    if (h->s.auto_reset && !h->primed) return fail(T2D_ERR_STATE, "t2d_step: auto_reset needs one t2d_reset before stepping");
     DeviceGuard guard(h->device);
-    hipLaunchKernelGGL((k_env<OP_STEP, false>), env_grid(h->s.n), dim3(256), 0, (hipStream_t)stream, h->s,
-                       act_tracker_dev, act_target_dev, act_dtype, nullptr, obs_dev, rew_dev, done_dev, 0u, 0u, 0u);
-    HIP_TRY(hipGetLastError());
-    return T2D_OK;
+    return step_impl<false>(h, (hipStream_t)stream, act_tracker_dev, act_target_dev, act_dtype, obs_dev, rew_dev,
+                            done_dev, 0u, 0u, 0u);
 }
 
 extern "C" int t2d_step_random(t2d_handle *h, int steps, uint64_t action_seed, float *obs_dev, float *rew_dev,
@@ -461,14 +577,13 @@ extern "C" int t2d_step_random(t2d_handle *h, int steps, uint64_t action_seed, f
 {
     if (!h) return fail(T2D_ERR_INVALID, "t2d_step_random: null handle");
     if (!rew_dev || !done_dev || steps < 0) return fail(T2D_ERR_INVALID, "t2d_step_random: bad argument");
-    if (!h->reset_done) return fail(T2D_ERR_STATE, "t2d_step_random: reset first");
+    if (!h->reset_done || (h->s.auto_reset && !h->primed)) return fail(T2D_ERR_STATE, "t2d_step_random: reset first");
     DeviceGuard guard(h->device);
     for (int i = 0; i < steps; i++) {
-        hipLaunchKernelGGL((k_env<OP_STEP, true>), env_grid(h->s.n), dim3(256), 0, (hipStream_t)stream, h->s,
-                           nullptr, nullptr, 0, nullptr, obs_dev, rew_dev, done_dev, (uint32_t)action_seed,
-                           (uint32_t)(action_seed >> 32), h->random_step++);
+        int rc = step_impl<true>(h, (hipStream_t)stream, nullptr, nullptr, 0, obs_dev, rew_dev, done_dev,
+                                 (uint32_t)action_seed, (uint32_t)(action_seed >> 32), h->random_step++);
+        if (rc) return rc;
     }
-    HIP_TRY(hipGetLastError());
     return T2D_OK;
 }
 
@@ -476,9 +591,18 @@ extern "C" int t2d_observe(t2d_handle *h, float *obs_dev, void *stream)
 {
     if (!h || !obs_dev) return fail(T2D_ERR_INVALID, "t2d_observe: null argument");
     DeviceGuard guard(h->device);
-    hipLaunchKernelGGL((k_env<OP_OBSERVE, false>), env_grid(h->s.n), dim3(256), 0, (hipStream_t)stream, h->s,
-                       nullptr, nullptr, 0, nullptr, obs_dev, nullptr, nullptr, 0u, 0u, 0u);
+    launch_env<OP_OBSERVE, false>(h, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, obs_dev, nullptr, nullptr, 0u, 0u,
+                                  0u, 0u);
     HIP_TRY(hipGetLastError());
+    return T2D_OK;
+}
+
+// Host-side accessors first refill pending slots, then synchronise (they are test/evaluator calls).
+static int quiesce(t2d_handle *h, hipStream_t st)
+{
+    int rc = flush_impl(h, st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
     return T2D_OK;
 }
 
@@ -499,6 +623,7 @@ extern "C" int t2d_inject(t2d_handle *h, int first, int count, int side, const u
     if (!maze_host || !pos_host) return fail(T2D_ERR_INVALID, "t2d_inject: null buffer");
     if (count == 0) return T2D_OK;
     DeviceGuard guard(h->device);
+    if ((rc = quiesce(h, (hipStream_t)stream))) return rc;
     std::vector<uint32_t> tiles((size_t)count * kTileWords, 0u), pos((size_t)count), goals((size_t)count, 0u),
         cnt((size_t)count), zero((size_t)count, 0u), d2((size_t)count), navgoal((size_t)count);
     for (int i = 0; i < count; i++) {
@@ -549,6 +674,7 @@ extern "C" int t2d_inject_plan(t2d_handle *h, int env, const int32_t *plan_host,
         p |= (uint32_t)plan_host[i] << (2 * i);
     }
     DeviceGuard guard(h->device);
+    if ((rc = quiesce(h, (hipStream_t)stream))) return rc;
     HIP_TRY(hipMemcpyAsync(h->s.plan + env, &p, sizeof(p), hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return T2D_OK;
@@ -570,6 +696,7 @@ extern "C" int t2d_get_state(t2d_handle *h, int first, int count, int32_t *pos_h
     if (count == 0) return T2D_OK;
     DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
+    if ((rc = quiesce(h, st))) return rc;
     std::vector<uint32_t> pos, goals, cnt, ep, d2;
     if ((rc = fetch(h->s.pos, first, count, pos, st))) return rc;
     if ((rc = fetch(h->s.goals, first, count, goals, st))) return rc;
@@ -599,6 +726,7 @@ extern "C" int t2d_get_maps(t2d_handle *h, int first, int count, uint8_t *maps_h
     if (count == 0) return T2D_OK;
     DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
+    if ((rc = quiesce(h, st))) return rc;
     std::vector<uint32_t> tiles((size_t)count * kTileWords);
     HIP_TRY(hipMemcpyAsync(tiles.data(), h->s.maps + (size_t)first * kTileWords, tiles.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -620,6 +748,7 @@ extern "C" int t2d_get_target(t2d_handle *h, int first, int count, int32_t *plan
     if (count == 0) return T2D_OK;
     DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
+    if ((rc = quiesce(h, st))) return rc;
     std::vector<uint32_t> plan, ng;
     if ((rc = fetch(h->s.plan, first, count, plan, st))) return rc;
     if ((rc = fetch(h->s.navgoal, first, count, ng, st))) return rc;

@@ -88,6 +88,9 @@ class VecEnv(object):
         obs, rew, done = self.core.step(a0, a1)
         return self._stack(obs, done), rew, done, {}
 
+    def flush(self):
+        self.core.flush()
+
     def close(self):
         self.core.close()
 

@@ -72,6 +72,8 @@ def rollout(player, num_steps):
         player.model.cache_dense(True)   # expand conv weights once per rollout (released in compute_grads)
     for _ in range(num_steps):
         player.action_train()
+    if hasattr(player.env, "flush"):
+        player.env.flush()               # join the env's generator stream (required before a hipGraph capture ends)
 
 
 class GraphedIteration(object):

@@ -43,7 +43,7 @@ _lib = None
 ABI_SYMBOLS = (
     "t2d_last_error", "t2d_abi_version", "t2d_create", "t2d_destroy", "t2d_num_envs", "t2d_reset", "t2d_step",
     "t2d_observe", "t2d_inject", "t2d_inject_plan", "t2d_get_state", "t2d_get_maps", "t2d_get_target",
-    "t2d_get_faults", "t2d_step_random", "t2d_reward_table",
+    "t2d_get_faults", "t2d_step_random", "t2d_reward_table", "t2d_flush",
 )
 
 
@@ -71,6 +71,8 @@ def load_library():
     L.t2d_step.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     L.t2d_observe.restype = i32
     L.t2d_observe.argtypes = [vp, vp, vp]
+    L.t2d_flush.restype = i32
+    L.t2d_flush.argtypes = [vp, vp]
     L.t2d_inject.restype = i32
     L.t2d_inject.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.t2d_inject_plan.restype = i32
@@ -212,6 +214,10 @@ class VecTrack2D(object):
         _check(self.L.t2d_step_random(self.h, int(steps), int(action_seed), C.c_void_p(obs.data_ptr()),
                                       C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), self._stream()))
         return obs, rew, done
+
+    def flush(self):
+        """Join the library's generator stream into the current stream (see t2d_flush in include/track2d.h)."""
+        _check(self.L.t2d_flush(self.h, self._stream()))
 
     def observe(self, out=None):
         obs = out if out is not None else self._new_obs()

@@ -92,6 +92,12 @@ int t2d_reset(t2d_handle *h, const uint8_t *mask_dev, float *obs_dev, void *stre
 int t2d_step(t2d_handle *h, const void *act_tracker_dev, const void *act_target_dev, int act_dtype,
              float *obs_dev, float *rew_dev, uint8_t *done_dev, void *stream);
 
+/* With auto_reset, finished envs switch to a pre-generated "next episode" slot inside the step launch; the
+ * library refills consumed slots with a generator launch every <= 10 steps on the caller's stream (a slot
+ * cannot be needed again sooner: done needs 11 consecutive far steps). t2d_flush runs the generator now for
+ * whatever is pending (used before state readback; t2d_reset / t2d_inject / t2d_get_* flush implicitly). */
+int t2d_flush(t2d_handle *h, void *stream);
+
 /* _get_obs() of the current state without stepping (G/envs/track_1v1.py:287-293). */
 int t2d_observe(t2d_handle *h, float *obs_dev, void *stream);
 

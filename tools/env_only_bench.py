@@ -12,9 +12,19 @@ ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--warmup", type=int, default=200)
 ap.add_argument("--no-auto-reset", action="store_true")
+ap.add_argument("--no-obs", action="store_true")
 args = ap.parse_args()
 env = VecTrack2D(args.env, num_envs=args.n, seed=1, auto_reset=not args.no_auto_reset)
 out = (env.reset(), torch.empty((args.n, 2), device="cuda"), torch.empty((args.n,), dtype=torch.uint8, device="cuda"))
+if args.no_obs:
+    import ctypes as C
+    class _Null(object):
+        def data_ptr(self): return None
+    _real = out
+    def _sr(steps):
+        from active_tracking_rl_amd.vec_env import _check
+        _check(env.L.t2d_step_random(env.h, int(steps), 1, None, C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()), env._stream()))
+    env.step_random = lambda steps, seed, o: _sr(steps)
 env.step_random(args.warmup, 1, out)
 torch.cuda.synchronize()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
