@@ -71,6 +71,38 @@ def sample_action(logit, test=False):
     return action, entropy, log_prob
 
 
+def lstm_sequence(lstm, feats, h, c, keep):
+    """Run an nn.LSTMCell over a time-major feature sequence with the per-step episode-boundary mask applied AFTER
+    each step (what Agent.action_train does): feats [T, N, F], h/c [N, R], keep [T, N] (0 where the env finished at
+    that step). The input projection is ONE GEMM over all T*N rows; only the hidden GEMM + pointwise are sequential.
+    Returns h_seq [T, N, R] (the hidden state each step's heads see), and the final masked (h, c)."""
+    T, N = feats.shape[0], feats.shape[1]
+    igates = F.linear(feats.reshape(T * N, -1), lstm.weight_ih).view(T, N, -1)
+    fused = feats.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell")
+    outs = []
+    for t in range(T):
+        hgates = F.linear(h, lstm.weight_hh)
+        if fused:
+            h, c, _ = torch.ops.aten._thnn_fused_lstm_cell(igates[t], hgates, c, lstm.bias_ih, lstm.bias_hh)
+        else:
+            g = igates[t] + hgates + lstm.bias_ih + lstm.bias_hh
+            i, f, gg, o = g.chunk(4, 1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+        k = keep[t].unsqueeze(1)
+        h, c = h * k, c * k
+    return torch.stack(outs, 0), h, c
+
+
+def policy_stats(logit, action):
+    """entropy and log-prob of given actions (the train branch of sample_action with the action fixed)."""
+    prob = F.softmax(logit, dim=1)
+    log_prob = F.log_softmax(logit, dim=1)
+    entropy = -(log_prob * prob).sum(1, keepdim=True)
+    return entropy, log_prob.gather(1, action.unsqueeze(1))
+
+
 class ValueNet(nn.Module):
     def __init__(self, input_dim):
         super(ValueNet, self).__init__()
@@ -254,6 +286,18 @@ class A3C(nn.Module):
         return value, action, entropy, log_prob, (hx, cx)
 
 
+    def forward_sequence(self, x_seq, actions, h, c, keep):
+        """Time-batched re-evaluation of T stored steps: x_seq [T, N, F, C, 13, 13], actions [T, N] -> values [T,N,1],
+        entropies [T,N,1], log_probs [T,N,1], final (h, c). Same math as T calls of forward()."""
+        T, N = x_seq.shape[0], x_seq.shape[1]
+        feats = self.encoder(x_seq.reshape(T * N, *x_seq.shape[2:])).view(T, N, -1)
+        h_seq, h, c = lstm_sequence(self.lstm, feats, h, c, keep)
+        flat = h_seq.reshape(T * N, -1)
+        value = self.critic(flat)
+        entropy, log_prob = policy_stats(self.actor.actor_linear(flat), actions.reshape(T * N))
+        return value.view(T, N, 1), entropy.view(T, N, 1), log_prob.view(T, N, 1), (h, c)
+
+
 class TAT(nn.Module):
     """Tracker-aware target, model.py:148-209."""
 
@@ -289,6 +333,19 @@ class TAT(nn.Module):
         action, entropy, log_prob = self.actor(hx, test)
         R_pred = self.reward_aux(hx) if self.sub_task else None
         return value, action, entropy, log_prob, (hx, cx), R_pred
+
+
+    def forward_sequence(self, x_seq, actions, action_tracker, h, c, keep):
+        """x_seq [T, N, 2F, C, 13, 13] (tracker frames then target frames), action_tracker one-hot [T, N, n_act]."""
+        T, N = x_seq.shape[0], x_seq.shape[1]
+        feats = self.encoder(x_seq.reshape(T * N, *x_seq.shape[2:]))
+        feats = (feats + self.fc_action_tracker(action_tracker.reshape(T * N, -1))).view(T, N, -1)
+        h_seq, h, c = lstm_sequence(self.lstm, feats, h, c, keep)
+        flat = h_seq.reshape(T * N, -1)
+        value = self.critic(flat)
+        entropy, log_prob = policy_stats(self.actor.actor_linear(flat), actions.reshape(T * N))
+        R_pred = self.reward_aux(flat).view(T, N, 1) if self.sub_task else None
+        return value.view(T, N, 1), entropy.view(T, N, 1), log_prob.view(T, N, 1), (h, c), R_pred
 
 
 class A3C_Dueling(nn.Module):
@@ -355,6 +412,23 @@ class A3C_Dueling(nn.Module):
                torch.stack([log_prob_0, log_prob_1], 1), (torch.stack([hx_0, hx1], 1), torch.stack([cx_0, cx1], 1)),
                R_pred)
         return self._to_ref(out) if ref_layout else out
+
+    def forward_sequence(self, states_seq, actions_seq, hx, cx, keep):
+        """Re-evaluate T stored steps with gradients, time-batched (the learner half of the rollout driver):
+        states_seq [T, N, 2, stack, C, 13, 13], actions_seq [T, N, 2] int64, hx/cx [N, 2, R] at the start of the
+        rollout, keep [T, N] float (0 where the env finished at that step). Returns values [T,N,2,1], entropies
+        [T,N,2,1], log_probs [T,N,2,1], R_pred [T,N,1] (0 when not tat). Numerically the same quantities as T calls
+        of forward() with those actions; the encoder and all heads run as single GEMMs over T*N rows."""
+        T, N = states_seq.shape[0], states_seq.shape[1]
+        v0, e0, l0, _ = self.player0.forward_sequence(states_seq[:, :, 0], actions_seq[:, :, 0], hx[:, 0], cx[:, 0], keep)
+        R_pred = 0
+        if self.tat:
+            a2t = F.one_hot(actions_seq[:, :, 0], self.action_dim_tracker).to(states_seq.dtype)
+            x1 = states_seq.reshape(T, N, -1, states_seq.shape[4], states_seq.shape[5], states_seq.shape[6])
+            v1, e1, l1, _, R_pred = self.player1.forward_sequence(x1, actions_seq[:, :, 1], a2t, hx[:, 1], cx[:, 1], keep)
+        else:
+            v1, e1, l1, _ = self.player1.forward_sequence(states_seq[:, :, 1], actions_seq[:, :, 1], hx[:, 1], cx[:, 1], keep)
+        return torch.stack([v0, v1], 2), torch.stack([e0, e1], 2), torch.stack([l0, l1], 2), R_pred
 
     @staticmethod
     def _to_ref(out):

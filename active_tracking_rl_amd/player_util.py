@@ -33,6 +33,7 @@ class Agent(object):
         self.device = device
         self.rnn_out = args.rnn_out
         self.values, self.log_probs, self.rewards, self.entropies, self.preds, self.dones = [], [], [], [], [], []
+        self.states, self.actions, self.h0, self.c0 = [], [], None, None
         self.done = torch.ones(self.num_envs, dtype=torch.uint8, device=device)
         self.info = None
         self.reward = 0
@@ -70,6 +71,34 @@ class Agent(object):
         self.dones.append(done)
         return self
 
+    def action_rollout(self):
+        """Actor half of the fast path: the same step as action_train, but the policy runs without building an
+        autograd graph; what the learner needs to re-evaluate the step (state, actions, done) is stored instead."""
+        self.n_steps += 1
+        with torch.no_grad():
+            _, action_env_multi, _, _, (self.hxs, self.cxs), _ = self.model((self.state, (self.hxs, self.cxs)))
+        self.states.append(self.state)
+        self.actions.append(torch.stack(action_env_multi, 1))
+        state_multi, reward_multi, done, self.info = self.env.step(action_env_multi)
+        self.reward_org = reward_multi
+        self.reward = reward_multi
+        self.state = state_multi
+        self.done = done
+        keep = (done == 0)
+        self.eps_len = (self.eps_len + 1) * keep.to(self.eps_len.dtype)
+        k = keep.to(self.hxs.dtype).view(-1, 1, 1)
+        self.hxs = self.hxs * k
+        self.cxs = self.cxs * k
+        self.rewards.append(reward_multi.unsqueeze(2))
+        self.dones.append(done)
+        return self
+
+    def begin_rollout(self):
+        """Remember the LSTM state the rollout starts from (the learner re-runs the recurrence from it)."""
+        self.update_rnn_hiden()
+        self.h0, self.c0 = self.hxs, self.cxs
+        self.states, self.actions = [], []
+
     def action_test(self):
         with torch.no_grad():
             value_multi, action_env_multi, entropy, log_prob, (self.hxs, self.cxs), R_pred = self.model(
@@ -93,6 +122,7 @@ class Agent(object):
 
     def clear_actions(self):
         self.values, self.log_probs, self.rewards, self.entropies, self.preds, self.dones = [], [], [], [], [], []
+        self.states, self.actions = [], []
         return self
 
     def reset_rnn_hiden(self):
@@ -145,9 +175,54 @@ class Agent(object):
             loss = loss + pred_loss.mean()
         return loss, policy_loss, value_loss, entropies, pred_loss
 
+    def loss_recompute(self, training_mode):
+        """Learner half of the fast path: the loss of player_util.py:108-154 over the stored rollout, evaluated
+        time-batched. The n-step returns R_t and the GAE terms use only rewards, done flags and DETACHED values
+        (`.data` at :135), so they are constants computed first; the differentiable part is then one vectorised
+        expression over [T, N, A]. Same value and gradients as loss() on an action_train rollout."""
+        args = self.args
+        N, A, T = self.num_envs, self.num_agents, len(self.rewards)
+        dev = self.device
+        states = torch.stack(self.states, 0)
+        actions = torch.stack(self.actions, 0)
+        rewards = torch.stack(self.rewards, 0)                               # [T, N, A, 1]
+        nd = (torch.stack(self.dones, 0) == 0).to(rewards.dtype)             # [T, N]
+        values, entropies, log_probs, preds = self.model.forward_sequence(states, actions, self.h0, self.c0, nd)
+        with torch.no_grad():
+            boot, _, _, _, _, _ = self.model((self.state, (self.hxs, self.cxs)))
+            v = torch.cat([values.detach(), boot.unsqueeze(0)], 0)           # [T+1, N, A, 1]
+            ndv = nd.view(T, N, 1, 1)
+            R = torch.empty_like(rewards)
+            gae = torch.empty_like(rewards)
+            r_run, g_run = v[T], torch.zeros_like(v[T])
+            for i in reversed(range(T)):
+                r_run = args.gamma * r_run * ndv[i] + rewards[i]
+                delta_t = rewards[i] + args.gamma * v[i + 1] * ndv[i] - v[i]
+                g_run = g_run * args.gamma * args.tau * ndv[i] + delta_t
+                R[i], gae[i] = r_run, g_run
+        w_entropies = float(args.entropy) * torch.ones(1, 1, A, 1, device=dev)
+        if A > 1:
+            w_entropies[:, :, 1:] = float(self.w_entropy_target)
+        value_loss = (0.5 * (R - values).pow(2)).sum(0)                      # [N, A, 1]
+        policy_loss = (-(log_probs * gae) - w_entropies * entropies).sum(0)
+        use_aux = 'reward' in args.aux
+        pred_loss = (preds - rewards[:, :, 0]).abs().sum(0) if use_aux else torch.zeros(N, 1, device=dev)
+        loss_tracker = (policy_loss[:, 0] + 0.5 * value_loss[:, 0]).mean()
+        loss_target = (policy_loss[:, 1] + 0.5 * value_loss[:, 1]).mean() if A > 1 else 0
+        if training_mode == 0:
+            loss = loss_tracker
+        elif training_mode == 1:
+            loss = loss_target
+        else:
+            loss = loss_tracker + loss_target
+        if use_aux and training_mode != 0:
+            loss = loss + pred_loss.mean()
+        return loss, policy_loss, value_loss, entropies.detach().sum(0), pred_loss
+
     def compute_grads(self, optimizer, training_mode):
         """loss -> backward into the flat gradient bucket (hipGraph-capturable: no host sync)."""
-        loss, policy_loss, value_loss, entropies, pred_loss = self.loss(training_mode)
+        fast = len(self.states) > 0
+        loss, policy_loss, value_loss, entropies, pred_loss = (self.loss_recompute if fast else self.loss)(training_mode)
         optimizer.zero_grad()
         loss.backward()
         self.clear_actions()

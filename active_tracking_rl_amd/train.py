@@ -65,13 +65,20 @@ def make_player(args, device, rank=0, world_size=1, env=None, model=None, optimi
     return player, optimizer
 
 
-def rollout(player, num_steps):
-    """train.py:79-88 without the early break (done is a per-env mask)."""
-    player.update_rnn_hiden()
+def rollout(player, num_steps, fast=True):
+    """train.py:79-88 without the early break (done is a per-env mask). fast=True: actor/learner split — the policy
+    steps without autograd (action_rollout) and Agent.loss_recompute re-evaluates the stored rollout time-batched;
+    fast=False: the reference-shaped per-step autograd path (action_train + loss)."""
     if hasattr(player.model, "cache_dense"):
         player.model.cache_dense(True)   # expand conv weights once per rollout (released in compute_grads)
-    for _ in range(num_steps):
-        player.action_train()
+    if fast:
+        player.begin_rollout()
+        for _ in range(num_steps):
+            player.action_rollout()
+    else:
+        player.update_rnn_hiden()
+        for _ in range(num_steps):
+            player.action_train()
     if hasattr(player.env, "flush"):
         player.env.flush()               # join the env's generator stream (required before a hipGraph capture ends)
 
@@ -85,8 +92,8 @@ class GraphedIteration(object):
     in static tensors that the captured region reads first and writes last; the env state itself is device-resident
     inside the HIP library."""
 
-    def __init__(self, player, optimizer, args, warmup=2):
-        self.player, self.optimizer, self.args = player, optimizer, args
+    def __init__(self, player, optimizer, args, warmup=2, fast=True):
+        self.player, self.optimizer, self.args, self.fast = player, optimizer, args, fast
         dev = player.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -101,7 +108,7 @@ class GraphedIteration(object):
         with torch.cuda.graph(self.g_roll):
             player.state, player.hxs, player.cxs = self.carry["state"], self.carry["hxs"], self.carry["cxs"]
             player.done, player.eps_len = self.carry["done"], self.carry["eps_len"]
-            rollout(player, args.num_steps)
+            rollout(player, args.num_steps, fast=fast)
             self.stats = player.compute_grads(optimizer, args.train_mode)
             self.carry["state"].copy_(player.state)
             self.carry["hxs"].copy_(player.hxs.detach())
@@ -114,7 +121,7 @@ class GraphedIteration(object):
         player.done, player.eps_len = self.carry["done"], self.carry["eps_len"]
 
     def _eager(self):
-        rollout(self.player, self.args.num_steps)
+        rollout(self.player, self.args.num_steps, fast=self.fast)
         self.player.optimize(None, self.optimizer, self.player.model, self.args.train_mode, self.player.device)
 
     def run(self):

@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--network", default="tat-maze-lstm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the iteration eagerly instead of as hipGraphs")
+    ap.add_argument("--per-step-autograd", action="store_true",
+                    help="reference-shaped learner (autograd graph built during the rollout) instead of the "
+                         "actor/learner split with time-batched re-evaluation")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     a = ap.parse_args()
 
@@ -76,13 +79,13 @@ def main():
     player, optimizer = make_player(args, device, rank, world)
 
     def eager_iteration():
-        rollout(player, T)
+        rollout(player, T, fast=not a.per_step_autograd)
         player.optimize(None, optimizer, player.model, args.train_mode, device)
 
     iteration, graphed = eager_iteration, False
     if not a.no_graph:
         try:
-            iteration = GraphedIteration(player, optimizer, args).run
+            iteration = GraphedIteration(player, optimizer, args, fast=not a.per_step_autograd).run
             graphed = True
         except Exception as ex:  # fall back to eager, and say so in the JSON line
             print("hipGraph capture failed, running eagerly: %r" % (ex,), file=sys.stderr)
@@ -109,22 +112,37 @@ def main():
     value = steps * n_total / dt
 
     # ---- roofline of the step/observe kernel: HIP events on the launch stream --------------------------
+    # M policy-shaped launches (int64 action tensors, fresh per launch) are captured once into a hipGraph and
+    # replayed, so the events bracket back-to-back GPU work rather than the Python/ctypes launch rate. The time
+    # includes the generator launch (k_gen) every 10th step — the amortised cost of in-launch auto-reset.
     core = player.env.core
     n = a.envs_per_gpu
-    M = 300
+    M, REPS = 100, 5
     acts = torch.randint(0, 4, (M, 2, n), device=device)
     out = (torch.empty((n, 2, 13, 13), device=device), torch.empty((n, 2), device=device),
            torch.empty((n,), dtype=torch.uint8, device=device))
-    for i in range(20):
-        core.step(acts[i, 0], acts[i, 1], out)
+    core.flush()
+    torch.cuda.synchronize(device)
+    side = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(side):
+        for i in range(20):
+            core.step(acts[i, 0], acts[i, 1], out)
+        core.flush()
+    torch.cuda.synchronize(device)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(M):
+            core.step(acts[i, 0], acts[i, 1], out)
+        core.flush()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g.replay()
     torch.cuda.synchronize(device)
     e0.record()
-    for i in range(M):
-        core.step(acts[i, 0], acts[i, 1], out)
+    for _ in range(REPS):
+        g.replay()
     e1.record()
     torch.cuda.synchronize(device)
-    k_us = e0.elapsed_time(e1) * 1e3 / M
+    k_us = e0.elapsed_time(e1) * 1e3 / (M * REPS)
     achieved = B_STEP * n / (k_us * 1e-6) / 1e9
     # env-only loop with on-device random actions
     core.step_random(50, 7, out)

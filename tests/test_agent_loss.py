@@ -93,3 +93,39 @@ def test_batched_loss_is_mean_of_per_env_losses_with_mid_rollout_boundaries():
     for k in range(1, 5):
         np.testing.assert_allclose(whole[k].numpy(), (first[k] + second[k]).numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(float(whole[0]), float(first[0] + second[0]), rtol=1e-5)
+
+
+def test_recompute_path_equals_per_step_autograd_path():
+    """Actor/learner split (action_rollout + loss_recompute, time-batched) vs the reference-shaped per-step path
+    (action_train + loss): same loss, same gradients, on the same env stream and the same sampled actions."""
+    from test_distributed_cpu import FakeVecEnv
+    from active_tracking_rl_amd.model import build_model
+    from active_tracking_rl_amd.train import rollout
+    saved = torch.Tensor.multinomial
+    torch.Tensor.multinomial = lambda self, n, *a, **k: self.argmax(1, keepdim=True)
+    try:
+        for net, aux in (("tat-maze-lstm", "reward"), ("maze-lstm", "none")):
+            outs = []
+            for fast in (False, True):
+                args = default_args(network=net, aux=aux, num_envs=5, num_steps=7)
+                torch.manual_seed(4)
+                env = FakeVecEnv(range(5))
+                model = build_model(env.observation_space, env.action_space, args, torch.device("cpu"))
+                ag = Agent(model, env, args, None, torch.device("cpu"))
+                ag.reset()
+                for it in range(2):                       # second rollout starts from a non-zero LSTM state
+                    rollout(ag, args.num_steps, fast=fast)
+                    loss, pl, vl, en, pr = (ag.loss_recompute if fast else ag.loss)(-1)
+                    model.zero_grad()
+                    loss.backward()
+                    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+                    outs.append((float(loss), pl.detach(), vl.detach(), en.detach(), pr.detach(), grads.clone()))
+                    ag.clear_actions()
+                    model.cache_dense(False)
+            for a, b in zip(outs[:2], outs[2:]):
+                assert abs(a[0] - b[0]) <= 1e-5 * max(1.0, abs(a[0]))
+                for x, y in zip(a[1:5], b[1:5]):
+                    np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-4, atol=1e-5)
+                np.testing.assert_allclose(a[5].numpy(), b[5].numpy(), rtol=1e-3, atol=2e-6)
+    finally:
+        torch.Tensor.multinomial = saved
