@@ -91,6 +91,10 @@ class VecEnv(object):
     def flush(self):
         self.core.flush()
 
+    def core_max_steps(self):
+        """Upper bound on the episode length (TimeLimit, gym_track2d/__init__.py:17)."""
+        return registry.MAX_EPISODE_STEPS
+
     def close(self):
         self.core.close()
 

@@ -1,0 +1,108 @@
+#!/usr/bin/env python
+"""main.py — drop-in for the reference's main.py (same flags, main.py:16-50) on the MI355X-native path.
+
+    python main.py --shared-optimizer --split --train-mode -1 --env Track2D-BlockPartialPZR-v0 --num-envs 4096
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 main.py ... (one rank per GPU)
+
+What changes: `--workers` CPU processes become `--num-envs` envs per GPU stepped by the HIP kernels; the Hogwild shared
+model becomes synchronous data parallel (one all-reduce of the flat gradient bucket per update); the evaluator
+(`test`) runs on rank 0 between training iterations instead of in a forked process. `--gpu-ids` picks the device of a
+single-process run; under torch.distributed.run each rank uses LOCAL_RANK.
+"""
+from __future__ import print_function, division
+import os
+os.environ["OMP_NUM_THREADS"] = "1"
+import argparse
+from datetime import datetime
+
+import torch
+import torch.distributed as dist
+
+from active_tracking_rl_amd import build
+from active_tracking_rl_amd.test import test
+from active_tracking_rl_amd.train import GraphedIteration, make_player
+
+parser = argparse.ArgumentParser(description='A3C (MI355X data-parallel)')
+parser.add_argument('--lr', type=float, default=0.001, metavar='LR', help='learning rate (2D: 0.001, 3D: 0.0001)')
+parser.add_argument('--gamma', type=float, default=0.9, metavar='G', help='discount factor for rewards (default: 0.9)')
+parser.add_argument('--tau', type=float, default=1.00, metavar='T', help='parameter for GAE (default: 1.00)')
+parser.add_argument('--entropy', type=float, default=0.01, metavar='E', help='parameter for entropy(for tracker)')
+parser.add_argument('--entropy-target', type=float, default=0.2, metavar='EC', help='parameter for entropy(for target)')
+parser.add_argument('--seed', type=int, default=1, metavar='S', help='random seed (default: 1)')
+parser.add_argument('--workers', type=int, default=1, metavar='W', help='accepted for compatibility (see --num-envs)')
+parser.add_argument('--num-envs', type=int, default=4096, metavar='N', help='parallel envs per GPU')
+parser.add_argument('--num-steps', type=int, default=20, metavar='NS', help='number of forward steps in A3C')
+parser.add_argument('--test-eps', type=int, default=100, metavar='TE', help='evaluation episodes per round')
+parser.add_argument('--test-every', type=int, default=200, metavar='TI', help='training iterations between evaluations')
+parser.add_argument('--env', default='Track2D-BlockPartialPZR-v0', metavar='ENV', help='environment to train on')
+parser.add_argument('--env-base', default='Track2D-BlockPartialNav-v0', metavar='ENVB', help='environment to test on ')
+parser.add_argument('--optimizer', default='Adam', metavar='OPT', help='Adam (SharedAdam numerics)')
+parser.add_argument('--amsgrad', default=True, metavar='AM', help='Adam optimizer amsgrad parameter')
+parser.add_argument('--load-model-dir', default=None, metavar='LMD', help='checkpoint to load')
+parser.add_argument('--log-dir', default='logs/', metavar='LG', help='folder to save logs')
+parser.add_argument('--network', default='tat-maze-lstm', metavar='M', help='config Network Architecture')
+parser.add_argument('--aux', default='reward', metavar='A', help='auxiliary task: reward/none')
+parser.add_argument('--gpu-ids', type=int, default=[0], nargs='+', help='GPU to use in a single-process run')
+parser.add_argument('--obs', default='img', metavar='O', help='img or vector')
+parser.add_argument('--single', dest='single', action='store_true', help='run on single agent env')
+parser.add_argument('--gray', dest='gray', action='store_true', help='gray image')
+parser.add_argument('--crop', dest='crop', action='store_true', help='crop image')
+parser.add_argument('--inv', dest='inv', action='store_true', help='inverse image')
+parser.add_argument('--rescale', dest='rescale', action='store_true', help='rescale image to [-1, 1]')
+parser.add_argument('--render', dest='render', action='store_true', help='(not supported on the batched path)')
+parser.add_argument('--shared-optimizer', dest='shared_optimizer', action='store_true', help='accepted for compatibility')
+parser.add_argument('--split', dest='split', action='store_true', help='split model to save')
+parser.add_argument('--train-mode', type=int, default=-1, metavar='TM', help='which agent to train(0:tracker 1:target)')
+parser.add_argument('--stack-frames', type=int, default=1, metavar='SF', help='Choose number of observations to stack')
+parser.add_argument('--input-size', type=int, default=80, metavar='IS', help='input image size')
+parser.add_argument('--rnn-out', type=int, default=128, metavar='LO', help='rnn output size')
+parser.add_argument('--sleep-time', type=int, default=0, metavar='ST', help='accepted for compatibility')
+parser.add_argument('--max-step', type=int, default=150000, metavar='MS', help='max learning steps (iterations)')
+parser.add_argument('--init-step', type=int, default=-1, metavar='IS', help='steps not update target at beginning')
+parser.add_argument('--max-grad-norm', type=float, default=None, help='clip (off by default, as the reference effectively is)')
+parser.add_argument('--no-graph', action='store_true', help='run iterations eagerly instead of as hipGraphs')
+
+if __name__ == '__main__':
+    args = parser.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(args.gpu_ids[0])))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    args.gpu_ids = [local_rank]
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if rank == 0:
+        build.build()
+    if world > 1:
+        dist.barrier()
+    args.log_dir = os.path.join(args.log_dir, args.env, datetime.now().strftime('%b%d_%H-%M'))
+    player, optimizer = make_player(args, device, rank, world)
+    if args.load_model_dir is not None:
+        saved_state = torch.load(args.load_model_dir, map_location=lambda storage, loc: storage)
+        player.model.load_state_dict(saved_state)
+    train_modes, n_iters = [args.train_mode] * world, [0] * world
+    step = GraphedIteration(player, optimizer, args).run if not args.no_graph else None
+    it = 0
+    while True:
+        if step is not None:
+            step()
+        else:
+            from active_tracking_rl_amd.train import rollout
+            rollout(player, args.num_steps)
+            player.optimize(None, optimizer, player.model, train_modes[rank], device)
+        it += 1
+        n_iters[:] = [it] * world
+        if it % args.test_every == 0 or it > args.max_step:
+            if rank == 0:
+                test(args, player.model, train_modes, n_iters, rounds=1)
+            if world > 1:
+                dist.barrier()
+        if it > args.max_step:
+            break
+    player.env.close()
+    if world > 1:
+        dist.destroy_process_group()

@@ -1,0 +1,87 @@
+"""-m gpu: the drop-in drivers on the HIP path — gym-protocol single env (Track2DEnv) against the oracle, a short
+training run (eager and hipGraph), the vectorised evaluator, reference-named checkpoints and gym_eval.py."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gym_protocol_single_env_matches_oracle():
+    from active_tracking_rl_amd.environment import create_env
+    from active_tracking_rl_amd.train import default_args
+    args = default_args(num_envs=1, seed=7)
+    env = create_env("Track2D-BlockPartialPZR-v0", args, num_envs=1)
+    assert len(env.observation_space) == 2 and env.observation_space[0].shape == (1, 13, 13)
+    assert env.action_space[0].n == 4
+    o = orc.OracleEnv("Block", "PZR", 0, 500, orc.RNG_PHILOX, 7, 0)
+    obs = env.reset()
+    assert obs.shape == (2, 1, 1, 13, 13) and obs.dtype == np.float32
+    assert np.array_equal(obs.reshape(2, 13, 13), o.reset().astype(np.float32))
+    rs = np.random.RandomState(0)
+    for t in range(80):
+        a = [np.array(rs.randint(4)), np.array(rs.randint(4))]      # 0-d arrays like model.py:50 produces
+        obs, rew, done, info = env.step(a)
+        wo, wr, wd, _ = o.step([int(a[0]), int(a[1])])
+        assert rew.dtype == np.float64 and isinstance(done, bool)
+        assert np.array_equal(obs.reshape(2, 13, 13), wo.astype(np.float32))
+        assert np.array_equal(rew, wr.astype(np.float32).astype(np.float64)) and done == wd
+        assert abs(info["distance"] - np.sqrt(o.state()["d2"])) < 1e-12
+        if done:
+            obs = env.reset()
+            assert np.array_equal(obs.reshape(2, 13, 13), o.reset().astype(np.float32))
+    env.close()
+
+
+def test_train_eager_and_graphed_then_evaluate_and_checkpoints(tmp_path):
+    from active_tracking_rl_amd.model import build_model
+    from active_tracking_rl_amd.test import evaluate, save_checkpoints, test
+    from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player, rollout
+    dev = torch.device("cuda:0")
+    args = default_args(num_envs=128, test_eps=6, log_dir=str(tmp_path), split=True, max_step=3,
+                        env_base="Track2D-BlockPartialRam-v0")
+    player, opt = make_player(args, dev)
+    w0 = opt.bucket.flat.clone()
+    rollout(player, args.num_steps)
+    stats = player.optimize(None, opt, player.model, -1, dev)
+    assert all(torch.isfinite(s).all() for s in stats)
+    it = GraphedIteration(player, opt, args)
+    for _ in range(3):
+        it.run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(opt.bucket.flat).all() and not torch.equal(w0, opt.bucket.flat)
+    # env invariants still hold after graph replays (generator launches inside the captured rollout)
+    st = player.env.core.get_state()
+    maps = player.env.core.get_maps()
+    idx = np.arange(128)
+    assert (maps[idx, st["pos"][:, 0, 0], st["pos"][:, 0, 1]] == 0).all()
+    assert (maps[:, 1:81, 1:81].reshape(128, -1).sum(1) <= 959).all()
+    rsum, length = evaluate(player.model, "Track2D-BlockPartialNav-v0", args, dev, 6)
+    assert rsum.shape == (6, 2) and (length >= 11).all() and (length <= 500).all()
+    train_modes, n_iters = [-1], [5]
+    test(args, player.model, train_modes, n_iters, rounds=1)
+    assert train_modes[0] == -100                                    # n_iter > max_step -> stop sentinel
+    names = sorted(os.listdir(str(tmp_path)))
+    assert "all-best-5.dat" in names and "tracker-best.dat" in names and "target-best.dat" in names
+    sd = torch.load(os.path.join(str(tmp_path), "tracker-best.dat"))
+    assert "encoder.conv1.weight" in sd and tuple(sd["lstm.weight_ih"].shape) == (512, 256)
+    m2 = build_model(player.env.observation_space, player.env.action_space, args, dev).to(dev)
+    m2.load_state_dict(torch.load(os.path.join(str(tmp_path), "all-best-5.dat")))
+    assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), player.model.state_dict().values()))
+    # gym_eval.py loads the reference-named checkpoints and writes the CSV row
+    csv_path = os.path.join(str(tmp_path), "eval.csv")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "gym_eval.py"), "--env", "Track2D-BlockPartialRam-v0",
+                        "--num-episodes", "5", "--load-tracker", os.path.join(str(tmp_path), "tracker-best.dat"),
+                        "--load-target", os.path.join(str(tmp_path), "target-best.dat"), "--log-dir",
+                        str(tmp_path) + "/", "--csv", csv_path], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = open(csv_path).read().strip().splitlines()
+    assert rows[0].startswith("Env,Seed,R_mean") and rows[1].startswith("Track2D-BlockPartialRam-v0,1,")
+    player.env.close()
