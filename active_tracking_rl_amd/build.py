@@ -6,8 +6,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtrack2d_hip.so")
-SOURCES = ["track2d_hip.hip"]
-HEADERS = ["t2d_device.h", os.path.join("..", "..", "include", "track2d.h")]
+SOURCES = ["track2d_hip.hip", "stem_hip.hip"]
+HEADERS = ["t2d_device.h", os.path.join("..", "..", "include", "track2d.h"),
+           os.path.join("..", "..", "include", "atr_policy.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

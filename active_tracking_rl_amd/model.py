@@ -77,7 +77,9 @@ def lstm_sequence(lstm, feats, h, c, keep):
     that step). The input projection is ONE GEMM over all T*N rows; only the hidden GEMM + pointwise are sequential.
     Returns h_seq [T, N, R] (the hidden state each step's heads see), and the final masked (h, c)."""
     T, N = feats.shape[0], feats.shape[1]
-    igates = F.linear(feats.reshape(T * N, -1), lstm.weight_ih).view(T, N, -1)
+    # unbind (not igates[t]): its backward is one stack, not T zero-filled [T,N,4R] tensors added together
+    igates = F.linear(feats.reshape(T * N, -1), lstm.weight_ih).view(T, N, -1).unbind(0)
+    keep = keep.unbind(0)
     fused = feats.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell")
     outs = []
     for t in range(T):
@@ -224,19 +226,30 @@ class CNN_maze(nn.Module):
 
     def cache_dense(self, on=True):
         """Build the expanded weights once and reuse them for every forward until cache_dense(False): the rollout
-        driver brackets the 20-step rollout + backward with it (weights only change at optimizer.step)."""
-        self._dense = self.dense_weights() if on else None
+        driver brackets the 20-step rollout + backward with it (weights only change at optimizer.step). Not needed
+        (and skipped) when the fused HIP stem is in use."""
+        fused_path = self.use_fused and self.conv1.weight.is_cuda and self.conv1.in_channels == 1
+        self._dense = self.dense_weights() if (on and not fused_path) else None
+
+    use_fused = True   # GPU tensors go through the fused HIP stem (csrc/stem_hip.hip); set False to force GEMMs
 
     def forward(self, x, fc=True):
         n, f = x.shape[0], x.shape[1]
-        W1, b1, W2, b2 = self._dense if self._dense is not None else self.dense_weights()
-        x = x.reshape(n * f, -1)
-        x = F.relu(F.linear(x, W1, b1))
-        x = F.relu(F.linear(x, W2, b2))
+        if x.is_cuda and self.use_fused and self.conv1.in_channels == 1:
+            from . import fused
+            x = fused.stem(x.reshape(n * f, -1), self.conv1, self.conv2)
+        else:
+            x = self.forward_dense_stem(x.reshape(n * f, -1))
         x = x.reshape(n, -1)
         if fc:
             x = F.relu(self.fc(x))
         return x
+
+    def forward_dense_stem(self, x):
+        """The two convs as plain fp32 GEMMs against Toeplitz-expanded weights (CPU path and GPU cross-check)."""
+        W1, b1, W2, b2 = self._dense if self._dense is not None else self.dense_weights()
+        x = F.relu(F.linear(x, W1, b1))
+        return F.relu(F.linear(x, W2, b2))
 
     def forward_conv2d(self, x, fc=True):
         """The same network through F.conv2d — the plain PyTorch fp32 reference used by the numerics tests."""
