@@ -105,7 +105,8 @@ class GraphedIteration(object):
         self.carry = dict(state=player.state.clone(), hxs=player.hxs.detach().clone(),
                           cxs=player.cxs.detach().clone(), done=player.done.clone(), eps_len=player.eps_len.clone())
         self.g_roll, self.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_roll):
+        # thread_local: an RCCL watchdog thread polling events must not invalidate the capture
+        with torch.cuda.graph(self.g_roll, capture_error_mode="thread_local"):
             player.state, player.hxs, player.cxs = self.carry["state"], self.carry["hxs"], self.carry["cxs"]
             player.done, player.eps_len = self.carry["done"], self.carry["eps_len"]
             rollout(player, args.num_steps, fast=fast)
@@ -115,7 +116,7 @@ class GraphedIteration(object):
             self.carry["cxs"].copy_(player.cxs.detach())
             self.carry["done"].copy_(player.done)
             self.carry["eps_len"].copy_(player.eps_len)
-        with torch.cuda.graph(self.g_opt):
+        with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             optimizer.step()
         player.state, player.hxs, player.cxs = self.carry["state"], self.carry["hxs"], self.carry["cxs"]
         player.done, player.eps_len = self.carry["done"], self.carry["eps_len"]

@@ -55,11 +55,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (not used by the driver): run N ranks on ONE GPU over gloo to exercise the N>1 code path
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
@@ -83,6 +90,10 @@ def main():
         player.optimize(None, optimizer, player.model, args.train_mode, device)
 
     iteration, graphed = eager_iteration, False
+    if world > 1:   # bring the communicator up (and its first-call allocations) before any hipGraph capture
+        _w = torch.zeros(1, device=device)
+        dist.all_reduce(_w)
+        torch.cuda.synchronize(device)
     if not a.no_graph:
         try:
             iteration = GraphedIteration(player, optimizer, args, fast=not a.per_step_autograd).run
@@ -130,7 +141,7 @@ def main():
         core.flush()
     torch.cuda.synchronize(device)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         for i in range(M):
             core.step(acts[i, 0], acts[i, 1], out)
         core.flush()
