@@ -164,6 +164,13 @@ def main():
     torch.cuda.synchronize(device)
     eo_us = e0.elapsed_time(e1) * 1e3 / 1000
 
+    traffic, traffic_src = None, None
+    try:   # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (cannot be taken inside this run)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pm.get("n_envs") == n:
+            traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    except Exception:
+        pass
     line = {
         "metric": "env steps/sec, Track2D-BlockPartialPZR-v0 @4096 envs, 1/2/4/8 GPU",
         "value": value, "unit": "env steps/s", "n_gpus": world, "steps": steps, "warmup": warm,
@@ -175,7 +182,8 @@ def main():
                    "global_envs": n_total, "rollout": T, "hipgraph": graphed, "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},
         "roofline": {"bound": "hbm", "kernel": "t2d::k_env<OP_STEP> (step+observe, in-launch auto-reset)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "bytes_per_launch": B_STEP * n, "avg_launch_us": k_us},
+                     "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": B_STEP * n,
+                     "avg_launch_us": k_us},
         "env_only": {"value": n * world / (eo_us * 1e-6), "unit": "env steps/s", "us_per_launch": eo_us,
                      "note": "same kernel, on-device random actions, one launch per batched step, per-rank x ranks"},
     }
