@@ -47,6 +47,9 @@ def select_params(model, train_mode):
 
 def make_player(args, device, rank=0, world_size=1, env=None, model=None, optimizer=None):
     """Build env shard + replica + optimizer + Agent for one rank."""
+    if device.type == 'cuda':
+        from . import gemm_tuning
+        gemm_tuning.enable()                  # read-only TunableOp picks for the policy GEMMs (no-op without the file)
     torch.manual_seed(args.seed)          # same init on every rank (replicas must start identical)
     if env is None:
         env = create_env(args.env, args, num_envs=args.num_envs, device=str(device),

@@ -76,6 +76,8 @@ def main():
         build.build()
     if world > 1:
         dist.barrier()
+    from active_tracking_rl_amd import gemm_tuning
+    tuned = gemm_tuning.enable() and os.environ.get("ATR_DISABLE_GEMM_TUNING") != "1"
     from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player, rollout
 
     T = 20
@@ -179,7 +181,8 @@ def main():
         "config": {"workload": "%s, %d envs/GPU x %d GPU, %s tracker+target, train-mode -1, 20-step A3C rollouts "
                                "(policy fwd + HIP env step + loss/backward + grad all-reduce + SharedAdam)"
                                % (a.env, n, world, a.network),
-                   "global_envs": n_total, "rollout": T, "hipgraph": graphed, "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},
+                   "global_envs": n_total, "rollout": T, "hipgraph": graphed,
+                   "gemm_algos": "TunableOp picks from tunableop_gfx950.csv" if tuned else "library default", "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},
         "roofline": {"bound": "hbm", "kernel": "t2d::k_env<OP_STEP> (step+observe, in-launch auto-reset)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": B_STEP * n,
