@@ -426,6 +426,25 @@ class A3C_Dueling(nn.Module):
                R_pred)
         return self._to_ref(out) if ref_layout else out
 
+    @torch.no_grad()
+    def act(self, states, hs, cs):
+        """Actor step of the fast path: sample both players' actions and advance their LSTM states, nothing else
+        (values, entropies and log-probs are re-evaluated by forward_sequence). states [N,2,stack,C,13,13]; hs, cs:
+        per-player lists of contiguous [N,R] tensors. Returns ([a_tracker, a_target], hs, cs)."""
+        n = states.shape[0]
+        p0, p1 = self.player0, self.player1
+        h0, c0 = p0.lstm(p0.encoder(states[:, 0]), (hs[0], cs[0]))
+        a0 = F.softmax(p0.actor.actor_linear(h0), dim=1).multinomial(1).squeeze(1)
+        if self.tat:
+            x1 = states.reshape(n, -1, states.shape[3], states.shape[4], states.shape[5])
+            fa = p1.fc_action_tracker
+            feat = p1.encoder(x1) + fa.weight.t()[a0] + fa.bias          # fc_action_tracker(one_hot(a0))
+        else:
+            feat = p1.encoder(states[:, 1])
+        h1, c1 = p1.lstm(feat, (hs[1], cs[1]))
+        a1 = F.softmax(p1.actor.actor_linear(h1), dim=1).multinomial(1).squeeze(1)
+        return [a0, a1], [h0, h1], [c0, c1]
+
     def forward_sequence(self, states_seq, actions_seq, hx, cx, keep):
         """Re-evaluate T stored steps with gradients, time-batched (the learner half of the rollout driver):
         states_seq [T, N, 2, stack, C, 13, 13], actions_seq [T, N, 2] int64, hx/cx [N, 2, R] at the start of the

@@ -72,23 +72,26 @@ class Agent(object):
         return self
 
     def action_rollout(self):
-        """Actor half of the fast path: the same step as action_train, but the policy runs without building an
-        autograd graph; what the learner needs to re-evaluate the step (state, actions, done) is stored instead."""
+        """Actor half of the fast path: the same step as action_train, but only what acting needs is computed
+        (model.act, no autograd graph); what the learner needs to re-evaluate the step (state, actions, done) is
+        stored instead. LSTM states are kept per player as contiguous [N,R] tensors during the rollout."""
         self.n_steps += 1
-        with torch.no_grad():
-            _, action_env_multi, _, _, (self.hxs, self.cxs), _ = self.model((self.state, (self.hxs, self.cxs)))
+        if hasattr(self.model, "act") and self.num_agents == 2 and not getattr(self.model, "single", False):
+            actions, self._hs, self._cs = self.model.act(self.state, self._hs, self._cs)
+        else:
+            with torch.no_grad():
+                _, actions, _, _, (hx, cx), _ = self.model((self.state, (torch.stack(self._hs, 1), torch.stack(self._cs, 1))))
+            self._hs, self._cs = list(hx.unbind(1)), list(cx.unbind(1))
         self.states.append(self.state)
-        self.actions.append(torch.stack(action_env_multi, 1))
-        state_multi, reward_multi, done, self.info = self.env.step(action_env_multi)
+        self.actions.append(torch.stack(actions, 1))
+        state_multi, reward_multi, done, self.info = self.env.step(actions)
         self.reward_org = reward_multi
         self.reward = reward_multi
         self.state = state_multi
         self.done = done
-        keep = (done == 0)
-        self.eps_len = (self.eps_len + 1) * keep.to(self.eps_len.dtype)
-        k = keep.to(self.hxs.dtype).view(-1, 1, 1)
-        self.hxs = self.hxs * k
-        self.cxs = self.cxs * k
+        k = (done == 0).to(self._hs[0].dtype).unsqueeze(1)       # finished envs restart from a zero LSTM state
+        self._hs = [h * k for h in self._hs]
+        self._cs = [c * k for c in self._cs]
         self.rewards.append(reward_multi.unsqueeze(2))
         self.dones.append(done)
         return self
@@ -97,7 +100,16 @@ class Agent(object):
         """Remember the LSTM state the rollout starts from (the learner re-runs the recurrence from it)."""
         self.update_rnn_hiden()
         self.h0, self.c0 = self.hxs, self.cxs
+        self._hs = [h.contiguous() for h in self.hxs.unbind(1)]
+        self._cs = [c.contiguous() for c in self.cxs.unbind(1)]
         self.states, self.actions = [], []
+
+    def end_rollout(self):
+        """Publish the per-player LSTM states back as hxs/cxs [N,A,R] and the episode-length counters."""
+        self.hxs, self.cxs = torch.stack(self._hs, 1), torch.stack(self._cs, 1)
+        nd = (torch.stack(self.dones, 0) == 0).to(self.eps_len.dtype)         # [T, N]
+        alive_since = torch.flip(torch.cumprod(torch.flip(nd, [0]), 0), [0])  # 1 while no done from t to the end
+        self.eps_len = self.eps_len * alive_since[0] + alive_since.sum(0)
 
     def action_test(self):
         with torch.no_grad():

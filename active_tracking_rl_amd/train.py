@@ -78,6 +78,7 @@ def rollout(player, num_steps, fast=True):
         player.begin_rollout()
         for _ in range(num_steps):
             player.action_rollout()
+        player.end_rollout()
     else:
         player.update_rnn_hiden()
         for _ in range(num_steps):
