@@ -363,9 +363,14 @@ using namespace atr;
 
 static int stem_grid(long long M)
 {
-    int dev = 0, cus = 256;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    static int cached_cus = 0;   // queried once: hipGetDeviceProperties is far too slow for a per-launch call
+    if (cached_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached_cus = n;
+    }
+    const int cus = cached_cus;
     const long long cap = (long long)cus * 4;   // 4 resident workgroups per CU
     return (int)(M < cap ? (M < 1 ? 1 : M) : cap);
 }
