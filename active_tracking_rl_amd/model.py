@@ -71,30 +71,36 @@ def sample_action(logit, test=False):
     return action, entropy, log_prob
 
 
-def lstm_sequence(lstm, feats, h, c, keep):
-    """Run an nn.LSTMCell over a time-major feature sequence with the per-step episode-boundary mask applied AFTER
-    each step (what Agent.action_train does): feats [T, N, F], h/c [N, R], keep [T, N] (0 where the env finished at
-    that step). The input projection is ONE GEMM over all T*N rows; only the hidden GEMM + pointwise are sequential.
-    Returns h_seq [T, N, R] (the hidden state each step's heads see), and the final masked (h, c)."""
-    T, N = feats.shape[0], feats.shape[1]
-    # unbind (not igates[t]): its backward is one stack, not T zero-filled [T,N,4R] tensors added together
-    igates = F.linear(feats.reshape(T * N, -1), lstm.weight_ih).view(T, N, -1).unbind(0)
-    keep = keep.unbind(0)
+def lstm_sequence(lstms, feats, h, c, keep):
+    """Run P independent nn.LSTMCells (same sizes, different weights — the two players) over time-major feature
+    sequences in lock step, with the per-step episode-boundary mask applied AFTER each step (what Agent.action_train
+    does). feats [T, P, N, F], h/c [P, N, R], keep [T, N] (0 where the env finished at that step).
+    The input projections are one GEMM per player over all T*N rows (both biases folded in); per step the P hidden
+    GEMMs are ONE bmm and the pointwise cell ONE fused kernel over P*N rows — the recurrence is launch-bound, so
+    batching the players halves its cost. Returns h_seq [T, P, N, R] and the final masked (h, c) [P, N, R]."""
+    T, P, N = feats.shape[0], feats.shape[1], feats.shape[2]
+    R = h.shape[-1]
+    ig = torch.stack([F.linear(feats[:, p].reshape(T * N, -1), l.weight_ih, l.bias_ih + l.bias_hh).view(T, N, -1)
+                      for p, l in enumerate(lstms)], 1)                       # [T, P, N, 4R]
+    # unbind (not ig[t]): its backward is one stack, not T zero-filled tensors added together
+    igates = ig.reshape(T, P * N, 4 * R).unbind(0)
+    whh = torch.stack([l.weight_hh.t() for l in lstms], 0)                     # [P, R, 4R]
+    keepm = keep.unsqueeze(1).expand(T, P, N).reshape(T, P * N, 1).unbind(0)
     fused = feats.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell")
+    h, c = h.reshape(P * N, R), c.reshape(P * N, R)
     outs = []
     for t in range(T):
-        hgates = F.linear(h, lstm.weight_hh)
+        hgates = torch.bmm(h.view(P, N, R), whh).view(P * N, 4 * R)
         if fused:
-            h, c, _ = torch.ops.aten._thnn_fused_lstm_cell(igates[t], hgates, c, lstm.bias_ih, lstm.bias_hh)
+            h, c, _ = torch.ops.aten._thnn_fused_lstm_cell(igates[t], hgates, c)
         else:
-            g = igates[t] + hgates + lstm.bias_ih + lstm.bias_hh
+            g = igates[t] + hgates
             i, f, gg, o = g.chunk(4, 1)
             c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
             h = torch.sigmoid(o) * torch.tanh(c)
         outs.append(h)
-        k = keep[t].unsqueeze(1)
-        h, c = h * k, c * k
-    return torch.stack(outs, 0), h, c
+        h, c = h * keepm[t], c * keepm[t]
+    return torch.stack(outs, 0).view(T, P, N, R), h.view(P, N, R), c.view(P, N, R)
 
 
 def policy_stats(logit, action):
@@ -299,16 +305,24 @@ class A3C(nn.Module):
         return value, action, entropy, log_prob, (hx, cx)
 
 
-    def forward_sequence(self, x_seq, actions, h, c, keep):
-        """Time-batched re-evaluation of T stored steps: x_seq [T, N, F, C, 13, 13], actions [T, N] -> values [T,N,1],
-        entropies [T,N,1], log_probs [T,N,1], final (h, c). Same math as T calls of forward()."""
+    def sequence_features(self, x_seq):
+        """Encoder over all T*N stored frames at once: x_seq [T, N, F, C, 13, 13] -> [T, N, 256]."""
         T, N = x_seq.shape[0], x_seq.shape[1]
-        feats = self.encoder(x_seq.reshape(T * N, *x_seq.shape[2:])).view(T, N, -1)
-        h_seq, h, c = lstm_sequence(self.lstm, feats, h, c, keep)
+        return self.encoder(x_seq.reshape(T * N, *x_seq.shape[2:])).view(T, N, -1)
+
+    def sequence_heads(self, h_seq, actions):
+        """Heads over all T*N hidden states at once: values, entropies, log-probs of the stored actions [T,N,1]."""
+        T, N = h_seq.shape[0], h_seq.shape[1]
         flat = h_seq.reshape(T * N, -1)
         value = self.critic(flat)
         entropy, log_prob = policy_stats(self.actor.actor_linear(flat), actions.reshape(T * N))
-        return value.view(T, N, 1), entropy.view(T, N, 1), log_prob.view(T, N, 1), (h, c)
+        return value.view(T, N, 1), entropy.view(T, N, 1), log_prob.view(T, N, 1)
+
+    def forward_sequence(self, x_seq, actions, h, c, keep):
+        """Time-batched re-evaluation of T stored steps for this player alone (same math as T calls of forward())."""
+        feats = self.sequence_features(x_seq)
+        h_seq, h, c = lstm_sequence([self.lstm], feats.unsqueeze(1), h.unsqueeze(0), c.unsqueeze(0), keep)
+        return self.sequence_heads(h_seq[:, 0], actions) + ((h[0], c[0]),)
 
 
 class TAT(nn.Module):
@@ -348,17 +362,25 @@ class TAT(nn.Module):
         return value, action, entropy, log_prob, (hx, cx), R_pred
 
 
-    def forward_sequence(self, x_seq, actions, action_tracker, h, c, keep):
+    def sequence_features(self, x_seq, action_tracker):
         """x_seq [T, N, 2F, C, 13, 13] (tracker frames then target frames), action_tracker one-hot [T, N, n_act]."""
         T, N = x_seq.shape[0], x_seq.shape[1]
         feats = self.encoder(x_seq.reshape(T * N, *x_seq.shape[2:]))
-        feats = (feats + self.fc_action_tracker(action_tracker.reshape(T * N, -1))).view(T, N, -1)
-        h_seq, h, c = lstm_sequence(self.lstm, feats, h, c, keep)
+        return (feats + self.fc_action_tracker(action_tracker.reshape(T * N, -1))).view(T, N, -1)
+
+    def sequence_heads(self, h_seq, actions):
+        T, N = h_seq.shape[0], h_seq.shape[1]
         flat = h_seq.reshape(T * N, -1)
         value = self.critic(flat)
         entropy, log_prob = policy_stats(self.actor.actor_linear(flat), actions.reshape(T * N))
         R_pred = self.reward_aux(flat).view(T, N, 1) if self.sub_task else None
-        return value.view(T, N, 1), entropy.view(T, N, 1), log_prob.view(T, N, 1), (h, c), R_pred
+        return value.view(T, N, 1), entropy.view(T, N, 1), log_prob.view(T, N, 1), R_pred
+
+    def forward_sequence(self, x_seq, actions, action_tracker, h, c, keep):
+        feats = self.sequence_features(x_seq, action_tracker)
+        h_seq, h, c = lstm_sequence([self.lstm], feats.unsqueeze(1), h.unsqueeze(0), c.unsqueeze(0), keep)
+        v, e, l, R_pred = self.sequence_heads(h_seq[:, 0], actions)
+        return v, e, l, (h[0], c[0]), R_pred
 
 
 class A3C_Dueling(nn.Module):
@@ -452,14 +474,23 @@ class A3C_Dueling(nn.Module):
         [T,N,2,1], log_probs [T,N,2,1], R_pred [T,N,1] (0 when not tat). Numerically the same quantities as T calls
         of forward() with those actions; the encoder and all heads run as single GEMMs over T*N rows."""
         T, N = states_seq.shape[0], states_seq.shape[1]
-        v0, e0, l0, _ = self.player0.forward_sequence(states_seq[:, :, 0], actions_seq[:, :, 0], hx[:, 0], cx[:, 0], keep)
-        R_pred = 0
+        p0, p1 = self.player0, self.player1
+        f0 = p0.sequence_features(states_seq[:, :, 0])
         if self.tat:
             a2t = F.one_hot(actions_seq[:, :, 0], self.action_dim_tracker).to(states_seq.dtype)
             x1 = states_seq.reshape(T, N, -1, states_seq.shape[4], states_seq.shape[5], states_seq.shape[6])
-            v1, e1, l1, _, R_pred = self.player1.forward_sequence(x1, actions_seq[:, :, 1], a2t, hx[:, 1], cx[:, 1], keep)
+            f1 = p1.sequence_features(x1, a2t)
         else:
-            v1, e1, l1, _ = self.player1.forward_sequence(states_seq[:, :, 1], actions_seq[:, :, 1], hx[:, 1], cx[:, 1], keep)
+            f1 = p1.sequence_features(states_seq[:, :, 1])
+        # both players' recurrences in lock step: one bmm + one fused cell per time step for the pair
+        h_seq, _, _ = lstm_sequence([p0.lstm, p1.lstm], torch.stack([f0, f1], 1),
+                                    hx.transpose(0, 1).contiguous(), cx.transpose(0, 1).contiguous(), keep)
+        v0, e0, l0 = p0.sequence_heads(h_seq[:, 0], actions_seq[:, :, 0])
+        R_pred = 0
+        if self.tat:
+            v1, e1, l1, R_pred = p1.sequence_heads(h_seq[:, 1], actions_seq[:, :, 1])
+        else:
+            v1, e1, l1 = p1.sequence_heads(h_seq[:, 1], actions_seq[:, :, 1])
         return torch.stack([v0, v1], 2), torch.stack([e0, e1], 2), torch.stack([l0, l1], 2), R_pred
 
     @staticmethod
