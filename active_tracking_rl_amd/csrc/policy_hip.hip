@@ -1,0 +1,93 @@
+// policy_hip.hip — small fused policy-side kernels (C ABI in include/atr_policy.h).
+//
+// atr_sample_actions: the actor head of the rollout in ONE launch — logits = W h + b (n_actions x R, R <= 256),
+// softmax, and one categorical draw per env by inverse CDF on a Philox4x32-10 uniform. It replaces
+// actor_linear -> softmax -> torch.multinomial (the reference's sample_action, model.py:41-49), which on ROCm is a
+// GEMM plus ~12 tiny launches (multinomial alone: min/max/nan asserts, exponential noise, divide, argmax ...).
+// The stream position lives in a device-side counter that the launch itself advances, so a hipGraph replay draws
+// fresh numbers. One thread per env; the head weights sit in LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/atr_policy.h"
+
+namespace atr {
+
+constexpr int kMaxActions = 8;
+constexpr int kMaxR = 256;
+
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sample_actions(const float *__restrict__ h, const float *__restrict__ w,
+                                                        const float *__restrict__ b, long long *__restrict__ actions,
+                                                        const unsigned long long *__restrict__ counter,
+                                                        unsigned long long seed, int n, int R, int A)
+{
+    __shared__ float ws[kMaxActions * kMaxR + kMaxActions];
+    for (int i = (int)threadIdx.x; i < A * R; i += (int)blockDim.x) ws[i] = w[i];
+    if ((int)threadIdx.x < A) ws[A * R + threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= n) return;
+    float logit[kMaxActions];
+#pragma unroll
+    for (int a = 0; a < kMaxActions; a++) logit[a] = a < A ? ws[A * R + a] : -INFINITY;
+    const float4 *hr = reinterpret_cast<const float4 *>(h + (size_t)e * R);
+    for (int j = 0; j < R / 4; j++) {
+        const float4 v = hr[j];
+#pragma unroll
+        for (int a = 0; a < kMaxActions; a++)
+            if (a < A) {
+                const float *wa = ws + a * R + 4 * j;
+                logit[a] = fmaf(v.x, wa[0], fmaf(v.y, wa[1], fmaf(v.z, wa[2], fmaf(v.w, wa[3], logit[a]))));
+            }
+    }
+    float mx = logit[0];
+#pragma unroll
+    for (int a = 1; a < kMaxActions; a++) mx = fmaxf(mx, logit[a]);
+    float p[kMaxActions], sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < kMaxActions; a++) { p[a] = a < A ? __expf(logit[a] - mx) : 0.f; sum += p[a]; }
+    const unsigned long long c = *counter;
+    uint32_t c0 = (uint32_t)e, c1 = (uint32_t)c, c2 = (uint32_t)(c >> 32), c3 = 0x5A3Du;
+    philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c0, c1, c2, c3);
+    const float u = ((c0 >> 8) + 0.5f) * (1.0f / 16777216.0f) * sum;    // uniform in (0, sum)
+    int act = A - 1;                                      // first a with u < cumulative(a)
+    float acc = 0.f;
+    bool found = false;
+#pragma unroll
+    for (int a = 0; a < kMaxActions; a++) {
+        if (a < A) {
+            acc += p[a];
+            if (!found && u < acc) { act = a; found = true; }
+        }
+    }
+    actions[e] = (long long)act;
+}
+
+__global__ void k_bump_counter(unsigned long long *counter) { *counter += 1ull; }
+
+} // namespace atr
+
+extern "C" int atr_sample_actions(const float *h, const float *w, const float *b, long long *actions,
+                                  unsigned long long *counter, unsigned long long seed, int n, int R, int A, void *stream)
+{
+    if (!h || !w || !b || !actions || !counter || n < 0 || R <= 0 || R > atr::kMaxR || (R & 3) || A < 1 || A > atr::kMaxActions)
+        return -1;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(atr::k_sample_actions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h, w, b, actions,
+                       counter, seed, n, R, A);
+    hipLaunchKernelGGL(atr::k_bump_counter, dim3(1), dim3(1), 0, st, counter);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

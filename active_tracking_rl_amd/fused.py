@@ -23,6 +23,8 @@ def lib():
         L.atr_stem_workspace_floats.argtypes = [ll]
         L.atr_stem_backward.restype = C.c_int
         L.atr_stem_backward.argtypes = [vp] * 11 + [ll, vp]
+        L.atr_sample_actions.restype = C.c_int
+        L.atr_sample_actions.argtypes = [vp, vp, vp, vp, vp, C.c_ulonglong, C.c_int, C.c_int, C.c_int, vp]
         _lib = L
     return _lib
 
@@ -68,3 +70,24 @@ class _Stem(torch.autograd.Function):
 def stem(x, conv1, conv2):
     """x [M, 169] (or [M,1,13,13]) float32 on the GPU -> [M, 512]."""
     return _Stem.apply(x.reshape(x.shape[0], -1), conv1.weight, conv1.bias, conv2.weight, conv2.bias)
+
+
+class ActionSampler(object):
+    """Fused actor head for the rollout: action ~ Categorical(softmax(W h + b)) in one launch (csrc/policy_hip.hip).
+    Holds the device-side stream counter (advanced by every call, hipGraph-safe) and the Philox seed."""
+
+    def __init__(self, device, seed=None):
+        self.counter = torch.zeros(1, dtype=torch.int64, device=device)
+        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+
+    @torch.no_grad()
+    def __call__(self, h, linear):
+        h = h.contiguous()
+        n, R = h.shape
+        A = linear.weight.shape[0]
+        actions = torch.empty(n, dtype=torch.int64, device=h.device)
+        rc = lib().atr_sample_actions(_p(h), _p(linear.weight), _p(linear.bias), _p(actions), _p(self.counter),
+                                      self.seed, n, R, A, _stream(h))
+        if rc != 0:
+            raise RuntimeError("atr_sample_actions failed (%d)" % rc)
+        return actions

@@ -448,6 +448,8 @@ class A3C_Dueling(nn.Module):
                R_pred)
         return self._to_ref(out) if ref_layout else out
 
+    fused_sampling = True   # GPU rollouts draw actions with the fused HIP head (csrc/policy_hip.hip)
+
     @torch.no_grad()
     def act(self, states, hs, cs):
         """Actor step of the fast path: sample both players' actions and advance their LSTM states, nothing else
@@ -455,8 +457,15 @@ class A3C_Dueling(nn.Module):
         per-player lists of contiguous [N,R] tensors. Returns ([a_tracker, a_target], hs, cs)."""
         n = states.shape[0]
         p0, p1 = self.player0, self.player1
+        if states.is_cuda and self.fused_sampling:
+            if getattr(self, "_sampler", None) is None:
+                from . import fused
+                self._sampler = fused.ActionSampler(states.device)
+            sample = self._sampler
+        else:
+            sample = lambda h, lin: F.softmax(lin(h), dim=1).multinomial(1).squeeze(1)
         h0, c0 = p0.lstm(p0.encoder(states[:, 0]), (hs[0], cs[0]))
-        a0 = F.softmax(p0.actor.actor_linear(h0), dim=1).multinomial(1).squeeze(1)
+        a0 = sample(h0, p0.actor.actor_linear)
         if self.tat:
             x1 = states.reshape(n, -1, states.shape[3], states.shape[4], states.shape[5])
             fa = p1.fc_action_tracker
@@ -464,7 +473,7 @@ class A3C_Dueling(nn.Module):
         else:
             feat = p1.encoder(states[:, 1])
         h1, c1 = p1.lstm(feat, (hs[1], cs[1]))
-        a1 = F.softmax(p1.actor.actor_linear(h1), dim=1).multinomial(1).squeeze(1)
+        a1 = sample(h1, p1.actor.actor_linear)
         return [a0, a1], [h0, h1], [c0, c1]
 
     def forward_sequence(self, states_seq, actions_seq, hx, cx, keep):

@@ -26,6 +26,13 @@ int atr_stem_backward(const float *x, const float *y, const float *dy, const flo
                       const float *w2, float *dw1, float *db1, float *dw2, float *db2, float *workspace,
                       long long M, void *stream);
 
+/* Actor head of the rollout in one launch (replaces actor_linear -> softmax -> multinomial, model.py:41-49 of the
+ * reference): logits = w h + b with h [n,R] (R <= 256, multiple of 4), w [A,R], b [A], A <= 8; one categorical draw
+ * per row by inverse CDF on a Philox4x32-10 uniform keyed (seed; row, *counter). `counter` is a device-side
+ * uint64 the call advances by one (in stream order), so hipGraph replays draw fresh numbers. actions: int64 [n]. */
+int atr_sample_actions(const float *h, const float *w, const float *b, long long *actions, unsigned long long *counter,
+                       unsigned long long seed, int n, int R, int A, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,3 +56,32 @@ def test_model_with_fused_stem_equals_gemm_stem():
     CNN_maze.use_fused = True
     for p, q in zip(*outs):
         torch.testing.assert_close(p, q, rtol=1e-4, atol=1e-5)
+
+
+def test_fused_action_sampler_draws_from_the_softmax_distribution():
+    """atr_sample_actions: empirical action frequencies match softmax(W h + b) (chi-square), draws differ call to
+    call (device-side counter) and across rows."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(128, 4).cuda()
+    with torch.no_grad():
+        lin.weight.mul_(8.0); lin.bias.normal_()
+    hrow = torch.randn(1, 128, device="cuda")
+    n = 200000
+    h = hrow.expand(n, 128).contiguous()
+    sampler = fused.ActionSampler(torch.device("cuda"), seed=123)
+    a = sampler(h, lin)
+    assert a.dtype == torch.int64 and int(a.min()) >= 0 and int(a.max()) <= 3
+    p = torch.softmax(lin(hrow), 1)[0].detach().double().cpu().numpy()
+    counts = np.bincount(a.cpu().numpy(), minlength=4).astype(np.float64)
+    chi2 = (((counts - n * p) ** 2) / (n * p + 1e-9)).sum()
+    assert chi2 < 30.0, (chi2, counts / n, p)            # dof 3: 30 is p ~ 1e-6
+    b = sampler(h, lin)
+    assert not torch.equal(a, b) and int(sampler.counter.item()) == 2
+    # different rows, different distributions: per-row probability of the sampled action is plausible on average
+    h2 = torch.randn(50000, 128, device="cuda")
+    a2 = sampler(h2, lin)
+    p2 = torch.softmax(lin(h2), 1).detach()
+    mean_p = float(p2.gather(1, a2.unsqueeze(1)).mean())
+    expect = float((p2 * p2).sum(1).mean())
+    assert abs(mean_p - expect) < 0.01, (mean_p, expect)
