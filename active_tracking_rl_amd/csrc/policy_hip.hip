@@ -5,7 +5,7 @@
 // actor_linear -> softmax -> torch.multinomial (the reference's sample_action, model.py:41-49), which on ROCm is a
 // GEMM plus ~12 tiny launches (multinomial alone: min/max/nan asserts, exponential noise, divide, argmax ...).
 // The stream position lives in a device-side counter that the launch itself advances, so a hipGraph replay draws
-// fresh numbers. One thread per env; the head weights sit in LDS.
+// fresh numbers. Sixteen lanes per env; the head weights sit in LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,6 +28,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
     }
 }
 
+// 16 lanes per env: each lane loads 2 x 16 B of the env's hidden row (coalesced 512 B per env), accumulates its
+// partial logits, the 16 partials are summed on the DPP/permute network and sub-lane 0 draws the action.
 __global__ __launch_bounds__(256) void k_sample_actions(const float *__restrict__ h, const float *__restrict__ w,
                                                         const float *__restrict__ b, long long *__restrict__ actions,
                                                         const unsigned long long *__restrict__ counter,
@@ -37,21 +39,34 @@ __global__ __launch_bounds__(256) void k_sample_actions(const float *__restrict_
     for (int i = (int)threadIdx.x; i < A * R; i += (int)blockDim.x) ws[i] = w[i];
     if ((int)threadIdx.x < A) ws[A * R + threadIdx.x] = b[threadIdx.x];
     __syncthreads();
-    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (e >= n) return;
+    const int sub = (int)(threadIdx.x & 15u);
+    const int e = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    const bool valid = e < n;
     float logit[kMaxActions];
 #pragma unroll
-    for (int a = 0; a < kMaxActions; a++) logit[a] = a < A ? ws[A * R + a] : -INFINITY;
-    const float4 *hr = reinterpret_cast<const float4 *>(h + (size_t)e * R);
-    for (int j = 0; j < R / 4; j++) {
-        const float4 v = hr[j];
+    for (int a = 0; a < kMaxActions; a++) logit[a] = 0.f;
+    if (valid) {
+        const float4 *hr = reinterpret_cast<const float4 *>(h + (size_t)e * R);
+        for (int j = sub; j < R / 4; j += 16) {
+            const float4 v = hr[j];
 #pragma unroll
-        for (int a = 0; a < kMaxActions; a++)
-            if (a < A) {
-                const float *wa = ws + a * R + 4 * j;
-                logit[a] = fmaf(v.x, wa[0], fmaf(v.y, wa[1], fmaf(v.z, wa[2], fmaf(v.w, wa[3], logit[a]))));
-            }
+            for (int a = 0; a < kMaxActions; a++)
+                if (a < A) {
+                    const float *wa = ws + a * R + 4 * j;
+                    logit[a] = fmaf(v.x, wa[0], fmaf(v.y, wa[1], fmaf(v.z, wa[2], fmaf(v.w, wa[3], logit[a]))));
+                }
+        }
     }
+#pragma unroll
+    for (int a = 0; a < kMaxActions; a++)
+        if (a < A) {
+            float v = logit[a];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            logit[a] = v + ws[A * R + a];
+        } else {
+            logit[a] = -INFINITY;
+        }
+    if (!valid || sub != 0) return;
     float mx = logit[0];
 #pragma unroll
     for (int a = 1; a < kMaxActions; a++) mx = fmaxf(mx, logit[a]);
@@ -86,7 +101,7 @@ extern "C" int atr_sample_actions(const float *h, const float *w, const float *b
         return -1;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(atr::k_sample_actions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h, w, b, actions,
+    hipLaunchKernelGGL(atr::k_sample_actions, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, h, w, b, actions,
                        counter, seed, n, R, A);
     hipLaunchKernelGGL(atr::k_bump_counter, dim3(1), dim3(1), 0, st, counter);
     return hipGetLastError() == hipSuccess ? 0 : -2;
