@@ -119,3 +119,15 @@ def test_frame_stack_matches_reference_wrapper_semantics():
     st = torch.rand(5, 2, 3, 1, 13, 13, device="cuda")
     v, a, e, lp, (h, c), rp = m((st, (torch.zeros(5, 2, 128, device="cuda"), torch.zeros(5, 2, 128, device="cuda"))))
     assert v.shape == (5, 2, 1) and rp.shape == (5, 1)
+
+
+def test_train_worker_loop_reference_signature(tmp_path):
+    """train(rank, args, shared_model, optimizer, train_modes, n_iters, env=None) — train.py:15 — runs, counts its
+    iterations in n_iters[rank] and stops by the test.py:129-134 rule (sum of iterations > max_step)."""
+    from active_tracking_rl_amd.train import default_args, train
+    args = default_args(num_envs=64, max_step=4, log_dir=str(tmp_path), env="Track2D-MazePartialFar-v1")
+    train_modes, n_iters = [], []
+    player = train(0, args, None, None, train_modes, n_iters)
+    assert n_iters == [5] and train_modes == [-1]
+    assert player.n_steps == 5 * args.num_steps
+    assert torch.isfinite(torch.cat([p.reshape(-1) for p in player.model.parameters()])).all()
