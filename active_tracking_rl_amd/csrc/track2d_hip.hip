@@ -42,6 +42,7 @@ struct DevState {
     int n;
     uint32_t env_base, k0, k1;
     int max_steps, auto_reset;
+    int obs_full, obs_side;   // obs_type 'Full': every env writes [2][obs_side][obs_side] floats
 };
 
 enum : int { OP_STEP = 0, OP_RESET = 1, OP_OBSERVE = 2 };
@@ -223,6 +224,23 @@ __device__ __forceinline__ void emit_obs(const uint32_t *tile, float *stage, uin
     }
 }
 
+// _get_obs for obs_type 'Full' (track_1v1.py:288-290,295-307): both agents get the whole map, tracker cell = 2,
+// target cell = 4 (painted last). One wave writes the env's two identical S x S planes, 256 B per store.
+__device__ __forceinline__ void emit_full_obs(const uint32_t *tile, uint32_t pos, int side, int lane, float *gobs)
+{
+    const int tr = (int)(pos & 0xffu) * side + (int)((pos >> 8) & 0xffu);
+    const int tg = (int)((pos >> 16) & 0xffu) * side + (int)(pos >> 24);
+    const int cells = side * side;
+    for (int idx = lane; idx < cells; idx += 64) {
+        const int r = idx / side, c = idx - r * side;
+        float v = (float)tile_bit(tile, r, c);
+        if (idx == tr) v = 2.0f;
+        if (idx == tg) v = 4.0f;
+        gobs[idx] = v;
+        gobs[cells + idx] = v;
+    }
+}
+
 template <int OP, bool RANDOM, bool NAV>
 __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const void *act1, int act_dtype,
                                              const uint8_t *mask, float *obs, float *rew, uint8_t *done_out,
@@ -348,7 +366,10 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         if (consume || dirty) { s.plan[e] = plan; s.tctr[e] = tctr; }
         if (navgoal_dirty && !consume) s.navgoal[e] = navgoal;
     }
-    if (obs != nullptr) emit_obs(tile, stages[wave], pos, (int)(cnt >> 24), lane, obs + (size_t)e * kObsPerEnv);
+    if (obs != nullptr) {
+        if (s.obs_full) emit_full_obs(tile, pos, (int)(cnt >> 24), lane, obs + (size_t)e * 2 * s.obs_side * s.obs_side);
+        else emit_obs(tile, stages[wave], pos, (int)(cnt >> 24), lane, obs + (size_t)e * kObsPerEnv);
+    }
 }
 
 __global__ void k_reward_table(const uint32_t *d2, int n, double w_p, float *r_track, float *r_target)
@@ -429,6 +450,8 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     const int n = cfg->num_envs;
     std::vector<uint32_t> hcfg((size_t)n);
     bool has_nav = false;
+    int n_maze = 0;
+    if (cfg->obs_type > T2D_OBS_FULL) return fail(T2D_ERR_INVALID, "t2d_create: obs_type %u", cfg->obs_type);
     for (int i = 0; i < n; i++) {
         uint32_t mt = cfg->map_type_per_env ? cfg->map_type_per_env[i] : cfg->map_type;
         uint32_t tm = cfg->target_mode_per_env ? cfg->target_mode_per_env[i] : cfg->target_mode;
@@ -436,9 +459,12 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         if (mt > T2D_MAP_EMPTY) return fail(T2D_ERR_INVALID, "t2d_create: map_type %u (env %d)", mt, i);
         if (tm > T2D_TGT_RAM) return fail(T2D_ERR_INVALID, "t2d_create: target_mode %u (env %d)", tm, i);
         has_nav = has_nav || tm == T2D_TGT_NAV;
+        n_maze += mt == T2D_MAP_MAZE;
         if (lv > 15) return fail(T2D_ERR_INVALID, "t2d_create: level %u (env %d)", lv, i);
         hcfg[(size_t)i] = mt | (tm << 2) | (lv << 5);
     }
+    if (cfg->obs_type == T2D_OBS_FULL && n_maze != 0 && n_maze != n)
+        return fail(T2D_ERR_INVALID, "t2d_create: obs_type Full needs one map side per handle (81 for Maze, else 82)");
     DeviceGuard guard(cfg->device);
     t2d_handle *h = new (std::nothrow) t2d_handle();
     if (!h) return fail(T2D_ERR_INVALID, "t2d_create: out of host memory");
@@ -455,6 +481,8 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     s.n = n; s.env_base = cfg->env_id_base;
     s.k0 = (uint32_t)cfg->seed; s.k1 = (uint32_t)(cfg->seed >> 32);
     s.max_steps = cfg->max_episode_steps; s.auto_reset = cfg->auto_reset ? 1 : 0;
+    s.obs_full = cfg->obs_type == T2D_OBS_FULL ? 1 : 0;
+    s.obs_side = n_maze == n ? 81 : 82;
     const size_t nb = (size_t)n * sizeof(uint32_t), tb = (size_t)n * kTileWords * sizeof(uint32_t),
                  db = (size_t)n * kDirWords * sizeof(uint32_t);
     hipError_t err = hipSuccess;
@@ -620,6 +648,8 @@ extern "C" int t2d_inject(t2d_handle *h, int first, int count, int side, const u
     int rc = check_range(h, first, count, "t2d_inject");
     if (rc) return rc;
     if (side != 81 && side != 82) return fail(T2D_ERR_INVALID, "t2d_inject: side must be 81 or 82");
+    if (h->s.obs_full && side != h->s.obs_side)
+        return fail(T2D_ERR_INVALID, "t2d_inject: obs_type Full handle is laid out for side %d", h->s.obs_side);
     if (!maze_host || !pos_host) return fail(T2D_ERR_INVALID, "t2d_inject: null buffer");
     if (count == 0) return T2D_OK;
     DeviceGuard guard(h->device);

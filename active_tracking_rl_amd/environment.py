@@ -37,8 +37,8 @@ class Box(object):
         self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
 
 
-def _spaces():
-    obs = [Box(0, 6, (1, 13, 13), np.float32) for _ in range(2)]
+def _spaces(obs_hw=(13, 13)):
+    obs = [Box(0, 6, (1,) + tuple(obs_hw), np.float32) for _ in range(2)]
     act = [Discrete(4) for _ in range(2)]
     return obs, act
 
@@ -52,9 +52,9 @@ class VecEnv(object):
         self.env_id = env_id
         self.num_envs = num_envs
         self.stack_frames = int(stack_frames)
-        self.observation_space, self.action_space = _spaces()
         self.core = VecTrack2D(env_id, num_envs=num_envs, device=device, seed=seed, env_id_base=env_id_base,
                                auto_reset=auto_reset, **overrides)
+        self.observation_space, self.action_space = _spaces(self.core.obs_hw)
         self.device = self.core.device
         self._frames = None
         self._seed = seed

@@ -208,12 +208,18 @@ class CNN_maze(nn.Module):
         self.conv1.weight.data.mul_(relu_gain)
         self.conv2.weight.data.mul_(relu_gain)
         assert obs_shape[1] == obs_shape[2], "square observations"
-        idx1, h1 = _toeplitz_index(obs_shape[0], 16, obs_shape[1], 3, 2, 1)
-        idx2, h2 = _toeplitz_index(16, 32, h1, 3, 2, 1)
-        self.register_buffer("_idx1", idx1, persistent=False)
-        self.register_buffer("_idx2", idx2, persistent=False)
-        self.register_buffer("_inv1", _inverse_index(idx1, self.conv1.weight.numel()), persistent=False)
-        self.register_buffer("_inv2", _inverse_index(idx2, self.conv2.weight.numel()), persistent=False)
+        # 13x13 crops ('Partial' ids): fused HIP stem on the GPU, Toeplitz GEMMs on the CPU. Whole-map observations
+        # ('Full' ids, 81/82 wide) would need 10^8-entry expansion tables: they go through F.conv2d.
+        self.small = obs_shape[1] <= 16
+        h1 = (obs_shape[1] + 2 - 3) // 2 + 1
+        h2 = (h1 + 2 - 3) // 2 + 1
+        if self.small:
+            idx1, _ = _toeplitz_index(obs_shape[0], 16, obs_shape[1], 3, 2, 1)
+            idx2, _ = _toeplitz_index(16, 32, h1, 3, 2, 1)
+            self.register_buffer("_idx1", idx1, persistent=False)
+            self.register_buffer("_idx2", idx2, persistent=False)
+            self.register_buffer("_inv1", _inverse_index(idx1, self.conv1.weight.numel()), persistent=False)
+            self.register_buffer("_inv2", _inverse_index(idx2, self.conv2.weight.numel()), persistent=False)
         self._hw1, self._hw2 = h1 * h1, h2 * h2
         cnn_dim = 32 * self._hw2 * stack_frames
         self.fc = nn.Linear(cnn_dim, 256)
@@ -235,13 +241,15 @@ class CNN_maze(nn.Module):
         driver brackets the 20-step rollout + backward with it (weights only change at optimizer.step). Not needed
         (and skipped) when the fused HIP stem is in use."""
         fused_path = self.use_fused and self.conv1.weight.is_cuda and self.conv1.in_channels == 1
-        self._dense = self.dense_weights() if (on and not fused_path) else None
+        self._dense = self.dense_weights() if (on and self.small and not fused_path) else None
 
     use_fused = True   # GPU tensors go through the fused HIP stem (csrc/stem_hip.hip); set False to force GEMMs
 
     def forward(self, x, fc=True):
         n, f = x.shape[0], x.shape[1]
-        if x.is_cuda and self.use_fused and self.conv1.in_channels == 1:
+        if not self.small:
+            return self.forward_conv2d(x, fc)
+        if x.is_cuda and self.use_fused and self.conv1.in_channels == 1 and x.shape[-1] == 13:
             from . import fused
             x = fused.stem(x.reshape(n * f, -1), self.conv1, self.conv2)
         else:

@@ -1,7 +1,7 @@
 """Env-id table: restates the registry loop of the reference (envs/gym-track2d/gym_track2d/__init__.py:3-18):
 72 ids `Track2D-{Maze,Block,Empty}{Full,Partial}{Adv,PZR,Far,Nav,Ram,RPF}-v{0,1}`, each with
-max_episode_steps=500. `Full` observations and the `RPF` target are registered by the reference but not built
-here yet — spec() raises for them instead of silently doing something else."""
+max_episode_steps=500. The `RPF` target is registered by the reference but not built here
+— spec() raises for it instead of silently doing something else."""
 
 MAP_TYPES = ("Maze", "Block", "Empty")
 OBS_TYPES = ("Full", "Partial")
@@ -24,8 +24,6 @@ def spec(env_id):
     if env_id not in REGISTRY:
         raise KeyError("unknown env id %r (72 Track2D ids are registered)" % (env_id,))
     s = dict(REGISTRY[env_id])
-    if s["obs_type"] != "Partial":
-        raise NotImplementedError("%s: 'Full' observations are not built yet" % env_id)
     if s["target_mode"] == "RPF":
         raise NotImplementedError("%s: the RPF target is not built yet" % env_id)
     return s

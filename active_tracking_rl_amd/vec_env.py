@@ -32,7 +32,7 @@ class _Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("device", C.c_int32), ("num_envs", C.c_int32), ("env_id_base", C.c_uint32),
         ("seed", C.c_uint64), ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32),
-        ("map_type", C.c_uint8), ("target_mode", C.c_uint8), ("level", C.c_uint8), ("reserved0", C.c_uint8),
+        ("map_type", C.c_uint8), ("target_mode", C.c_uint8), ("level", C.c_uint8), ("obs_type", C.c_uint8),
         ("map_type_per_env", C.c_void_p), ("target_mode_per_env", C.c_void_p), ("level_per_env", C.c_void_p),
     ]
 
@@ -115,13 +115,14 @@ class VecTrack2D(object):
 
     def __init__(self, env_id=None, num_envs=1, device="cuda:0", seed=1, env_id_base=0, auto_reset=True,
                  map_type=None, target_mode=None, level=0, max_episode_steps=None,
-                 map_type_per_env=None, target_mode_per_env=None, level_per_env=None):
+                 map_type_per_env=None, target_mode_per_env=None, level_per_env=None, obs_type="Partial"):
         if not torch.cuda.is_available():
             raise T2DError("VecTrack2D needs an MI355X visible to PyTorch-ROCm (no CPU fallback)")
         self.L = load_library()
         if env_id is not None:
             sp = registry.spec(env_id)
             map_type, target_mode, level = sp["map_type"], sp["target_mode"], sp["level"]
+            obs_type = sp["obs_type"]
             if max_episode_steps is None:
                 max_episode_steps = sp["max_episode_steps"]
         if max_episode_steps is None:
@@ -141,6 +142,13 @@ class VecTrack2D(object):
         cfg.map_type = registry.MAP_CODE[map_type]
         cfg.target_mode = registry.TARGET_CODE[target_mode]
         cfg.level = int(level)
+        cfg.obs_type = 1 if obs_type == "Full" else 0
+        self.obs_type = obs_type
+        if obs_type == "Full":   # track_1v1.py:254-256: Box(shape=(1, S, S)); S = 81 for Maze maps, else 82
+            all_maze = (map_type == "Maze") if map_type_per_env is None else bool((np.asarray(map_type_per_env) == 1).all())
+            self.obs_hw = (81, 81) if all_maze else (82, 82)
+        else:
+            self.obs_hw = (13, 13)
         self._keep = []
         for name, arr in (("map_type_per_env", map_type_per_env), ("target_mode_per_env", target_mode_per_env),
                           ("level_per_env", level_per_env)):
@@ -171,7 +179,7 @@ class VecTrack2D(object):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _new_obs(self):
-        return torch.empty((self.num_envs, 2, 13, 13), dtype=torch.float32, device=self.device)
+        return torch.empty((self.num_envs, 2) + self.obs_hw, dtype=torch.float32, device=self.device)
 
     # -- gym-protocol-shaped batched calls ----------------------------------------------------------
     def reset(self, mask=None, out=None):

@@ -40,6 +40,8 @@ enum { T2D_MAP_BLOCK = 0, T2D_MAP_MAZE = 1, T2D_MAP_EMPTY = 2 };
 enum { T2D_TGT_ADV = 0, T2D_TGT_PZR = 1, T2D_TGT_FAR = 2, T2D_TGT_NAV = 3, T2D_TGT_RAM = 4 };
 /* dtype codes for action arrays */
 enum { T2D_ACT_U8 = 0, T2D_ACT_I32 = 1, T2D_ACT_I64 = 2 };
+/* obs_type of the registry kwargs (G/__init__.py:11), define_observation at G/envs/track_1v1.py:251-262 */
+enum { T2D_OBS_PARTIAL = 0, T2D_OBS_FULL = 1 };
 
 #define T2D_NUM_AGENTS 2
 #define T2D_POB 6          /* pob_size, G/envs/track_1v1.py:16 */
@@ -62,7 +64,9 @@ typedef struct {
     int32_t auto_reset;        /* 1: step() regenerates finished envs in the same launch and returns the
                                      first observation of the next episode (vector-env convention);
                                   0: gym protocol, caller resets (t2d_reset with a mask) */
-    uint8_t map_type, target_mode, level, reserved0;
+    uint8_t map_type, target_mode, level;
+    uint8_t obs_type;          /* 0 'Partial': obs [N,2,13,13]; 1 'Full': obs [N,2,S,S], S = 82 (Block/Empty) or 81
+                                  (Maze), every env of the handle must then have the same S */
     /* optional per-env overrides (host pointers, num_envs bytes each, NULL = uniform): BASELINE config 5
      * mixes Block and Maze maps in one batch */
     const uint8_t *map_type_per_env;
@@ -81,7 +85,7 @@ int t2d_num_envs(const t2d_handle *h);
 /* Track1v1Env.reset() (G/envs/track_1v1.py:134-168) for every env whose mask byte is non-zero
  * (mask_dev == NULL: all). Generates map, spawns, goals and the scripted-target plan on the device,
  * zeroes the counters and, if obs_dev != NULL, writes all N observations: f32 [N,2,13,13] (values
- * 0,1,2,4 — what frame_stack's np.float32(obs) yields, environment.py:138). */
+ * 0,1,2,4 — what frame_stack's np.float32(obs) yields, environment.py:138); [N,2,S,S] for obs_type Full. */
 int t2d_reset(t2d_handle *h, const uint8_t *mask_dev, float *obs_dev, void *stream);
 
 /* Track1v1Env.step(action) wrapped by TimeLimit.step (G/envs/track_1v1.py:71-127) for all N envs in one

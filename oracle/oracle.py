@@ -40,6 +40,9 @@ def lib():
         L.orc_create.argtypes = [i32, i32, i32, i32, i32, u64, u32]
         L.orc_destroy.argtypes = [vp]
         L.orc_seed_np.argtypes = [vp, u32]
+        L.orc_set_obs_full.argtypes = [vp, i32]
+        L.orc_obs_size.restype = i32
+        L.orc_obs_size.argtypes = [vp]
         L.orc_reset.argtypes = [vp, pu8]
         L.orc_step.restype = i32
         L.orc_step.argtypes = [vp, pi, pu8, C.POINTER(f64), pi, pi]
@@ -85,12 +88,15 @@ class OracleEnv(object):
     """One scalar Track2D env (obs u8[2,13,13], rewards f64[2], done bool)."""
 
     def __init__(self, map_type="Block", target_mode="PZR", level=0, max_steps=500,
-                 rng_mode=RNG_NP, seed=0, env_id=0):
+                 rng_mode=RNG_NP, seed=0, env_id=0, obs_type="Partial"):
         self.L = lib()
         self.map_type, self.target_mode = map_type, target_mode
         self.h = self.L.orc_create(MAP[map_type], TGT[target_mode], level, max_steps, rng_mode,
                                    int(seed), int(env_id))
-        self._obs = np.zeros((2, 13, 13), np.uint8)
+        self.full = obs_type == "Full"
+        self.L.orc_set_obs_full(self.h, 1 if self.full else 0)
+        s = self.L.orc_side(self.h)
+        self._obs = np.zeros((2, s, s) if self.full else (2, 13, 13), np.uint8)
         self._rew = np.zeros(2, np.float64)
         self._done = C.c_int(0)
         self._applied = np.zeros(2, np.int32)
@@ -150,7 +156,7 @@ class OracleEnv(object):
         return dict(pos=pos, goals=goals, c_far=c_far.value, t=t.value, d2=d2.value)
 
     def obs(self):
-        o = np.zeros((2, 13, 13), np.uint8)
+        o = np.zeros_like(self._obs)
         self.L.orc_get_obs(self.h, _p(o, C.c_uint8))
         return o
 

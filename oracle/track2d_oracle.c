@@ -138,6 +138,7 @@ struct orc_env {
     int plan_len, plan_cur;
     uint8_t dir[ORC_MAX_SIDE * ORC_MAX_SIDE]; /* philox-mode Nav direction field */
     int nav_planb;                            /* philox-mode Nav: following the 10 random actions */
+    int obs_full;                             /* obs_type: 0 'Partial' (13x13 crops), 1 'Full' (whole map) */
 };
 
 static uint32_t next_u32(orc_env *e, int stream)
@@ -574,6 +575,15 @@ static int nav_step(orc_env *e, const int *state, int32_t *scratch)
 static void write_obs(const orc_env *e, uint8_t *obs)
 {
     int S = e->side;
+    if (e->obs_full) { /* obs_type 'Full': both agents get _get_full_obs() (:288-290,295-307), shape [2][S][S] */
+        for (int id = 0; id < 2; id++) {
+            uint8_t *o = obs + id * S * S;
+            memcpy(o, e->maze, (size_t)(S * S));
+            o[e->pos[0][0] * S + e->pos[0][1]] = 2;
+            o[e->pos[1][0] * S + e->pos[1][1]] = 4;
+        }
+        return;
+    }
     for (int id = 0; id < 2; id++) {
         int r0 = e->pos[id][0] - ORC_POB, c0 = e->pos[id][1] - ORC_POB;
         for (int y = 0; y < ORC_WIN; y++)
@@ -621,6 +631,8 @@ orc_env *orc_create(int map_type, int target_mode, int level, int max_steps, int
 }
 void orc_destroy(orc_env *e) { free(e); }
 void orc_seed_np(orc_env *e, uint32_t seed) { mt_seed(&e->mt, seed); }
+void orc_set_obs_full(orc_env *e, int full) { e->obs_full = full ? 1 : 0; }
+int orc_obs_size(const orc_env *e) { return e->obs_full ? 2 * e->side * e->side : 2 * ORC_OBS_CELLS; }
 
 /* Track1v1Env.init_maze — track_1v1.py:218-240. */
 static void init_maze(orc_env *e, int32_t *scratch)

@@ -47,6 +47,11 @@ orc_env *orc_create(int map_type, int target_mode, int level, int max_steps,
                     int rng_mode, uint64_t seed, uint32_t env_id);
 void orc_destroy(orc_env *e);
 
+/* obs_type: 0 = 'Partial' (default; obs u8[2][13][13]), 1 = 'Full' (obs u8[2][side][side], both agents see the
+ * whole map with the tracker painted 2 and the target 4 — track_1v1.py:288-290,295-307). orc_obs_size = bytes. */
+void orc_set_obs_full(orc_env *e, int full);
+int orc_obs_size(const orc_env *e);
+
 /* Re-seed the numpy-legacy stream (np.random.seed(int)). */
 void orc_seed_np(orc_env *e, uint32_t seed);
 

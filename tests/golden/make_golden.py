@@ -63,8 +63,8 @@ def chase_action(env, rs):
     return int(cands[rs.randint(0, len(cands))])
 
 
-def run_case(map_type, mode, level, seed, n_episodes, max_steps, policy="random", time_limit=500):
-    env = Track1v1Env(map_type=map_type, target_mode=mode, level=level)
+def run_case(map_type, mode, level, seed, n_episodes, max_steps, policy="random", time_limit=500, obs_type="Partial"):
+    env = Track1v1Env(map_type=map_type, target_mode=mode, level=level, obs_type=obs_type)
     emitted = []
     if env.Target:
         tgt = env.Target[0]
@@ -101,7 +101,7 @@ def run_case(map_type, mode, level, seed, n_episodes, max_steps, policy="random"
             if time_limit and t >= time_limit:
                 done = True
             rec["act_in"].append([a0, a1]); rec["act_applied"].append([a0, applied1])
-            rec["obs"].append(np.asarray(obs).astype(np.uint8).reshape(2, 13, 13))
+            rec["obs"].append(np.asarray(obs).astype(np.uint8).reshape(2, *np.asarray(obs).shape[-2:]))
             rec["rew"].append(np.asarray(rew, np.float64).copy()); rec["done"].append(bool(done))
             rec["cfar"].append(int(env.C_far))
             rec["pos"].append(np.array(env.state, np.int32).copy())
@@ -118,7 +118,7 @@ def flatten(prefix, eps, out):
         p = "%sep%d_" % (prefix, i)
         bits, side = pack_maze(r["maze"])
         out[p + "maze"] = bits; out[p + "side"] = np.int32(side)
-        out[p + "init"] = r["init"]; out[p + "goals"] = r["goals"]; out[p + "obs0"] = r["obs0"].reshape(2, 13, 13)
+        out[p + "init"] = r["init"]; out[p + "goals"] = r["goals"]; out[p + "obs0"] = r["obs0"].reshape(2, *r["obs0"].shape[-2:])
         out[p + "act_in"] = np.array(r["act_in"], np.uint8); out[p + "act_applied"] = np.array(r["act_applied"], np.uint8)
         out[p + "obs"] = np.array(r["obs"], np.uint8); out[p + "rew"] = np.array(r["rew"], np.float64)
         out[p + "done"] = np.array(r["done"], np.uint8); out[p + "cfar"] = np.array(r["cfar"], np.int32)
@@ -153,6 +153,21 @@ def episodes():
         print(name, [len(e["obs"]) for e in eps], [bool(e["done"][-1]) for e in eps])
     out["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "episodes.npz"), **out)
+
+
+def full_obs_episodes():
+    """obs_type='Full' ids (Track2D-*Full*-v*): short episodes, obs [2, S, S] per step."""
+    out = {}
+    names = []
+    for (mp, mode, lvl, seed) in (("Block", "PZR", 0, 31), ("Maze", "Ram", 0, 32), ("Block", "Nav", 1, 33)):
+        name = "%s_%s_l%d_s%d" % (mp, mode, lvl, seed)
+        eps = run_case(mp, mode, lvl, seed, 2, 25, "random", obs_type="Full")
+        flatten(name + "/", eps, out)
+        out[name + "/meta"] = np.array([mp, mode, str(lvl), str(seed), "random"])
+        names.append(name)
+        print("full", name, [len(e["obs"]) for e in eps], eps[0]["obs"][0].shape)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "episodes_full.npz"), **out)
 
 
 def edge_cases():
@@ -375,11 +390,15 @@ def loss_fixture():
 
 
 if __name__ == "__main__":
+    if "--full-only" in sys.argv:
+        full_obs_episodes()
+        sys.exit(0)
     if "--model-only" in sys.argv:
         model_fixture()
         loss_fixture()
         sys.exit(0)
     episodes()
+    full_obs_episodes()
     edge_cases()
     astar_cases()
     registry()

@@ -38,8 +38,9 @@ def test_registry_matches_reference():
         assert (r["map_type"], r["obs_type"], str(r["level"]), r["target_mode"], str(r["max_episode_steps"])) == \
             (str(mp), str(ob), str(lvl), str(tgt), str(mx))
     assert registry.spec("Track2D-BlockPartialPZR-v0")["target_mode"] == "PZR"
+    assert registry.spec("Track2D-BlockFullPZR-v0")["obs_type"] == "Full"
     with pytest.raises(NotImplementedError):
-        registry.spec("Track2D-BlockFullPZR-v0")
+        registry.spec("Track2D-BlockPartialRPF-v0")
     with pytest.raises(KeyError):
         registry.spec("Track2D-Nope-v0")
 

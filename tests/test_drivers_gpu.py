@@ -131,3 +131,18 @@ def test_train_worker_loop_reference_signature(tmp_path):
     assert n_iters == [5] and train_modes == [-1]
     assert player.n_steps == 5 * args.num_steps
     assert torch.isfinite(torch.cat([p.reshape(-1) for p in player.model.parameters()])).all()
+
+
+def test_full_observation_env_trains():
+    """A 'Full' id end to end: VecEnv spaces are (1, 82, 82), the policy falls back to F.conv2d for the big frames,
+    one rollout + update runs."""
+    from active_tracking_rl_amd.train import default_args, make_player, rollout
+    dev = torch.device("cuda:0")
+    args = default_args(env="Track2D-BlockFullAdv-v0", network="maze-lstm", aux="none", num_envs=16, num_steps=4)
+    player, opt = make_player(args, dev)
+    assert player.env.observation_space[0].shape == (1, 82, 82)
+    assert tuple(player.model.player0.encoder.fc.weight.shape) == (256, 32 * 21 * 21)
+    rollout(player, args.num_steps)
+    stats = player.optimize(None, opt, player.model, -1, dev)
+    assert all(torch.isfinite(s).all() for s in stats)
+    player.env.close()

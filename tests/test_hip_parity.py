@@ -214,6 +214,49 @@ def test_nav_plan_b_when_target_is_walled_in(vec):
     env.close()
 
 
+def test_full_observation_ids(vec):
+    """obs_type='Full' (Track2D-*Full*-v*): (a) reference golden episodes injected, (b) generated vs the oracle."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "episodes_full.npz"))
+    for name in [str(n) for n in g["names"]]:
+        mp, mode, lvl, seed, _ = [str(x) for x in g[name + "/meta"]]
+        for ep in range(int(g[name + "/n_eps"])):
+            p = "%s/ep%d_" % (name, ep)
+            S = int(g[p + "side"])
+            env = vec.VecTrack2D(num_envs=1, map_type=mp, target_mode="PZR" if mode == "PZR" else "Adv", level=1,
+                                 auto_reset=False, obs_type="Full")
+            env.inject(unpack_maze(g[p + "maze"], S)[None], g[p + "init"].reshape(1, 4))
+            obs0 = env.observe().cpu().numpy()
+            assert obs0.shape == (1, 2, S, S) and np.array_equal(obs0[0], g[p + "obs0"].astype(np.float32))
+            for t, a in enumerate(g[p + "act_applied"]):
+                at = torch.tensor([[int(a[0])], [int(a[1])]], device="cuda")
+                obs, rew, done = env.step(at[0], at[1])
+                assert np.array_equal(obs.cpu().numpy()[0], g[p + "obs"][t].astype(np.float32)), (name, ep, t)
+                assert np.array_equal(rew.cpu().numpy()[0], g[p + "rew"][t].astype(np.float32))
+                assert bool(done.item()) == bool(g[p + "done"][t])
+            env.close()
+    for env_id, mp, mode in (("Track2D-BlockFullPZR-v0", "Block", "PZR"), ("Track2D-MazeFullNav-v1", "Maze", "Nav")):
+        n = 6
+        lvl = int(env_id[-1])
+        env = vec.VecTrack2D(env_id, num_envs=n, seed=4)
+        oracles = [orc.OracleEnv(mp, mode, lvl, 500, orc.RNG_PHILOX, 4, i, obs_type="Full") for i in range(n)]
+        obs = env.reset().cpu().numpy()
+        assert np.array_equal(obs, np.stack([o.reset() for o in oracles]).astype(np.float32))
+        rs = np.random.RandomState(1)
+        for t in range(40):
+            acts = rs.randint(0, 4, size=(n, 2))
+            a = torch.from_numpy(acts).cuda()
+            obs, rew, done = env.step(a[:, 0].contiguous(), a[:, 1].contiguous())
+            for i, o in enumerate(oracles):
+                wo, wr, wd, _ = o.step(acts[i])
+                if wd:
+                    wo = o.reset()
+                assert np.array_equal(obs[i].cpu().numpy(), wo.astype(np.float32)), (env_id, t, i)
+                assert bool(done[i].item()) == wd
+        env.close()
+
+
 def test_generated_mixed_batch_and_sharding(vec):
     n = 40
     rs = np.random.RandomState(0)

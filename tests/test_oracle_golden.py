@@ -92,3 +92,25 @@ def test_time_limit_episode(golden_episodes):
     g = golden_episodes
     d = g["Block_PZR_l0_s16/ep0_done"]
     assert len(d) == 500 and d[-1] == 1 and d[:-1].sum() == 0
+
+
+def test_full_observation_cases_bit_exact():
+    """obs_type='Full' ids: both agents observe the whole map (tracker 2, target 4), reference fixtures."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "episodes_full.npz"))
+    for name in _names(g):
+        mp, mode, lvl, seed, _pol = [str(x) for x in g[name + "/meta"]]
+        env = orc.OracleEnv(mp, mode, int(lvl), 500, orc.RNG_NP, int(seed), obs_type="Full")
+        env.seed_np(int(seed))
+        for ep in range(int(g[name + "/n_eps"])):
+            p = "%s/ep%d_" % (name, ep)
+            obs0 = env.reset()
+            S = int(g[p + "side"])
+            assert obs0.shape == (2, S, S)
+            np.testing.assert_array_equal(obs0, g[p + "obs0"], err_msg=name)
+            for t, a in enumerate(g[p + "act_in"]):
+                obs, rew, done, applied = env.step(a)
+                assert np.array_equal(obs, g[p + "obs"][t]), (name, ep, t)
+                assert tuple(rew) == tuple(g[p + "rew"][t]) and done == bool(g[p + "done"][t])
+                assert np.array_equal(obs[0], obs[1])            # Full: identical for both agents
