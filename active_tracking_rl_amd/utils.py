@@ -6,6 +6,8 @@ import os
 
 def setup_logger(logger_name, log_file, level=logging.INFO):
     l = logging.getLogger(logger_name)
+    if l.handlers:          # the evaluator is called once per round here (a forked process in the reference)
+        return
     formatter = logging.Formatter('%(asctime)s : %(message)s')
     fileHandler = logging.FileHandler(log_file, mode='w')
     fileHandler.setFormatter(formatter)
