@@ -268,6 +268,45 @@ def test_generated_mixed_batch_and_sharding(vec):
     _check_generated(vec, 24, "Block", "PZR", 0, seed=7, steps=30, base=1000)
 
 
+def test_long_soak_with_chasing_tracker_reaches_time_limit(vec):
+    """1200-step lock-step soak against the oracle with a tracker that chases the target (episodes run into the
+    500-step TimeLimit, generator launches every 10 steps, Ram/Nav plans roll over many times)."""
+    for mode, n in (("Ram", 96), ("Nav", 48)):
+        env = vec.VecTrack2D(num_envs=n, map_type="Block", target_mode=mode, level=0, seed=77, auto_reset=True)
+        oracles = _oracle_batch(n, ["Block"] * n, [mode] * n, [0] * n, 77)
+        env.reset()
+        for o in oracles:
+            o.reset()
+        rs = np.random.RandomState(5)
+        limit_hits = far_hits = 0
+        pos = np.stack([o.state()["pos"] for o in oracles])
+        for t in range(1200):
+            d = pos[:, 1] - pos[:, 0]
+            vert = np.abs(d[:, 0]) >= np.abs(d[:, 1])
+            a0 = np.where(vert, np.where(d[:, 0] < 0, 0, 1), np.where(d[:, 1] < 0, 2, 3))
+            rnd = rs.rand(n) < 0.1
+            a0 = np.where(rnd, rs.randint(0, 4, n), a0)
+            acts = np.stack([a0, rs.randint(0, 4, n)], 1)
+            a = torch.from_numpy(acts).cuda()
+            obs, rew, done = env.step(a[:, 0].contiguous(), a[:, 1].contiguous())
+            obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+            for i, o in enumerate(oracles):
+                wo, wr, wd, _ = o.step(acts[i])
+                if wd:
+                    s = o.state()
+                    limit_hits += s["t"] >= 500
+                    far_hits += s["c_far"] > 10
+                    wo = o.reset()
+                assert bool(done[i]) == wd, (mode, t, i)
+                assert np.array_equal(rew[i], wr.astype(np.float32)), (mode, t, i)
+                assert np.array_equal(obs[i], wo.astype(np.float32)), (mode, t, i)
+                pos[i] = o.state()["pos"]
+        assert limit_hits + far_hits > 50 and (mode != "Ram" or limit_hits > 20), (mode, limit_hits, far_hits)
+        st = env.get_state()
+        assert np.array_equal(st["pos"], pos) and env.faults() == 0
+        env.close()
+
+
 def test_odd_batch_sizes_and_tail_blocks(vec):
     for n in (1, 2, 3, 5, 7):
         _check_generated(vec, n, "Block", "PZR", 0, seed=100 + n, steps=25)
