@@ -186,7 +186,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "t2d::k_env<OP_STEP> (step+observe, in-launch auto-reset)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": B_STEP * n,
-                     "avg_launch_us": k_us},
+                     "avg_launch_us": k_us,
+                     "note": "avg_launch_us = hipGraph of 100 policy-shaped step launches replayed 5x, HIP events on the "
+                             "launch stream; it includes the generator launch every 10th step (k_gen) and the "
+                             "inter-kernel boundaries, so it sits ~1.5 us above rocprofv3's k_env-only average "
+                             "(profiles/r01_env_only_kernel_stats.txt)"},
         "env_only": {"value": n * world / (eo_us * 1e-6), "unit": "env steps/s", "us_per_launch": eo_us,
                      "note": "same kernel, on-device random actions, one launch per batched step, per-rank x ranks"},
     }
