@@ -2,21 +2,25 @@
 // conv(1->16,k3,s2,p1) 13->7, ReLU, conv(16->32,k3,s2,p1) 7->4, ReLU) as hand-written HIP for gfx950.
 //
 // Why: per frame the stem is 0.16 MFLOP on 676 B of input. As library GEMMs (Toeplitz-expanded weights) it costs
-// 6.6x the FLOPs and round-trips a 784-wide activation through HBM (0.5 GB per 163 840-frame batch, forward and
-// backward); MIOpen launches one Im2Col kernel per sample. Here a 256-thread workgroup owns one frame at a time:
-// conv1's activation lives in LDS (double-buffered), each thread keeps a 72-value slice of the conv2 weights (or
-// of their gradient) in registers, so 4 workgroups (16 waves) fit per CU and hide each other's LDS/global latency.
+// 6.6x the FLOPs and round-trips a 784-wide activation through HBM; MIOpen launches one Im2Col kernel per sample.
+// Here ONE WAVEFRONT owns one frame at a time and never leaves the CU with it:
+//   conv1 (14 kFLOP)  packed-f32 VALU; lane = (channel pair, output row); the zero-bordered activation a1 stays in
+//                     the wave's own 7 KB of LDS.
+//   conv2 (147 kFLOP) the f32 matrix cores: v_mfma_f32_16x16x4_f32 (exact f32, an fmaf chain) on the implicit
+//                     im2col of a1 — per frame a [16 positions] x [144 taps] x [32 channels] product = 72 MFMAs whose
+//                     A operand is ONE ds_read_b32 per lane (lane base + immediate offset: the tap order is chosen
+//                     so that the 4 k-values of a step are 4 input channels) and whose B operand (the conv2
+//                     weights) sits in 72 VGPRs for the whole kernel.
+// The backward runs the same way in ONE pass over (x, y, dy): dW2 = dz2^T x im2col(a1) (72 MFMAs per frame into 72
+// accumulator VGPRs) and da1 = dz2 x W2 (72 MFMAs, col2im done in registers with one cross-lane shift), conv1
+// recomputed per frame; no gradient w.r.t. the observation is needed. Waves are independent (wave-local LDS, no workgroup barriers in the
+// frame loop), so on each SIMD the MFMA pipe of one wave overlaps the VALU/LDS phases of the others.
 //
 //   forward   x[M,169] -> y[M,512] (c,h,w order, post-ReLU)                         atr_stem_forward
 //   backward  (x, y, dy) -> dW1[16,9], db1[16], dW2[32,144], db2[32]                atr_stem_backward
-//             (conv1 is recomputed per frame; no gradient w.r.t. the observation is needed)
 //
-// Thread roles on the conv2 side (forward, dW2): tid = cp*16 + oh*4 + ciq — a pair of output channels {2cp, 2cp+1},
-// one output row oh (4 positions) and a quarter of the input channels ci in [4ciq, 4ciq+4). One 16-byte LDS read of
-// an a1 row feeds 3 taps x 4 positions x 2 channels = 24 FMAs; the four ci-quarters of a quad are summed with DPP.
-// On the da1 side (conv2 transposed): tid = ci*16 + oh*4 + coq — input channel ci, output row oh, a quarter of the
-// output channels; the 3x9 window of a1-gradients is reduced over the quad and added into LDS.
-// fp32 FMA throughout (the reference computes in fp32); no MFMA: fp32 MFMA runs at the vector rate on gfx950.
+// MFMA operand maps (16x16x4 f32): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it receives
+// D[i = 4*(l>>4) + r][j = l&15] in accumulator register r.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,315 +28,344 @@
 
 namespace atr {
 
-constexpr int kIn = 13, kInPad = 15;         // input side, padded by 1
-constexpr int kC1 = 16, kH1 = 7;             // conv1 channels / output side
-constexpr int kC2 = 32;                      // conv2 channels (4x4 outputs)
-constexpr int kA1Rows = 9, kA1Stride = 12;   // a1 padded to rows -1..7, cols -1..7 (+3 so a row is 3 x 16 B)
-constexpr int kA1Ch = kA1Rows * kA1Stride;   // 108 floats per channel
-constexpr int kA1Size = kC1 * kA1Ch;         // 1728 floats
-constexpr int kXSize = 228;                  // 15*15 = 225, rounded to a multiple of 4
-constexpr int kW2 = kC2 * kC1 * 9;           // 4608
-constexpr int kPartial = kW2 + kC2 + kC1 * 9 + kC1;  // per-workgroup partial gradient record: 4800 floats
-constexpr int kThreads = 256;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// quad reduction on the DPP crossbar; wider ones through the permute network
-__device__ __forceinline__ float quad_sum(float v)
+constexpr int kXS = 16, kXRows = 17;          // zero-bordered 15x15 input, rows padded to 16 floats (+2 zero rows)
+constexpr int kXSize = kXS * kXRows;          // 272
+constexpr int kC1 = 16, kC2 = 32;
+constexpr int kA1Row = 12, kA1Ch = 109;       // a1 zero-bordered to 9x9 (rows of 12 floats); odd channel stride
+constexpr int kA1Size = kC1 * kA1Ch;          // 1744
+constexpr int kW2 = kC2 * kC1 * 9;            // 4608
+constexpr int kPartial = kW2 + kC2 + kC1 * 9 + kC1;  // per-workgroup partial gradient record: 4800 floats
+constexpr int kWaves = 4, kThreads = 64 * kWaves;
+
+struct LdsF { float x[kXSize]; float a1[kA1Size]; };                   // 8064 B per wave
+struct LdsB { float x[kXSize]; float a1[kA1Size]; float dz[512]; };    // 10112 B per wave
+
+__device__ __forceinline__ void wave_lds_sync()
 {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true));
-    return v;
+    // DS operations of one wave execute in order; this only stops the compiler from moving LDS accesses across
+    // the point, so that values written by other lanes of the wave are re-read.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ float xor_sum(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// Cooperative conv1 + ReLU of one frame: thread = (channel c = tid>>4, part = tid&15), outputs q = part + 16 i.
-// xpad: 15x15 zero-bordered input; a1pad[16][9][12] zero-bordered output. w[9], bias: this thread's conv1 filter.
-__device__ __forceinline__ void conv1_frame(const float *xpad, float *a1pad, const float (&w)[9], float bias, int tid)
+// A frame's 169 floats: lane l holds elements l, l+64, l+128.
+struct XRegs { float v[3]; };
+__device__ __forceinline__ XRegs load_x(const float *__restrict__ x, long long m, long long M, long long xs, int l)
 {
-    const int c = tid >> 4, part = tid & 15;
+    XRegs r;
+    const float *p = x + m * xs;
+    const bool ok = m < M;
+    r.v[0] = ok ? p[l] : 0.f;
+    r.v[1] = ok ? p[l + 64] : 0.f;
+    r.v[2] = (ok && l < 41) ? p[l + 128] : 0.f;
+    return r;
+}
+__device__ __forceinline__ int xpad_addr(int i) { const int r = i / 13; return (r + 1) * kXS + (i - r * 13) + 1; }
+__device__ __forceinline__ void store_x(float *xpad, const XRegs &r, int l)
+{
+    xpad[xpad_addr(l)] = r.v[0];
+    xpad[xpad_addr(l + 64)] = r.v[1];
+    if (l < 41) xpad[xpad_addr(l + 128)] = r.v[2];
+}
+
+// conv1 + ReLU of the wave's frame on packed f32 FMAs (v_pk_fma_f32: two channels per lane). Lane = (channel pair
+// cp = l&7 -> channels 2cp, 2cp+1; output row oh = l>>3). Branch-free: the non-existent row oh = 7 reads the zero rows
+// below the frame and writes zeros into a1's zero border. MFMA and VALU issue share the SIMD's f32 lanes (measured:
+// their times add), so conv1's instruction count matters even next to 72 MFMAs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Conv1W { f32x2 w[9]; f32x2 b; };
+__device__ __forceinline__ Conv1W load_conv1_w(const float *__restrict__ w1, const float *__restrict__ b1, int l)
+{
+    Conv1W r;
+    const int cp = l & 7;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int q = part + 16 * i;
-        if (q < 49) {
-            const int oh = q / kH1, ow = q - oh * kH1;
-            const float *xr = xpad + (2 * oh) * kInPad + 2 * ow;
-            float acc = bias;
+    for (int k = 0; k < 9; k++) r.w[k] = f32x2{w1[(2 * cp) * 9 + k], w1[(2 * cp + 1) * 9 + k]};
+    r.b = f32x2{b1[2 * cp], b1[2 * cp + 1]};
+    return r;
+}
+__device__ __forceinline__ void conv1_wave(const float *xpad, float *a1, const Conv1W &cw, int l)
+{
+    const int cp = l & 7, oh = l >> 3;
+    f32x2 acc[7];
 #pragma unroll
-            for (int kh = 0; kh < 3; kh++)
+    for (int ow = 0; ow < 7; ow++) acc[ow] = cw.b;
 #pragma unroll
-                for (int kw = 0; kw < 3; kw++) acc = fmaf(xr[kh * kInPad + kw], w[kh * 3 + kw], acc);
-            a1pad[c * kA1Ch + (oh + 1) * kA1Stride + ow + 1] = fmaxf(acc, 0.0f);
-        }
+    for (int kh = 0; kh < 3; kh++) {
+        const float4 *row = reinterpret_cast<const float4 *>(xpad + (2 * oh + kh) * kXS);
+        const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+        const float r[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+            for (int ow = 0; ow < 7; ow++)
+                acc[ow] = __builtin_elementwise_fma(f32x2{r[2 * ow + kw], r[2 * ow + kw]}, cw.w[kh * 3 + kw], acc[ow]);
+    }
+    float *o0 = a1 + (2 * cp) * kA1Ch + (oh + 1) * kA1Row + 1, *o1 = o0 + kA1Ch;
+    const bool live = oh < 7;
+#pragma unroll
+    for (int ow = 0; ow < 7; ow++) {
+        o0[ow] = live ? fmaxf(acc[ow].x, 0.0f) : 0.0f;
+        o1[ow] = live ? fmaxf(acc[ow].y, 0.0f) : 0.0f;
     }
 }
 
-__device__ __forceinline__ void store_x(float *xpad, float v, int tid)
+__device__ __forceinline__ void zero_wave(float *p, int n, int l)
 {
-    if (tid < kIn * kIn) {
-        const int r = tid / kIn, c = tid - r * kIn;
-        xpad[(r + 1) * kInPad + c + 1] = v;
-    }
-}
-
-struct LdsF {
-    float x[2][kXSize];
-    float a1[2][kA1Size];
-};
-
-__device__ __forceinline__ void zero_lds(float *p, int n, int tid)
-{
-    for (int i = tid; i < n; i += kThreads) p[i] = 0.0f;
+    for (int i = l; i < n; i += 64) p[i] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void k_stem_fwd(const float *__restrict__ x, const float *__restrict__ w1,
-                                                     const float *__restrict__ b1, const float *__restrict__ w2,
-                                                     const float *__restrict__ b2, float *__restrict__ y, long long M)
+// forward: D[pos][co] = sum_k im2col(a1)[pos][k] * W2[co][k]; step s = t*4 + cq covers tap t = kh*3+kw of the
+// input channels 4cq..4cq+3 (k within the step = ci & 3).
+__global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(const float *__restrict__ x, const float *__restrict__ w1,
+                                                          const float *__restrict__ b1, const float *__restrict__ w2,
+                                                          const float *__restrict__ b2, float *__restrict__ y,
+                                                          long long M, long long xs)
 {
-    __shared__ __attribute__((aligned(16))) LdsF s;
-    const int tid = (int)threadIdx.x;
-    zero_lds(&s.x[0][0], 2 * kXSize, tid);
-    zero_lds(&s.a1[0][0], 2 * kA1Size, tid);
-    const int ciq = tid & 3, oh = (tid >> 2) & 3, cp = tid >> 4;
+    __shared__ __attribute__((aligned(16))) LdsF lds[kWaves];
+    const int l = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    LdsF &s = lds[wave];
+    const long long stride = (long long)gridDim.x * kWaves;
+    long long m = (long long)blockIdx.x * kWaves + wave;
+    XRegs xv = load_x(x, m, M, xs, l);
+    zero_wave(s.x, kXSize, l);
+    zero_wave(s.a1, kA1Size, l);
+    const int c = l & 15, q = l >> 4;
     float W[2][36];
 #pragma unroll
-    for (int i = 0; i < 36; i++) {
-        W[0][i] = w2[(2 * cp) * 144 + ciq * 36 + i];
-        W[1][i] = w2[(2 * cp + 1) * 144 + ciq * 36 + i];
-    }
-    const float bias0 = b2[2 * cp], bias1 = b2[2 * cp + 1];
-    float w1r[9];
+    for (int t = 0; t < 9; t++)
 #pragma unroll
-    for (int k = 0; k < 9; k++) w1r[k] = w1[(tid >> 4) * 9 + k];
-    const float b1r = b1[tid >> 4];
-    __syncthreads();
-    long long m = blockIdx.x;
-    float xv = (m < M && tid < 169) ? x[m * 169 + tid] : 0.f;
-    int buf = 0;
-    for (; m < M; m += gridDim.x, buf ^= 1) {
-        store_x(s.x[buf], xv, tid);
-        __syncthreads();
-        conv1_frame(s.x[buf], s.a1[buf], w1r, b1r, tid);
-        const long long mn = m + gridDim.x;
-        xv = (mn < M && tid < 169) ? x[mn * 169 + tid] : 0.f;     // prefetch the next frame under conv2
-        __syncthreads();
-        float acc[2][4];
+        for (int cq = 0; cq < 4; cq++) {
+            W[0][t * 4 + cq] = w2[c * 144 + (4 * cq + q) * 9 + t];
+            W[1][t * 4 + cq] = w2[(16 + c) * 144 + (4 * cq + q) * 9 + t];
+        }
+    const float bias0 = b2[c], bias1 = b2[16 + c];
+    const Conv1W cw = load_conv1_w(w1, b1, l);
+    // A operand: position p = l&15 (oh = p>>2, ow = p&3), channel-in-step q
+    const float *ap = s.a1 + q * kA1Ch + (2 * (c >> 2)) * kA1Row + 2 * (c & 3);
+    wave_lds_sync();
+    for (; m < M; m += stride) {
+        store_x(s.x, xv, l);
+        xv = load_x(x, m + stride, M, xs, l);        // prefetch the next frame under this one's math
+        wave_lds_sync();
+        conv1_wave(s.x, s.a1, cw, l);
+        wave_lds_sync();
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; j++) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
-        const float *a1 = s.a1[buf] + (ciq * 4) * kA1Ch + (2 * oh) * kA1Stride;
+        for (int t = 0; t < 9; t++)
 #pragma unroll
-        for (int ci = 0; ci < 4; ci++) {
-#pragma unroll
-            for (int kh = 0; kh < 3; kh++) {
-                const float4 *row = reinterpret_cast<const float4 *>(a1 + ci * kA1Ch + kh * kA1Stride);
-                const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-                const float r[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-#pragma unroll
-                for (int kw = 0; kw < 3; kw++) {
-                    const float wa = W[0][ci * 9 + kh * 3 + kw], wb = W[1][ci * 9 + kh * 3 + kw];
-#pragma unroll
-                    for (int ow = 0; ow < 4; ow++) {
-                        acc[0][ow] = fmaf(r[2 * ow + kw], wa, acc[0][ow]);
-                        acc[1][ow] = fmaf(r[2 * ow + kw], wb, acc[1][ow]);
-                    }
-                }
+            for (int cq = 0; cq < 4; cq++) {
+                const float a = ap[cq * 4 * kA1Ch + (t / 3) * kA1Row + (t % 3)];
+                acc0 = mfma(a, W[0][t * 4 + cq], acc0);
+                acc1 = mfma(a, W[1][t * 4 + cq], acc1);
             }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) { acc[0][j] = quad_sum(acc[0][j]); acc[1][j] = quad_sum(acc[1][j]); }
-        if (ciq < 2) {   // lane 0 of the quad stores channel 2cp, lane 1 channel 2cp+1
-            const float b = ciq ? bias1 : bias0;
-            const float4 v = ciq ? make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3])
-                                 : make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-            reinterpret_cast<float4 *>(y + m * 512)[(2 * cp + ciq) * 4 + oh] =
-                make_float4(fmaxf(v.x + b, 0.f), fmaxf(v.y + b, 0.f), fmaxf(v.z + b, 0.f), fmaxf(v.w + b, 0.f));
-        }
+        float4 *yo = reinterpret_cast<float4 *>(y + m * 512);
+        yo[c * 4 + q] = make_float4(fmaxf(acc0[0] + bias0, 0.f), fmaxf(acc0[1] + bias0, 0.f),
+                                    fmaxf(acc0[2] + bias0, 0.f), fmaxf(acc0[3] + bias0, 0.f));
+        yo[(16 + c) * 4 + q] = make_float4(fmaxf(acc1[0] + bias1, 0.f), fmaxf(acc1[1] + bias1, 0.f),
+                                           fmaxf(acc1[2] + bias1, 0.f), fmaxf(acc1[3] + bias1, 0.f));
     }
 }
 
-// dW2 / db2: same thread roles as the forward; the 72 registers hold gradient accumulators instead of weights.
-__global__ __launch_bounds__(256, 4) void k_stem_bwd_w2(const float *__restrict__ x, const float *__restrict__ y,
-                                                        const float *__restrict__ dy, const float *__restrict__ w1,
-                                                        const float *__restrict__ b1, float *__restrict__ partial, long long M)
+// dz2 = dy * (y > 0) of one frame: lane (c, q) holds channels c and 16+c, positions 4q..4q+3.
+struct DzRegs { float4 y0, y1, d0, d1; };
+__device__ __forceinline__ DzRegs load_dz(const float *__restrict__ y, const float *__restrict__ dy, long long m,
+                                          long long M, int c, int q)
 {
-    __shared__ __attribute__((aligned(16))) LdsF s;
-    const int tid = (int)threadIdx.x;
-    zero_lds(&s.x[0][0], 2 * kXSize, tid);
-    zero_lds(&s.a1[0][0], 2 * kA1Size, tid);
-    const int ciq = tid & 3, oh = (tid >> 2) & 3, cp = tid >> 4;
-    float G[2][36];
-#pragma unroll
-    for (int i = 0; i < 36; i++) { G[0][i] = 0.f; G[1][i] = 0.f; }
-    float gb0 = 0.f, gb1 = 0.f;
-    float w1r[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) w1r[k] = w1[(tid >> 4) * 9 + k];
-    const float b1r = b1[tid >> 4];
-    __syncthreads();
-    long long m = blockIdx.x;
-    float xv = (m < M && tid < 169) ? x[m * 169 + tid] : 0.f;
-    int buf = 0;
-    for (; m < M; m += gridDim.x, buf ^= 1) {
-        store_x(s.x[buf], xv, tid);
+    DzRegs r;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) {
         const float4 *yy = reinterpret_cast<const float4 *>(y + m * 512), *dd = reinterpret_cast<const float4 *>(dy + m * 512);
-        const float4 ya = yy[(2 * cp) * 4 + oh], yb = yy[(2 * cp + 1) * 4 + oh];
-        const float4 da = dd[(2 * cp) * 4 + oh], db = dd[(2 * cp + 1) * 4 + oh];
-        __syncthreads();
-        conv1_frame(s.x[buf], s.a1[buf], w1r, b1r, tid);
-        const long long mn = m + gridDim.x;
-        xv = (mn < M && tid < 169) ? x[mn * 169 + tid] : 0.f;
-        __syncthreads();
-        const float dz[2][4] = {{ya.x > 0.f ? da.x : 0.f, ya.y > 0.f ? da.y : 0.f, ya.z > 0.f ? da.z : 0.f, ya.w > 0.f ? da.w : 0.f},
-                                {yb.x > 0.f ? db.x : 0.f, yb.y > 0.f ? db.y : 0.f, yb.z > 0.f ? db.z : 0.f, yb.w > 0.f ? db.w : 0.f}};
-        if (ciq == 0) {
-            gb0 += dz[0][0] + dz[0][1] + dz[0][2] + dz[0][3];
-            gb1 += dz[1][0] + dz[1][1] + dz[1][2] + dz[1][3];
+        r.y0 = yy[c * 4 + q]; r.y1 = yy[(16 + c) * 4 + q];
+        r.d0 = dd[c * 4 + q]; r.d1 = dd[(16 + c) * 4 + q];
+    } else {
+        r.y0 = z; r.y1 = z; r.d0 = z; r.d1 = z;
+    }
+    return r;
+}
+__device__ __forceinline__ float4 relu_mask(const float4 &yv, const float4 &dv)
+{
+    return make_float4(yv.x > 0.f ? dv.x : 0.f, yv.y > 0.f ? dv.y : 0.f, yv.z > 0.f ? dv.z : 0.f, yv.w > 0.f ? dv.w : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward, one pass over (x, y, dy) per frame:
+//  (1) dW2[co][ci][t] = sum_{frames, pos} dz2[co][pos] * a1pad[ci][2oh+kh][2ow+kw]: per output row s = oh the MFMA step
+//      is A = dz2^T [co x 4 positions of the row], B = im2col rows [4 positions x 16 ci] for tap t -> 72 accumulator
+//      VGPRs held across the whole frame loop.
+//  (2) da1 = conv2^T(dz2): P_t[pos][ci] = sum_co dz2[pos][co] * W2[co][ci][t] (72 MFMAs, W2 in 72 VGPRs), scattered
+//      to a1pad[ci][2oh+kh][2ow+kw] in registers: lane (ci = l&15, oh = l>>4) ends up with the a1-gradient of the
+//      real rows 2oh (tap row kh=1) and 2oh+1 (kh=2 of its own output row + kh=0 of the next one, fetched from lane
+//      l+16); dz1 = da1 * (a1 > 0) -> dW1 / db1 against the frame's input rows.
+__global__ __launch_bounds__(kThreads, 2) void k_stem_bwd(const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ dy, const float *__restrict__ w1,
+                                                          const float *__restrict__ b1, const float *__restrict__ w2,
+                                                          float *__restrict__ partial, long long M, long long xs)
+{
+    __shared__ __attribute__((aligned(16))) LdsB lds[kWaves];
+    __shared__ float w2s[kW2];
+    const int l = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    LdsB &s = lds[wave];
+    const long long stride = (long long)gridDim.x * kWaves;
+    long long m = (long long)blockIdx.x * kWaves + wave;
+    const int c = l & 15, q = l >> 4;
+    XRegs xv = load_x(x, m, M, xs, l);
+    DzRegs zv = load_dz(y, dy, m, M, c, q);
+    zero_wave(s.x, kXSize, l);
+    zero_wave(s.a1, kA1Size, l);
+    f32x4 acc[2][9];        // dW2 tiles: rows co = 16n + 4q + r, column ci = c, tap t
+#pragma unroll
+    for (int t = 0; t < 9; t++) { acc[0][t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float gb0 = 0.f, gb1 = 0.f;
+    // B operand of (2): W2[co = 4 st + q][ci = c][t], shared by the workgroup's waves in LDS (bank-conflict free in
+    // the native [co][ci][t] order: 9c + 16q mod 64 is injective over the wave)
+    for (int i = (int)threadIdx.x; i < kW2; i += kThreads) w2s[i] = w2[i];
+    const float *wq = w2s + q * 144 + c * 9;
+    const Conv1W cw = load_conv1_w(w1, b1, l);
+    f32x2 g01[3], gAB[3];   // dW1 accumulators: taps (kh, 0..1) | {tap (2,kw) via row A, tap (0,kw) via row B}
+    float g2[3];            // taps (kh, 2)
+#pragma unroll
+    for (int k = 0; k < 3; k++) { g01[k] = f32x2{0.f, 0.f}; gAB[k] = f32x2{0.f, 0.f}; g2[k] = 0.f; }
+    float gb = 0.f;
+    const float *bp = s.a1 + c * kA1Ch + 2 * q;       // B operand of (1): input channel c, output column q of row s
+    __syncthreads();
+    for (; m < M; m += stride) {
+        store_x(s.x, xv, l);
+        const float4 z0 = relu_mask(zv.y0, zv.d0), z1 = relu_mask(zv.y1, zv.d1);
+        gb0 += (z0.x + z0.y) + (z0.z + z0.w);
+        gb1 += (z1.x + z1.y) + (z1.z + z1.w);
+        reinterpret_cast<float4 *>(s.dz)[c * 4 + q] = z0;
+        reinterpret_cast<float4 *>(s.dz)[(16 + c) * 4 + q] = z1;
+        xv = load_x(x, m + stride, M, xs, l);
+        zv = load_dz(y, dy, m + stride, M, c, q);
+        wave_lds_sync();
+        conv1_wave(s.x, s.a1, cw, l);
+        wave_lds_sync();
+        // (1) dW2
+#pragma unroll
+        for (int r = 0; r < 4; r++) {               // output row oh = r: positions 4r + q
+            const float a0 = s.dz[c * 16 + 4 * r + q], a1v = s.dz[(16 + c) * 16 + 4 * r + q];
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const float b = bp[(2 * r + t / 3) * kA1Row + (t % 3)];
+                acc[0][t] = mfma(a0, b, acc[0][t]);
+                acc[1][t] = mfma(a1v, b, acc[1][t]);
+            }
         }
-        const float *a1 = s.a1[buf] + (ciq * 4) * kA1Ch + (2 * oh) * kA1Stride;
+        // (2) da1 -> dz1 -> dW1, db1
+        f32x4 P[9];
 #pragma unroll
-        for (int ci = 0; ci < 4; ci++) {
+        for (int t = 0; t < 9; t++) P[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kh = 0; kh < 3; kh++) {
-                const float4 *row = reinterpret_cast<const float4 *>(a1 + ci * kA1Ch + kh * kA1Stride);
-                const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-                const float r[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+        for (int st = 0; st < 8; st++) {
+            const float a = s.dz[(4 * st + q) * 16 + c];       // A[pos = l&15][co = 4 st + q]
+#pragma unroll
+            for (int t = 0; t < 9; t++) P[t] = mfma(a, wq[st * 4 * 144 + t], P[t]);
+        }
+        // lane (ci = c, oh = q): P[kh*3+kw][ow] -> window columns 2ow+kw (padded 0..8), real columns 1..7
+        float pw[3][7];
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            const f32x4 p0 = P[kh * 3], p1 = P[kh * 3 + 1], p2 = P[kh * 3 + 2];
+            pw[kh][0] = p1[0];
+            pw[kh][1] = p2[0] + p0[1];
+            pw[kh][2] = p1[1];
+            pw[kh][3] = p2[1] + p0[2];
+            pw[kh][4] = p1[2];
+            pw[kh][5] = p2[2] + p0[3];
+            pw[kh][6] = p1[3];
+        }
+        const float *a1c = s.a1 + c * kA1Ch + (2 * q + 1) * kA1Row + 1;
+        float dzA[7], dzB[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const float up = __shfl_down(pw[0][j], 16, 64);      // kh = 0 row of output row oh+1
+            const float aA = a1c[j], aB = a1c[kA1Row + j];
+            dzA[j] = aA > 0.f ? pw[1][j] : 0.f;
+            dzB[j] = (q < 3 && aB > 0.f) ? pw[2][j] + up : 0.f;
+            gb += dzA[j] + dzB[j];
+        }
+        // a1 row r, tap kh reads padded input row 2r + kh: row A (r = 2q) uses rows 4q..4q+2, row B rows 4q+2..4q+4.
+        // Packed FMAs: taps kw = 0,1 pair up against two neighbouring input values; on the shared input row (j = 2)
+        // the rows A and B pair up against one broadcast input value.
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const float4 *row = reinterpret_cast<const float4 *>(s.x + (4 * q + j) * kXS);
+            const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+            const float r[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+            if (j == 2) {
 #pragma unroll
                 for (int kw = 0; kw < 3; kw++) {
-                    float ga = G[0][ci * 9 + kh * 3 + kw], gb = G[1][ci * 9 + kh * 3 + kw];
+                    f32x2 g = gAB[kw];                      // {tap (2,kw) of row A, tap (0,kw) of row B}
 #pragma unroll
-                    for (int ow = 0; ow < 4; ow++) {
-                        ga = fmaf(r[2 * ow + kw], dz[0][ow], ga);
-                        gb = fmaf(r[2 * ow + kw], dz[1][ow], gb);
-                    }
-                    G[0][ci * 9 + kh * 3 + kw] = ga; G[1][ci * 9 + kh * 3 + kw] = gb;
+                    for (int cc = 0; cc < 7; cc++)
+                        g = __builtin_elementwise_fma(f32x2{dzA[cc], dzB[cc]}, f32x2{r[2 * cc + kw], r[2 * cc + kw]}, g);
+                    gAB[kw] = g;
                 }
+            } else {
+                const int kh = j < 2 ? j : j - 2;           // rows 0,1 feed row A; rows 3,4 feed row B (taps 1,2)
+                const float(&dz)[7] = j < 2 ? dzA : dzB;
+                f32x2 g = g01[kh];
+                float g2v = g2[kh];
+#pragma unroll
+                for (int cc = 0; cc < 7; cc++) {
+                    g = __builtin_elementwise_fma(f32x2{dz[cc], dz[cc]}, f32x2{r[2 * cc], r[2 * cc + 1]}, g);
+                    g2v = fmaf(dz[cc], r[2 * cc + 2], g2v);
+                }
+                g01[kh] = g;
+                g2[kh] = g2v;
             }
         }
     }
-    // sum over the 4 output rows (tid bits 2..3), then one record per workgroup
-    float *rec = partial + (size_t)blockIdx.x * kPartial;
-#pragma unroll
-    for (int i = 0; i < 36; i++) {
-        const float a = xor_sum(xor_sum(G[0][i], 4), 8), b = xor_sum(xor_sum(G[1][i], 4), 8);
-        if (oh == 0) { rec[(2 * cp) * 144 + ciq * 36 + i] = a; rec[(2 * cp + 1) * 144 + ciq * 36 + i] = b; }
-    }
-    gb0 = xor_sum(xor_sum(gb0, 4), 8); gb1 = xor_sum(xor_sum(gb1, 4), 8);
-    if (oh == 0 && ciq == 0) { rec[kW2 + 2 * cp] = gb0; rec[kW2 + 2 * cp + 1] = gb1; }
-}
-
-constexpr int kPwSize = kC1 * 4 * 3 * kA1Stride;   // per (ci, oh): its 3x9 window of a1-gradients, rows padded to 12
-struct LdsB {
-    float x[2][kXSize];
-    float a1[kA1Size];
-    float pw[2][kPwSize];    // double-buffered with dz: both are (re)written before the frame's first barrier,
-    float dz[2][512];        // while slower threads may still be reading the previous frame's copies
-};
-
-// da1 = conv2^T(dz2) -> dz1 = da1 * (a1 > 0) -> dW1 / db1.
-__global__ __launch_bounds__(256, 3) void k_stem_bwd_w1(const float *__restrict__ x, const float *__restrict__ y,
-                                                        const float *__restrict__ dy, const float *__restrict__ w1,
-                                                        const float *__restrict__ b1, const float *__restrict__ w2,
-                                                        float *__restrict__ partial, long long M)
-{
-    __shared__ __attribute__((aligned(16))) LdsB s;
-    const int tid = (int)threadIdx.x;
-    zero_lds(&s.x[0][0], 2 * kXSize, tid);
-    zero_lds(s.a1, kA1Size, tid);
-    const int coq = tid & 3, oh = (tid >> 2) & 3, ci = tid >> 4;
-    float Wt[8][9];   // w2[co][ci][k] for co in [8coq, 8coq+8)
-#pragma unroll
-    for (int c = 0; c < 8; c++)
-#pragma unroll
-        for (int k = 0; k < 9; k++) Wt[c][k] = w2[(8 * coq + c) * 144 + ci * 9 + k];
-    float w1r[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) w1r[k] = w1[(tid >> 4) * 9 + k];
-    const float b1r = b1[tid >> 4];
+    // fold the packed accumulators back into the 3x3 filter gradient
     float g1[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) g1[k] = 0.f;
-    float gb = 0.f;
+    for (int kh = 0; kh < 3; kh++) { g1[kh * 3] = g01[kh].x; g1[kh * 3 + 1] = g01[kh].y; g1[kh * 3 + 2] = g2[kh]; }
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++) { g1[6 + kw] += gAB[kw].x; g1[kw] += gAB[kw].y; }
+#pragma unroll
+    for (int k = 0; k < 9; k++) g1[k] = xor_sum(xor_sum(g1[k], 16), 32);
+    gb = xor_sum(xor_sum(gb, 16), 32);
+    gb0 = xor_sum(xor_sum(gb0, 16), 32);
+    gb1 = xor_sum(xor_sum(gb1, 16), 32);
+    // one record per workgroup: the four waves add up in wave order (fixed order -> reproducible sums)
     __syncthreads();
-    long long m = blockIdx.x;
-    float xv = (m < M && tid < 169) ? x[m * 169 + tid] : 0.f;
-    int buf = 0;
-    for (; m < M; m += gridDim.x, buf ^= 1) {
-        store_x(s.x[buf], xv, tid);
-        if (tid < 128) {   // dz2 = dy * (y > 0) -> LDS [co][p]
-            const float4 yv = reinterpret_cast<const float4 *>(y + m * 512)[tid], dv = reinterpret_cast<const float4 *>(dy + m * 512)[tid];
-            reinterpret_cast<float4 *>(s.dz[buf])[tid] = make_float4(yv.x > 0.f ? dv.x : 0.f, yv.y > 0.f ? dv.y : 0.f,
-                                                                  yv.z > 0.f ? dv.z : 0.f, yv.w > 0.f ? dv.w : 0.f);
-        }
-        __syncthreads();                       // every thread has left the previous frame: a1 may be rewritten
-        conv1_frame(s.x[buf], s.a1, w1r, b1r, tid);
-        const long long mn = m + gridDim.x;
-        xv = (mn < M && tid < 169) ? x[mn * 169 + tid] : 0.f;
-        // window of a1-gradients touched by conv2 output row oh: padded rows 2oh..2oh+2, padded cols 0..8
-        float P[3][9];
+    float *red = reinterpret_cast<float *>(lds);
+    float *rec = partial + (size_t)blockIdx.x * kPartial;
+    for (int wv = 0; wv < kWaves; wv++) {
+        if (wave == wv) {
 #pragma unroll
-        for (int a = 0; a < 3; a++)
+            for (int n = 0; n < 2; n++)
 #pragma unroll
-            for (int b = 0; b < 9; b++) P[a][b] = 0.f;
-        const float4 *dzr = reinterpret_cast<const float4 *>(s.dz[buf]);
+                for (int t = 0; t < 9; t++)
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const float4 d4 = dzr[(8 * coq + c) * 4 + oh];
-            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-            for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-                for (int kw = 0; kw < 3; kw++) {
-                    const float w = Wt[c][kh * 3 + kw];
-#pragma unroll
-                    for (int ow = 0; ow < 4; ow++) P[kh][2 * ow + kw] = fmaf(d[ow], w, P[kh][2 * ow + kw]);
-                }
-        }
-        // each (ci, oh) owns its window in LDS (no atomics, no clearing); overlapping rows are summed by the reader
-        float *pw = s.pw[buf] + (ci * 4 + oh) * 3 * kA1Stride;
-#pragma unroll
-        for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-            for (int b = 0; b < 9; b++) {
-                const float v = quad_sum(P[kh][b]);
-                if (((kh * 9 + b) & 3) == coq) pw[kh * kA1Stride + b] = v;   // the quad shares the 27 stores
-            }
-        __syncthreads();
-        {   // dz1 and conv1 weight gradients: thread = (channel c, part), positions q = part + 16 i
-            const int c = tid >> 4, part = tid & 15;
-            const float *a1c = s.a1 + c * kA1Ch, *pwc = s.pw[buf] + c * 4 * 3 * kA1Stride;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int q = part + 16 * i;
-                if (q < 49) {
-                    const int r = q / 7, cc = q - r * 7;
-                    const float a = a1c[(r + 1) * kA1Stride + cc + 1];
-                    // padded row R = r+1 = 2*oh + kh: odd R <- (oh=(R-1)/2, kh=1); even R <- (R/2-1, kh=2) and (R/2, kh=0)
-                    const int R = r + 1;
-                    float da;
-                    if (R & 1) da = pwc[(((R - 1) >> 1) * 3 + 1) * kA1Stride + cc + 1];
-                    else {
-                        da = pwc[(((R >> 1) - 1) * 3 + 2) * kA1Stride + cc + 1];
-                        if ((R >> 1) < 4) da += pwc[((R >> 1) * 3 + 0) * kA1Stride + cc + 1];
+                    for (int r = 0; r < 4; r++) {
+                        const int slot = ((n * 9 + t) * 4 + r) * 64 + l;
+                        const float v = acc[n][t][r] + (wv ? red[slot] : 0.f);
+                        if (wv < kWaves - 1) red[slot] = v;
+                        else rec[(16 * n + 4 * q + r) * 144 + c * 9 + t] = v;
                     }
-                    const float dzv = a > 0.f ? da : 0.f;
-                    gb += dzv;
-                    const float *xr = s.x[buf] + (2 * r) * kInPad + 2 * cc;
+            if (q == 0) {
+                const float v0 = gb0 + (wv ? red[kW2 + c] : 0.f), v1 = gb1 + (wv ? red[kW2 + 16 + c] : 0.f);
+                if (wv < kWaves - 1) { red[kW2 + c] = v0; red[kW2 + 16 + c] = v1; }
+                else { rec[kW2 + c] = v0; rec[kW2 + 16 + c] = v1; }
 #pragma unroll
-                    for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-                        for (int kw = 0; kw < 3; kw++) g1[kh * 3 + kw] = fmaf(dzv, xr[kh * kInPad + kw], g1[kh * 3 + kw]);
+                for (int k = 0; k < 10; k++) {
+                    const int slot = kW2 + kC2 + k * 16 + c;
+                    const float v = (k < 9 ? g1[k < 9 ? k : 0] : gb) + (wv ? red[slot] : 0.f);
+                    if (wv < kWaves - 1) red[slot] = v;
+                    else if (k < 9) rec[kW2 + kC2 + c * 9 + k] = v;
+                    else rec[kW2 + kC2 + 144 + c] = v;
                 }
             }
         }
+        __syncthreads();
     }
-    float *rec = partial + (size_t)blockIdx.x * kPartial + kW2 + kC2;
-    const int c = tid >> 4, part = tid & 15;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const float v = xor_sum(xor_sum(xor_sum(xor_sum(g1[k], 1), 2), 4), 8);
-        if (part == 0) rec[c * 9 + k] = v;
-    }
-    gb = xor_sum(xor_sum(xor_sum(xor_sum(gb, 1), 2), 4), 8);
-    if (part == 0) rec[144 + c] = gb;
 }
 
 // Fixed-order reduction of the per-workgroup records: 16 record elements x 64 record slices per block.
@@ -361,7 +394,7 @@ __global__ __launch_bounds__(1024) void k_stem_reduce(const float *__restrict__ 
 
 using namespace atr;
 
-static int stem_grid(long long M)
+static int stem_grid(long long M, int blocks_per_cu)
 {
     static int cached_cus = 0;   // queried once: hipGetDeviceProperties is far too slow for a per-launch call
     if (cached_cus == 0) {
@@ -370,31 +403,32 @@ static int stem_grid(long long M)
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         cached_cus = n;
     }
-    const int cus = cached_cus;
-    const long long cap = (long long)cus * 4;   // 4 resident workgroups per CU
-    return (int)(M < cap ? (M < 1 ? 1 : M) : cap);
+    const long long cap = (long long)cached_cus * blocks_per_cu, need = (M + kWaves - 1) / kWaves;
+    return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
 }
+constexpr int kFwdBlocksPerCu = 3, kBwdBlocksPerCu = 2;
 
-extern "C" long long atr_stem_workspace_floats(long long M) { return (long long)stem_grid(M) * kPartial; }
+extern "C" long long atr_stem_workspace_floats(long long M) { return (long long)stem_grid(M, kBwdBlocksPerCu) * kPartial; }
 
-extern "C" int atr_stem_forward(const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
-                                float *y, long long M, void *stream)
+extern "C" int atr_stem_forward(const float *x, long long x_stride, const float *w1, const float *b1, const float *w2,
+                                const float *b2, float *y, long long M, void *stream)
 {
-    if (!x || !w1 || !b1 || !w2 || !b2 || !y || M < 0) return -1;
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || M < 0 || x_stride < 169) return -1;
     if (M == 0) return 0;
-    hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)stem_grid(M)), dim3(kThreads), 0, (hipStream_t)stream, x, w1, b1, w2, b2, y, M);
+    hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)stem_grid(M, kFwdBlocksPerCu)), dim3(kThreads), 0, (hipStream_t)stream,
+                       x, w1, b1, w2, b2, y, M, x_stride);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern "C" int atr_stem_backward(const float *x, const float *y, const float *dy, const float *w1, const float *b1,
-                                 const float *w2, float *dw1, float *db1, float *dw2, float *db2, float *workspace,
-                                 long long M, void *stream)
+extern "C" int atr_stem_backward(const float *x, long long x_stride, const float *y, const float *dy, const float *w1,
+                                 const float *b1, const float *w2, float *dw1, float *db1, float *dw2, float *db2,
+                                 float *workspace, long long M, void *stream)
 {
-    if (!x || !y || !dy || !w1 || !b1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !workspace || M <= 0) return -1;
-    const int grid = stem_grid(M);
+    if (!x || !y || !dy || !w1 || !b1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !workspace || M <= 0 || x_stride < 169)
+        return -1;
+    const int grid = stem_grid(M, kBwdBlocksPerCu);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_stem_bwd_w2, dim3((unsigned)grid), dim3(kThreads), 0, st, x, y, dy, w1, b1, workspace, M);
-    hipLaunchKernelGGL(k_stem_bwd_w1, dim3((unsigned)grid), dim3(kThreads), 0, st, x, y, dy, w1, b1, w2, workspace, M);
+    hipLaunchKernelGGL(k_stem_bwd, dim3((unsigned)grid), dim3(kThreads), 0, st, x, y, dy, w1, b1, w2, workspace, M, x_stride);
     hipLaunchKernelGGL(k_stem_reduce, dim3((kPartial + 15) / 16), dim3(1024), 0, st, workspace, grid, dw1, db1, dw2, db2);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -82,11 +82,25 @@ class VecEnv(object):
     def reset(self):
         return self._stack(self.core.reset(), fill=True)
 
-    def step(self, actions):
+    def step(self, actions, out=None):
+        """out: optional (obs [N,A,h,w] f32, rew [N,A] f32, done [N] u8) device tensors the kernel writes directly
+        (a slot of rollout_buffers)."""
         a0 = actions[0]
         a1 = actions[1] if len(actions) > 1 else None
-        obs, rew, done = self.core.step(a0, a1)
+        obs, rew, done = self.core.step(a0, a1, out=out)
         return self._stack(obs, done), rew, done, {}
+
+    def rollout_buffers(self, num_steps):
+        """Storage for one rollout the step kernel writes in place — obs [T+1,N,A,h,w] (slot 0 = the state the
+        rollout starts from), rewards [T,N,A], done [T,N] — so the learner reads the rollout without a stacking
+        copy (110 MB per 20-step, 4096-env rollout). None when frames are stacked host-side."""
+        if self.stack_frames != 1:
+            return None
+        h, w = self.core.obs_hw
+        dev = self.device
+        return (torch.empty((num_steps + 1, self.num_envs, 2, h, w), dtype=torch.float32, device=dev),
+                torch.empty((num_steps, self.num_envs, 2), dtype=torch.float32, device=dev),
+                torch.empty((num_steps, self.num_envs), dtype=torch.uint8, device=dev))
 
     def flush(self):
         self.core.flush()

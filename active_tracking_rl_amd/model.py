@@ -251,7 +251,7 @@ class CNN_maze(nn.Module):
             return self.forward_conv2d(x, fc)
         if x.is_cuda and self.use_fused and self.conv1.in_channels == 1 and x.shape[-1] == 13:
             from . import fused
-            x = fused.stem(x.reshape(n * f, -1), self.conv1, self.conv2)
+            x = fused.stem(x, self.conv1, self.conv2)       # strided views of the obs tensor are read in place
         else:
             x = self.forward_dense_stem(x.reshape(n * f, -1))
         x = x.reshape(n, -1)

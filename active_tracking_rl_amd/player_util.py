@@ -34,6 +34,7 @@ class Agent(object):
         self.rnn_out = args.rnn_out
         self.values, self.log_probs, self.rewards, self.entropies, self.preds, self.dones = [], [], [], [], [], []
         self.states, self.actions, self.h0, self.c0 = [], [], None, None
+        self._buf = None
         self.done = torch.ones(self.num_envs, dtype=torch.uint8, device=device)
         self.info = None
         self.reward = 0
@@ -84,7 +85,12 @@ class Agent(object):
             self._hs, self._cs = list(hx.unbind(1)), list(cx.unbind(1))
         self.states.append(self.state)
         self.actions.append(torch.stack(actions, 1))
-        state_multi, reward_multi, done, self.info = self.env.step(actions)
+        if self._buf is not None:                       # the step kernel writes straight into the rollout storage
+            t = len(self.states) - 1
+            state_multi, reward_multi, done, self.info = self.env.step(
+                actions, out=(self._buf[0][t + 1], self._buf[1][t], self._buf[2][t]))
+        else:
+            state_multi, reward_multi, done, self.info = self.env.step(actions)
         self.reward_org = reward_multi
         self.reward = reward_multi
         self.state = state_multi
@@ -96,8 +102,14 @@ class Agent(object):
         self.dones.append(done)
         return self
 
-    def begin_rollout(self):
-        """Remember the LSTM state the rollout starts from (the learner re-runs the recurrence from it)."""
+    def begin_rollout(self, num_steps=None):
+        """Remember the LSTM state the rollout starts from (the learner re-runs the recurrence from it). With
+        num_steps and an env that offers rollout_buffers, the rollout is stored in place (no stacking copies)."""
+        self._buf = None
+        if num_steps is not None and hasattr(self.env, "rollout_buffers"):
+            self._buf = self.env.rollout_buffers(num_steps)
+            if self._buf is not None:
+                self._buf[0][0].copy_(self.state.reshape(self._buf[0][0].shape))
         self.update_rnn_hiden()
         self.h0, self.c0 = self.hxs, self.cxs
         self._hs = [h.contiguous() for h in self.hxs.unbind(1)]
@@ -107,7 +119,9 @@ class Agent(object):
     def end_rollout(self):
         """Publish the per-player LSTM states back as hxs/cxs [N,A,R] and the episode-length counters."""
         self.hxs, self.cxs = torch.stack(self._hs, 1), torch.stack(self._cs, 1)
-        nd = (torch.stack(self.dones, 0) == 0).to(self.eps_len.dtype)         # [T, N]
+        dones = self._buf[2] if self._buf is not None and len(self.dones) == self._buf[2].shape[0] \
+            else torch.stack(self.dones, 0)
+        nd = (dones == 0).to(self.eps_len.dtype)                              # [T, N]
         alive_since = torch.flip(torch.cumprod(torch.flip(nd, [0]), 0), [0])  # 1 while no done from t to the end
         self.eps_len = self.eps_len * alive_since[0] + alive_since.sum(0)
 
@@ -195,10 +209,15 @@ class Agent(object):
         args = self.args
         N, A, T = self.num_envs, self.num_agents, len(self.rewards)
         dev = self.device
-        states = torch.stack(self.states, 0)
         actions = torch.stack(self.actions, 0)
-        rewards = torch.stack(self.rewards, 0)                               # [T, N, A, 1]
-        nd = (torch.stack(self.dones, 0) == 0).to(rewards.dtype)             # [T, N]
+        if self._buf is not None and T == self._buf[1].shape[0]:
+            states = self._buf[0][:T].unsqueeze(3).unsqueeze(4)              # [T, N, A, 1, 1, h, w] views
+            rewards = self._buf[1].unsqueeze(3)
+            nd = (self._buf[2] == 0).to(rewards.dtype)
+        else:
+            states = torch.stack(self.states, 0)
+            rewards = torch.stack(self.rewards, 0)                           # [T, N, A, 1]
+            nd = (torch.stack(self.dones, 0) == 0).to(rewards.dtype)         # [T, N]
         values, entropies, log_probs, preds = self.model.forward_sequence(states, actions, self.h0, self.c0, nd)
         with torch.no_grad():
             boot, _, _, _, _, _ = self.model((self.state, (self.hxs, self.cxs)))

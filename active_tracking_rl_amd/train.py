@@ -75,7 +75,7 @@ def rollout(player, num_steps, fast=True):
     if hasattr(player.model, "cache_dense"):
         player.model.cache_dense(True)   # expand conv weights once per rollout (released in compute_grads)
     if fast:
-        player.begin_rollout()
+        player.begin_rollout(num_steps)
         for _ in range(num_steps):
             player.action_rollout()
         player.end_rollout()
