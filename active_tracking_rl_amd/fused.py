@@ -25,6 +25,13 @@ def lib():
         L.atr_stem_backward.argtypes = [vp, ll] + [vp] * 10 + [ll, vp]
         L.atr_sample_actions.restype = C.c_int
         L.atr_sample_actions.argtypes = [vp, vp, vp, vp, vp, C.c_ulonglong, C.c_int, C.c_int, C.c_int, vp]
+        i32 = C.c_int
+        L.atr_lstm_cell_forward.restype = i32
+        L.atr_lstm_cell_forward.argtypes = [vp, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp]
+        L.atr_lstm_cell_backward.restype = i32
+        L.atr_lstm_cell_backward.argtypes = [vp, ll, vp, vp, vp, vp, vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, i32, vp]
+        L.atr_gae_returns.restype = i32
+        L.atr_gae_returns.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, i32, vp]
         _lib = L
     return _lib
 
@@ -108,3 +115,110 @@ class ActionSampler(object):
         if rc != 0:
             raise RuntimeError("atr_sample_actions failed (%d)" % rc)
         return actions
+
+
+def _pn(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def lstm_cell(ig, hg, c_prev, keep=None, done=None):
+    """One no-grad LSTMCell step for the rollout (csrc/lstm_hip.hip): ig [N,4R] = x W_ih^T + b_ih + b_hh, hg [N,4R] =
+    h_prev W_hh^T with h_prev NOT masked; the previous step's episode-boundary mask (keep [N] float, or done [N] uint8)
+    is applied inside. Returns (h, c) [N,R]."""
+    N, R = c_prev.shape
+    h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
+    rc = lib().atr_lstm_cell_forward(_p(ig), None, _p(hg), _p(c_prev), 0, _pn(keep), _pn(done), _p(h), 0, _p(c), 0,
+                                     None, 0, 1, N, R, _stream(ig))
+    if rc != 0:
+        raise RuntimeError("atr_lstm_cell_forward failed (%d)" % rc)
+    return h, c
+
+
+class _LstmSeq(torch.autograd.Function):
+    """Two (or one) independent LSTMCells over T time-major steps with the per-step episode mask, as ONE autograd
+    node: per step one batched hidden GEMM + one fused cell launch forward, one fused cell-backward launch + one
+    batched GEMM backward; the weight gradient of W_hh is a single GEMM over all T*N rows at the end.
+    ig0/ig1 [T*N,4R] (input projections incl. both biases), whh [P,R,4R] (= W_hh^T per player), h0/c0 [P,N,R]
+    (already masked), keep [T,N] float. Returns per player h_seq [T,N,R] (the un-masked step outputs, what the heads
+    read) and, last, the un-masked final cell state [P,N,R] (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, ig0, ig1, whh, h0, c0, keep):
+        L = lib()
+        P, N, R = h0.shape
+        T = keep.shape[0]
+        dev = h0.device
+        ig0, whh, keep = ig0.contiguous(), whh.contiguous(), keep.contiguous()
+        ig1 = ig1.contiguous() if ig1 is not None else None
+        h_all = torch.empty((P, T + 1, N, R), dtype=torch.float32, device=dev)   # slot 0 = h0, slot t+1 = h_t
+        c_all = torch.empty((P, T + 1, N, R), dtype=torch.float32, device=dev)
+        acts = torch.empty((P, T, N, 4 * R), dtype=torch.float32, device=dev)
+        h_all[:, 0].copy_(h0)
+        c_all[:, 0].copy_(c0)
+        hg = torch.empty((P, N, 4 * R), dtype=torch.float32, device=dev)
+        st = _stream(h0)
+        ps, pa, step, astep = (T + 1) * N * R, T * N * 4 * R, N * R * 4, N * 4 * R * 4   # strides: floats / bytes
+        for t in range(T):
+            torch.bmm(h_all[:, t], whh, out=hg)
+            off = t * N * 4 * R * 4
+            rc = L.atr_lstm_cell_forward(
+                C.c_void_p(ig0.data_ptr() + off), C.c_void_p(ig1.data_ptr() + off) if ig1 is not None else None,
+                _p(hg), C.c_void_p(c_all.data_ptr() + t * step), ps, _p(keep[t - 1]) if t else None, None,
+                C.c_void_p(h_all.data_ptr() + (t + 1) * step), ps, C.c_void_p(c_all.data_ptr() + (t + 1) * step), ps,
+                C.c_void_p(acts.data_ptr() + t * astep), pa, P, N, R, st)
+            if rc != 0:
+                raise RuntimeError("atr_lstm_cell_forward failed (%d)" % rc)
+        ctx.save_for_backward(whh, keep, h_all, c_all, acts)
+        ctx.two = ig1 is not None
+        c_last = c_all[:, T].clone()                                             # un-masked final cell state
+        ctx.mark_non_differentiable(c_last)
+        return tuple(h_all[p, 1:] for p in range(P)) + (c_last,)                 # per player [T,N,R], contiguous
+
+    @staticmethod
+    def backward(ctx, *dhs):
+        L = lib()
+        dhs = dhs[:-1]
+        whh, keep, h_all, c_all, acts = ctx.saved_tensors
+        P, T1, N, R = h_all.shape
+        T = T1 - 1
+        dev = h_all.device
+        dhs = [torch.zeros((T, N, R), dtype=torch.float32, device=dev) if d is None else d.contiguous() for d in dhs]
+        pd = (dhs[1].data_ptr() - dhs[0].data_ptr()) // 4 if P > 1 else 0          # player stride between the two grads
+        dG = torch.empty((P, T, N, 4 * R), dtype=torch.float32, device=dev)
+        dhn = torch.empty((P, N, R), dtype=torch.float32, device=dev)
+        dcc = torch.empty((P, N, R), dtype=torch.float32, device=dev)
+        whh_t = whh.transpose(1, 2)                                               # [P,4R,R]
+        st = _stream(h_all)
+        ps, pa, step, astep = (T + 1) * N * R, T * N * 4 * R, N * R * 4, N * 4 * R * 4
+        for t in range(T - 1, -1, -1):
+            rc = L.atr_lstm_cell_backward(
+                C.c_void_p(dhs[0].data_ptr() + t * step), pd, _p(dhn), _p(dcc), _p(keep[t]),
+                _p(keep[t - 1]) if t else None, C.c_void_p(acts.data_ptr() + t * astep), pa,
+                C.c_void_p(c_all.data_ptr() + (t + 1) * step), ps, C.c_void_p(c_all.data_ptr() + t * step), ps,
+                C.c_void_p(dG.data_ptr() + t * astep), pa, 1 if t < T - 1 else 0, P, N, R, st)
+            if rc != 0:
+                raise RuntimeError("atr_lstm_cell_backward failed (%d)" % rc)
+            torch.bmm(dG[:, t], whh_t, out=dhn)                                   # gradient into h_{t-1}
+        # W_hh: sum_t (k_{t-1} h_{t-1})^T dG_t as one GEMM per player over all T*N rows
+        kprev = torch.cat([torch.ones_like(keep[:1]), keep[:-1]], 0).view(1, T, N, 1)
+        hm = (h_all[:, :T] * kprev).view(P, T * N, R)
+        dwhh = torch.bmm(hm.transpose(1, 2), dG.view(P, T * N, 4 * R))
+        dg = dG.view(P, T * N, 4 * R)
+        return dg[0], (dg[1] if ctx.two else None), dwhh, dhn, dcc, None
+
+
+def lstm_sequence(ig0, ig1, whh, h0, c0, keep):
+    return _LstmSeq.apply(ig0, ig1, whh, h0, c0, keep)
+
+
+@torch.no_grad()
+def gae_returns(rewards, values, notdone, gamma, tau):
+    """rewards [T,N,A,1], values [T+1,N,A,1] (row T = bootstrap), notdone [T,N] float -> (returns, gae) [T,N,A,1]."""
+    T, N, A = rewards.shape[0], rewards.shape[1], rewards.shape[2]
+    rewards, values, notdone = rewards.contiguous(), values.contiguous(), notdone.contiguous()
+    ret, gae = torch.empty_like(rewards), torch.empty_like(rewards)
+    rc = lib().atr_gae_returns(_p(rewards), _p(values), _p(notdone), float(gamma), float(tau), _p(ret), _p(gae),
+                               T, N, A, _stream(rewards))
+    if rc != 0:
+        raise RuntimeError("atr_gae_returns failed (%d)" % rc)
+    return ret, gae

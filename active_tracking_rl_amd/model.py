@@ -71,13 +71,36 @@ def sample_action(logit, test=False):
     return action, entropy, log_prob
 
 
+fused_lstm = True   # GPU tensors: recurrence through the fused HIP cell kernels (csrc/lstm_hip.hip); False = ATen ops
+
+
+def lstm_sequence_fused(lstms, feats, h, c, keep):
+    """lstm_sequence on the fused kernels: feats = per-player list of [T, N, F] (no stacking copy). One autograd node
+    for the whole recurrence (fused.lstm_sequence); returns (h_seq as a per-player list of [T, N, R], final masked h
+    [P, N, R], final masked c [P, N, R] (c not differentiable))."""
+    from . import fused
+    T, N = feats[0].shape[0], feats[0].shape[1]
+    igs = [F.linear(f.reshape(T * N, -1), l.weight_ih, l.bias_ih + l.bias_hh) for f, l in zip(feats, lstms)]
+    whh = torch.stack([l.weight_hh.t() for l in lstms], 0)
+    outs = fused.lstm_sequence(igs[0], igs[1] if len(igs) > 1 else None, whh, h.contiguous(), c.contiguous(), keep)
+    h_seq, k_last = list(outs[:-1]), keep[-1].view(1, N, 1)
+    return h_seq, torch.stack([o[-1] for o in h_seq], 0) * k_last, outs[-1] * k_last
+
+
 def lstm_sequence(lstms, feats, h, c, keep):
     """Run P independent nn.LSTMCells (same sizes, different weights — the two players) over time-major feature
     sequences in lock step, with the per-step episode-boundary mask applied AFTER each step (what Agent.action_train
     does). feats [T, P, N, F], h/c [P, N, R], keep [T, N] (0 where the env finished at that step).
     The input projections are one GEMM per player over all T*N rows (both biases folded in); per step the P hidden
     GEMMs are ONE bmm and the pointwise cell ONE fused kernel over P*N rows — the recurrence is launch-bound, so
-    batching the players halves its cost. Returns h_seq [T, P, N, R] and the final masked (h, c) [P, N, R]."""
+    batching the players halves its cost. Returns h_seq [T, P, N, R] and the final masked (h, c) [P, N, R].
+    feats may also be a per-player list of [T, N, F]: on the GPU that selects the fused HIP recurrence
+    (lstm_sequence_fused; h_seq then comes back as a per-player list of [T, N, R]) without a stacking copy."""
+    if isinstance(feats, (list, tuple)):
+        f0 = feats[0]
+        if f0.is_cuda and fused_lstm and len(feats) <= 2 and h.shape[-1] % 4 == 0 and f0.dtype == torch.float32:
+            return lstm_sequence_fused(lstms, list(feats), h, c, keep)
+        feats = torch.stack(list(feats), 1)
     T, P, N = feats.shape[0], feats.shape[1], feats.shape[2]
     R = h.shape[-1]
     ig = torch.stack([F.linear(feats[:, p].reshape(T * N, -1), l.weight_ih, l.bias_ih + l.bias_hh).view(T, N, -1)
@@ -101,6 +124,11 @@ def lstm_sequence(lstms, feats, h, c, keep):
         outs.append(h)
         h, c = h * keepm[t], c * keepm[t]
     return torch.stack(outs, 0).view(T, P, N, R), h.view(P, N, R), c.view(P, N, R)
+
+
+def _player(h_seq, p):
+    """Player p's [T, N, R] outputs from either form lstm_sequence returns."""
+    return h_seq[p] if isinstance(h_seq, (list, tuple)) else h_seq[:, p]
 
 
 def policy_stats(logit, action):
@@ -329,8 +357,8 @@ class A3C(nn.Module):
     def forward_sequence(self, x_seq, actions, h, c, keep):
         """Time-batched re-evaluation of T stored steps for this player alone (same math as T calls of forward())."""
         feats = self.sequence_features(x_seq)
-        h_seq, h, c = lstm_sequence([self.lstm], feats.unsqueeze(1), h.unsqueeze(0), c.unsqueeze(0), keep)
-        return self.sequence_heads(h_seq[:, 0], actions) + ((h[0], c[0]),)
+        h_seq, h, c = lstm_sequence([self.lstm], [feats], h.unsqueeze(0), c.unsqueeze(0), keep)
+        return self.sequence_heads(_player(h_seq, 0), actions) + ((h[0], c[0]),)
 
 
 class TAT(nn.Module):
@@ -386,8 +414,8 @@ class TAT(nn.Module):
 
     def forward_sequence(self, x_seq, actions, action_tracker, h, c, keep):
         feats = self.sequence_features(x_seq, action_tracker)
-        h_seq, h, c = lstm_sequence([self.lstm], feats.unsqueeze(1), h.unsqueeze(0), c.unsqueeze(0), keep)
-        v, e, l, R_pred = self.sequence_heads(h_seq[:, 0], actions)
+        h_seq, h, c = lstm_sequence([self.lstm], [feats], h.unsqueeze(0), c.unsqueeze(0), keep)
+        v, e, l, R_pred = self.sequence_heads(_player(h_seq, 0), actions)
         return v, e, l, (h[0], c[0]), R_pred
 
 
@@ -459,10 +487,31 @@ class A3C_Dueling(nn.Module):
     fused_sampling = True   # GPU rollouts draw actions with the fused HIP head (csrc/policy_hip.hip)
 
     @torch.no_grad()
-    def act(self, states, hs, cs):
+    def begin_act(self):
+        """Per-rollout constants of act() (the weights do not change inside a rollout): b_ih + b_hh per player."""
+        self._bsum = [l.bias_ih + l.bias_hh for l in (self.player0.lstm, self.player1.lstm)]
+
+    def _act_cell(self, i, lstm, feat, h, c, done):
+        """One LSTMCell step of the actor. (h, c) are the previous step's UN-masked outputs and `done` [N] uint8 that
+        step's done flags (None: nothing pending): on the GPU the mask is applied inside the fused cell kernel
+        (csrc/lstm_hip.hip); otherwise here, before nn.LSTMCell."""
+        if feat.is_cuda and fused_lstm and feat.dtype == torch.float32 and h.shape[1] % 4 == 0:
+            from . import fused
+            bsum = getattr(self, "_bsum", None)
+            b = bsum[i] if bsum is not None else lstm.bias_ih + lstm.bias_hh
+            return fused.lstm_cell(torch.addmm(b, feat, lstm.weight_ih.t()), torch.mm(h, lstm.weight_hh.t()), c, done=done)
+        if done is not None:
+            k = (done == 0).to(h.dtype).unsqueeze(1)
+            h, c = h * k, c * k
+        return lstm(feat, (h, c))
+
+    @torch.no_grad()
+    def act(self, states, hs, cs, done=None):
         """Actor step of the fast path: sample both players' actions and advance their LSTM states, nothing else
         (values, entropies and log-probs are re-evaluated by forward_sequence). states [N,2,stack,C,13,13]; hs, cs:
-        per-player lists of contiguous [N,R] tensors. Returns ([a_tracker, a_target], hs, cs)."""
+        per-player lists of contiguous [N,R] tensors, the previous step's un-masked outputs; done [N] uint8: the
+        previous step's done flags, whose LSTM reset is applied here (None: hs/cs are ready to use).
+        Returns ([a_tracker, a_target], hs, cs)."""
         n = states.shape[0]
         p0, p1 = self.player0, self.player1
         if states.is_cuda and self.fused_sampling:
@@ -472,7 +521,7 @@ class A3C_Dueling(nn.Module):
             sample = self._sampler
         else:
             sample = lambda h, lin: F.softmax(lin(h), dim=1).multinomial(1).squeeze(1)
-        h0, c0 = p0.lstm(p0.encoder(states[:, 0]), (hs[0], cs[0]))
+        h0, c0 = self._act_cell(0, p0.lstm, p0.encoder(states[:, 0]), hs[0], cs[0], done)
         a0 = sample(h0, p0.actor.actor_linear)
         if self.tat:
             x1 = states.reshape(n, -1, states.shape[3], states.shape[4], states.shape[5])
@@ -480,7 +529,7 @@ class A3C_Dueling(nn.Module):
             feat = p1.encoder(x1) + fa.weight.t()[a0] + fa.bias          # fc_action_tracker(one_hot(a0))
         else:
             feat = p1.encoder(states[:, 1])
-        h1, c1 = p1.lstm(feat, (hs[1], cs[1]))
+        h1, c1 = self._act_cell(1, p1.lstm, feat, hs[1], cs[1], done)
         a1 = sample(h1, p1.actor.actor_linear)
         return [a0, a1], [h0, h1], [c0, c1]
 
@@ -500,14 +549,14 @@ class A3C_Dueling(nn.Module):
         else:
             f1 = p1.sequence_features(states_seq[:, :, 1])
         # both players' recurrences in lock step: one bmm + one fused cell per time step for the pair
-        h_seq, _, _ = lstm_sequence([p0.lstm, p1.lstm], torch.stack([f0, f1], 1),
+        h_seq, _, _ = lstm_sequence([p0.lstm, p1.lstm], [f0, f1],
                                     hx.transpose(0, 1).contiguous(), cx.transpose(0, 1).contiguous(), keep)
-        v0, e0, l0 = p0.sequence_heads(h_seq[:, 0], actions_seq[:, :, 0])
+        v0, e0, l0 = p0.sequence_heads(_player(h_seq, 0), actions_seq[:, :, 0])
         R_pred = 0
         if self.tat:
-            v1, e1, l1, R_pred = p1.sequence_heads(h_seq[:, 1], actions_seq[:, :, 1])
+            v1, e1, l1, R_pred = p1.sequence_heads(_player(h_seq, 1), actions_seq[:, :, 1])
         else:
-            v1, e1, l1 = p1.sequence_heads(h_seq[:, 1], actions_seq[:, :, 1])
+            v1, e1, l1 = p1.sequence_heads(_player(h_seq, 1), actions_seq[:, :, 1])
         return torch.stack([v0, v1], 2), torch.stack([e0, e1], 2), torch.stack([l0, l1], 2), R_pred
 
     @staticmethod

@@ -34,7 +34,7 @@ class Agent(object):
         self.rnn_out = args.rnn_out
         self.values, self.log_probs, self.rewards, self.entropies, self.preds, self.dones = [], [], [], [], [], []
         self.states, self.actions, self.h0, self.c0 = [], [], None, None
-        self._buf = None
+        self._buf, self._pending_done = None, None
         self.done = torch.ones(self.num_envs, dtype=torch.uint8, device=device)
         self.info = None
         self.reward = 0
@@ -78,8 +78,9 @@ class Agent(object):
         stored instead. LSTM states are kept per player as contiguous [N,R] tensors during the rollout."""
         self.n_steps += 1
         if hasattr(self.model, "act") and self.num_agents == 2 and not getattr(self.model, "single", False):
-            actions, self._hs, self._cs = self.model.act(self.state, self._hs, self._cs)
+            actions, self._hs, self._cs = self.model.act(self.state, self._hs, self._cs, self._pending_done)
         else:
+            self._apply_pending_done()
             with torch.no_grad():
                 _, actions, _, _, (hx, cx), _ = self.model((self.state, (torch.stack(self._hs, 1), torch.stack(self._cs, 1))))
             self._hs, self._cs = list(hx.unbind(1)), list(cx.unbind(1))
@@ -95,12 +96,17 @@ class Agent(object):
         self.reward = reward_multi
         self.state = state_multi
         self.done = done
-        k = (done == 0).to(self._hs[0].dtype).unsqueeze(1)       # finished envs restart from a zero LSTM state
-        self._hs = [h * k for h in self._hs]
-        self._cs = [c * k for c in self._cs]
-        self.rewards.append(reward_multi.unsqueeze(2))
+        self._pending_done = done                                # finished envs restart from a zero LSTM state:
+        self.rewards.append(reward_multi.unsqueeze(2))           # applied by the next act() / end_rollout
         self.dones.append(done)
         return self
+
+    def _apply_pending_done(self):
+        if self._pending_done is not None:
+            k = (self._pending_done == 0).to(self._hs[0].dtype).unsqueeze(1)
+            self._hs = [h * k for h in self._hs]
+            self._cs = [c * k for c in self._cs]
+            self._pending_done = None
 
     def begin_rollout(self, num_steps=None):
         """Remember the LSTM state the rollout starts from (the learner re-runs the recurrence from it). With
@@ -115,9 +121,15 @@ class Agent(object):
         self._hs = [h.contiguous() for h in self.hxs.unbind(1)]
         self._cs = [c.contiguous() for c in self.cxs.unbind(1)]
         self.states, self.actions = [], []
+        self._pending_done = None
+        if hasattr(self.model, "begin_act"):
+            self.model.begin_act()
 
     def end_rollout(self):
         """Publish the per-player LSTM states back as hxs/cxs [N,A,R] and the episode-length counters."""
+        self._apply_pending_done()
+        if hasattr(self.model, "_bsum"):
+            self.model._bsum = None                               # per-rollout cache; the weights change next
         self.hxs, self.cxs = torch.stack(self._hs, 1), torch.stack(self._cs, 1)
         dones = self._buf[2] if self._buf is not None and len(self.dones) == self._buf[2].shape[0] \
             else torch.stack(self.dones, 0)
@@ -223,14 +235,18 @@ class Agent(object):
             boot, _, _, _, _, _ = self.model((self.state, (self.hxs, self.cxs)))
             v = torch.cat([values.detach(), boot.unsqueeze(0)], 0)           # [T+1, N, A, 1]
             ndv = nd.view(T, N, 1, 1)
-            R = torch.empty_like(rewards)
-            gae = torch.empty_like(rewards)
-            r_run, g_run = v[T], torch.zeros_like(v[T])
-            for i in reversed(range(T)):
-                r_run = args.gamma * r_run * ndv[i] + rewards[i]
-                delta_t = rewards[i] + args.gamma * v[i + 1] * ndv[i] - v[i]
-                g_run = g_run * args.gamma * args.tau * ndv[i] + delta_t
-                R[i], gae[i] = r_run, g_run
+            if v.is_cuda and v.dtype == torch.float32:
+                from . import fused
+                R, gae = fused.gae_returns(rewards, v, nd, args.gamma, args.tau)   # one launch (csrc/lstm_hip.hip)
+            else:
+                R = torch.empty_like(rewards)
+                gae = torch.empty_like(rewards)
+                r_run, g_run = v[T], torch.zeros_like(v[T])
+                for i in reversed(range(T)):
+                    r_run = args.gamma * r_run * ndv[i] + rewards[i]
+                    delta_t = rewards[i] + args.gamma * v[i + 1] * ndv[i] - v[i]
+                    g_run = g_run * args.gamma * args.tau * ndv[i] + delta_t
+                    R[i], gae[i] = r_run, g_run
         w_entropies = float(args.entropy) * torch.ones(1, 1, A, 1, device=dev)
         if A > 1:
             w_entropies[:, :, 1:] = float(self.w_entropy_target)

@@ -34,6 +34,31 @@ int atr_stem_backward(const float *x, long long x_stride, const float *y, const 
 int atr_sample_actions(const float *h, const float *w, const float *b, long long *actions, unsigned long long *counter,
                        unsigned long long seed, int n, int R, int A, void *stream);
 
+/* One LSTMCell step (torch.nn.LSTMCell semantics, gate order i,f,g,o; model.py:110,172 of the reference) for P <= 2
+ * players x N envs x R hidden units (R multiple of 4), given the two GEMM results:
+ *   ig0/ig1 [N,4R] per player   x W_ih^T + b_ih + b_hh
+ *   hg      [P,N,4R]            h_prev W_hh^T, h_prev NOT yet masked
+ * with the episode-boundary mask of the previous step folded in (k[n] = keep[n], or done[n] == 0, or 1 if both are
+ * NULL): gates = ig + k hg, c' = f (k c_prev) + i g, h' = o tanh(c') — identical to masking h_prev and c_prev first.
+ * Per-player tensors are addressed as base + p * pstride + n * R (floats). acts (nullable) receives the activated
+ * gates [N,4R] per player for atr_lstm_cell_backward. */
+int atr_lstm_cell_forward(const float *ig0, const float *ig1, const float *hg, const float *c_prev,
+                          long long c_prev_pstride, const float *keep, const unsigned char *done, float *h_out,
+                          long long h_pstride, float *c_out, long long c_pstride, float *acts, long long acts_pstride,
+                          int P, int N, int R, void *stream);
+/* One step of back-propagation through time for the cell above. dh_out: dL/dh' from the heads; dh_next [P,N,R]:
+ * dg_{t+1} W_hh (gradient arriving through the next step's hidden GEMM, unmasked); dc_carry [P,N,R]: in = dc f of step
+ * t+1, out = dc f of this step; both are scaled by keep_out (this step's mask k_t) when has_next != 0 and ignored
+ * otherwise. keep_in = k_{t-1}. dg: pre-activation gate gradients [N,4R] per player = dL/d ig. */
+int atr_lstm_cell_backward(const float *dh_out, long long dh_pstride, const float *dh_next, float *dc_carry,
+                           const float *keep_out, const float *keep_in, const float *acts, long long acts_pstride,
+                           const float *c, long long c_pstride, const float *c_prev, long long c_prev_pstride, float *dg,
+                           long long dg_pstride, int has_next, int P, int N, int R, void *stream);
+/* n-step returns and GAE terms of the A3C loss (player_util.py:118-141 of the reference) for all (env, agent) pairs:
+ * rewards [T,N,A], values [T+1,N,A] (row T = bootstrap value), notdone [T,N] -> returns, gae [T,N,A]. */
+int atr_gae_returns(const float *rewards, const float *values, const float *notdone, float gamma, float tau,
+                    float *returns, float *gae, int T, int N, int A, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

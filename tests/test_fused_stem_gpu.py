@@ -85,3 +85,94 @@ def test_fused_action_sampler_draws_from_the_softmax_distribution():
     mean_p = float(p2.gather(1, a2.unsqueeze(1)).mean())
     expect = float((p2 * p2).sum(1).mean())
     assert abs(mean_p - expect) < 0.01, (mean_p, expect)
+
+
+def test_fused_lstm_sequence_matches_the_aten_recurrence():
+    """csrc/lstm_hip.hip (one autograd node for the masked two-player recurrence) against the per-step ATen path:
+    outputs, final state and every gradient (fp32; tolerances cover sigmoid/tanh implementation differences)."""
+    from active_tracking_rl_amd import model as M
+    torch.manual_seed(3)
+    T, P, N, Fdim, R = 7, 2, 37, 256, 128
+    lstms = [torch.nn.LSTMCell(Fdim, R).cuda() for _ in range(P)]
+    feats = torch.randn(T, P, N, Fdim, device="cuda", requires_grad=True)
+    h0 = torch.randn(P, N, R, device="cuda", requires_grad=True)
+    c0 = torch.randn(P, N, R, device="cuda", requires_grad=True)
+    keep = (torch.rand(T, N, device="cuda") > 0.3).float()
+    gout = torch.randn(T, P, N, R, device="cuda")
+    gh, gc = torch.randn(P, N, R, device="cuda"), torch.randn(P, N, R, device="cuda")
+    params = [p for l in lstms for p in l.parameters()]
+    res = []
+    for fused_on in (True, False):
+        M.fused_lstm = fused_on
+        try:
+            f_in = [feats[:, p] for p in range(P)] if fused_on else feats
+            h_seq, h, c = M.lstm_sequence(lstms, f_in, h0, c0, keep)
+        finally:
+            M.fused_lstm = True
+        if isinstance(h_seq, (list, tuple)):
+            h_seq = torch.stack(list(h_seq), 1)
+        loss = (h_seq * gout).sum() + (h * gh).sum()
+        grads = torch.autograd.grad(loss, params + [feats, h0, c0])
+        res.append((h_seq.detach(), h.detach(), c.detach(), grads))
+    (hs_a, h_a, c_a, g_a), (hs_b, h_b, c_b, g_b) = res
+    torch.testing.assert_close(hs_a, hs_b, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(h_a, h_b, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c_a, c_b, rtol=1e-4, atol=2e-5)
+    for a, b in zip(g_a, g_b):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-4 * scale, (a.shape, float((a - b).abs().max()), scale)
+
+
+def test_fused_lstm_single_player_and_rollout_cell():
+    from active_tracking_rl_amd import fused, model as M
+    torch.manual_seed(4)
+    N, Fdim, R = 50, 256, 128
+    lstm = torch.nn.LSTMCell(Fdim, R).cuda()
+    x, h, c = torch.randn(N, Fdim, device="cuda"), torch.randn(N, R, device="cuda"), torch.randn(N, R, device="cuda")
+    done = (torch.rand(N, device="cuda") > 0.5).to(torch.uint8)
+    with torch.no_grad():
+        k = (done == 0).float().unsqueeze(1)
+        h_ref, c_ref = lstm(x, (h * k, c * k))
+        ig = torch.addmm(lstm.bias_ih + lstm.bias_hh, x, lstm.weight_ih.t())
+        h_f, c_f = fused.lstm_cell(ig, torch.mm(h, lstm.weight_hh.t()), c, done=done)
+        h_n, c_n = fused.lstm_cell(ig, torch.mm(h, lstm.weight_hh.t()), c)
+        h_r2, c_r2 = lstm(x, (h, c))
+    torch.testing.assert_close(h_f, h_ref, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c_f, c_ref, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(h_n, h_r2, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(c_n, c_r2, rtol=1e-4, atol=2e-5)
+    # single-player sequence (P = 1), final state included
+    T = 5
+    feats = torch.randn(T, N, Fdim, device="cuda")
+    keep = (torch.rand(T, N, device="cuda") > 0.3).float()
+    outs = []
+    for fused_on in (True, False):
+        M.fused_lstm = fused_on
+        try:
+            f_in = [feats] if fused_on else feats.unsqueeze(1)
+            with torch.no_grad():
+                h_seq, hT, cT = M.lstm_sequence([lstm], f_in, h.unsqueeze(0), c.unsqueeze(0), keep)
+        finally:
+            M.fused_lstm = True
+        outs.append((M._player(h_seq, 0), hT, cT))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5)
+
+
+def test_gae_kernel_matches_the_reference_recursion():
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(5)
+    T, N, A = 20, 300, 2
+    rew = torch.randn(T, N, A, 1, device="cuda")
+    val = torch.randn(T + 1, N, A, 1, device="cuda")
+    nd = (torch.rand(T, N, device="cuda") > 0.1).float()
+    gamma, tau = 0.9, 1.0
+    R, gae = fused.gae_returns(rew, val, nd, gamma, tau)
+    ndv = nd.view(T, N, 1, 1)
+    r_run, g_run = val[T], torch.zeros_like(val[T])
+    for i in reversed(range(T)):                              # player_util.py:118-141 of the reference
+        r_run = gamma * r_run * ndv[i] + rew[i]
+        delta_t = rew[i] + gamma * val[i + 1] * ndv[i] - val[i]
+        g_run = g_run * gamma * tau * ndv[i] + delta_t
+        torch.testing.assert_close(R[i], r_run, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(gae[i], g_run, rtol=1e-6, atol=1e-6)
