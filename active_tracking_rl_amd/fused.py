@@ -62,17 +62,80 @@ class _Stem(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, w1, b1, w2 = ctx.saved_tensors
-        dy = dy.contiguous()
-        M = x.shape[0]
-        L = lib()
-        ws = torch.empty(L.atr_stem_workspace_floats(M), dtype=torch.float32, device=x.device)
-        dw1, db1 = torch.empty(144, device=x.device), torch.empty(16, device=x.device)
-        dw2, db2 = torch.empty(4608, device=x.device), torch.empty(32, device=x.device)
-        rc = L.atr_stem_backward(_p(x), x.stride(0), _p(y), _p(dy), _p(w1), _p(b1), _p(w2), _p(dw1), _p(db1), _p(dw2),
-                                 _p(db2), _p(ws), M, _stream(x))
-        if rc != 0:
-            raise RuntimeError("atr_stem_backward failed (%d)" % rc)
-        return None, dw1.view(ctx.shapes[0]), db1, dw2.view(ctx.shapes[1]), db2
+        return (None,) + _stem_backward(x, y, dy, w1, b1, w2, ctx.shapes)
+
+
+def _stem_backward(x, y, dy, w1, b1, w2, shapes):
+    dy = dy.contiguous()
+    M = x.shape[0]
+    L = lib()
+    ws = torch.empty(L.atr_stem_workspace_floats(M), dtype=torch.float32, device=x.device)
+    dw1, db1 = torch.empty(144, device=x.device), torch.empty(16, device=x.device)
+    dw2, db2 = torch.empty(4608, device=x.device), torch.empty(32, device=x.device)
+    rc = L.atr_stem_backward(_p(x), x.stride(0), _p(y), _p(dy), _p(w1), _p(b1), _p(w2), _p(dw1), _p(db1), _p(dw2),
+                             _p(db2), _p(ws), M, _stream(x))
+    if rc != 0:
+        raise RuntimeError("atr_stem_backward failed (%d)" % rc)
+    return dw1.view(shapes[0]), db1, dw2.view(shapes[1]), db2
+
+
+class _StemCached(torch.autograd.Function):
+    """The stem as an autograd node whose forward was already evaluated (by stem_into during the rollout, with the
+    same weights): forward hands back the stored output, backward is the ordinary stem backward."""
+
+    @staticmethod
+    def forward(ctx, x, y, w1, b1, w2, b2):
+        w1c, b1c, w2c = w1.contiguous(), b1.contiguous(), w2.contiguous()
+        ctx.save_for_backward(x, y, w1c, b1c, w2c)
+        ctx.shapes = (w1.shape, w2.shape)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, w1, b1, w2 = ctx.saved_tensors
+        return (None, None) + _stem_backward(x, y, dy, w1, b1, w2, ctx.shapes)
+
+
+@torch.no_grad()
+def stem_into(x, conv1, conv2, out):
+    """No-grad stem forward of frames x [..., 13, 13] written into out [M, 512] (a slot of the rollout cache)."""
+    x = rows169(x)
+    if x.stride(1) != 1 or x.stride(0) < 169:
+        x = x.contiguous()
+    M = x.shape[0]
+    assert out.is_contiguous() and out.numel() == M * 512
+    rc = lib().atr_stem_forward(_p(x), x.stride(0), _p(conv1.weight), _p(conv1.bias), _p(conv2.weight), _p(conv2.bias),
+                                _p(out), M, _stream(x))
+    if rc != 0:
+        raise RuntimeError("atr_stem_forward failed (%d)" % rc)
+    return out
+
+
+def stem_cached(x, y, conv1, conv2):
+    x = rows169(x)
+    if x.stride(1) != 1 or x.stride(0) < 169:
+        x = x.contiguous()
+    return _StemCached.apply(x, y, conv1.weight, conv1.bias, conv2.weight, conv2.bias)
+
+
+class _LinearReluCached(torch.autograd.Function):
+    """relu(x W^T + b) whose value f is already known (computed in the rollout with the same weights): forward
+    returns f, backward is the usual one (dx, dW, db through the ReLU mask f > 0)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, f):
+        ctx.save_for_backward(x, w, f)
+        return f.view_as(f)
+
+    @staticmethod
+    def backward(ctx, df):
+        x, w, f = ctx.saved_tensors
+        dpre = torch.ops.aten.threshold_backward(df.contiguous(), f, 0.0)
+        return dpre @ w, dpre.t() @ x, dpre.sum(0), None
+
+
+def linear_relu_cached(x, linear, f):
+    return _LinearReluCached.apply(x, linear.weight, linear.bias, f)
 
 
 def rows169(x):
@@ -176,35 +239,86 @@ class _LstmSeq(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dhs):
-        L = lib()
-        dhs = dhs[:-1]
         whh, keep, h_all, c_all, acts = ctx.saved_tensors
-        P, T1, N, R = h_all.shape
-        T = T1 - 1
-        dev = h_all.device
-        dhs = [torch.zeros((T, N, R), dtype=torch.float32, device=dev) if d is None else d.contiguous() for d in dhs]
-        pd = (dhs[1].data_ptr() - dhs[0].data_ptr()) // 4 if P > 1 else 0          # player stride between the two grads
-        dG = torch.empty((P, T, N, 4 * R), dtype=torch.float32, device=dev)
-        dhn = torch.empty((P, N, R), dtype=torch.float32, device=dev)
-        dcc = torch.empty((P, N, R), dtype=torch.float32, device=dev)
-        whh_t = whh.transpose(1, 2)                                               # [P,4R,R]
-        st = _stream(h_all)
-        ps, pa, step, astep = (T + 1) * N * R, T * N * 4 * R, N * R * 4, N * 4 * R * 4
-        for t in range(T - 1, -1, -1):
-            rc = L.atr_lstm_cell_backward(
-                C.c_void_p(dhs[0].data_ptr() + t * step), pd, _p(dhn), _p(dcc), _p(keep[t]),
-                _p(keep[t - 1]) if t else None, C.c_void_p(acts.data_ptr() + t * astep), pa,
-                C.c_void_p(c_all.data_ptr() + (t + 1) * step), ps, C.c_void_p(c_all.data_ptr() + t * step), ps,
-                C.c_void_p(dG.data_ptr() + t * astep), pa, 1 if t < T - 1 else 0, P, N, R, st)
-            if rc != 0:
-                raise RuntimeError("atr_lstm_cell_backward failed (%d)" % rc)
-            torch.bmm(dG[:, t], whh_t, out=dhn)                                   # gradient into h_{t-1}
-        # W_hh: sum_t (k_{t-1} h_{t-1})^T dG_t as one GEMM per player over all T*N rows
-        kprev = torch.cat([torch.ones_like(keep[:1]), keep[:-1]], 0).view(1, T, N, 1)
-        hm = (h_all[:, :T] * kprev).view(P, T * N, R)
-        dwhh = torch.bmm(hm.transpose(1, 2), dG.view(P, T * N, 4 * R))
-        dg = dG.view(P, T * N, 4 * R)
-        return dg[0], (dg[1] if ctx.two else None), dwhh, dhn, dcc, None
+        dG, dhn, dcc, dwhh = _lstm_bptt(whh, keep, h_all, c_all, acts, dhs[:-1])
+        return dG[0], (dG[1] if ctx.two else None), dwhh, dhn, dcc, None
+
+
+def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs):
+    """Back-propagation through time over stored activations: dhs = per-player dL/dh_seq [T,N,R] (None = zero).
+    Returns dG [P, T*N, 4R] (= dL/d ig), dL/dh0, dL/dc0 [P,N,R] and dL/dW_hh^T [P,R,4R]."""
+    L = lib()
+    P, T1, N, R = h_all.shape
+    T = T1 - 1
+    dev = h_all.device
+    dhs = [torch.zeros((T, N, R), dtype=torch.float32, device=dev) if d is None else d.contiguous() for d in dhs]
+    pd = (dhs[1].data_ptr() - dhs[0].data_ptr()) // 4 if P > 1 else 0          # player stride between the two grads
+    dG = torch.empty((P, T, N, 4 * R), dtype=torch.float32, device=dev)
+    dhn = torch.empty((P, N, R), dtype=torch.float32, device=dev)
+    dcc = torch.empty((P, N, R), dtype=torch.float32, device=dev)
+    whh_t = whh.transpose(1, 2)                                               # [P,4R,R]
+    st = _stream(h_all)
+    ps, pa, step, astep = (T + 1) * N * R, T * N * 4 * R, N * R * 4, N * 4 * R * 4
+    for t in range(T - 1, -1, -1):
+        rc = L.atr_lstm_cell_backward(
+            C.c_void_p(dhs[0].data_ptr() + t * step), pd, _p(dhn), _p(dcc), _p(keep[t]),
+            _p(keep[t - 1]) if t else None, C.c_void_p(acts.data_ptr() + t * astep), pa,
+            C.c_void_p(c_all.data_ptr() + (t + 1) * step), ps, C.c_void_p(c_all.data_ptr() + t * step), ps,
+            C.c_void_p(dG.data_ptr() + t * astep), pa, 1 if t < T - 1 else 0, P, N, R, st)
+        if rc != 0:
+            raise RuntimeError("atr_lstm_cell_backward failed (%d)" % rc)
+        torch.bmm(dG[:, t], whh_t, out=dhn)                                   # gradient into h_{t-1}
+    # W_hh: sum_t (k_{t-1} h_{t-1})^T dG_t as one GEMM per player over all T*N rows
+    kprev = torch.cat([torch.ones_like(keep[:1]), keep[:-1]], 0).view(1, T, N, 1)
+    hm = (h_all[:, :T] * kprev).view(P, T * N, R)
+    dG = dG.view(P, T * N, 4 * R)
+    dwhh = torch.bmm(hm.transpose(1, 2), dG)
+    return dG, dhn, dcc, dwhh
+
+
+class _LstmSeqCached(torch.autograd.Function):
+    """The input projection + masked recurrence of both players as an autograd node whose forward was already
+    evaluated step by step during the rollout (lstm_cell_into, same weights): h_all/c_all/acts hold every step.
+    Inputs: per-player features [T*N,F] and LSTMCell parameters; output: per-player h_seq [T,N,R]."""
+
+    @staticmethod
+    def forward(ctx, keep, h_all, c_all, acts, *fw):
+        P = h_all.shape[0]
+        feats, wih, whh_l = fw[:P], fw[P:2 * P], fw[2 * P:3 * P]
+        whh = torch.stack([w.t() for w in whh_l], 0).contiguous()
+        ctx.save_for_backward(keep.contiguous(), h_all, c_all, acts, whh, *feats, *wih)
+        ctx.P = P
+        return tuple(h_all[p, 1:] for p in range(P))
+
+    @staticmethod
+    def backward(ctx, *dhs):
+        P = ctx.P
+        keep, h_all, c_all, acts, whh = ctx.saved_tensors[:5]
+        feats, wih = ctx.saved_tensors[5:5 + P], ctx.saved_tensors[5 + P:5 + 2 * P]
+        dG, _, _, dwhh = _lstm_bptt(whh, keep, h_all, c_all, acts, dhs)
+        dfeat = [dG[p] @ wih[p] for p in range(P)]
+        dwih = [dG[p].t() @ feats[p] for p in range(P)]
+        dwhh_l = [dwhh[p].t() for p in range(P)]
+        db = [dG[p].sum(0) for p in range(P)]
+        return (None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + tuple(db)
+
+
+def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts):
+    """feats: per-player [T*N, F] (with grad); lstms: the nn.LSTMCells; stored activations from the rollout."""
+    P = len(lstms)
+    args = list(feats) + [l.weight_ih for l in lstms] + [l.weight_hh for l in lstms] + \
+        [l.bias_ih for l in lstms] + [l.bias_hh for l in lstms]
+    return _LstmSeqCached.apply(keep, h_all, c_all, acts, *args)
+
+
+@torch.no_grad()
+def lstm_cell_into(ig, hg, c_prev, done, h_out, c_out, acts):
+    """The rollout's LSTM step for one player, writing h, c and the activated gates into rollout-cache slots."""
+    N, R = c_prev.shape
+    rc = lib().atr_lstm_cell_forward(_p(ig), None, _p(hg), _p(c_prev), 0, None, _pn(done), _p(h_out), 0, _p(c_out), 0,
+                                     _p(acts), 0, 1, N, R, _stream(ig))
+    if rc != 0:
+        raise RuntimeError("atr_lstm_cell_forward failed (%d)" % rc)
 
 
 def lstm_sequence(ig0, ig1, whh, h0, c0, keep):

@@ -419,6 +419,10 @@ class TAT(nn.Module):
         return v, e, l, (h[0], c[0]), R_pred
 
 
+class RolloutCache(object):
+    """Forward activations of one rollout (see A3C_Dueling.new_cache)."""
+
+
 class A3C_Dueling(nn.Module):
     """Two-player wrapper, model.py:212-265.
 
@@ -532,6 +536,93 @@ class A3C_Dueling(nn.Module):
         h1, c1 = self._act_cell(1, p1.lstm, feat, hs[1], cs[1], done)
         a1 = sample(h1, p1.actor.actor_linear)
         return [a0, a1], [h0, h1], [c0, c1]
+
+    # ---- rollout cache: the learner back-propagates through the forward pass the actor already evaluated -------
+    def new_cache(self, num_steps, states):
+        """Storage for one rollout's forward activations (per player: stem outputs, fc features, LSTM gates / cell /
+        hidden states for every step), filled by act_cached and consumed by forward_sequence_cached — the reference
+        also evaluates the forward pass once, inside the rollout (player_util.py:46-73). None when the fused GPU path
+        does not apply (CPU tensors, non-maze encoders, fused kernels switched off)."""
+        p0, p1 = self.player0, self.player1
+        ok = (states.is_cuda and states.dtype == torch.float32 and fused_lstm and not self.single
+              and all(isinstance(p.encoder, CNN_maze) and p.encoder.small and p.encoder.use_fused
+                      and p.encoder.conv1.in_channels == 1 for p in (p0, p1))
+              and states.shape[-1] == 13 and states.shape[-2] == 13 and p0.lstm.hidden_size % 4 == 0
+              and p0.lstm.hidden_size == p1.lstm.hidden_size)
+        if not ok:
+            return None
+        T, N, dev = num_steps, states.shape[0], states.device
+        R = p0.lstm.hidden_size
+        stack = states.shape[2]
+        frames = [stack, 2 * stack if self.tat else stack]
+        c = RolloutCache()
+        c.T, c.N, c.frames = T, N, frames
+        c.y = [torch.empty((T, N * f, 512), device=dev) for f in frames]
+        c.f = [torch.empty((T, N, p.encoder.outdim), device=dev) for p in (p0, p1)]
+        c.feat1 = torch.empty((T, N, p1.encoder.outdim), device=dev) if self.tat else None
+        c.acts = torch.empty((2, T, N, 4 * R), device=dev)
+        c.h_all = torch.empty((2, T + 1, N, R), device=dev)
+        c.c_all = torch.empty((2, T + 1, N, R), device=dev)
+        c.bsum = [l.bias_ih + l.bias_hh for l in (p0.lstm, p1.lstm)]
+        if self.tat:
+            fa = p1.fc_action_tracker
+            c.emb = fa.weight.t() + fa.bias                        # row a = fc_action_tracker(one_hot(a))
+        return c
+
+    @torch.no_grad()
+    def act_cached(self, states, cache, t, done=None):
+        """act() for step t of a cached rollout: same sampling and state update, every intermediate written into the
+        cache's slot t (LSTM state of step t lives in cache.h_all/c_all[:, t], the new one goes to slot t+1)."""
+        from . import fused
+        n = states.shape[0]
+        p0, p1 = self.player0, self.player1
+        if getattr(self, "_sampler", None) is None:
+            self._sampler = fused.ActionSampler(states.device)
+        sample = self._sampler if self.fused_sampling else \
+            (lambda h, lin: F.softmax(lin(h), dim=1).multinomial(1).squeeze(1))
+        x_in = [states[:, 0], states.reshape(n, -1, states.shape[3], states.shape[4], states.shape[5])
+                if self.tat else states[:, 1]]
+        acts_out = []
+        for i, p in enumerate((p0, p1)):
+            enc = p.encoder
+            y = fused.stem_into(x_in[i], enc.conv1, enc.conv2, cache.y[i][t])
+            f = torch.addmm(enc.fc.bias, y.view(n, -1), enc.fc.weight.t(), out=cache.f[i][t]).relu_()
+            if i == 1 and self.tat:
+                f = torch.add(f, cache.emb[acts_out[0]], out=cache.feat1[t])
+            ig = torch.addmm(cache.bsum[i], f, p.lstm.weight_ih.t())
+            hg = torch.mm(cache.h_all[i, t], p.lstm.weight_hh.t())
+            fused.lstm_cell_into(ig, hg, cache.c_all[i, t], done, cache.h_all[i, t + 1], cache.c_all[i, t + 1],
+                                 cache.acts[i, t])
+            acts_out.append(sample(cache.h_all[i, t + 1], p.actor.actor_linear))
+        return acts_out
+
+    def forward_sequence_cached(self, cache, states_seq, actions_seq, keep):
+        """forward_sequence over a cached rollout: the differentiable graph (stem -> fc -> [+ tracker-action
+        embedding] -> LSTM -> heads) is rebuilt around the stored activations, so only the heads are evaluated
+        forward; the backward pass is the same as forward_sequence's. Same return values."""
+        from . import fused
+        T, N = cache.T, cache.N
+        p0, p1 = self.player0, self.player1
+        x_in = [states_seq[:, :, 0],
+                states_seq.reshape(T, N, -1, states_seq.shape[4], states_seq.shape[5], states_seq.shape[6])
+                if self.tat else states_seq[:, :, 1]]
+        feats = []
+        for i, p in enumerate((p0, p1)):
+            enc = p.encoder
+            y = fused.stem_cached(x_in[i], cache.y[i].view(-1, 512), enc.conv1, enc.conv2)
+            f = fused.linear_relu_cached(y.view(T * N, -1), enc.fc, cache.f[i].view(T * N, -1))
+            if i == 1 and self.tat:
+                a2t = F.one_hot(actions_seq[:, :, 0].reshape(T * N), self.action_dim_tracker).to(f.dtype)
+                f = f + p.fc_action_tracker(a2t)
+            feats.append(f)
+        h_seq = fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, cache.acts)
+        v0, e0, l0 = p0.sequence_heads(h_seq[0], actions_seq[:, :, 0])
+        R_pred = 0
+        if self.tat:
+            v1, e1, l1, R_pred = p1.sequence_heads(h_seq[1], actions_seq[:, :, 1])
+        else:
+            v1, e1, l1 = p1.sequence_heads(h_seq[1], actions_seq[:, :, 1])
+        return torch.stack([v0, v1], 2), torch.stack([e0, e1], 2), torch.stack([l0, l1], 2), R_pred
 
     def forward_sequence(self, states_seq, actions_seq, hx, cx, keep):
         """Re-evaluate T stored steps with gradients, time-batched (the learner half of the rollout driver):

@@ -34,7 +34,8 @@ class Agent(object):
         self.rnn_out = args.rnn_out
         self.values, self.log_probs, self.rewards, self.entropies, self.preds, self.dones = [], [], [], [], [], []
         self.states, self.actions, self.h0, self.c0 = [], [], None, None
-        self._buf, self._pending_done = None, None
+        self._buf, self._pending_done, self._cache = None, None, None
+        self.cache_rollout = True   # fast path on the GPU: learner back-propagates through the actor's forward pass
         self.done = torch.ones(self.num_envs, dtype=torch.uint8, device=device)
         self.info = None
         self.reward = 0
@@ -77,7 +78,9 @@ class Agent(object):
         (model.act, no autograd graph); what the learner needs to re-evaluate the step (state, actions, done) is
         stored instead. LSTM states are kept per player as contiguous [N,R] tensors during the rollout."""
         self.n_steps += 1
-        if hasattr(self.model, "act") and self.num_agents == 2 and not getattr(self.model, "single", False):
+        if self._cache is not None:
+            actions = self.model.act_cached(self.state, self._cache, len(self.states), self._pending_done)
+        elif hasattr(self.model, "act") and self.num_agents == 2 and not getattr(self.model, "single", False):
             actions, self._hs, self._cs = self.model.act(self.state, self._hs, self._cs, self._pending_done)
         else:
             self._apply_pending_done()
@@ -102,6 +105,10 @@ class Agent(object):
         return self
 
     def _apply_pending_done(self):
+        if self._cache is not None:                               # state of the last step lives in the cache
+            T = len(self.states)
+            self._hs = list(self._cache.h_all[:, T].unbind(0))
+            self._cs = list(self._cache.c_all[:, T].unbind(0))
         if self._pending_done is not None:
             k = (self._pending_done == 0).to(self._hs[0].dtype).unsqueeze(1)
             self._hs = [h * k for h in self._hs]
@@ -118,10 +125,17 @@ class Agent(object):
                 self._buf[0][0].copy_(self.state.reshape(self._buf[0][0].shape))
         self.update_rnn_hiden()
         self.h0, self.c0 = self.hxs, self.cxs
-        self._hs = [h.contiguous() for h in self.hxs.unbind(1)]
-        self._cs = [c.contiguous() for c in self.cxs.unbind(1)]
         self.states, self.actions = [], []
         self._pending_done = None
+        self._cache = None
+        if num_steps is not None and self.cache_rollout and hasattr(self.model, "new_cache") and self.num_agents == 2:
+            self._cache = self.model.new_cache(num_steps, self.state)
+        if self._cache is not None:                               # LSTM state lives in the cache: slot t -> t+1
+            self._cache.h_all[:, 0].copy_(self.hxs.transpose(0, 1))
+            self._cache.c_all[:, 0].copy_(self.cxs.transpose(0, 1))
+            return
+        self._hs = [h.contiguous() for h in self.hxs.unbind(1)]
+        self._cs = [c.contiguous() for c in self.cxs.unbind(1)]
         if hasattr(self.model, "begin_act"):
             self.model.begin_act()
 
@@ -230,7 +244,10 @@ class Agent(object):
             states = torch.stack(self.states, 0)
             rewards = torch.stack(self.rewards, 0)                           # [T, N, A, 1]
             nd = (torch.stack(self.dones, 0) == 0).to(rewards.dtype)         # [T, N]
-        values, entropies, log_probs, preds = self.model.forward_sequence(states, actions, self.h0, self.c0, nd)
+        if self._cache is not None and T == self._cache.T:
+            values, entropies, log_probs, preds = self.model.forward_sequence_cached(self._cache, states, actions, nd)
+        else:
+            values, entropies, log_probs, preds = self.model.forward_sequence(states, actions, self.h0, self.c0, nd)
         with torch.no_grad():
             boot, _, _, _, _, _ = self.model((self.state, (self.hxs, self.cxs)))
             v = torch.cat([values.detach(), boot.unsqueeze(0)], 0)           # [T+1, N, A, 1]

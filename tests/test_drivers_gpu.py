@@ -146,3 +146,44 @@ def test_full_observation_env_trains():
     stats = player.optimize(None, opt, player.model, -1, dev)
     assert all(torch.isfinite(s).all() for s in stats)
     player.env.close()
+
+
+def test_cached_rollout_learner_matches_the_recompute_learner():
+    """Actor/learner with the rollout cache (forward evaluated once, in the rollout: model.act_cached +
+    forward_sequence_cached) against the recompute learner (forward_sequence) on the SAME rollout: loss terms and
+    every parameter gradient agree to fp32 round-off (different GEMM shapes -> different summation orders)."""
+    from active_tracking_rl_amd.train import default_args, make_player, rollout
+    args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=256, num_steps=6, network="tat-maze-lstm", seed=11)
+    args.gpu_ids = [0]
+    player, optimizer = make_player(args, torch.device("cuda:0"), 0, 1)
+    assert player.cache_rollout
+    rollout(player, args.num_steps, fast=True)
+    assert player._cache is not None
+    outs = []
+    for cached in (True, False):
+        cache = player._cache
+        if not cached:
+            player._cache = None
+        # the bootstrap value of the tracker-aware target depends on a freshly SAMPLED tracker action: pin the draw
+        torch.manual_seed(5)
+        if getattr(player.model, "_sampler", None) is not None:
+            player.model._sampler.counter.zero_()
+        loss, pl, vl, ent, pred = player.loss_recompute(args.train_mode)
+        player._cache = cache
+        params = [p for p in player.model.parameters()]
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        outs.append((loss.detach(), pl.detach(), vl.detach(), ent, pred.detach(), grads, params))
+    (la, pla, vla, ea, pa, ga, params), (lb, plb, vlb, eb, pb, gb, _) = outs
+    torch.testing.assert_close(la, lb, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(pla, plb, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(vla, vlb, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(ea, eb, rtol=1e-4, atol=1e-4)
+    n_checked = 0
+    for a, b in zip(ga, gb):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        scale = float(b.abs().max()) + 1e-7
+        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (a.shape, float((a - b).abs().max()), scale)
+        n_checked += 1
+    assert n_checked >= 20
