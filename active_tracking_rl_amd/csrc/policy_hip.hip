@@ -4,8 +4,9 @@
 // softmax, and one categorical draw per env by inverse CDF on a Philox4x32-10 uniform. It replaces
 // actor_linear -> softmax -> torch.multinomial (the reference's sample_action, model.py:41-49), which on ROCm is a
 // GEMM plus ~12 tiny launches (multinomial alone: min/max/nan asserts, exponential noise, divide, argmax ...).
-// The stream position lives in a device-side counter that the launch itself advances, so a hipGraph replay draws
-// fresh numbers. Sixteen lanes per env; the head weights sit in LDS.
+// The stream position is (device-side counter, host-side ordinal): the counter is advanced in stream order (by the
+// call itself when bump != 0, e.g. once per rollout), so a hipGraph replay draws fresh numbers; the ordinal tells the
+// launches between two bumps apart. Sixteen lanes per env; the head weights sit in LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,7 +34,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
 __global__ __launch_bounds__(256) void k_sample_actions(const float *__restrict__ h, const float *__restrict__ w,
                                                         const float *__restrict__ b, long long *__restrict__ actions,
                                                         const unsigned long long *__restrict__ counter,
-                                                        unsigned long long seed, int n, int R, int A)
+                                                        unsigned long long seed, unsigned ordinal, int n, int R, int A)
 {
     __shared__ float ws[kMaxActions * kMaxR + kMaxActions];
     for (int i = (int)threadIdx.x; i < A * R; i += (int)blockDim.x) ws[i] = w[i];
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_sample_actions(const float *__restrict_
 #pragma unroll
     for (int a = 0; a < kMaxActions; a++) { p[a] = a < A ? __expf(logit[a] - mx) : 0.f; sum += p[a]; }
     const unsigned long long c = *counter;
-    uint32_t c0 = (uint32_t)e, c1 = (uint32_t)c, c2 = (uint32_t)(c >> 32), c3 = 0x5A3Du;
+    uint32_t c0 = (uint32_t)e, c1 = (uint32_t)c, c2 = (uint32_t)(c >> 32), c3 = 0x5A3D0000u ^ ordinal;
     philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c0, c1, c2, c3);
     const float u = ((c0 >> 8) + 0.5f) * (1.0f / 16777216.0f) * sum;    // uniform in (0, sum)
     int act = A - 1;                                      // first a with u < cumulative(a)
@@ -95,14 +96,18 @@ __global__ void k_bump_counter(unsigned long long *counter) { *counter += 1ull; 
 } // namespace atr
 
 extern "C" int atr_sample_actions(const float *h, const float *w, const float *b, long long *actions,
-                                  unsigned long long *counter, unsigned long long seed, int n, int R, int A, void *stream)
+                                  unsigned long long *counter, unsigned long long seed, unsigned ordinal, int bump,
+                                  int n, int R, int A, void *stream)
 {
     if (!h || !w || !b || !actions || !counter || n < 0 || R <= 0 || R > atr::kMaxR || (R & 3) || A < 1 || A > atr::kMaxActions)
         return -1;
-    if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        if (bump) hipLaunchKernelGGL(atr::k_bump_counter, dim3(1), dim3(1), 0, st, counter);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     hipLaunchKernelGGL(atr::k_sample_actions, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, h, w, b, actions,
-                       counter, seed, n, R, A);
-    hipLaunchKernelGGL(atr::k_bump_counter, dim3(1), dim3(1), 0, st, counter);
+                       counter, seed, ordinal, n, R, A);
+    if (bump) hipLaunchKernelGGL(atr::k_bump_counter, dim3(1), dim3(1), 0, st, counter);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

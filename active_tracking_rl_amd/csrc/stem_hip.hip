@@ -122,16 +122,30 @@ __device__ __forceinline__ void zero_wave(float *p, int n, int l)
 // ------------------------------------------------------------------------------------------------------
 // forward: D[pos][co] = sum_k im2col(a1)[pos][k] * W2[co][k]; step s = t*4 + cq covers tap t = kh*3+kw of the
 // input channels 4cq..4cq+3 (k within the step = ci & 3).
-__global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(const float *__restrict__ x, const float *__restrict__ w1,
-                                                          const float *__restrict__ b1, const float *__restrict__ w2,
-                                                          const float *__restrict__ b2, float *__restrict__ y,
-                                                          long long M, long long xs)
+struct StemProblem {
+    const float *x, *w1, *b1, *w2, *b2;
+    float *y;
+    long long M, xs;
+};
+// Up to two independent problems per launch (the rollout's tracker and target encoders: different weights, same
+// step): workgroups [0, split) work on p[0], the rest on p[1], so the chip is filled by one launch.
+struct StemPair { StemProblem p[2]; int split; };
+
+__global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
 {
     __shared__ __attribute__((aligned(16))) LdsF lds[kWaves];
     const int l = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     LdsF &s = lds[wave];
-    const long long stride = (long long)gridDim.x * kWaves;
-    long long m = (long long)blockIdx.x * kWaves + wave;
+    const bool second = (int)blockIdx.x >= pr.split;
+    const StemProblem &pb = pr.p[second ? 1 : 0];
+    const float *__restrict__ x = pb.x, *__restrict__ w1 = pb.w1, *__restrict__ b1 = pb.b1, *__restrict__ w2 = pb.w2,
+                             *__restrict__ b2 = pb.b2;
+    float *__restrict__ y = pb.y;
+    const long long M = pb.M, xs = pb.xs;
+    const int blk = second ? (int)blockIdx.x - pr.split : (int)blockIdx.x;
+    const int nblk = second ? (int)gridDim.x - pr.split : pr.split;
+    const long long stride = (long long)nblk * kWaves;
+    long long m = (long long)blk * kWaves + wave;
     XRegs xv = load_x(x, m, M, xs, l);
     zero_wave(s.x, kXSize, l);
     zero_wave(s.a1, kA1Size, l);
@@ -410,13 +424,48 @@ constexpr int kFwdBlocksPerCu = 3, kBwdBlocksPerCu = 2;
 
 extern "C" long long atr_stem_workspace_floats(long long M) { return (long long)stem_grid(M, kBwdBlocksPerCu) * kPartial; }
 
+static StemProblem make_problem(const float *x, long long x_stride, const float *w1, const float *b1, const float *w2,
+                                const float *b2, float *y, long long M)
+{
+    StemProblem p;
+    p.x = x; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.y = y; p.M = M; p.xs = x_stride;
+    return p;
+}
+
 extern "C" int atr_stem_forward(const float *x, long long x_stride, const float *w1, const float *b1, const float *w2,
                                 const float *b2, float *y, long long M, void *stream)
 {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || M < 0 || x_stride < 169) return -1;
     if (M == 0) return 0;
-    hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)stem_grid(M, kFwdBlocksPerCu)), dim3(kThreads), 0, (hipStream_t)stream,
-                       x, w1, b1, w2, b2, y, M, x_stride);
+    StemPair pr;
+    pr.p[0] = pr.p[1] = make_problem(x, x_stride, w1, b1, w2, b2, y, M);
+    pr.split = stem_grid(M, kFwdBlocksPerCu);
+    hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)pr.split), dim3(kThreads), 0, (hipStream_t)stream, pr);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int atr_stem_forward2(const float *x0, long long x0_stride, const float *w1_0, const float *b1_0,
+                                 const float *w2_0, const float *b2_0, float *y0, long long M0, const float *x1,
+                                 long long x1_stride, const float *w1_1, const float *b1_1, const float *w2_1,
+                                 const float *b2_1, float *y1, long long M1, void *stream)
+{
+    if (!x0 || !w1_0 || !b1_0 || !w2_0 || !b2_0 || !y0 || M0 <= 0 || x0_stride < 169 || !x1 || !w1_1 || !b1_1 ||
+        !w2_1 || !b2_1 || !y1 || M1 <= 0 || x1_stride < 169)
+        return -1;
+    StemPair pr;
+    pr.p[0] = make_problem(x0, x0_stride, w1_0, b1_0, w2_0, b2_0, y0, M0);
+    pr.p[1] = make_problem(x1, x1_stride, w1_1, b1_1, w2_1, b2_1, y1, M1);
+    // split the resident workgroups in proportion to the frame counts (every wave gets the same number of frames)
+    const int total = stem_grid(M0 + M1, kFwdBlocksPerCu);
+    int g0 = (int)(((long long)total * M0 + (M0 + M1) / 2) / (M0 + M1));
+    const int need0 = (int)((M0 + kWaves - 1) / kWaves), need1 = (int)((M1 + kWaves - 1) / kWaves);
+    if (g0 < 1) g0 = 1;
+    if (g0 > need0) g0 = need0;
+    int g1 = total - g0;
+    if (g1 < 1) g1 = 1;
+    if (g1 > need1) g1 = need1;
+    pr.split = g0;
+    hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)(g0 + g1)), dim3(kThreads), 0, (hipStream_t)stream, pr);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

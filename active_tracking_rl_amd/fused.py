@@ -19,12 +19,14 @@ def lib():
         vp, ll = C.c_void_p, C.c_longlong
         L.atr_stem_forward.restype = C.c_int
         L.atr_stem_forward.argtypes = [vp, ll, vp, vp, vp, vp, vp, ll, vp]
+        L.atr_stem_forward2.restype = C.c_int
+        L.atr_stem_forward2.argtypes = [vp, ll, vp, vp, vp, vp, vp, ll] * 2 + [vp]
         L.atr_stem_workspace_floats.restype = ll
         L.atr_stem_workspace_floats.argtypes = [ll]
         L.atr_stem_backward.restype = C.c_int
         L.atr_stem_backward.argtypes = [vp, ll] + [vp] * 10 + [ll, vp]
         L.atr_sample_actions.restype = C.c_int
-        L.atr_sample_actions.argtypes = [vp, vp, vp, vp, vp, C.c_ulonglong, C.c_int, C.c_int, C.c_int, vp]
+        L.atr_sample_actions.argtypes = [vp, vp, vp, vp, vp, C.c_ulonglong, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         i32 = C.c_int
         L.atr_lstm_cell_forward.restype = i32
         L.atr_lstm_cell_forward.argtypes = [vp, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp]
@@ -111,6 +113,26 @@ def stem_into(x, conv1, conv2, out):
     return out
 
 
+@torch.no_grad()
+def stem_into2(xa, enc_a, out_a, xb, enc_b, out_b):
+    """stem_into for two encoders (different weights) in one launch: the rollout step's tracker and target stems."""
+    xs = []
+    for x in (xa, xb):
+        x = rows169(x)
+        if x.stride(1) != 1 or x.stride(0) < 169:
+            x = x.contiguous()
+        xs.append(x)
+    args = []
+    for x, enc, out in ((xs[0], enc_a, out_a), (xs[1], enc_b, out_b)):
+        assert out.is_contiguous() and out.numel() == x.shape[0] * 512
+        args += [_p(x), x.stride(0), _p(enc.conv1.weight), _p(enc.conv1.bias), _p(enc.conv2.weight), _p(enc.conv2.bias),
+                 _p(out), x.shape[0]]
+    rc = lib().atr_stem_forward2(*(args + [_stream(xs[0])]))
+    if rc != 0:
+        raise RuntimeError("atr_stem_forward2 failed (%d)" % rc)
+    return out_a, out_b
+
+
 def stem_cached(x, y, conv1, conv2):
     x = rows169(x)
     if x.stride(1) != 1 or x.stride(0) < 169:
@@ -161,11 +183,27 @@ def stem(x, conv1, conv2):
 
 class ActionSampler(object):
     """Fused actor head for the rollout: action ~ Categorical(softmax(W h + b)) in one launch (csrc/policy_hip.hip).
-    Holds the device-side stream counter (advanced by every call, hipGraph-safe) and the Philox seed."""
+    Holds the device-side stream counter (hipGraph-safe) and the Philox seed. Stand-alone calls advance the counter
+    themselves; inside begin_block() ... the counter is advanced once and the calls are told apart by their ordinal
+    (saves one tiny launch per call in the rollout)."""
 
     def __init__(self, device, seed=None):
         self.counter = torch.zeros(1, dtype=torch.int64, device=device)
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        self._ordinal = None
+
+    @torch.no_grad()
+    def begin_block(self):
+        """Advance the counter once (in stream order); the following calls use ordinals 1, 2, ... until end_block."""
+        dummy = self.counter
+        rc = lib().atr_sample_actions(_p(dummy), _p(dummy), _p(dummy), _p(dummy), _p(self.counter), self.seed, 0, 1,
+                                      0, 4, 1, _stream(self.counter))
+        if rc != 0:
+            raise RuntimeError("atr_sample_actions failed (%d)" % rc)
+        self._ordinal = 0
+
+    def end_block(self):
+        self._ordinal = None
 
     @torch.no_grad()
     def __call__(self, h, linear):
@@ -173,8 +211,13 @@ class ActionSampler(object):
         n, R = h.shape
         A = linear.weight.shape[0]
         actions = torch.empty(n, dtype=torch.int64, device=h.device)
+        if self._ordinal is None:
+            ordinal, bump = 0, 1
+        else:
+            self._ordinal += 1
+            ordinal, bump = self._ordinal, 0
         rc = lib().atr_sample_actions(_p(h), _p(linear.weight), _p(linear.bias), _p(actions), _p(self.counter),
-                                      self.seed, n, R, A, _stream(h))
+                                      self.seed, ordinal, bump, n, R, A, _stream(h))
         if rc != 0:
             raise RuntimeError("atr_sample_actions failed (%d)" % rc)
         return actions

@@ -419,6 +419,16 @@ class TAT(nn.Module):
         return v, e, l, (h[0], c[0]), R_pred
 
 
+use_addmm_activation = hasattr(torch, "_addmm_activation")
+
+
+def _addmm_relu(bias, x, w_t, out):
+    """relu(x w_t + bias) into `out`: the GEMM's fused ReLU epilogue where this PyTorch build offers it."""
+    if use_addmm_activation:
+        return torch._addmm_activation(bias, x, w_t, out=out)
+    return torch.addmm(bias, x, w_t, out=out).relu_()
+
+
 class RolloutCache(object):
     """Forward activations of one rollout (see A3C_Dueling.new_cache)."""
 
@@ -564,6 +574,7 @@ class A3C_Dueling(nn.Module):
         c.h_all = torch.empty((2, T + 1, N, R), device=dev)
         c.c_all = torch.empty((2, T + 1, N, R), device=dev)
         c.bsum = [l.bias_ih + l.bias_hh for l in (p0.lstm, p1.lstm)]
+        c.whh_t = torch.stack([l.weight_hh.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, R, 4R]
         if self.tat:
             fa = p1.fc_action_tracker
             c.emb = fa.weight.t() + fa.bias                        # row a = fc_action_tracker(one_hot(a))
@@ -583,15 +594,16 @@ class A3C_Dueling(nn.Module):
         x_in = [states[:, 0], states.reshape(n, -1, states.shape[3], states.shape[4], states.shape[5])
                 if self.tat else states[:, 1]]
         acts_out = []
+        # both players' stems in one launch, both hidden GEMMs in one bmm (neither depends on the tracker's action)
+        ys = fused.stem_into2(x_in[0], p0.encoder, cache.y[0][t], x_in[1], p1.encoder, cache.y[1][t])
+        hgs = torch.bmm(cache.h_all[:, t], cache.whh_t)
         for i, p in enumerate((p0, p1)):
             enc = p.encoder
-            y = fused.stem_into(x_in[i], enc.conv1, enc.conv2, cache.y[i][t])
-            f = torch.addmm(enc.fc.bias, y.view(n, -1), enc.fc.weight.t(), out=cache.f[i][t]).relu_()
+            f = _addmm_relu(enc.fc.bias, ys[i].view(n, -1), enc.fc.weight.t(), cache.f[i][t])
             if i == 1 and self.tat:
                 f = torch.add(f, cache.emb[acts_out[0]], out=cache.feat1[t])
             ig = torch.addmm(cache.bsum[i], f, p.lstm.weight_ih.t())
-            hg = torch.mm(cache.h_all[i, t], p.lstm.weight_hh.t())
-            fused.lstm_cell_into(ig, hg, cache.c_all[i, t], done, cache.h_all[i, t + 1], cache.c_all[i, t + 1],
+            fused.lstm_cell_into(ig, hgs[i], cache.c_all[i, t], done, cache.h_all[i, t + 1], cache.c_all[i, t + 1],
                                  cache.acts[i, t])
             acts_out.append(sample(cache.h_all[i, t + 1], p.actor.actor_linear))
         return acts_out

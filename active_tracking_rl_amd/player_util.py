@@ -128,6 +128,9 @@ class Agent(object):
         self.states, self.actions = [], []
         self._pending_done = None
         self._cache = None
+        sampler = getattr(self.model, "_sampler", None)
+        if sampler is not None:
+            sampler.begin_block()                                 # one counter bump per rollout, ordinals inside
         if num_steps is not None and self.cache_rollout and hasattr(self.model, "new_cache") and self.num_agents == 2:
             self._cache = self.model.new_cache(num_steps, self.state)
         if self._cache is not None:                               # LSTM state lives in the cache: slot t -> t+1
@@ -142,6 +145,8 @@ class Agent(object):
     def end_rollout(self):
         """Publish the per-player LSTM states back as hxs/cxs [N,A,R] and the episode-length counters."""
         self._apply_pending_done()
+        if getattr(self.model, "_sampler", None) is not None:
+            self.model._sampler.end_block()
         if hasattr(self.model, "_bsum"):
             self.model._bsum = None                               # per-rollout cache; the weights change next
         self.hxs, self.cxs = torch.stack(self._hs, 1), torch.stack(self._cs, 1)

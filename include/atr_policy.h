@@ -19,6 +19,12 @@ extern "C" {
 
 int atr_stem_forward(const float *x, long long x_stride, const float *w1, const float *b1, const float *w2,
                      const float *b2, float *y, long long M, void *stream);
+/* Two independent stems (different weights and inputs — the rollout's tracker and target encoders) in ONE launch:
+ * the workgroups are split between the problems in proportion to M0 : M1. Same result as two atr_stem_forward calls. */
+int atr_stem_forward2(const float *x0, long long x0_stride, const float *w1_0, const float *b1_0, const float *w2_0,
+                      const float *b2_0, float *y0, long long M0, const float *x1, long long x1_stride,
+                      const float *w1_1, const float *b1_1, const float *w2_1, const float *b2_1, float *y1,
+                      long long M1, void *stream);
 /* Floats of scratch atr_stem_backward needs for M frames (per-wave partial gradient records). */
 long long atr_stem_workspace_floats(long long M);
 /* Gradients of the four parameter tensors given dy = dL/dy (the observation needs no gradient). Outputs are
@@ -29,10 +35,13 @@ int atr_stem_backward(const float *x, long long x_stride, const float *y, const 
 
 /* Actor head of the rollout in one launch (replaces actor_linear -> softmax -> multinomial, model.py:41-49 of the
  * reference): logits = w h + b with h [n,R] (R <= 256, multiple of 4), w [A,R], b [A], A <= 8; one categorical draw
- * per row by inverse CDF on a Philox4x32-10 uniform keyed (seed; row, *counter). `counter` is a device-side
- * uint64 the call advances by one (in stream order), so hipGraph replays draw fresh numbers. actions: int64 [n]. */
+ * per row by inverse CDF on a Philox4x32-10 uniform keyed (seed; row, *counter, ordinal). `counter` is a device-side
+ * uint64 that the call advances by one in stream order when bump != 0, so hipGraph replays draw fresh numbers;
+ * `ordinal` distinguishes the calls made between two bumps (e.g. bump once per rollout, ordinal = call index inside
+ * it: one tiny launch per rollout instead of one per call). n == 0 with bump != 0 only advances the counter.
+ * actions: int64 [n]. */
 int atr_sample_actions(const float *h, const float *w, const float *b, long long *actions, unsigned long long *counter,
-                       unsigned long long seed, int n, int R, int A, void *stream);
+                       unsigned long long seed, unsigned ordinal, int bump, int n, int R, int A, void *stream);
 
 /* One LSTMCell step (torch.nn.LSTMCell semantics, gate order i,f,g,o; model.py:110,172 of the reference) for P <= 2
  * players x N envs x R hidden units (R multiple of 4), given the two GEMM results:

@@ -176,3 +176,19 @@ def test_gae_kernel_matches_the_reference_recursion():
         g_run = g_run * gamma * tau * ndv[i] + delta_t
         torch.testing.assert_close(R[i], r_run, rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(gae[i], g_run, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("M0,M1", [(4096, 8192), (5, 3), (1, 700)])
+def test_paired_stem_launch_equals_two_launches(M0, M1):
+    from active_tracking_rl_amd import fused
+    from active_tracking_rl_amd.model import CNN_maze
+    torch.manual_seed(M0 + M1)
+    enc = [CNN_maze((1, 13, 13), 1).cuda(), CNN_maze((1, 13, 13), 2).cuda()]
+    obs = torch.randint(0, 5, (max(M0, (M1 + 1) // 2), 2, 13, 13), device="cuda").float()
+    xa = obs[:M0, 0]                                   # strided view (one agent's frames)
+    xb = obs.reshape(-1, 13, 13)[:M1]                  # contiguous frames
+    ya, yb = torch.empty(M0, 512, device="cuda"), torch.empty(M1, 512, device="cuda")
+    fused.stem_into2(xa, enc[0], ya, xb, enc[1], yb)
+    ra = fused.stem_into(xa, enc[0].conv1, enc[0].conv2, torch.empty_like(ya))
+    rb = fused.stem_into(xb, enc[1].conv1, enc[1].conv2, torch.empty_like(yb))
+    assert torch.equal(ya, ra) and torch.equal(yb, rb)
