@@ -206,11 +206,12 @@ class ActionSampler(object):
         self._ordinal = None
 
     @torch.no_grad()
-    def __call__(self, h, linear):
+    def __call__(self, h, linear, out=None):
         h = h.contiguous()
         n, R = h.shape
         A = linear.weight.shape[0]
-        actions = torch.empty(n, dtype=torch.int64, device=h.device)
+        actions = torch.empty(n, dtype=torch.int64, device=h.device) if out is None else out
+        assert actions.is_contiguous() and actions.dtype == torch.int64 and actions.numel() == n
         if self._ordinal is None:
             ordinal, bump = 0, 1
         else:

@@ -573,6 +573,7 @@ class A3C_Dueling(nn.Module):
         c.acts = torch.empty((2, T, N, 4 * R), device=dev)
         c.h_all = torch.empty((2, T + 1, N, R), device=dev)
         c.c_all = torch.empty((2, T + 1, N, R), device=dev)
+        c.actions = torch.empty((T, 2, N), dtype=torch.int64, device=dev) if self.fused_sampling else None
         c.bsum = [l.bias_ih + l.bias_hh for l in (p0.lstm, p1.lstm)]
         c.whh_t = torch.stack([l.weight_hh.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, R, 4R]
         if self.tat:
@@ -605,7 +606,10 @@ class A3C_Dueling(nn.Module):
             ig = torch.addmm(cache.bsum[i], f, p.lstm.weight_ih.t())
             fused.lstm_cell_into(ig, hgs[i], cache.c_all[i, t], done, cache.h_all[i, t + 1], cache.c_all[i, t + 1],
                                  cache.acts[i, t])
-            acts_out.append(sample(cache.h_all[i, t + 1], p.actor.actor_linear))
+            if cache.actions is not None:
+                acts_out.append(sample(cache.h_all[i, t + 1], p.actor.actor_linear, out=cache.actions[t, i]))
+            else:
+                acts_out.append(sample(cache.h_all[i, t + 1], p.actor.actor_linear))
         return acts_out
 
     def forward_sequence_cached(self, cache, states_seq, actions_seq, keep):

@@ -34,7 +34,7 @@ class Agent(object):
         self.rnn_out = args.rnn_out
         self.values, self.log_probs, self.rewards, self.entropies, self.preds, self.dones = [], [], [], [], [], []
         self.states, self.actions, self.h0, self.c0 = [], [], None, None
-        self._buf, self._pending_done, self._cache = None, None, None
+        self._buf, self._pending_done, self._cache, self._actions_buf = None, None, None, None
         self.cache_rollout = True   # fast path on the GPU: learner back-propagates through the actor's forward pass
         self.done = torch.ones(self.num_envs, dtype=torch.uint8, device=device)
         self.info = None
@@ -88,7 +88,8 @@ class Agent(object):
                 _, actions, _, _, (hx, cx), _ = self.model((self.state, (torch.stack(self._hs, 1), torch.stack(self._cs, 1))))
             self._hs, self._cs = list(hx.unbind(1)), list(cx.unbind(1))
         self.states.append(self.state)
-        self.actions.append(torch.stack(actions, 1))
+        if self._actions_buf is None:                            # else the sampler wrote them in place
+            self.actions.append(torch.stack(actions, 1))
         if self._buf is not None:                       # the step kernel writes straight into the rollout storage
             t = len(self.states) - 1
             state_multi, reward_multi, done, self.info = self.env.step(
@@ -133,6 +134,7 @@ class Agent(object):
             sampler.begin_block()                                 # one counter bump per rollout, ordinals inside
         if num_steps is not None and self.cache_rollout and hasattr(self.model, "new_cache") and self.num_agents == 2:
             self._cache = self.model.new_cache(num_steps, self.state)
+        self._actions_buf = getattr(self._cache, "actions", None)
         if self._cache is not None:                               # LSTM state lives in the cache: slot t -> t+1
             self._cache.h_all[:, 0].copy_(self.hxs.transpose(0, 1))
             self._cache.c_all[:, 0].copy_(self.cxs.transpose(0, 1))
@@ -240,7 +242,10 @@ class Agent(object):
         args = self.args
         N, A, T = self.num_envs, self.num_agents, len(self.rewards)
         dev = self.device
-        actions = torch.stack(self.actions, 0)
+        if self._actions_buf is not None:
+            actions = self._actions_buf.transpose(1, 2)                      # [T, N, A] view of the [T, A, N] store
+        else:
+            actions = torch.stack(self.actions, 0)
         if self._buf is not None and T == self._buf[1].shape[0]:
             states = self._buf[0][:T].unsqueeze(3).unsqueeze(4)              # [T, N, A, 1, 1, h, w] views
             rewards = self._buf[1].unsqueeze(3)
@@ -292,8 +297,12 @@ class Agent(object):
         """loss -> backward into the flat gradient bucket (hipGraph-capturable: no host sync)."""
         fast = len(self.states) > 0
         loss, policy_loss, value_loss, entropies, pred_loss = (self.loss_recompute if fast else self.loss)(training_mode)
-        optimizer.zero_grad()
-        loss.backward()
+        bucket = getattr(optimizer, "bucket", None)
+        if bucket is not None and hasattr(bucket, "set_grads"):
+            bucket.set_grads(torch.autograd.grad(loss, bucket.params, allow_unused=True))
+        else:
+            optimizer.zero_grad()
+            loss.backward()
         self.clear_actions()
         if hasattr(self.model, "cache_dense"):
             self.model.cache_dense(False)

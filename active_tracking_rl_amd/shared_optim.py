@@ -42,6 +42,30 @@ class FlatParams(object):
             off += n
 
 
+    def grad_views(self):
+        views, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            views.append(self.grad[off:off + n].view_as(p.data))
+            off += n
+        return views
+
+    def set_grads(self, grads):
+        """Store freshly computed gradients (torch.autograd.grad output, None = unused) in the bucket with one
+        multi-tensor copy — instead of zeroing the bucket and letting autograd accumulate into ~40 views one add
+        kernel at a time."""
+        if getattr(self, "_views", None) is None:
+            self._views = self.grad_views()
+        if any(g is None for g in grads):
+            self.grad.zero_()
+        dst = [v for v, g in zip(self._views, grads) if g is not None]
+        src = [g for g in grads if g is not None]
+        torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params, self._views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+
+
 class SharedAdam(torch.optim.Optimizer):
     """Adam+AMSGrad with the reference's SharedAdam numerics over a FlatParams bucket."""
 
