@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "../../include/atr_policy.h"
+#include "atr_sample.h"
 
 namespace atr {
 
@@ -39,9 +40,19 @@ struct CellFwd {
     float *acts;               // nullable: + p * acts_ps + n * 4R, activated gates (i, f, g, o)
     long long acts_ps;
     int P, N, R;
+    // actor extras (k_lstm_cell_fwd<true>, P == 1): tracker-action embedding added to the gates, and the actor head +
+    // categorical draw on the fresh hidden row (R/4 lanes of one wave hold a row)
+    const float *emb;          // nullable: [n_in, 4R] rows added to the pre-activations, row = act_in[n]
+    const long long *act_in;
+    const float *actor_w, *actor_b;   // [A, R], [A]
+    long long *actions_out;    // [N]
+    const unsigned long long *counter;
+    unsigned long long seed;
+    unsigned ordinal;
+    int A;
 };
 
-__global__ __launch_bounds__(256) void k_lstm_cell_fwd(CellFwd a)
+template <bool ACT> __global__ __launch_bounds__(256) void k_lstm_cell_fwd(CellFwd a)
 {
     const int rq = a.R >> 2;
     const long long total = (long long)a.P * a.N * rq;
@@ -52,10 +63,15 @@ __global__ __launch_bounds__(256) void k_lstm_cell_fwd(CellFwd a)
         const float k = a.keep ? a.keep[n] : (a.done ? (a.done[n] == 0 ? 1.0f : 0.0f) : 1.0f);
         const float *ig = a.ig[p] + (long long)n * 4 * a.R + j;
         const float *hg = a.hg + ((long long)p * a.N + n) * 4 * a.R + j;
-        const float4 pi = fma4(k, ld4(hg), ld4(ig));
-        const float4 pf = fma4(k, ld4(hg + a.R), ld4(ig + a.R));
-        const float4 pg = fma4(k, ld4(hg + 2 * a.R), ld4(ig + 2 * a.R));
-        const float4 po = fma4(k, ld4(hg + 3 * a.R), ld4(ig + 3 * a.R));
+        float4 pi = fma4(k, ld4(hg), ld4(ig));
+        float4 pf = fma4(k, ld4(hg + a.R), ld4(ig + a.R));
+        float4 pg = fma4(k, ld4(hg + 2 * a.R), ld4(ig + 2 * a.R));
+        float4 po = fma4(k, ld4(hg + 3 * a.R), ld4(ig + 3 * a.R));
+        if (ACT && a.emb) {
+            const float *e = a.emb + a.act_in[n] * 4 * a.R + j;
+            pi = fma4(1.0f, ld4(e), pi); pf = fma4(1.0f, ld4(e + a.R), pf);
+            pg = fma4(1.0f, ld4(e + 2 * a.R), pg); po = fma4(1.0f, ld4(e + 3 * a.R), po);
+        }
         const float4 cp = ld4(a.c_prev + p * a.c_prev_ps + (long long)n * a.R + j);
         const float4 gi = make_float4(sigmoidf_(pi.x), sigmoidf_(pi.y), sigmoidf_(pi.z), sigmoidf_(pi.w));
         const float4 gf = make_float4(sigmoidf_(pf.x), sigmoidf_(pf.y), sigmoidf_(pf.z), sigmoidf_(pf.w));
@@ -69,6 +85,26 @@ __global__ __launch_bounds__(256) void k_lstm_cell_fwd(CellFwd a)
         if (a.acts) {
             float *ac = a.acts + p * a.acts_ps + (long long)n * 4 * a.R + j;
             st4(ac, gi); st4(ac + a.R, gf); st4(ac + 2 * a.R, gg); st4(ac + 3 * a.R, go);
+        }
+        if (ACT) {      // actor head on the fresh row: partial logits over this lane's 4 units, summed over the row's lanes
+            float logit[kMaxActions];
+#pragma unroll
+            for (int q = 0; q < kMaxActions; q++) {
+                logit[q] = 0.f;
+                if (q < a.A) {
+                    const float4 w = ld4(a.actor_w + q * a.R + j);
+                    logit[q] = fmaf(h.x, w.x, fmaf(h.y, w.y, fmaf(h.z, w.z, h.w * w.w)));
+                }
+            }
+            for (int msk = 1; msk < rq; msk <<= 1)
+#pragma unroll
+                for (int q = 0; q < kMaxActions; q++)
+                    if (q < a.A) logit[q] += __shfl_xor(logit[q], msk, 64);
+            if (j == 0) {
+#pragma unroll
+                for (int q = 0; q < kMaxActions; q++) logit[q] = q < a.A ? logit[q] + a.actor_b[q] : -INFINITY;
+                a.actions_out[n] = (long long)draw_action(logit, a.A, n, *a.counter, a.seed, a.ordinal);
+            }
         }
     }
 }
@@ -182,7 +218,29 @@ extern "C" int atr_lstm_cell_forward(const float *ig0, const float *ig1, const f
     a.ig[0] = ig0; a.ig[1] = ig1; a.hg = hg; a.c_prev = c_prev; a.c_prev_ps = c_prev_pstride; a.keep = keep; a.done = done;
     a.h_out = h_out; a.c_out = c_out; a.h_ps = h_pstride; a.c_ps = c_pstride; a.acts = acts; a.acts_ps = acts_pstride;
     a.P = P; a.N = N; a.R = R;
-    hipLaunchKernelGGL(k_lstm_cell_fwd, dim3(grid_for((long long)P * N * (R / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    a.emb = nullptr; a.act_in = nullptr; a.actor_w = nullptr; a.actor_b = nullptr; a.actions_out = nullptr;
+    a.counter = nullptr; a.seed = 0; a.ordinal = 0; a.A = 0;
+    hipLaunchKernelGGL(k_lstm_cell_fwd<false>, dim3(grid_for((long long)P * N * (R / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int atr_lstm_cell_forward_act(const float *ig, const float *hg, const float *c_prev, const unsigned char *done,
+                                         float *h_out, float *c_out, float *acts, const float *emb,
+                                         const long long *act_in, const float *actor_w, const float *actor_b, int A,
+                                         long long *actions_out, const unsigned long long *counter,
+                                         unsigned long long seed, unsigned ordinal, int N, int R, void *stream)
+{
+    const int rq = R / 4;
+    if (!ig || !hg || !c_prev || !h_out || !c_out || !actor_w || !actor_b || !actions_out || !counter || N < 0 || R <= 0 ||
+        (R & 3) || (rq != 16 && rq != 32 && rq != 64) || A < 1 || A > kMaxActions || ((emb != nullptr) != (act_in != nullptr)))
+        return -1;
+    if (N == 0) return 0;
+    CellFwd a;
+    a.ig[0] = ig; a.ig[1] = nullptr; a.hg = hg; a.c_prev = c_prev; a.c_prev_ps = 0; a.keep = nullptr; a.done = done;
+    a.h_out = h_out; a.c_out = c_out; a.h_ps = 0; a.c_ps = 0; a.acts = acts; a.acts_ps = 0; a.P = 1; a.N = N; a.R = R;
+    a.emb = emb; a.act_in = act_in; a.actor_w = actor_w; a.actor_b = actor_b; a.actions_out = actions_out;
+    a.counter = counter; a.seed = seed; a.ordinal = ordinal; a.A = A;
+    hipLaunchKernelGGL(k_lstm_cell_fwd<true>, dim3(grid_for((long long)N * rq)), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -579,6 +579,7 @@ class A3C_Dueling(nn.Module):
         if self.tat:
             fa = p1.fc_action_tracker
             c.emb = fa.weight.t() + fa.bias                        # row a = fc_action_tracker(one_hot(a))
+            c.emb_ih = c.emb @ p1.lstm.weight_ih.t()               # ... projected through W_ih: [n_act, 4R]
         return c
 
     @torch.no_grad()
@@ -598,12 +599,22 @@ class A3C_Dueling(nn.Module):
         # both players' stems in one launch, both hidden GEMMs in one bmm (neither depends on the tracker's action)
         ys = fused.stem_into2(x_in[0], p0.encoder, cache.y[0][t], x_in[1], p1.encoder, cache.y[1][t])
         hgs = torch.bmm(cache.h_all[:, t], cache.whh_t)
+        R = cache.h_all.shape[-1]
+        one_launch = (cache.actions is not None and self._sampler._ordinal is not None and R // 4 in (16, 32, 64)
+                      and p0.actor.actor_linear.weight.shape[0] <= 8 and p1.actor.actor_linear.weight.shape[0] <= 8)
         for i, p in enumerate((p0, p1)):
             enc = p.encoder
             f = _addmm_relu(enc.fc.bias, ys[i].view(n, -1), enc.fc.weight.t(), cache.f[i][t])
-            if i == 1 and self.tat:
+            tat = i == 1 and self.tat
+            if tat and not one_launch:
                 f = torch.add(f, cache.emb[acts_out[0]], out=cache.feat1[t])
             ig = torch.addmm(cache.bsum[i], f, p.lstm.weight_ih.t())
+            if one_launch:   # cell (+ tracker-action embedding, projected through W_ih once per rollout) + actor head + draw
+                acts_out.append(fused.lstm_cell_act_into(
+                    ig, hgs[i], cache.c_all[i, t], done, cache.h_all[i, t + 1], cache.c_all[i, t + 1], cache.acts[i, t],
+                    self._sampler, p.actor.actor_linear, cache.actions[t, i],
+                    emb=cache.emb_ih if tat else None, act_in=acts_out[0] if tat else None))
+                continue
             fused.lstm_cell_into(ig, hgs[i], cache.c_all[i, t], done, cache.h_all[i, t + 1], cache.c_all[i, t + 1],
                                  cache.acts[i, t])
             if cache.actions is not None:

@@ -51,16 +51,13 @@ class FlatParams(object):
         return views
 
     def set_grads(self, grads):
-        """Store freshly computed gradients (torch.autograd.grad output, None = unused) in the bucket with one
-        multi-tensor copy — instead of zeroing the bucket and letting autograd accumulate into ~40 views one add
+        """Store freshly computed gradients (torch.autograd.grad output, None = unused) in the bucket with ONE batched
+        concatenation kernel — instead of zeroing the bucket and letting autograd accumulate into ~40 views one add
         kernel at a time."""
         if getattr(self, "_views", None) is None:
             self._views = self.grad_views()
-        if any(g is None for g in grads):
-            self.grad.zero_()
-        dst = [v for v, g in zip(self._views, grads) if g is not None]
-        src = [g for g in grads if g is not None]
-        torch._foreach_copy_(dst, src)
+        flat = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, self.params)]
+        torch.cat(flat, out=self.grad)
         for p, v in zip(self.params, self._views):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 p.grad = v

@@ -166,6 +166,46 @@ def main():
     torch.cuda.synchronize(device)
     eo_us = e0.elapsed_time(e1) * 1e3 / 1000
 
+    # ---- the policy-side hot kernels (the largest single kernels of the iteration): f32-MFMA roofline ------------
+    # learner shape of the target's encoder: 2 frames x 4096 envs x 20 steps. ALGORITHMIC FLOPs = taps that read real
+    # pixels (conv1 16 x 361, conv2 32 x 16 x 100 MACs per frame; backward = 2x conv2 + conv1 recompute + dW1); the
+    # kernels issue the dense zero-padded products (16 x 49 x 9 and 32 x 16 x 144 MACs: 1.42x), reported alongside.
+    stem_roof = None
+    try:
+        from active_tracking_rl_amd import fused
+        enc = player.model.player1.encoder
+        Ms = 2 * n * T
+        xs_ = torch.randint(0, 5, (Ms, 169), device=device).float()
+        ys_ = torch.empty((Ms, 512), device=device)
+        dys_ = torch.randn((Ms, 512), device=device)
+        prm = [enc.conv1.weight.detach(), enc.conv1.bias.detach(), enc.conv2.weight.detach(), enc.conv2.bias.detach()]
+
+        def t_us(fn, reps=10):
+            fn(); fn()
+            torch.cuda.synchronize(device)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(device)
+            return e0.elapsed_time(e1) * 1e3 / reps
+        f_us = t_us(lambda: fused.stem_into(xs_, enc.conv1, enc.conv2, ys_))
+        b_us = t_us(lambda: fused._stem_backward(xs_, ys_, dys_, prm[0].contiguous(), prm[1], prm[2].contiguous(),
+                                                 (prm[0].shape, prm[2].shape)))
+        c1, c2, c1d, c2d = 16 * 361, 32 * 16 * 100, 16 * 49 * 9, 32 * 16 * 144
+        f_tf = 2.0 * (c1 + c2) * Ms / (f_us * 1e-6) / 1e12
+        b_tf = 2.0 * (2 * c2 + 2 * c1) * Ms / (b_us * 1e-6) / 1e12
+        dense = float(c1d + c2d) / (c1 + c2)
+        stem_roof = {"bound": "mfma", "kernel": "atr::k_stem_fwd / atr::k_stem_bwd (v_mfma_f32_16x16x4_f32)",
+                     "frames": Ms, "fwd_us": f_us, "bwd_us": b_us,
+                     "achieved": f_tf, "achieved_bwd": b_tf, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": f_tf / 157.3, "frac_bwd": b_tf / 157.3, "issued_over_algorithmic": dense,
+                     "note": "dense f32 MFMA peak (MI355X_MICROARCH.md); informational — `roofline` above stays the "
+                             "env step kernel of SURVEY 8(d)"}
+        del xs_, ys_, dys_
+    except Exception as ex:
+        stem_roof = {"error": repr(ex)}
+
     traffic, traffic_src = None, None
     try:   # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (cannot be taken inside this run)
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
@@ -193,6 +233,7 @@ def main():
                              "(profiles/r01_env_only_kernel_stats.txt)"},
         "env_only": {"value": n * world / (eo_us * 1e-6), "unit": "env steps/s", "us_per_launch": eo_us,
                      "note": "same kernel, on-device random actions, one launch per batched step, per-rank x ranks"},
+        "policy_stem": stem_roof,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:

@@ -55,6 +55,15 @@ int atr_lstm_cell_forward(const float *ig0, const float *ig1, const float *hg, c
                           long long c_prev_pstride, const float *keep, const unsigned char *done, float *h_out,
                           long long h_pstride, float *c_out, long long c_pstride, float *acts, long long acts_pstride,
                           int P, int N, int R, void *stream);
+/* The actor's step for ONE player in one launch: the cell above (P = 1, done-flag mask) and, on the fresh hidden row,
+ * the actor head + categorical draw of atr_sample_actions (same key: seed; row, *counter, ordinal — the counter is NOT
+ * advanced here). Optionally adds emb[act_in[n]] ([*,4R] rows: the tracker-action embedding already projected through
+ * W_ih, model.py:178 of the reference) to the pre-activations. R/4 must be 16, 32 or 64 (a row's lanes share a wave). */
+int atr_lstm_cell_forward_act(const float *ig, const float *hg, const float *c_prev, const unsigned char *done,
+                              float *h_out, float *c_out, float *acts, const float *emb, const long long *act_in,
+                              const float *actor_w, const float *actor_b, int A, long long *actions_out,
+                              const unsigned long long *counter, unsigned long long seed, unsigned ordinal, int N,
+                              int R, void *stream);
 /* One step of back-propagation through time for the cell above. dh_out: dL/dh' from the heads; dh_next [P,N,R]:
  * dg_{t+1} W_hh (gradient arriving through the next step's hidden GEMM, unmasked); dc_carry [P,N,R]: in = dc f of step
  * t+1, out = dc f of this step; both are scaled by keep_out (this step's mask k_t) when has_next != 0 and ignored

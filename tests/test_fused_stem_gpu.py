@@ -192,3 +192,44 @@ def test_paired_stem_launch_equals_two_launches(M0, M1):
     ra = fused.stem_into(xa, enc[0].conv1, enc[0].conv2, torch.empty_like(ya))
     rb = fused.stem_into(xb, enc[1].conv1, enc[1].conv2, torch.empty_like(yb))
     assert torch.equal(ya, ra) and torch.equal(yb, rb)
+
+
+def test_actor_cell_kernel_cell_embedding_and_draw():
+    """atr_lstm_cell_forward_act: same (h, c, gates) as the plain cell on ig + emb[a], and actions distributed as
+    softmax(actor(h)) (chi-square on identical rows), different across ordinals."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(6)
+    N, R, A = 100000, 128, 4
+    actor = torch.nn.Linear(R, A).cuda()
+    with torch.no_grad():
+        actor.weight.mul_(6.0); actor.bias.normal_()
+    ig = torch.randn(1, 4 * R, device="cuda").expand(N, 4 * R).contiguous()
+    hg = torch.randn(1, 4 * R, device="cuda").expand(N, 4 * R).contiguous()
+    c = torch.randn(1, R, device="cuda").expand(N, R).contiguous()
+    emb = torch.randn(4, 4 * R, device="cuda")
+    a_in = torch.full((N,), 2, dtype=torch.int64, device="cuda")
+    done = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    sampler = fused.ActionSampler(torch.device("cuda"), seed=99)
+    sampler.begin_block()
+    outs = [torch.empty(N, R, device="cuda") for _ in range(2)] + [torch.empty(N, 4 * R, device="cuda")]
+    acts1 = fused.lstm_cell_act_into(ig, hg, c, done, outs[0], outs[1], outs[2], sampler, actor,
+                                     torch.empty(N, dtype=torch.int64, device="cuda"), emb=emb, act_in=a_in)
+    h_ref, c_ref = fused.lstm_cell(ig + emb[2], hg, c, done=done)
+    torch.testing.assert_close(outs[0], h_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(outs[1], c_ref, rtol=1e-5, atol=1e-6)
+    p = torch.softmax(actor(h_ref[:1]), 1)[0].detach().double().cpu().numpy()
+    counts = np.bincount(acts1.cpu().numpy(), minlength=A).astype(np.float64)
+    chi2 = (((counts - N * p) ** 2) / (N * p + 1e-9)).sum()
+    assert chi2 < 30.0, (chi2, counts / N, p)
+    acts2 = fused.lstm_cell_act_into(ig, hg, c, done, outs[0], outs[1], None, sampler, actor,
+                                     torch.empty(N, dtype=torch.int64, device="cuda"), emb=emb, act_in=a_in)
+    sampler.end_block()
+    assert not torch.equal(acts1, acts2)
+    # done rows restart from a zero state
+    done[: N // 2] = 1
+    sampler.begin_block()
+    fused.lstm_cell_act_into(ig, hg, c, done, outs[0], outs[1], None, sampler, actor,
+                             torch.empty(N, dtype=torch.int64, device="cuda"))
+    sampler.end_block()
+    h_ref, c_ref = fused.lstm_cell(ig, hg, c, done=done)
+    torch.testing.assert_close(outs[0], h_ref, rtol=1e-5, atol=1e-6)
