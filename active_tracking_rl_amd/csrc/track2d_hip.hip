@@ -39,6 +39,7 @@ struct DevState {
     uint32_t *n_maps, *n_pos, *n_goals, *n_plan, *n_tctr, *n_navgoal, *n_d2, *n_dirf;
     uint32_t *gen_req;  // [N] 0 = next slot valid; s > 0 = consumed at step stamp s, to be regenerated
     uint32_t *faults;   // [1]
+    const float2 *rew_lut;    // [3][kLutN] (r_track, r_target) as float32(float64 formula), by w_p class and d^2
     int n;
     uint32_t env_base, k0, k1;
     int max_steps, auto_reset;
@@ -46,6 +47,11 @@ struct DevState {
 };
 
 enum : int { OP_STEP = 0, OP_RESET = 1, OP_OBSERVE = 2 };
+// The reward is a pure function of the integer squared distance (<= 2 * 81^2) and the mode's w_p in {0, 1, -0.5}
+// (track_1v1.py:96-104,147-152): the float64 formula is evaluated once per handle into a table by the same
+// reward_f64 device code the exhaustive parity test checks against the oracle; the step kernel then replaces a
+// dependent f64 sqrt/divide chain that every lane would execute redundantly by one 8-byte scalar load.
+constexpr int kLutN = 2 * 81 * 81 + 1;
 
 __device__ __forceinline__ int load_action(const void *p, int dtype, int e, uint32_t *faults)
 {
@@ -241,11 +247,17 @@ __device__ __forceinline__ void emit_full_obs(const uint32_t *tile, uint32_t pos
     }
 }
 
-template <int OP, bool RANDOM, bool NAV>
+// MULTI (random-action rollouts only, no Nav targets): `nsteps` consecutive env steps per launch with the env's
+// state held in registers / its map tile in LDS; step k writes its outputs to obs/rew/done + k * (per-step size) and is
+// stamped stamp + k. nsteps <= gen_every, so at most one episode switch happens per env per launch (an episode lasts
+// >= 11 steps) and the single pre-generated slot suffices. Results are identical to nsteps single-step launches.
+template <int OP, bool RANDOM, bool NAV, bool MULTI = false>
 __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const void *act1, int act_dtype,
                                              const uint8_t *mask, float *obs, float *rew, uint8_t *done_out,
-                                             uint32_t aseed_lo, uint32_t aseed_hi, uint32_t step_idx, uint32_t stamp)
+                                             uint32_t aseed_lo, uint32_t aseed_hi, uint32_t step_idx, uint32_t stamp,
+                                             int nsteps)
 {
+    static_assert(!MULTI || (OP == OP_STEP && RANDOM && !NAV), "MULTI is the fused random-action rollout");
     __shared__ __attribute__((aligned(16))) uint32_t tiles[kWavesPerBlock][kTileWords];
     __shared__ __attribute__((aligned(16))) float stages[kWavesPerBlock][kObsPerEnv + 2];
 
@@ -259,11 +271,13 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
     reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(gtile)[lane];
     uint32_t pos = s.pos[e], cnt = s.cnt[e];
     const uint32_t cfg = s.cfg[e];
-    uint32_t plan = 0, tctr = 0, navgoal = 0, d2 = 0;
+    uint32_t plan = 0, tctr = 0, navgoal = 0, d2 = 0, episode = 0;
     const int mode = (int)((cfg >> 2) & 7u);
-    bool consume = false, dirty = false, navgoal_dirty = false;
+    if (MULTI) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }   // carried in registers across steps
     wave_lds_sync();
 
+  for (int k = 0; k < (MULTI ? nsteps : 1); k++) {
+    bool consume = false, dirty = false, navgoal_dirty = false;
     if (OP == OP_RESET) consume = (mask == nullptr) || (mask[e] != 0);
 
     if (OP == OP_STEP) {
@@ -272,16 +286,16 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         int c_far = (int)(cnt & 0xffu), t = (int)((cnt >> 8) & 0xffffu);
         int a_tr, a_tg;
         if (RANDOM) {
-            u32x4 w = philox4x32_10(aseed_lo, aseed_hi, step_idx, 0u, genv, STREAM_ACTION);
+            u32x4 w = philox4x32_10(aseed_lo, aseed_hi, step_idx + (uint32_t)k, 0u, genv, STREAM_ACTION);
             a_tr = (int)(w.x & 3u); a_tg = (int)(w.y & 3u);
         } else {
             a_tr = load_action(act0, act_dtype, e, s.faults);
             a_tg = act1 ? load_action(act1, act_dtype, e, s.faults) : 0;
         }
         if (mode == TGT_RAM) { // track_1v1.py:81-82
-            plan = s.plan[e]; tctr = s.tctr[e];
+            if (!MULTI) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }
             Stream ts;
-            ts.init(s.k0, s.k1, s.episode[e], genv, STREAM_TARGET, tctr);
+            ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, tctr);
             a_tg = (int)ram_step(plan, ts);
             tctr = ts.ctr;
             dirty = true;
@@ -328,17 +342,16 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         pos = (uint32_t)r0 | ((uint32_t)c0 << 8) | ((uint32_t)r1 << 16) | ((uint32_t)c1 << 24);
         const int dr = r1 - r0, dc = c1 - c0;
         d2 = (uint32_t)(dr * dr + dc * dc);
-        const double w_p = mode == TGT_PZR ? 1.0 : (mode == TGT_FAR ? -0.5 : 0.0); // track_1v1.py:147-152
-        double rt, rg;
-        reward_f64(d2, w_p, rt, rg);
+        // w_p = 1 (PZR), -0.5 (Far), else 0 (track_1v1.py:147-152) selects the table
+        const float2 rwd = s.rew_lut[(mode == TGT_PZR ? kLutN : (mode == TGT_FAR ? 2 * kLutN : 0)) + (int)d2];
         c_far = d2 <= 36u ? 0 : min(c_far + 1, 255);  // distance <= 6 (track_1v1.py:106-109)
         int dn = c_far > 10;
         t = min(t + 1, 65535);
         if (s.max_steps > 0 && t >= s.max_steps) dn = 1; // gym TimeLimit
         cnt = (uint32_t)c_far | ((uint32_t)t << 8) | ((uint32_t)side << 24);
         if (lane == 0) {
-            reinterpret_cast<float2 *>(rew)[e] = make_float2((float)rt, (float)rg);
-            done_out[e] = (uint8_t)dn;
+            reinterpret_cast<float2 *>(rew)[(size_t)k * s.n + e] = rwd;
+            done_out[(size_t)k * s.n + e] = (uint8_t)dn;
         }
         consume = dn && s.auto_reset;
     }
@@ -355,9 +368,11 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         }
         pos = s.n_pos[e]; plan = s.n_plan[e]; tctr = s.n_tctr[e]; navgoal = s.n_navgoal[e]; d2 = s.n_d2[e];
         cnt = (uint32_t)side_of_cfg(cfg) << 24;
+        if (!MULTI) episode = s.episode[e];
+        episode += 1u;
         if (lane == 0) {
-            s.goals[e] = s.n_goals[e]; s.episode[e] = s.episode[e] + 1u; s.navgoal[e] = navgoal;
-            s.gen_req[e] = stamp;
+            s.goals[e] = s.n_goals[e]; s.episode[e] = episode; s.navgoal[e] = navgoal;
+            s.gen_req[e] = stamp + (uint32_t)k;
         }
         wave_lds_sync();
     }
@@ -367,9 +382,22 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         if (navgoal_dirty && !consume) s.navgoal[e] = navgoal;
     }
     if (obs != nullptr) {
-        if (s.obs_full) emit_full_obs(tile, pos, (int)(cnt >> 24), lane, obs + (size_t)e * 2 * s.obs_side * s.obs_side);
-        else emit_obs(tile, stages[wave], pos, (int)(cnt >> 24), lane, obs + (size_t)e * kObsPerEnv);
+        if (s.obs_full)
+            emit_full_obs(tile, pos, (int)(cnt >> 24), lane, obs + ((size_t)k * s.n + e) * 2 * s.obs_side * s.obs_side);
+        else
+            emit_obs(tile, stages[wave], pos, (int)(cnt >> 24), lane, obs + ((size_t)k * s.n + e) * kObsPerEnv);
     }
+  }
+}
+
+__global__ void k_build_reward_lut(float2 *lut)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= 3 * kLutN) return;
+    const int cls = i / kLutN;
+    double a, b;
+    reward_f64((uint32_t)(i - cls * kLutN), cls == 1 ? 1.0 : (cls == 2 ? -0.5 : 0.0), a, b);
+    lut[i] = make_float2((float)a, (float)b);
 }
 
 __global__ void k_reward_table(const uint32_t *d2, int n, double w_p, float *r_track, float *r_target)
@@ -496,6 +524,14 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     for (auto a : arrs) alloc(a, nb);
     if (has_nav) { alloc(&s.dirf, db); alloc(&s.n_dirf, db); }
     alloc(&s.faults, sizeof(uint32_t));
+    float2 *lut = nullptr;
+    if (err == hipSuccess) err = hipMalloc((void **)&lut, (size_t)3 * kLutN * sizeof(float2));
+    s.rew_lut = lut;
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(k_build_reward_lut, dim3((3 * kLutN + 255) / 256), dim3(256), 0, 0, lut);
+        err = hipGetLastError();
+        if (err == hipSuccess) err = hipDeviceSynchronize();
+    }
     if (err == hipSuccess) err = hipMemcpy(s.cfg, hcfg.data(), nb, hipMemcpyHostToDevice);
     if (err != hipSuccess) {
         t2d_destroy(h);
@@ -511,7 +547,8 @@ extern "C" int t2d_destroy(t2d_handle *h)
     DeviceGuard guard(h->device);
     DevState &s = h->s;
     void *ptrs[] = {s.maps, s.n_maps, s.pos, s.goals, s.cnt, s.cfg, s.episode, s.plan, s.tctr, s.navgoal, s.d2,
-                    s.n_pos, s.n_goals, s.n_plan, s.n_tctr, s.n_navgoal, s.n_d2, s.gen_req, s.dirf, s.n_dirf, s.faults};
+                    s.n_pos, s.n_goals, s.n_plan, s.n_tctr, s.n_navgoal, s.n_d2, s.gen_req, s.dirf, s.n_dirf, s.faults,
+                    (void *)s.rew_lut};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -532,10 +569,10 @@ static void launch_env(t2d_handle *h, hipStream_t st, const void *a0, const void
 {
     if (h->has_nav)
         hipLaunchKernelGGL((k_env<OP, RANDOM, true>), env_grid(h->s.n), dim3(256), 0, st, h->s, a0, a1, adt, mask, obs,
-                           rew, done, slo, shi, sidx, stamp);
+                           rew, done, slo, shi, sidx, stamp, 1);
     else
         hipLaunchKernelGGL((k_env<OP, RANDOM, false>), env_grid(h->s.n), dim3(256), 0, st, h->s, a0, a1, adt, mask, obs,
-                           rew, done, slo, shi, sidx, stamp);
+                           rew, done, slo, shi, sidx, stamp, 1);
 }
 
 // Regenerate every consumed next-episode slot, in order on `st`, and restart the stamps.
@@ -611,6 +648,47 @@ extern "C" int t2d_step_random(t2d_handle *h, int steps, uint64_t action_seed, f
         int rc = step_impl<true>(h, (hipStream_t)stream, nullptr, nullptr, 0, obs_dev, rew_dev, done_dev,
                                  (uint32_t)action_seed, (uint32_t)(action_seed >> 32), h->random_step++);
         if (rc) return rc;
+    }
+    return T2D_OK;
+}
+
+extern "C" int t2d_rollout_random(t2d_handle *h, int steps, uint64_t action_seed, float *obs_dev, float *rew_dev,
+                                  uint8_t *done_dev, void *stream)
+{
+    if (!h) return fail(T2D_ERR_INVALID, "t2d_rollout_random: null handle");
+    if (!rew_dev || !done_dev || steps < 0) return fail(T2D_ERR_INVALID, "t2d_rollout_random: bad argument");
+    if (!h->reset_done || (h->s.auto_reset && !h->primed)) return fail(T2D_ERR_STATE, "t2d_rollout_random: reset first");
+    DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)h->s.n, obs_elems = h->s.obs_full ? (size_t)2 * h->s.obs_side * h->s.obs_side : (size_t)kObsPerEnv;
+    int done_steps = 0;
+    while (done_steps < steps) {
+        float *o = obs_dev ? obs_dev + (size_t)done_steps * n * obs_elems : nullptr;
+        float *r = rew_dev + (size_t)done_steps * n * 2;
+        uint8_t *d = done_dev + (size_t)done_steps * n;
+        if (h->has_nav) { // Nav re-planning writes a direction field other lanes re-read: one step per launch
+            int rc = step_impl<true>(h, st, nullptr, nullptr, 0, o, r, d, (uint32_t)action_seed,
+                                     (uint32_t)(action_seed >> 32), h->random_step++);
+            if (rc) return rc;
+            done_steps++;
+            continue;
+        }
+        // up to the next generator pass (at most one episode switch per env in between)
+        int chunk = steps - done_steps;
+        if (h->s.auto_reset && chunk > (int)(h->gen_every - h->phase)) chunk = (int)(h->gen_every - h->phase);
+        hipLaunchKernelGGL((k_env<OP_STEP, true, false, true>), env_grid(h->s.n), dim3(256), 0, st, h->s, nullptr, nullptr,
+                           0, nullptr, o, r, d, (uint32_t)action_seed, (uint32_t)(action_seed >> 32), h->random_step,
+                           h->phase + 1u, chunk);
+        HIP_TRY(hipGetLastError());
+        h->random_step += (uint32_t)chunk;
+        done_steps += chunk;
+        if (h->s.auto_reset) {
+            h->phase += (uint32_t)chunk;
+            if (h->phase >= h->gen_every) {
+                int rc = flush_impl(h, st);
+                if (rc) return rc;
+            }
+        }
     }
     return T2D_OK;
 }

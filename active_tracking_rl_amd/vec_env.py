@@ -43,7 +43,7 @@ _lib = None
 ABI_SYMBOLS = (
     "t2d_last_error", "t2d_abi_version", "t2d_create", "t2d_destroy", "t2d_num_envs", "t2d_reset", "t2d_step",
     "t2d_observe", "t2d_inject", "t2d_inject_plan", "t2d_get_state", "t2d_get_maps", "t2d_get_target",
-    "t2d_get_faults", "t2d_step_random", "t2d_reward_table", "t2d_flush",
+    "t2d_get_faults", "t2d_step_random", "t2d_rollout_random", "t2d_reward_table", "t2d_flush",
 )
 
 
@@ -87,6 +87,8 @@ def load_library():
     L.t2d_get_faults.argtypes = [vp, vp, vp]
     L.t2d_step_random.restype = i32
     L.t2d_step_random.argtypes = [vp, i32, u64, vp, vp, vp, vp]
+    L.t2d_rollout_random.restype = i32
+    L.t2d_rollout_random.argtypes = [vp, i32, u64, vp, vp, vp, vp]
     L.t2d_reward_table.restype = i32
     L.t2d_reward_table.argtypes = [vp, vp, i32, C.c_double, vp, vp, vp]
     if L.t2d_abi_version() != ABI_VERSION:
@@ -221,6 +223,20 @@ class VecTrack2D(object):
         obs, rew, done = out
         _check(self.L.t2d_step_random(self.h, int(steps), int(action_seed), C.c_void_p(obs.data_ptr()),
                                       C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), self._stream()))
+        return obs, rew, done
+
+    def rollout_random(self, steps, action_seed=1, out=None, keep_obs=True):
+        """`steps` random-policy steps, up to 10 per launch (t2d_rollout_random), keeping every step's outputs:
+        obs [steps,N,2,h,w] (None with keep_obs=False), rewards [steps,N,2], done [steps,N]."""
+        if out is None:
+            h, w = self.obs_hw
+            obs = torch.empty((steps, self.num_envs, 2, h, w), dtype=torch.float32, device=self.device) if keep_obs else None
+            out = (obs, torch.empty((steps, self.num_envs, 2), dtype=torch.float32, device=self.device),
+                   torch.empty((steps, self.num_envs), dtype=torch.uint8, device=self.device))
+        obs, rew, done = out
+        _check(self.L.t2d_rollout_random(self.h, int(steps), int(action_seed),
+                                         C.c_void_p(obs.data_ptr()) if obs is not None else None,
+                                         C.c_void_p(rew.data_ptr()), C.c_void_p(done.data_ptr()), self._stream()))
         return obs, rew, done
 
     def flush(self):

@@ -165,6 +165,16 @@ def main():
     e1.record()
     torch.cuda.synchronize(device)
     eo_us = e0.elapsed_time(e1) * 1e3 / 1000
+    # persistent mode: up to 10 steps per launch, every step's outputs written (t2d_rollout_random)
+    fo = core.rollout_random(T, 7)
+    torch.cuda.synchronize(device)
+    e0.record()
+    for _ in range(50):
+        core.rollout_random(T, 7, fo)
+    e1.record()
+    torch.cuda.synchronize(device)
+    eof_us = e0.elapsed_time(e1) * 1e3 / (50 * T)
+    del fo
 
     # ---- the policy-side hot kernels (the largest single kernels of the iteration): f32-MFMA roofline ------------
     # learner shape of the target's encoder: 2 frames x 4096 envs x 20 steps. ALGORITHMIC FLOPs = taps that read real
@@ -232,7 +242,12 @@ def main():
                              "inter-kernel boundaries, so it sits ~1.5 us above rocprofv3's k_env-only average "
                              "(profiles/r01_env_only_kernel_stats.txt)"},
         "env_only": {"value": n * world / (eo_us * 1e-6), "unit": "env steps/s", "us_per_launch": eo_us,
-                     "note": "same kernel, on-device random actions, one launch per batched step, per-rank x ranks"},
+                     "note": "same kernel, on-device random actions, one launch per batched step, per-rank x ranks",
+                     "fused_value": n * world / (eof_us * 1e-6), "fused_us_per_step": eof_us,
+                     "fused_gbs": B_STEP * n / (eof_us * 1e-6) / 1e9,
+                     "fused_note": "t2d_rollout_random: up to 10 env steps per launch (state in registers, map tile in "
+                                   "LDS), all %d steps' observations/rewards/done written; bit-identical to the "
+                                   "per-step launches" % T},
         "policy_stem": stem_roof,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

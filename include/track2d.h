@@ -132,6 +132,14 @@ int t2d_get_faults(t2d_handle *h, uint32_t *faults_host, void *stream);
 int t2d_step_random(t2d_handle *h, int steps, uint64_t action_seed, float *obs_dev, float *rew_dev,
                     uint8_t *done_dev, void *stream);
 
+/* The same random-policy steps as t2d_step_random, but up to 10 consecutive steps per LAUNCH (the env's state stays in
+ * registers and its map tile in LDS between steps; a generator pass runs between launches exactly where the
+ * per-step path runs it), and EVERY step's outputs are kept: obs_dev [steps,N,2,13,13] (or NULL), rew_dev
+ * [steps,N,2], done_dev [steps,N]. Bit-identical to `steps` calls of t2d_step_random(h, 1, ...). This is the
+ * "persistent T-step" env-only mode of SURVEY.md 8(d)(ii); handles with Nav targets fall back to one step per launch. */
+int t2d_rollout_random(t2d_handle *h, int steps, uint64_t action_seed, float *obs_dev, float *rew_dev,
+                       uint8_t *done_dev, void *stream);
+
 /* Pure helper exposed for the exhaustive reward parity test: rewards for n squared distances. */
 int t2d_reward_table(t2d_handle *h, const uint32_t *d2_dev, int n, double w_p, float *r_track_dev,
                      float *r_target_dev, void *stream);

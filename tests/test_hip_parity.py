@@ -390,3 +390,31 @@ def test_invariants_at_baseline_sizes(vec, n, map_type, mode):
     assert (o[:, 0, 6, 6] == 2).all() and (o[:, 1, 6, 6] == 4).all()
     assert set(np.unique(o)) <= {0.0, 1.0, 2.0, 4.0}
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["Track2D-BlockPartialPZR-v0", "Track2D-BlockPartialRam-v0", "Track2D-MazePartialFar-v0",
+                                    "Track2D-MazePartialNav-v0"])
+def test_fused_random_rollout_is_bit_identical_to_single_step_launches(env_id):
+    """t2d_rollout_random (up to 10 env steps per launch, state in registers / tile in LDS) against the same number of
+    one-step launches from the same seed: every step's observations, rewards and done flags, and the final state."""
+    import torch
+    from active_tracking_rl_amd.vec_env import VecTrack2D
+    n, steps = 777, 47          # odd sizes: chunks of 10 + a tail, several episode switches (max_episode_steps=25)
+    a = VecTrack2D(env_id, num_envs=n, seed=5, max_episode_steps=25)
+    b = VecTrack2D(env_id, num_envs=n, seed=5, max_episode_steps=25)
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    a.step_random(3, 9)                                  # un-aligned start: 3 steps into the generator window
+    b.step_random(3, 9)
+    obs, rew, done = a.rollout_random(steps, 9)
+    for t in range(steps):
+        o1, r1, d1 = b.step_random(1, 9)
+        assert torch.equal(obs[t], o1), (env_id, t)
+        assert torch.equal(rew[t], r1) and torch.equal(done[t], d1), (env_id, t)
+    assert int(done.sum()) > n                           # the time limit alone ends every episode once
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(a.get_maps(), b.get_maps())
+    a.close(); b.close()
