@@ -53,12 +53,16 @@ enum : int { OP_STEP = 0, OP_RESET = 1, OP_OBSERVE = 2 };
 // dependent f64 sqrt/divide chain that every lane would execute redundantly by one 8-byte scalar load.
 constexpr int kLutN = 2 * 81 * 81 + 1;
 
-__device__ __forceinline__ int load_action(const void *p, int dtype, int e, uint32_t *faults)
+// Action fetch in two halves so that the load is issued at the top of the kernel, next to the state and tile loads
+// (one memory round trip for all of them), and only checked where the action is used.
+template <int ADT> __device__ __forceinline__ long long load_action_raw(const void *p, int e)
 {
-    long long v;
-    if (dtype == T2D_ACT_U8) v = reinterpret_cast<const uint8_t *>(p)[e];
-    else if (dtype == T2D_ACT_I32) v = reinterpret_cast<const int32_t *>(p)[e];
-    else v = reinterpret_cast<const long long *>(p)[e];
+    if (ADT == T2D_ACT_U8) return reinterpret_cast<const uint8_t *>(p)[e];
+    if (ADT == T2D_ACT_I32) return reinterpret_cast<const int32_t *>(p)[e];
+    return reinterpret_cast<const long long *>(p)[e];
+}
+__device__ __forceinline__ int check_action(long long v, uint32_t *faults)
+{
     if (v < 0 || v > 3) { atomicOr(faults, 1u); v &= 3; }
     return (int)v;
 }
@@ -251,7 +255,10 @@ __device__ __forceinline__ void emit_full_obs(const uint32_t *tile, uint32_t pos
 // state held in registers / its map tile in LDS; step k writes its outputs to obs/rew/done + k * (per-step size) and is
 // stamped stamp + k. nsteps <= gen_every, so at most one episode switch happens per env per launch (an episode lasts
 // >= 11 steps) and the single pre-generated slot suffices. Results are identical to nsteps single-step launches.
-template <int OP, bool RANDOM, bool NAV, bool MULTI = false>
+// ADT: element type of the action tensors (compile-time, so that the action loads are straight-line code issued
+// together with the state and tile loads); act1 is never null here (the host passes act0 again when the target is
+// scripted — its value is then overridden by the Ram/Nav plan).
+template <int OP, bool RANDOM, bool NAV, bool MULTI = false, int ADT = T2D_ACT_I64>
 __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const void *act1, int act_dtype,
                                              const uint8_t *mask, float *obs, float *rew, uint8_t *done_out,
                                              uint32_t aseed_lo, uint32_t aseed_hi, uint32_t step_idx, uint32_t stamp,
@@ -271,6 +278,11 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
     reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(gtile)[lane];
     uint32_t pos = s.pos[e], cnt = s.cnt[e];
     const uint32_t cfg = s.cfg[e];
+    long long act_raw0 = 0, act_raw1 = 0;
+    if (OP == OP_STEP && !RANDOM) {
+        act_raw0 = load_action_raw<ADT>(act0, e);
+        act_raw1 = load_action_raw<ADT>(act1, e);
+    }
     uint32_t plan = 0, tctr = 0, navgoal = 0, d2 = 0, episode = 0;
     const int mode = (int)((cfg >> 2) & 7u);
     if (MULTI) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }   // carried in registers across steps
@@ -289,8 +301,8 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
             u32x4 w = philox4x32_10(aseed_lo, aseed_hi, step_idx + (uint32_t)k, 0u, genv, STREAM_ACTION);
             a_tr = (int)(w.x & 3u); a_tg = (int)(w.y & 3u);
         } else {
-            a_tr = load_action(act0, act_dtype, e, s.faults);
-            a_tg = act1 ? load_action(act1, act_dtype, e, s.faults) : 0;
+            a_tr = check_action(act_raw0, s.faults);
+            a_tg = check_action(act_raw1, s.faults);
         }
         if (mode == TGT_RAM) { // track_1v1.py:81-82
             if (!MULTI) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }
@@ -567,12 +579,18 @@ template <int OP, bool RANDOM>
 static void launch_env(t2d_handle *h, hipStream_t st, const void *a0, const void *a1, int adt, const uint8_t *mask,
                        float *obs, float *rew, uint8_t *done, uint32_t slo, uint32_t shi, uint32_t sidx, uint32_t stamp)
 {
-    if (h->has_nav)
-        hipLaunchKernelGGL((k_env<OP, RANDOM, true>), env_grid(h->s.n), dim3(256), 0, st, h->s, a0, a1, adt, mask, obs,
-                           rew, done, slo, shi, sidx, stamp, 1);
-    else
-        hipLaunchKernelGGL((k_env<OP, RANDOM, false>), env_grid(h->s.n), dim3(256), 0, st, h->s, a0, a1, adt, mask, obs,
-                           rew, done, slo, shi, sidx, stamp, 1);
+    if (a1 == nullptr) a1 = a0;   // scripted target: the value is overridden in the kernel
+#define T2D_LAUNCH(NAVF, ADTV)                                                                                          \
+    hipLaunchKernelGGL((k_env<OP, RANDOM, NAVF, false, ADTV>), env_grid(h->s.n), dim3(256), 0, st, h->s, a0, a1, adt,   \
+                       mask, obs, rew, done, slo, shi, sidx, stamp, 1)
+    if (OP != OP_STEP || RANDOM || adt == T2D_ACT_I64) {
+        if (h->has_nav) T2D_LAUNCH(true, T2D_ACT_I64); else T2D_LAUNCH(false, T2D_ACT_I64);
+    } else if (adt == T2D_ACT_I32) {
+        if (h->has_nav) T2D_LAUNCH(true, T2D_ACT_I32); else T2D_LAUNCH(false, T2D_ACT_I32);
+    } else {
+        if (h->has_nav) T2D_LAUNCH(true, T2D_ACT_U8); else T2D_LAUNCH(false, T2D_ACT_U8);
+    }
+#undef T2D_LAUNCH
 }
 
 // Regenerate every consumed next-episode slot, in order on `st`, and restart the stamps.

@@ -17,10 +17,11 @@ for n in 4096 262144; do
   python $R/tools/summarize_prof.py pmc /tmp/p_write_$n > $O/env_only_pmc_write_$n.txt
 done
 for n in 4096 65536 262144 1048576; do python $R/tools/env_only_bench.py --n $n --steps 500 --warmup 50; done > $O/env_only_sweep.txt 2>&1
+for n in 4096 65536; do python $R/tools/env_only_bench.py --n $n --steps 1000 --warmup 100 --fused; done > $O/env_only_fused.txt 2>&1
 for e in Track2D-BlockPartialRam-v0 Track2D-MazePartialNav-v0 Track2D-BlockPartialAdv-v0; do python $R/tools/env_only_bench.py --n 8192 --env $e --steps 300 --warmup 30; done > $O/env_only_other_configs.txt 2>&1
 python $R/tools/stem_bench.py > $O/stem_bench.txt 2>&1
 python $R/tools/learning_check.py --iters 1000 > $O/learning_check_ram_tracker.txt 2>&1
 python $R/tools/learning_check.py --iters 600 --env Track2D-BlockPartialPZR-v0 --network tat-maze-lstm --train-mode -1 > $O/learning_check_pzr_dueling.txt 2>&1
 ls -la $O
 cat $O/bench.json | cut -c1-2500
-cat $O/env_only_pmc_*.txt $O/env_only_sweep.txt $O/env_only_other_configs.txt
+cat $O/env_only_pmc_*.txt $O/env_only_sweep.txt $O/env_only_fused.txt $O/env_only_other_configs.txt
