@@ -19,7 +19,7 @@ constexpr int kWavesPerBlock = 4; // 256-thread workgroups: 4 envs per block
 constexpr int kObsPerEnv = 338;   // 2 agents x 13 x 13
 
 enum : int { MAP_BLOCK = 0, MAP_MAZE = 1, MAP_EMPTY = 2 };
-enum : int { TGT_ADV = 0, TGT_PZR = 1, TGT_FAR = 2, TGT_NAV = 3, TGT_RAM = 4 };
+enum : int { TGT_ADV = 0, TGT_PZR = 1, TGT_FAR = 2, TGT_NAV = 3, TGT_RAM = 4, TGT_RPF = 5 };
 enum : uint32_t { STREAM_MAP = 0, STREAM_SPAWN = 1, STREAM_TARGET = 2, STREAM_ACTION = 7 };
 
 // ---- wave-level helpers -----------------------------------------------------------------------------
@@ -426,7 +426,19 @@ __device__ __forceinline__ uint32_t rowbits_get(const RowBits &a, const RowBits 
     return (word >> (c & 31)) & 1u;
 }
 
-__device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, int lane, int gr, int gc, NavField &f)
+// The four patrol cells of the 'RPF' ids (MazeGenerator.static_goals, generators.py:12-19): (S/6, S/6), (5S/6, S/6),
+// (5S/6, 5S/6), (S/6, 5S/6) as r | c << 8.
+__device__ __forceinline__ uint32_t rpf_cell(int side, int i)
+{
+    const uint32_t lo = (uint32_t)(side / 6), hi = (uint32_t)(side * 5 / 6);
+    const uint32_t r = (i == 1 || i == 2) ? hi : lo, c = (i >= 2) ? hi : lo;
+    return r | (c << 8);
+}
+
+// clear_rpf: plan on the GENERATOR's map of an RPF env, i.e. the env's tile with the four patrol cells free
+// (track_1v1.py:233-236). (qr, qc) / dist: optional BFS distance of one query cell (-1 if unreachable).
+__device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, int lane, int gr, int gc, NavField &f,
+                                              bool clear_rpf = false, int qr = -1, int qc = -1, int *dist = nullptr)
 {
     RowBits freeA, freeB, frA, frB;
     const uint32_t m2 = valid_mask_w2(side);
@@ -438,6 +450,19 @@ __device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, in
         frA.w[j] = 0u; frB.w[j] = 0u;
         f.d0A.w[j] = f.d0B.w[j] = f.d1A.w[j] = f.d1B.w[j] = 0u;
     }
+    if (clear_rpf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t cell = rpf_cell(side, i);
+            const int r = (int)(cell & 0xffu), c = (int)(cell >> 8);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (j == (c >> 5) && r < 64 && lane == r) freeA.w[j] |= 1u << (c & 31);
+                if (j == (c >> 5) && r >= 64 && lane == r - 64) freeB.w[j] |= 1u << (c & 31);
+            }
+        }
+    }
+    int level = 0, found = (qr == gr && qc == gc) ? 0 : -1;
     {   // seed the frontier with the goal cell
         const uint32_t bit = 1u << (gc & 31);
         const int j = gc >> 5;
@@ -485,8 +510,19 @@ __device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, in
                 f.visB.w[j] |= nw; frB.w[j] = nw; any |= nw;
             }
         }
+        level++;
+        if (dist != nullptr && found < 0) {   // did this level reach the query cell?
+            uint32_t hit = 0u;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (j == (qc >> 5) && qr < 64 && lane == qr) hit = frA.w[j] & (1u << (qc & 31));
+                if (j == (qc >> 5) && qr >= 64 && lane == qr - 64) hit = frB.w[j] & (1u << (qc & 31));
+            }
+            if (__ballot(hit != 0u) != 0ull) found = level;
+        }
         if (__ballot(any != 0u) == 0ull) break;
     }
+    if (dist != nullptr) *dist = found;
 }
 
 // direction-plane tile in HBM: plane 0 = words 0..245, plane 1 = words 256..501 (same row layout as the map)

@@ -33,10 +33,11 @@ struct DevState {
     uint32_t *plan;     // [N] scripted-target plan word
     uint32_t *tctr;     // [N] TARGET stream word counter
     uint32_t *navgoal;  // [N] r | c<<8
+    uint32_t *nav2;     // [N] RPF patrol: virtual position r | c<<8 | remaining plan steps<<16 (14 bits) | vector<<30
     uint32_t *d2;       // [N] last squared distance
     uint32_t *dirf;     // [N][512] Nav direction planes (only if some env has a Nav target)
     // ---- next episode, generated ahead of time by k_gen (episode[e] + 1) ----
-    uint32_t *n_maps, *n_pos, *n_goals, *n_plan, *n_tctr, *n_navgoal, *n_d2, *n_dirf;
+    uint32_t *n_maps, *n_pos, *n_goals, *n_plan, *n_tctr, *n_navgoal, *n_nav2, *n_d2, *n_dirf;
     uint32_t *gen_req;  // [N] 0 = next slot valid; s > 0 = consumed at step stamp s, to be regenerated
     uint32_t *faults;   // [1]
     const float2 *rew_lut;    // [3][kLutN] (r_track, r_target) as float32(float64 formula), by w_p class and d^2
@@ -69,21 +70,30 @@ __device__ __forceinline__ int check_action(long long v, uint32_t *faults)
 
 // Navigator.reset / the re-plan branch of Navigator.step (navigator.py:43-63, :15-38): plan from (fr, fc) to navgoal;
 // unreachable or empty plan -> resample the goal, the 6th failure -> plan B (10 random actions).
+// RPF (nav2 != nullptr): goals cycle the four patrol cells without random draws (generators.py:48-50), the plan is made
+// on the generator's map (patrol cells free) and *nav2 receives the open-loop plan: virtual position = (fr, fc),
+// remaining = BFS distance, vector.
 template <class S>
 __device__ __forceinline__ void nav_plan(const uint32_t *tile, int side, int lane, int fr, int fc, const FreeIndex &fi,
-                                         uint32_t &navgoal, S &ts, uint32_t &plan, NavField &f)
+                                         uint32_t &navgoal, S &ts, uint32_t &plan, NavField &f, uint32_t *nav2 = nullptr)
 {
     int count_res = 0;
     bool planb = false;
+    const bool rpf = nav2 != nullptr;
+    uint32_t vector = rpf ? (*nav2 >> 30) : 0u;
+    int dist = -1;
     for (;;) {
         const int gr = (int)(navgoal & 0xffu), gc = (int)(navgoal >> 8);
-        bfs_dir_field(tile, side, lane, gr, gc, f);
+        bfs_dir_field(tile, side, lane, gr, gc, f, rpf, fr, fc, rpf ? &dist : nullptr);
         const bool ok = rowbits_get(f.visA, f.visB, fr, fc) != 0u && !(fr == gr && fc == gc);
         if (ok) break;
         if (++count_res > 5) { planb = true; break; }
-        navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+        if (rpf) { vector = (vector + 1u) & 3u; navgoal = rpf_cell(side, (int)vector); }
+        else navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
     }
     plan = planb ? (plan_random(ts, 10u) | (1u << 28)) : 0u;
+    if (rpf)
+        *nav2 = (uint32_t)fr | ((uint32_t)fc << 8) | ((planb ? 0u : ((uint32_t)dist & 0x3fffu)) << 16) | (vector << 30);
 }
 __device__ __forceinline__ uint32_t nav_dir_from_regs(const NavField &f, int r, int c)
 {
@@ -97,8 +107,10 @@ __device__ __forceinline__ int side_of_cfg(uint32_t cfg) { return (cfg & 3u) == 
 template <bool NAV>
 __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint32_t *tile, int lane, uint32_t cfg,
                                                  uint32_t episode, uint32_t *gdir, uint32_t &pos, uint32_t &goals,
-                                                 uint32_t &plan, uint32_t &tctr, uint32_t &navgoal, uint32_t &d2)
+                                                 uint32_t &plan, uint32_t &tctr, uint32_t &navgoal, uint32_t &d2,
+                                                 uint32_t &nav2)
 {
+    nav2 = 0u;
     const int map_type = cfg & 3, mode = (cfg >> 2) & 7, level = (cfg >> 5) & 15;
     const uint32_t genv = s.env_base + (uint32_t)e;
     VStream ms;
@@ -125,23 +137,28 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
         g0 = select_free(tile, side, fi, i0, lane);
         g1 = select_free(tile, side, fi, i1, lane);
     };
-    sample_goal2();
+    // RPF (static goals): both goals = patrol cell 1, tracker spawn = patrol cell 0, no draws for either; the spawn
+    // window is searched on the generator's map, where the patrol cells are free (generators.py:12-19,48-50,68)
+    const bool rpf = mode == TGT_RPF;
+    if (rpf) g0 = g1 = rpf_cell(side, 1);
+    else sample_goal2();
     // sample_close_states(2, 1), generators.py:53-77 + get_around :82-94 (2x2 block up-left of the tracker)
-    const uint32_t tr = select_free(tile, side, fi, (int)ss.bounded((uint32_t)(n - 1)), lane);
+    const uint32_t tr = rpf ? rpf_cell(side, 0) : select_free(tile, side, fi, (int)ss.bounded((uint32_t)(n - 1)), lane);
     const int r = (int)(tr & 0xffu), c = (int)(tr >> 8);
     const int x0 = max(0, r - 1), x1 = min(side - 1, r + 1), y0 = max(0, c - 1), y1 = min(side - 1, c + 1);
+    auto gen_free = [&](int rr, int cc) { return tile_bit(tile, rr, cc) == 0u || (rpf && rr == r && cc == c); };
     int m = 0;
     for (int rr = x0; rr < x1; rr++)
-        for (int cc = y0; cc < y1; cc++) m += (int)(tile_bit(tile, rr, cc) == 0u);
+        for (int cc = y0; cc < y1; cc++) m += (int)gen_free(rr, cc);
     int j = (int)ss.bounded((uint32_t)(m - 1));
     uint32_t tg = tr;
     for (int rr = x0; rr < x1; rr++)
         for (int cc = y0; cc < y1; cc++)
-            if (tile_bit(tile, rr, cc) == 0u) {
+            if (gen_free(rr, cc)) {
                 if (j == 0) tg = (uint32_t)rr | ((uint32_t)cc << 8);
                 j--;
             }
-    while (tr == g0 || tr == g1) sample_goal2(); // goal_test loop, track_1v1.py:239-240
+    while (!rpf && (tr == g0 || tr == g1)) sample_goal2(); // goal_test loop, track_1v1.py:239-240
     pos = tr | (tg << 16);
     goals = g0 | (g1 << 16);
     VStream ts;
@@ -149,9 +166,11 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
     plan = 0;
     navgoal = g1;
     if (mode == TGT_RAM) plan = ram_reset(ts);
-    if (NAV && mode == TGT_NAV) { // Navigator.reset (navigator.py:43-63): plan from the target spawn to goal_states[1]
+    if (NAV && (mode == TGT_NAV || rpf)) { // Navigator.reset (navigator.py:43-63): plan from the target spawn to goal_states[1]
         NavField nf;
-        nav_plan(tile, side, lane, (int)(tg & 0xffu), (int)(tg >> 8), fi, navgoal, ts, plan, nf);
+        nav2 = 1u << 30;                   // RPF: sample_goal(2) at reset advanced the patrol vector to 1
+        nav_plan(tile, side, lane, (int)(tg & 0xffu), (int)(tg >> 8), fi, navgoal, ts, plan, nf, rpf ? &nav2 : nullptr);
+        if (!rpf) nav2 = 0u;
         if (((plan >> 28) & 1u) == 0u) store_dir_field(gdir, nf, side, lane);
     }
     tctr = ts.ctr;
@@ -175,14 +194,15 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t upto, int forc
     if (!force && (req == 0u || req > upto)) return;
     uint32_t *tile = tiles[wave];
     const uint32_t cfg = s.cfg[e];
-    uint32_t pos, goals, plan, tctr, navgoal, d2;
+    uint32_t pos, goals, plan, tctr, navgoal, d2, nav2;
     uint32_t *gdir = NAV ? s.n_dirf + (size_t)e * kDirWords : nullptr;
-    generate_episode<NAV>(s, e, tile, lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2);
+    generate_episode<NAV>(s, e, tile, lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2, nav2);
     wave_lds_sync();
     reinterpret_cast<uint4 *>(s.n_maps + (size_t)e * kTileWords)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
     if (lane == 0) {
         s.n_pos[e] = pos; s.n_goals[e] = goals; s.n_plan[e] = plan; s.n_tctr[e] = tctr;
         s.n_navgoal[e] = navgoal; s.n_d2[e] = d2; s.gen_req[e] = 0u;
+        if (NAV) s.n_nav2[e] = nav2;
     }
 }
 
@@ -314,26 +334,40 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         }
         int r0 = (int)(pos & 0xffu), c0 = (int)((pos >> 8) & 0xffu);
         int r1 = (int)((pos >> 16) & 0xffu), c1 = (int)(pos >> 24);
-        if (NAV && mode == TGT_NAV) { // track_1v1.py:83-84 -> Navigator.step(old_state[1], ...) (navigator.py:11-41)
+        if (NAV && (mode == TGT_NAV || mode == TGT_RPF)) { // track_1v1.py:83-84 -> Navigator.step(old_state[1], ...) (navigator.py:11-41)
             plan = s.plan[e]; tctr = s.tctr[e]; navgoal = s.navgoal[e];
+            const bool rpf = mode == TGT_RPF;
+            uint32_t nav2 = rpf ? s.nav2[e] : 0u;
             uint32_t *gdir = s.dirf + (size_t)e * kDirWords;
             Stream ts;
             ts.init(s.k0, s.k1, s.episode[e], genv, STREAM_TARGET, tctr);
             bool planb = ((plan >> 28) & 1u) != 0u;
+            // RPF: the plan is an open-loop action list made on the generator's map (the env may hold walls on the
+            // patrol cells): follow the field from a virtual position for exactly the planned number of steps
             const bool exhausted = planb ? (plan_cur(plan) >= plan_len(plan))
+                                   : rpf ? (((nav2 >> 16) & 0x3fffu) == 0u)
                                          : (r1 == (int)(navgoal & 0xffu) && c1 == (int)(navgoal >> 8));
+            int qr = rpf ? (int)(nav2 & 0xffu) : r1, qc = rpf ? (int)((nav2 >> 8) & 0xffu) : c1;
             uint32_t dir = 0;
             if (exhausted) {
                 const FreeIndex fi = build_free_index(tile, side, lane);
-                navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+                if (rpf) { nav2 = (nav2 & 0x3fffffffu) | ((((nav2 >> 30) + 1u) & 3u) << 30); navgoal = rpf_cell(side, (int)(nav2 >> 30)); }
+                else navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
                 NavField nf;
-                nav_plan(tile, side, lane, r1, c1, fi, navgoal, ts, plan, nf);
+                nav_plan(tile, side, lane, r1, c1, fi, navgoal, ts, plan, nf, rpf ? &nav2 : nullptr);
                 planb = ((plan >> 28) & 1u) != 0u;
-                if (!planb) { store_dir_field(gdir, nf, side, lane); dir = nav_dir_from_regs(nf, r1, c1); }
+                qr = r1; qc = c1;
+                if (!planb) { store_dir_field(gdir, nf, side, lane); dir = nav_dir_from_regs(nf, qr, qc); }
                 navgoal_dirty = true;
             } else if (!planb) {
-                dir = load_dir(gdir, r1, c1);
+                dir = load_dir(gdir, qr, qc);
             }
+            if (rpf && !planb) {   // advance the virtual position along the field, one planned step consumed
+                qr += dir == 0u ? -1 : (dir == 1u ? 1 : 0); qc += dir == 2u ? -1 : (dir == 3u ? 1 : 0);
+                const uint32_t rem = ((nav2 >> 16) & 0x3fffu) - 1u;
+                nav2 = (uint32_t)qr | ((uint32_t)qc << 8) | ((rem & 0x3fffu) << 16) | (nav2 & 0xc0000000u);
+            }
+            if (rpf && lane == 0) s.nav2[e] = nav2;
             if (planb) {
                 const uint32_t cur = plan_cur(plan);
                 a_tg = (int)plan_act(plan, cur);
@@ -373,12 +407,13 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         const uint4 nt = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)e * kTileWords)[lane];
         reinterpret_cast<uint4 *>(tile)[lane] = nt;
         reinterpret_cast<uint4 *>(gtile)[lane] = nt;
-        if (NAV && mode == TGT_NAV) {
+        if (NAV && (mode == TGT_NAV || mode == TGT_RPF)) {
             const uint4 *src = reinterpret_cast<const uint4 *>(s.n_dirf + (size_t)e * kDirWords);
             uint4 *dst = reinterpret_cast<uint4 *>(s.dirf + (size_t)e * kDirWords);
             dst[lane] = src[lane]; dst[lane + 64] = src[lane + 64];
         }
         pos = s.n_pos[e]; plan = s.n_plan[e]; tctr = s.n_tctr[e]; navgoal = s.n_navgoal[e]; d2 = s.n_d2[e];
+        if (NAV && lane == 0) s.nav2[e] = s.n_nav2[e];
         cnt = (uint32_t)side_of_cfg(cfg) << 24;
         if (!MULTI) episode = s.episode[e];
         episode += 1u;
@@ -434,6 +469,7 @@ struct t2d_handle {
     bool reset_done;   // every env has a current episode
     bool primed;       // every env has a valid next slot
     bool has_nav;
+    bool has_rpf;      // some env has the RPF patrol target (an agent may then stand on a wall of the env's own map)
     uint32_t random_step;
     uint32_t gen_every; // generator launch period in steps (see step_impl)
     uint32_t phase;     // steps since the last generator launch = stamp of the last step launch
@@ -489,7 +525,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         return fail(T2D_ERR_INVALID, "t2d_create: device %d out of range (%d visible)", cfg->device, ndev);
     const int n = cfg->num_envs;
     std::vector<uint32_t> hcfg((size_t)n);
-    bool has_nav = false;
+    bool has_nav = false, has_rpf = false;
     int n_maze = 0;
     if (cfg->obs_type > T2D_OBS_FULL) return fail(T2D_ERR_INVALID, "t2d_create: obs_type %u", cfg->obs_type);
     for (int i = 0; i < n; i++) {
@@ -497,8 +533,9 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         uint32_t tm = cfg->target_mode_per_env ? cfg->target_mode_per_env[i] : cfg->target_mode;
         uint32_t lv = cfg->level_per_env ? cfg->level_per_env[i] : cfg->level;
         if (mt > T2D_MAP_EMPTY) return fail(T2D_ERR_INVALID, "t2d_create: map_type %u (env %d)", mt, i);
-        if (tm > T2D_TGT_RAM) return fail(T2D_ERR_INVALID, "t2d_create: target_mode %u (env %d)", tm, i);
-        has_nav = has_nav || tm == T2D_TGT_NAV;
+        if (tm > T2D_TGT_RPF) return fail(T2D_ERR_INVALID, "t2d_create: target_mode %u (env %d)", tm, i);
+        has_nav = has_nav || tm == T2D_TGT_NAV || tm == T2D_TGT_RPF;
+        has_rpf = has_rpf || tm == T2D_TGT_RPF;
         n_maze += mt == T2D_MAP_MAZE;
         if (lv > 15) return fail(T2D_ERR_INVALID, "t2d_create: level %u (env %d)", lv, i);
         hcfg[(size_t)i] = mt | (tm << 2) | (lv << 5);
@@ -510,7 +547,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     if (!h) return fail(T2D_ERR_INVALID, "t2d_create: out of host memory");
     std::memset(&h->s, 0, sizeof(h->s));
     h->device = cfg->device;
-    h->reset_done = false; h->primed = false; h->has_nav = has_nav;
+    h->reset_done = false; h->primed = false; h->has_nav = has_nav; h->has_rpf = has_rpf;
     h->random_step = 0; h->phase = 0;
     // A slot consumed at step q cannot be needed again before step q + min(11, max_episode_steps): done needs 11
     // consecutive far steps (track_1v1.py:106-111) or the TimeLimit. Launching the generator every G <= that many
@@ -532,7 +569,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     };
     alloc(&s.maps, tb); alloc(&s.n_maps, tb);
     uint32_t **arrs[] = {&s.pos, &s.goals, &s.cnt, &s.cfg, &s.episode, &s.plan, &s.tctr, &s.navgoal, &s.d2,
-                         &s.n_pos, &s.n_goals, &s.n_plan, &s.n_tctr, &s.n_navgoal, &s.n_d2, &s.gen_req};
+                         &s.n_pos, &s.n_goals, &s.n_plan, &s.n_tctr, &s.n_navgoal, &s.n_d2, &s.gen_req, &s.nav2, &s.n_nav2};
     for (auto a : arrs) alloc(a, nb);
     if (has_nav) { alloc(&s.dirf, db); alloc(&s.n_dirf, db); }
     alloc(&s.faults, sizeof(uint32_t));
@@ -560,7 +597,7 @@ extern "C" int t2d_destroy(t2d_handle *h)
     DevState &s = h->s;
     void *ptrs[] = {s.maps, s.n_maps, s.pos, s.goals, s.cnt, s.cfg, s.episode, s.plan, s.tctr, s.navgoal, s.d2,
                     s.n_pos, s.n_goals, s.n_plan, s.n_tctr, s.n_navgoal, s.n_d2, s.gen_req, s.dirf, s.n_dirf, s.faults,
-                    (void *)s.rew_lut};
+                    (void *)s.rew_lut, s.nav2, s.n_nav2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -761,7 +798,8 @@ extern "C" int t2d_inject(t2d_handle *h, int first, int count, int side, const u
         const int32_t *p = pos_host + (size_t)i * 4;
         for (int k = 0; k < 4; k++)
             if (p[k] < 0 || p[k] >= side) return fail(T2D_ERR_INVALID, "t2d_inject: position outside the map (env %d)", first + i);
-        if (m[p[0] * side + p[1]] || m[p[2] * side + p[3]])
+        // RPF: the fixed tracker spawn may be a wall in the env's own map (track_1v1.py:233-236), so this is legal there
+        if (!h->has_rpf && (m[p[0] * side + p[1]] || m[p[2] * side + p[3]]))
             return fail(T2D_ERR_INVALID, "t2d_inject: agent placed on a wall (env %d)", first + i);
         pos[(size_t)i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
         if (goals_host) {
@@ -783,6 +821,7 @@ extern "C" int t2d_inject(t2d_handle *h, int first, int count, int side, const u
     HIP_TRY(hipMemcpyAsync(s.d2 + first, d2.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s.navgoal + first, navgoal.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s.plan + first, zero.data(), nb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s.nav2 + first, zero.data(), nb, hipMemcpyHostToDevice, st));   // RPF: re-plan to patrol cell 1
     HIP_TRY(hipStreamSynchronize(st));
     if (first == 0 && count == s.n) h->reset_done = true;
     return T2D_OK;

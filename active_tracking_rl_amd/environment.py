@@ -48,13 +48,17 @@ class VecEnv(object):
     step([a_tracker [N], a_target [N]]) -> (obs, rewards [N, A] f32, done [N] uint8, info)."""
 
     def __init__(self, env_id, num_envs, device="cuda:0", seed=1, stack_frames=1, env_id_base=0, auto_reset=True,
-                 **overrides):
+                 rescale=False, **overrides):
         self.env_id = env_id
         self.num_envs = num_envs
         self.stack_frames = int(stack_frames)
+        self.rescale = bool(rescale)    # environment.Rescale (environment.py:35-79) without --inv: [0,255] -> [-1,1]
         self.core = VecTrack2D(env_id, num_envs=num_envs, device=device, seed=seed, env_id_base=env_id_base,
                                auto_reset=auto_reset, **overrides)
         self.observation_space, self.action_space = _spaces(self.core.obs_hw)
+        if self.rescale:
+            for box in self.observation_space:
+                box.low, box.high = -1.0, 1.0
         self.device = self.core.device
         self._frames = None
         self._seed = seed
@@ -66,6 +70,8 @@ class VecEnv(object):
 
     def _stack(self, obs, done=None, fill=False):
         # obs [N, A, 13, 13] -> [N, A, stack, 1, 13, 13]
+        if self.rescale:   # Rescale.rescale, same float32 operation order: ((clip(x) - 0) * 2) / 255 + (-1)
+            obs = obs.clamp(0.0, 255.0).mul(2.0).div(255.0).add(-1.0)
         cur = obs.unsqueeze(2).unsqueeze(3)
         if self.stack_frames == 1:
             return cur
@@ -94,7 +100,7 @@ class VecEnv(object):
         """Storage for one rollout the step kernel writes in place — obs [T+1,N,A,h,w] (slot 0 = the state the
         rollout starts from), rewards [T,N,A], done [T,N] — so the learner reads the rollout without a stacking
         copy (110 MB per 20-step, 4096-env rollout). None when frames are stacked host-side."""
-        if self.stack_frames != 1:
+        if self.stack_frames != 1 or self.rescale:
             return None
         h, w = self.core.obs_hw
         dev = self.device
@@ -119,8 +125,9 @@ class VecEnv(object):
 class Track2DEnv(object):
     """One env behind the reference's exact gym protocol (TimeLimit + frame_stack included)."""
 
-    def __init__(self, env_id, device="cuda:0", seed=1, stack_frames=1):
-        self.vec = VecEnv(env_id, 1, device=device, seed=seed, stack_frames=stack_frames, auto_reset=False)
+    def __init__(self, env_id, device="cuda:0", seed=1, stack_frames=1, rescale=False):
+        self.vec = VecEnv(env_id, 1, device=device, seed=seed, stack_frames=stack_frames, auto_reset=False,
+                          rescale=rescale)
         self.observation_space, self.action_space = self.vec.observation_space, self.vec.action_space
 
     def seed(self, seed=None):
@@ -154,8 +161,11 @@ def create_env(env_id, args, num_envs=None, device=None, env_id_base=0):
     if '2D' not in env_id:
         raise NotImplementedError("only the Track2D-* ids are in scope (Unreal envs need UE4 binaries)")
     registry.spec(env_id)
-    if getattr(args, "single", False) or getattr(args, "rescale", False):
-        raise NotImplementedError("--single / --rescale wrappers belong to the image envs")
+    if getattr(args, "single", False):
+        raise NotImplementedError("--single (listspace) wraps single-agent image envs; Track2D envs have two agents")
+    rescale = bool(getattr(args, "rescale", False))
+    if rescale and getattr(args, "inv", False):
+        raise NotImplementedError("--inv (random image inversion, environment.py:62-76) is an image-env augmentation")
     n = num_envs if num_envs is not None else getattr(args, "num_envs", 1)
     if device is None:
         gpu_ids = getattr(args, "gpu_ids", [0])
@@ -164,5 +174,5 @@ def create_env(env_id, args, num_envs=None, device=None, env_id_base=0):
     stack = getattr(args, "stack_frames", 1)
     seed = getattr(args, "seed", 1)
     if n > 1:
-        return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base)
-    return Track2DEnv(env_id, device=device, seed=seed, stack_frames=stack)
+        return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base, rescale=rescale)
+    return Track2DEnv(env_id, device=device, seed=seed, stack_frames=stack, rescale=rescale)

@@ -1,7 +1,7 @@
 """Env-id table: restates the registry loop of the reference (envs/gym-track2d/gym_track2d/__init__.py:3-18):
 72 ids `Track2D-{Maze,Block,Empty}{Full,Partial}{Adv,PZR,Far,Nav,Ram,RPF}-v{0,1}`, each with
-max_episode_steps=500. The `RPF` target is registered by the reference but not built here
-— spec() raises for it instead of silently doing something else."""
+max_episode_steps=500. All 72 are built (`RPF` = the Navigator patrolling the four static goal cells,
+generators.py:12-19)."""
 
 MAP_TYPES = ("Maze", "Block", "Empty")
 OBS_TYPES = ("Full", "Partial")
@@ -9,7 +9,7 @@ TARGET_MODES = ("Adv", "PZR", "Far", "Nav", "Ram", "RPF")
 MAX_EPISODE_STEPS = 500
 
 MAP_CODE = {"Block": 0, "Maze": 1, "Empty": 2}
-TARGET_CODE = {"Adv": 0, "PZR": 1, "Far": 2, "Nav": 3, "Ram": 4}
+TARGET_CODE = {"Adv": 0, "PZR": 1, "Far": 2, "Nav": 3, "Ram": 4, "RPF": 5}
 
 REGISTRY = {}
 for _m in MAP_TYPES:
@@ -23,7 +23,4 @@ for _m in MAP_TYPES:
 def spec(env_id):
     if env_id not in REGISTRY:
         raise KeyError("unknown env id %r (72 Track2D ids are registered)" % (env_id,))
-    s = dict(REGISTRY[env_id])
-    if s["target_mode"] == "RPF":
-        raise NotImplementedError("%s: the RPF target is not built yet" % env_id)
-    return s
+    return dict(REGISTRY[env_id])

@@ -159,7 +159,7 @@ class VecTrack2D(object):
                 assert a.shape == (self.num_envs,)
                 self._keep.append(a)
                 setattr(cfg, name, a.ctypes.data)
-        self.scripted_target = target_mode in ("Ram", "Nav") and target_mode_per_env is None
+        self.scripted_target = target_mode in ("Ram", "Nav", "RPF") and target_mode_per_env is None
         h = C.c_void_p()
         _check(self.L.t2d_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -209,7 +209,7 @@ class VecTrack2D(object):
             assert a1.is_cuda and a1.is_contiguous() and a1.numel() == self.num_envs and a1.dtype == a0.dtype
             a1p = C.c_void_p(a1.data_ptr())
         elif not self.scripted_target:
-            raise T2DError("act_target is required unless every env has a scripted (Ram/Nav) target")
+            raise T2DError("act_target is required unless every env has a scripted (Ram/Nav/RPF) target")
         _check(self.L.t2d_step(self.h, C.c_void_p(a0.data_ptr()), a1p, _ACT_DTYPE[a0.dtype],
                                C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()),
                                C.c_void_p(done.data_ptr()), self._stream()))

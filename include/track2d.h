@@ -37,7 +37,7 @@ typedef enum {
 
 /* map_type / target_mode values: the kwargs of the registry, G/__init__.py:3-18 */
 enum { T2D_MAP_BLOCK = 0, T2D_MAP_MAZE = 1, T2D_MAP_EMPTY = 2 };
-enum { T2D_TGT_ADV = 0, T2D_TGT_PZR = 1, T2D_TGT_FAR = 2, T2D_TGT_NAV = 3, T2D_TGT_RAM = 4 };
+enum { T2D_TGT_ADV = 0, T2D_TGT_PZR = 1, T2D_TGT_FAR = 2, T2D_TGT_NAV = 3, T2D_TGT_RAM = 4, T2D_TGT_RPF = 5 };
 /* dtype codes for action arrays */
 enum { T2D_ACT_U8 = 0, T2D_ACT_I32 = 1, T2D_ACT_I64 = 2 };
 /* obs_type of the registry kwargs (G/__init__.py:11), define_observation at G/envs/track_1v1.py:251-262 */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libtrack2d_oracle.so")
 
 MAP = {"Block": 0, "Maze": 1, "Empty": 2}
-TGT = {"Adv": 0, "PZR": 1, "Far": 2, "Nav": 3, "Ram": 4}
+TGT = {"Adv": 0, "PZR": 1, "Far": 2, "Nav": 3, "Ram": 4, "RPF": 5}
 RNG_NP, RNG_PHILOX = 0, 1
 
 

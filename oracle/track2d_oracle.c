@@ -138,6 +138,11 @@ struct orc_env {
     int plan_len, plan_cur;
     uint8_t dir[ORC_MAX_SIDE * ORC_MAX_SIDE]; /* philox-mode Nav direction field */
     int nav_planb;                            /* philox-mode Nav: following the 10 random actions */
+    /* RPF (static goals, generators.py:12-19): the generator's maze has the four patrol cells cleared AFTER the env
+     * copied it (track_1v1.py:233-236), so spawning/planning use gmaze while moves and observations use maze. */
+    uint8_t gmaze[ORC_MAX_SIDE * ORC_MAX_SIDE];
+    int cand[4][2], vector;
+    int vpos[2], remaining;                   /* philox-mode RPF: open-loop plan = field descent of a virtual position */
     int obs_full;                             /* obs_type: 0 'Partial' (13x13 crops), 1 'Full' (whole map) */
 };
 
@@ -206,17 +211,21 @@ static void np_choice_norep(orc_env *e, int n, int k, int32_t *out, int32_t *scr
 }
 
 /* ---- free-cell helpers: np.where(maze == 0) row-major order (generators.py:42-43) ---- */
+/* the generator's maze: identical to the env's except in RPF mode */
+static const uint8_t *gen_maze_of(const orc_env *e) { return e->target_mode == ORC_TGT_RPF ? e->gmaze : e->maze; }
 static int count_free(const orc_env *e)
 {
     int n = 0, S = e->side;
-    for (int i = 0; i < S * S; i++) n += (e->maze[i] == 0);
+    const uint8_t *m = gen_maze_of(e);
+    for (int i = 0; i < S * S; i++) n += (m[i] == 0);
     return n;
 }
 static void select_free(const orc_env *e, int k, int *rc)
 {
     int S = e->side;
+    const uint8_t *m = gen_maze_of(e);
     for (int i = 0; i < S * S; i++)
-        if (e->maze[i] == 0 && k-- == 0) { rc[0] = i / S; rc[1] = i % S; return; }
+        if (m[i] == 0 && k-- == 0) { rc[0] = i / S; rc[1] = i % S; return; }
     rc[0] = rc[1] = -1;
 }
 
@@ -245,9 +254,10 @@ static void get_around(orc_env *e, const int *st, int *out, int32_t *scratch)
     int x0 = st[0] - 1 < 0 ? 0 : st[0] - 1, x1 = st[0] + 1 > S - 1 ? S - 1 : st[0] + 1;
     int y0 = st[1] - 1 < 0 ? 0 : st[1] - 1, y1 = st[1] + 1 > S - 1 ? S - 1 : st[1] + 1;
     int cand[4][2], m = 0;
+    const uint8_t *gm = gen_maze_of(e);
     for (int r = x0; r < x1; r++)
         for (int c = y0; c < y1; c++)
-            if (e->maze[r * S + c] == 0) { cand[m][0] = r; cand[m][1] = c; m++; }
+            if (gm[r * S + c] == 0) { cand[m][0] = r; cand[m][1] = c; m++; }
     int j;
     if (e->rng_mode == ORC_RNG_NP) {
         int32_t idx[1];
@@ -266,12 +276,14 @@ static void sample_close_states(orc_env *e, int32_t *scratch)
     int n = count_free(e);
     if (e->rng_mode == ORC_RNG_NP) {
         int32_t idx[2];
-        np_choice_norep(e, n, 2, idx, scratch);
-        select_free(e, idx[0], e->pos[0]);
+        np_choice_norep(e, n, 2, idx, scratch);   /* drawn even when static (:61) */
+        if (e->target_mode == ORC_TGT_RPF) { e->pos[0][0] = e->cand[0][0]; e->pos[0][1] = e->cand[0][1]; } /* :68 */
+        else select_free(e, idx[0], e->pos[0]);
         get_around(e, e->pos[0], e->pos[1], scratch);
         np_choice_norep(e, n, 0, idx, scratch); /* sample_state(num-2 = 0): choice(n, 0) */
     } else {
-        select_free(e, (int)bounded(e, STREAM_SPAWN, (uint32_t)(n - 1)), e->pos[0]);
+        if (e->target_mode == ORC_TGT_RPF) { e->pos[0][0] = e->cand[0][0]; e->pos[0][1] = e->cand[0][1]; }
+        else select_free(e, (int)bounded(e, STREAM_SPAWN, (uint32_t)(n - 1)), e->pos[0]);
         get_around(e, e->pos[0], e->pos[1], scratch);
     }
 }
@@ -507,6 +519,11 @@ static int ram_step(orc_env *e)
 /* sample_goal(1)[0] as used by the Navigator (navigator.py:17,28,56). */
 static void nav_sample_goal(orc_env *e, int *g, int32_t *scratch)
 {
+    if (e->target_mode == ORC_TGT_RPF) { /* static: next patrol cell, no random draw (generators.py:48-50) */
+        e->vector = (e->vector + 1) % 4;
+        g[0] = e->cand[e->vector][0]; g[1] = e->cand[e->vector][1];
+        return;
+    }
     int n = count_free(e);
     int idx;
     if (e->rng_mode == ORC_RNG_NP) {
@@ -527,13 +544,16 @@ static void nav_plan(orc_env *e, const int *from, int32_t *scratch)
     for (;;) {
         int ok;
         if (e->rng_mode == ORC_RNG_NP) {
-            int len = orc_astar(e->side, e->maze, from, e->nav_goal, e->plan, PLAN_CAP);
+            int len = orc_astar(e->side, gen_maze_of(e), from, e->nav_goal, e->plan, PLAN_CAP);
             ok = len >= 1;
             if (ok) e->plan_len = len;
         } else {
-            orc_bfs_field(e->side, e->maze, e->nav_goal, e->dir, NULL);
+            int32_t *dist = (int32_t *)malloc(sizeof(int32_t) * ORC_MAX_SIDE * ORC_MAX_SIDE);
+            orc_bfs_field(e->side, gen_maze_of(e), e->nav_goal, e->dir, dist);
             uint8_t d = e->dir[from[0] * e->side + from[1]];
             ok = d < 4; /* reachable and not already at the goal */
+            if (ok) { e->vpos[0] = from[0]; e->vpos[1] = from[1]; e->remaining = dist[from[0] * e->side + from[1]]; }
+            free(dist);
         }
         if (ok) break;
         if (++count_res > 5) { planb = 1; break; }
@@ -560,14 +580,25 @@ static int nav_step(orc_env *e, const int *state, int32_t *scratch)
         return e->plan[e->plan_cur++];
     }
     /* device spec: closed-loop descent of the BFS field; "plan exhausted" == standing on the goal
-     * (or the 10 plan-B actions used up). */
+     * (or the 10 plan-B actions used up). RPF: the plan was made on the generator's map, which differs from the
+     * env's at the patrol cells, so the reference's OPEN-LOOP action list is reproduced by descending the field
+     * from a virtual position that ignores the env's extra walls, for exactly the planned number of steps. */
+    const int rpf = e->target_mode == ORC_TGT_RPF;
     int exhausted = e->nav_planb ? (e->plan_cur >= e->plan_len)
-                                 : (state[0] == e->nav_goal[0] && state[1] == e->nav_goal[1]);
+                    : rpf ? (e->remaining <= 0)
+                          : (state[0] == e->nav_goal[0] && state[1] == e->nav_goal[1]);
     if (exhausted) {
         nav_sample_goal(e, e->nav_goal, scratch);
         nav_plan(e, state, scratch);
     }
     if (e->nav_planb) return e->plan[e->plan_cur++];
+    if (rpf) {
+        static const int DR[4] = {-1, 1, 0, 0}, DC[4] = {0, 0, -1, 1};
+        int a = e->dir[e->vpos[0] * e->side + e->vpos[1]];
+        e->vpos[0] += DR[a]; e->vpos[1] += DC[a];
+        e->remaining--;
+        return a;
+    }
     return e->dir[state[0] * e->side + state[1]];
 }
 
@@ -646,6 +677,17 @@ static void init_maze(orc_env *e, int32_t *scratch)
     } else {
         gen_block(e, 0.0, scratch);
     }
+    if (e->target_mode == ORC_TGT_RPF) { /* static_goals() after the env copied the maze (track_1v1.py:233-236) */
+        int S = e->side;
+        int lo = S / 6, hi = S * 5 / 6;
+        int c4[4][2] = {{lo, lo}, {hi, lo}, {hi, hi}, {lo, hi}};
+        memcpy(e->gmaze, e->maze, (size_t)(S * S));
+        for (int i = 0; i < 4; i++) { e->cand[i][0] = c4[i][0]; e->cand[i][1] = c4[i][1]; e->gmaze[c4[i][0] * S + c4[i][1]] = 0; }
+        e->vector = 1;                    /* sample_goal(2): vector = (0 + 1) % 4, both agents get that cell */
+        for (int i = 0; i < 2; i++) { e->goal[i][0] = e->cand[1][0]; e->goal[i][1] = e->cand[1][1]; }
+        sample_close_states(e, scratch);
+        return;                           /* goal_test(init_states[0]) is false: spawn = cell 0, goal = cell 1 */
+    }
     sample_goal(e, 2, e->goal, scratch);
     sample_close_states(e, scratch);
     while ((e->pos[0][0] == e->goal[0][0] && e->pos[0][1] == e->goal[0][1]) ||
@@ -665,7 +707,7 @@ void orc_reset(orc_env *e, uint8_t *obs)
     e->episode++;
     for (int s = 0; s < NUM_STREAMS; s++) { e->ctr[s] = 0; e->cache_blk[s] = 0xffffffffu; }
     init_maze(e, scratch);
-    if (e->target_mode == ORC_TGT_NAV) {
+    if (e->target_mode == ORC_TGT_NAV || e->target_mode == ORC_TGT_RPF) {
         e->nav_goal[0] = e->goal[1][0]; e->nav_goal[1] = e->goal[1][1];
         nav_plan(e, e->pos[1], scratch);
     }
@@ -692,7 +734,7 @@ int orc_step(orc_env *e, const int *actions, uint8_t *obs, double *rewards, int 
     int act[2] = {actions[0], actions[1]};
     int32_t *scratch = NULL;
     if (e->target_mode == ORC_TGT_RAM) act[1] = ram_step(e);
-    if (e->target_mode == ORC_TGT_NAV) {
+    if (e->target_mode == ORC_TGT_NAV || e->target_mode == ORC_TGT_RPF) {
         scratch = (int32_t *)malloc(sizeof(int32_t) * ORC_MAX_SIDE * ORC_MAX_SIDE);
         act[1] = nav_step(e, e->pos[1], scratch); /* old_state[1] (:84) */
         free(scratch);
@@ -729,6 +771,13 @@ int orc_inject(orc_env *e, int side, const uint8_t *maze, const int *pos, const 
     /* scripted-target plan cleared: a Nav target re-plans at its next step */
     e->plan_len = 0; e->plan_cur = 0; e->nav_planb = 0;
     e->nav_goal[0] = e->pos[1][0]; e->nav_goal[1] = e->pos[1][1];
+    if (e->target_mode == ORC_TGT_RPF) { /* the injected map is the env's; the planning map clears the patrol cells */
+        int lo = side / 6, hi = side * 5 / 6;
+        int c4[4][2] = {{lo, lo}, {hi, lo}, {hi, hi}, {lo, hi}};
+        memcpy(e->gmaze, e->maze, sizeof(e->maze));
+        for (int i = 0; i < 4; i++) { e->cand[i][0] = c4[i][0]; e->cand[i][1] = c4[i][1]; e->gmaze[c4[i][0] * side + c4[i][1]] = 0; }
+        e->vector = 0; e->remaining = 0;
+    }
     int dr = e->pos[1][0] - e->pos[0][0], dc = e->pos[1][1] - e->pos[0][1];
     e->d2 = (int64_t)dr * dr + (int64_t)dc * dc;
     return 0;

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 enum { ORC_MAP_BLOCK = 0, ORC_MAP_MAZE = 1, ORC_MAP_EMPTY = 2 };
-enum { ORC_TGT_ADV = 0, ORC_TGT_PZR = 1, ORC_TGT_FAR = 2, ORC_TGT_NAV = 3, ORC_TGT_RAM = 4 };
+enum { ORC_TGT_ADV = 0, ORC_TGT_PZR = 1, ORC_TGT_FAR = 2, ORC_TGT_NAV = 3, ORC_TGT_RAM = 4, ORC_TGT_RPF = 5 };
 enum { ORC_RNG_NP = 0, ORC_RNG_PHILOX = 1 };
 
 #define ORC_MAX_SIDE 82

@@ -63,7 +63,8 @@ def chase_action(env, rs):
     return int(cands[rs.randint(0, len(cands))])
 
 
-def run_case(map_type, mode, level, seed, n_episodes, max_steps, policy="random", time_limit=500, obs_type="Partial"):
+def run_case(map_type, mode, level, seed, n_episodes, max_steps, policy="random", time_limit=500, obs_type="Partial",
+             stop_on_done=True):
     env = Track1v1Env(map_type=map_type, target_mode=mode, level=level, obs_type=obs_type)
     emitted = []
     if env.Target:
@@ -87,7 +88,7 @@ def run_case(map_type, mode, level, seed, n_episodes, max_steps, policy="random"
                    act_in=[], act_applied=[], obs=[], rew=[], done=[], cfar=[], pos=[])
         if mode == "Ram":
             rec["plan0"] = np.array(env.Target[0].plan_actions, np.int32).copy()
-        if mode == "Nav":
+        if mode in ("Nav", "RPF"):
             rec["plan0"] = np.array(env.Target[0].plan_actions, np.int32).copy()
             rec["navgoal0"] = np.array(env.Target[0].goal_states, np.int32).copy()
         t = 0
@@ -106,7 +107,7 @@ def run_case(map_type, mode, level, seed, n_episodes, max_steps, policy="random"
             rec["cfar"].append(int(env.C_far))
             rec["pos"].append(np.array(env.state, np.int32).copy())
             assert set(np.unique(rec["obs"][-1])) <= {0, 1, 2, 4}
-            if done or t >= max_steps:
+            if (done and stop_on_done) or t >= max_steps:
                 break
         eps.append(rec)
     return eps
@@ -153,6 +154,32 @@ def episodes():
         print(name, [len(e["obs"]) for e in eps], [bool(e["done"][-1]) for e in eps])
     out["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "episodes.npz"), **out)
+
+
+def rpf_episodes():
+    """target_mode='RPF' ids (static goals, generators.py:12-19,48-50,68): the target patrols four fixed cells; the
+    env keeps walls the generator cleared at those cells (track_1v1.py:233-236). Seeds are searched so that at least
+    one Block case has a wall on a candidate cell in the env's own map."""
+    out = {}
+    names = []
+    cases = [("Block", 0, 41, 2, 260, "chase"), ("Maze", 0, 42, 2, 200, "chase"), ("Empty", 0, 43, 1, 150, "random"),
+             ("Block", 1, None, 2, 300, "chase")]
+    for (mp, lvl, seed, n_ep, mx, pol) in cases:
+        if seed is None:                    # find a level-1 Block seed whose env map has a wall on a patrol cell
+            for seed in range(50, 400):
+                eps = run_case(mp, "RPF", lvl, seed, n_ep, 3, pol)
+                cand = [(13, 13), (68, 13), (68, 68), (13, 68)]
+                if any(e["maze"][r][c] == 1 for e in eps for (r, c) in cand[1:]):
+                    break
+        name = "%s_RPF_l%d_s%d" % (mp, lvl, seed)
+        eps = run_case(mp, "RPF", lvl, seed, n_ep, mx, pol, stop_on_done=False)   # keep stepping: patrol re-plans
+        flatten(name + "/", eps, out)
+        out[name + "/meta"] = np.array([mp, "RPF", str(lvl), str(seed), pol])
+        names.append(name)
+        print("rpf", name, [len(e["obs"]) for e in eps], [[int(e["maze"][r][c]) for (r, c) in
+              ((13, 13), (e["maze"].shape[0] * 5 // 6, 13))] for e in eps])
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "episodes_rpf.npz"), **out)
 
 
 def full_obs_episodes():
@@ -393,12 +420,16 @@ if __name__ == "__main__":
     if "--full-only" in sys.argv:
         full_obs_episodes()
         sys.exit(0)
+    if "--rpf-only" in sys.argv:
+        rpf_episodes()
+        sys.exit(0)
     if "--model-only" in sys.argv:
         model_fixture()
         loss_fixture()
         sys.exit(0)
     episodes()
     full_obs_episodes()
+    rpf_episodes()
     edge_cases()
     astar_cases()
     registry()

@@ -39,8 +39,9 @@ def test_registry_matches_reference():
             (str(mp), str(ob), str(lvl), str(tgt), str(mx))
     assert registry.spec("Track2D-BlockPartialPZR-v0")["target_mode"] == "PZR"
     assert registry.spec("Track2D-BlockFullPZR-v0")["obs_type"] == "Full"
-    with pytest.raises(NotImplementedError):
-        registry.spec("Track2D-BlockPartialRPF-v0")
+    assert registry.spec("Track2D-BlockPartialRPF-v0")["target_mode"] == "RPF"
+    for env_id in registry.REGISTRY:                       # all 72 ids resolve
+        assert registry.spec(env_id)["max_episode_steps"] == 500
     with pytest.raises(KeyError):
         registry.spec("Track2D-Nope-v0")
 

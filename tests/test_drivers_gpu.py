@@ -187,3 +187,21 @@ def test_cached_rollout_learner_matches_the_recompute_learner():
         assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (a.shape, float((a - b).abs().max()), scale)
         n_checked += 1
     assert n_checked >= 20
+
+
+def test_rescale_wrapper_matches_the_reference_formula():
+    """--rescale (environment.Rescale, environment.py:51-56): float32 ((clip(x,0,255) - 0) * 2) / 255 + (-1)."""
+    import argparse
+    from active_tracking_rl_amd.environment import create_env
+    args = argparse.Namespace(stack_frames=1, seed=3, gpu_ids=[0], rescale=True, single=False, inv=False, num_envs=64)
+    plain = argparse.Namespace(**dict(vars(args), rescale=False))
+    a, b = create_env("Track2D-BlockPartialPZR-v0", args), create_env("Track2D-BlockPartialPZR-v0", plain)
+    oa, ob = a.reset().cpu().numpy(), b.reset().cpu().numpy()
+    want = (((np.float32(ob).clip(0.0, 255.0) - 0.0) * (1.0 - -1.0)) / 255.0) + -1.0
+    assert oa.dtype == np.float32 and np.array_equal(oa, want.astype(np.float32))
+    act = [torch.zeros(64, dtype=torch.int64, device="cuda"), torch.ones(64, dtype=torch.int64, device="cuda")]
+    oa, ob = a.step(act)[0].cpu().numpy(), b.step(act)[0].cpu().numpy()
+    want = (((np.float32(ob).clip(0.0, 255.0) - 0.0) * 2.0) / 255.0) + -1.0
+    assert np.array_equal(oa, want.astype(np.float32))
+    assert a.rollout_buffers(5) is None
+    a.close(); b.close()

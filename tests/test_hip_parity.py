@@ -418,3 +418,57 @@ def test_fused_random_rollout_is_bit_identical_to_single_step_launches(env_id):
         assert np.array_equal(sa[k], sb[k]), k
     assert np.array_equal(a.get_maps(), b.get_maps())
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_generated_rpf_matches_oracle(vec):
+    """RPF ids: fixed tracker spawn, patrol goals without random draws, plans on the generator's map (patrol cells
+    free) executed open-loop on the env's own map — generated episodes against the oracle's device-spec mode."""
+    assert _check_generated(vec, 32, "Block", "RPF", 0, seed=21, steps=100) > 20
+    _check_generated(vec, 16, "Maze", "RPF", 0, seed=22, steps=80)
+    _check_generated(vec, 24, "Block", "RPF", 1, seed=23, steps=80)
+    _check_generated(vec, 8, "Empty", "RPF", 0, seed=24, steps=60)
+
+
+@pytest.mark.gpu
+def test_rpf_patrol_replans_and_bumps_into_walled_patrol_cells(vec):
+    """Long patrols without resets: the target walks the four patrol cells in order; two of them are walls in the
+    env's own map (the generator cleared them only in its copy, track_1v1.py:233-236), so the open-loop plan bumps."""
+    rs = np.random.RandomState(3)
+    n = 6
+    mazes = []
+    for i in range(n):
+        m = (rs.rand(82, 82) < 0.04).astype(np.uint8)
+        m[0, :] = m[-1, :] = 1; m[:, 0] = m[:, -1] = 1
+        m[13, 13] = 0; m[12:14, 12:14] = 0
+        m[68, 13] = 1 if i % 2 == 0 else 0                  # patrol cell 1 walled in every other env
+        m[68, 68] = 1 if i % 3 == 0 else 0
+        mazes.append(m)
+    mazes = np.stack(mazes)
+    pos = np.tile(np.array([[13, 13], [12, 13]], np.int32), (n, 1, 1))
+    env = vec.VecTrack2D(num_envs=n, map_type="Block", target_mode="RPF", level=1, seed=9, auto_reset=False,
+                         max_episode_steps=0)
+    oracles = [orc.OracleEnv("Block", "RPF", 1, 0, orc.RNG_PHILOX, 9, i) for i in range(n)]
+    env.reset()
+    for o in oracles:
+        o.reset()
+    env.inject(mazes, pos.reshape(n, 4))
+    for i, o in enumerate(oracles):
+        o.inject(mazes[i], pos[i])
+    visited = set()
+    for t in range(420):
+        acts = rs.randint(0, 4, size=(n, 2))
+        a = torch.from_numpy(acts).cuda()
+        obs, rew, done = env.step(a[:, 0].contiguous(), a[:, 1].contiguous())
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for i, o in enumerate(oracles):
+            wo, wr, wd, applied = o.step(acts[i])
+            assert np.array_equal(obs[i], wo.astype(np.float32)), (t, i)
+            assert np.array_equal(rew[i], wr.astype(np.float32)), (t, i)
+            visited.add((i, tuple(o.state()["pos"][1])))
+    st = env.get_state()
+    for i, o in enumerate(oracles):
+        assert np.array_equal(st["pos"][i], o.state()["pos"])
+    # the patrol really went round: env 1 (nothing walled) stood on at least three patrol cells
+    assert sum(((1, c) in visited) for c in ((13, 13), (68, 13), (68, 68), (13, 68))) >= 3
+    env.close()

@@ -114,3 +114,41 @@ def test_full_observation_cases_bit_exact():
                 assert np.array_equal(obs, g[p + "obs"][t]), (name, ep, t)
                 assert tuple(rew) == tuple(g[p + "rew"][t]) and done == bool(g[p + "done"][t])
                 assert np.array_equal(obs[0], obs[1])            # Full: identical for both agents
+
+
+def test_rpf_static_goal_cases_bit_exact():
+    """target_mode='RPF' (static patrol goals, generators.py:12-19,48-50,68): maps, the fixed tracker spawn, goals,
+    the Navigator's first plan and every step (the target's emitted actions included) against the reference,
+    including an episode whose first patrol cell is a wall in the env's own copy of the map (track_1v1.py:233-236)."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "episodes_rpf.npz"))
+    steps, walled = 0, 0
+    for name in _names(g):
+        mp, mode, lvl, seed, _pol = [str(x) for x in g[name + "/meta"]]
+        env = orc.OracleEnv(mp, mode, int(lvl), 500, orc.RNG_NP, int(seed))
+        env.seed_np(int(seed))
+        for ep in range(int(g[name + "/n_eps"])):
+            p = "%s/ep%d_" % (name, ep)
+            obs0 = env.reset()
+            maze = unpack_maze(g[p + "maze"], g[p + "side"])
+            np.testing.assert_array_equal(env.maze, maze, err_msg=name + " maze")
+            S = maze.shape[0]
+            walled += int(maze[S * 5 // 6, S // 6] == 1)
+            st = env.state()
+            np.testing.assert_array_equal(st["pos"], g[p + "init"], err_msg=name + " init")
+            assert tuple(st["pos"][0]) == (S // 6, S // 6)
+            np.testing.assert_array_equal(st["goals"], g[p + "goals"], err_msg=name + " goals")
+            np.testing.assert_array_equal(obs0, g[p + "obs0"], err_msg=name + " obs0")
+            plan, cur = env.plan()
+            np.testing.assert_array_equal(plan, g[p + "plan0"], err_msg=name + " plan0")
+            for t, a in enumerate(g[p + "act_in"]):
+                obs, rew, done, applied = env.step(a)
+                assert np.array_equal(applied, g[p + "act_applied"][t]), (name, ep, t)
+                assert np.array_equal(obs, g[p + "obs"][t]), (name, ep, t)
+                assert tuple(rew) == tuple(g[p + "rew"][t]), (name, ep, t)
+                assert done == bool(g[p + "done"][t]), (name, ep, t)
+                assert np.array_equal(env.state()["pos"], g[p + "pos"][t]), (name, ep, t)
+                assert env.state()["c_far"] == g[p + "cfar"][t]
+                steps += 1
+    assert steps > 1500 and walled >= 1

@@ -5,7 +5,7 @@ import sys
 from collections import defaultdict
 
 
-def kernel_stats(path, top=25):
+def kernel_stats(path, top=60):
     rows = list(csv.DictReader(open(path)))
     tot = sum(int(r["TotalDurationNs"]) for r in rows)
     print("# %s\n# total kernel time %.3f ms over %d kernel names" % (path, tot / 1e6, len(rows)))
