@@ -34,6 +34,13 @@ def lib():
         L.atr_lstm_cell_forward_act.argtypes = [vp] * 11 + [i32, vp, vp, C.c_ulonglong, C.c_uint, i32, i32, vp]
         L.atr_lstm_cell_backward.restype = i32
         L.atr_lstm_cell_backward.argtypes = [vp, ll, vp, vp, vp, vp, vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, i32, vp]
+        L.atr_heads_values.restype = i32
+        L.atr_heads_values.argtypes = [vp, vp, vp, vp, ll, i32, i32, i32, vp]
+        L.atr_heads_workspace_floats.restype = ll
+        L.atr_heads_workspace_floats.argtypes = [ll, i32, i32]
+        L.atr_heads_loss.restype = i32
+        L.atr_heads_loss.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, C.c_float, C.c_float,
+                                     C.c_float, vp, vp, vp, ll, i32, i32, vp]
         L.atr_gae_returns.restype = i32
         L.atr_gae_returns.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, i32, vp]
         _lib = L
@@ -399,3 +406,64 @@ def gae_returns(rewards, values, notdone, gamma, tau):
     if rc != 0:
         raise RuntimeError("atr_gae_returns failed (%d)" % rc)
     return ret, gae
+
+
+@torch.no_grad()
+def heads_values(h, critic, values, off):
+    """values[..., off] = critic(h) for h [rows, R] (csrc/heads_hip.hip); values: contiguous [..., A] float32 whose
+    leading dims flatten to >= rows."""
+    h = h.contiguous()
+    rows, R = h.shape
+    A = values.shape[-2] if values.shape[-1] == 1 else values.shape[-1]
+    rc = lib().atr_heads_values(_p(h), _p(critic.weight), _p(critic.bias), _p(values), rows, R, A, off, _stream(h))
+    if rc != 0:
+        raise RuntimeError("atr_heads_values failed (%d)" % rc)
+
+
+class _HeadsLoss(torch.autograd.Function):
+    """One player's heads + A3C loss terms over all stored steps as ONE autograd node (csrc/heads_hip.hip): forward
+    launches the fused kernel, which already produces dL/dh and the head-parameter gradients; backward hands them
+    out. The output must enter the objective with coefficient 1 (Agent.loss_recompute adds the players' terms)."""
+
+    @staticmethod
+    def forward(ctx, h, wa, ba, wc, bc, waux, baux, actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent):
+        L = lib()
+        h = h.contiguous()
+        rows, R = h.shape
+        A = wa.shape[0]
+        stride = ret.shape[-2] if ret.shape[-1] == 1 else ret.shape[-1]
+        rec = (A + 2) * R + (A + 2) + 4
+        dh = torch.empty_like(h)
+        gs = torch.empty(rec + 1, dtype=torch.float32, device=h.device)
+        ws = torch.empty(L.atr_heads_workspace_floats(rows, R, A), dtype=torch.float32, device=h.device)
+        actions = actions.contiguous()
+        aux_stride = 0
+        if r_aux is not None:
+            aux_stride = r_aux.shape[-2] if r_aux.shape[-1] == 1 else r_aux.shape[-1]
+        rc = L.atr_heads_loss(_p(h), _p(actions), _p(ret), _p(gae), _p(val), stride, off, _pn(r_aux), aux_stride, aux_off,
+                              _p(wa), _p(ba), _p(wc), _pn(waux), _pn(baux), float(scale), float(scale_aux), float(w_ent),
+                              _p(dh), _p(gs), _p(ws), rows, R, A, _stream(h))
+        if rc != 0:
+            raise RuntimeError("atr_heads_loss failed (%d)" % rc)
+        ctx.save_for_backward(dh, gs)
+        ctx.dims = (A, R, waux is not None)
+        stats = gs[rec - 4:rec]
+        ctx.mark_non_differentiable(stats)
+        return gs[rec], stats
+
+    @staticmethod
+    def backward(ctx, gloss, gstats):
+        dh, gs = ctx.saved_tensors
+        A, R, has_aux = ctx.dims
+        o = (A + 2) * R
+        dwa, dwc, dwx = gs[:A * R].view(A, R), gs[A * R:(A + 1) * R].view(1, R), gs[(A + 1) * R:o].view(1, R)
+        dba, dbc, dbx = gs[o:o + A], gs[o + A:o + A + 1], gs[o + A + 1:o + A + 2]
+        return (dh, dwa, dba, dwc, dbc, dwx if has_aux else None, dbx if has_aux else None) + (None,) * 10
+
+
+def heads_loss(h, actor, critic, aux, actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent):
+    """-> (objective contribution (0-dim, differentiable w.r.t. h and the head parameters),
+           stats [4] = unscaled sums: policy term, value term, entropy, |aux error|)."""
+    return _HeadsLoss.apply(h, actor.weight, actor.bias, critic.weight, critic.bias,
+                            aux.weight if aux is not None else None, aux.bias if aux is not None else None,
+                            actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent)

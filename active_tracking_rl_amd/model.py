@@ -623,10 +623,10 @@ class A3C_Dueling(nn.Module):
                 acts_out.append(sample(cache.h_all[i, t + 1], p.actor.actor_linear))
         return acts_out
 
-    def forward_sequence_cached(self, cache, states_seq, actions_seq, keep):
-        """forward_sequence over a cached rollout: the differentiable graph (stem -> fc -> [+ tracker-action
-        embedding] -> LSTM -> heads) is rebuilt around the stored activations, so only the heads are evaluated
-        forward; the backward pass is the same as forward_sequence's. Same return values."""
+    def cached_hidden(self, cache, states_seq, actions_seq, keep):
+        """The differentiable graph (stem -> fc -> [+ tracker-action embedding] -> LSTM) rebuilt around a cached
+        rollout's stored activations: per-player hidden sequences [T, N, R] with autograd history, nothing evaluated
+        forward."""
         from . import fused
         T, N = cache.T, cache.N
         p0, p1 = self.player0, self.player1
@@ -642,7 +642,13 @@ class A3C_Dueling(nn.Module):
                 a2t = F.one_hot(actions_seq[:, :, 0].reshape(T * N), self.action_dim_tracker).to(f.dtype)
                 f = f + p.fc_action_tracker(a2t)
             feats.append(f)
-        h_seq = fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, cache.acts)
+        return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, cache.acts)
+
+    def forward_sequence_cached(self, cache, states_seq, actions_seq, keep):
+        """forward_sequence over a cached rollout: only the heads are evaluated forward; the backward pass is the
+        same as forward_sequence's. Same return values."""
+        p0, p1 = self.player0, self.player1
+        h_seq = self.cached_hidden(cache, states_seq, actions_seq, keep)
         v0, e0, l0 = p0.sequence_heads(h_seq[0], actions_seq[:, :, 0])
         R_pred = 0
         if self.tat:

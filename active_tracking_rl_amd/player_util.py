@@ -36,6 +36,7 @@ class Agent(object):
         self.states, self.actions, self.h0, self.c0 = [], [], None, None
         self._buf, self._pending_done, self._cache, self._actions_buf = None, None, None, None
         self.cache_rollout = True   # fast path on the GPU: learner back-propagates through the actor's forward pass
+        self.fused_heads = True     # ... and evaluates heads + loss terms as one fused HIP node per player
         self.done = torch.ones(self.num_envs, dtype=torch.uint8, device=device)
         self.info = None
         self.reward = 0
@@ -254,6 +255,8 @@ class Agent(object):
             states = torch.stack(self.states, 0)
             rewards = torch.stack(self.rewards, 0)                           # [T, N, A, 1]
             nd = (torch.stack(self.dones, 0) == 0).to(rewards.dtype)         # [T, N]
+        if self._cache is not None and T == self._cache.T and self.fused_heads:
+            return self._loss_fused_heads(training_mode, states, actions, rewards, nd)
         if self._cache is not None and T == self._cache.T:
             values, entropies, log_probs, preds = self.model.forward_sequence_cached(self._cache, states, actions, nd)
         else:
@@ -292,6 +295,46 @@ class Agent(object):
         if use_aux and training_mode != 0:
             loss = loss + pred_loss.mean()
         return loss, policy_loss, value_loss, entropies.detach().sum(0), pred_loss
+
+    def _loss_fused_heads(self, training_mode, states, actions, rewards, nd):
+        """loss_recompute over a cached rollout with each player's heads + loss terms as one fused HIP node
+        (fused.heads_loss, csrc/heads_hip.hip): values first (the returns / GAE need them detached), then per player
+        one launch that yields the objective contribution, dL/dh and the head gradients. Returns the same tuple as
+        loss_recompute, the per-env statistics already averaged over envs (shape [1, A, 1] / [1, 1])."""
+        from . import fused
+        args, model = self.args, self.model
+        T, N, A = self._cache.T, self.num_envs, self.num_agents
+        dev = self.device
+        players = (model.player0, model.player1)
+        h_seq = model.cached_hidden(self._cache, states, actions, nd)        # per player [T, N, R], with history
+        R_dim = h_seq[0].shape[-1]
+        v = torch.empty((T + 1, N, A, 1), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p in range(A):
+                fused.heads_values(h_seq[p].detach().reshape(T * N, R_dim), players[p].critic.critic_linear, v, p)
+            boot, _, _, _, _, _ = model((self.state, (self.hxs, self.cxs)))
+            v[T].copy_(boot)
+            R, gae = fused.gae_returns(rewards.contiguous(), v, nd, args.gamma, args.tau)
+        use_aux = 'reward' in args.aux and getattr(model, "tat", False) and getattr(model.player1, "sub_task", False)
+        w_ent = [float(args.entropy)] + [float(self.w_entropy_target)] * (A - 1)
+        scale = [1.0 / N if training_mode in (0, -1) else 0.0, 1.0 / N if training_mode in (1, -1) else 0.0]
+        if training_mode not in (0, 1, -1):
+            scale = [1.0 / N, 1.0 / N]
+        scale_aux = 1.0 / N if (use_aux and training_mode != 0) else 0.0
+        rew_c = rewards.contiguous()
+        loss, stats = 0, []
+        for p in range(A):
+            aux = players[p].reward_aux if (p == 1 and use_aux) else None
+            lp, st = fused.heads_loss(h_seq[p].reshape(T * N, R_dim), players[p].actor.actor_linear,
+                                      players[p].critic.critic_linear, aux, actions[:, :, p].reshape(T * N), R, gae, v, p,
+                                      rew_c if aux is not None else None, 0, scale[p], scale_aux if aux is not None else 0.0,
+                                      w_ent[p])
+            loss = loss + lp
+            stats.append(st)
+        st = torch.stack(stats, 0) / N                                       # [A, 4]: policy, value, entropy, |aux|
+        policy_loss, value_loss, entropies = (st[:, k].reshape(1, A, 1) for k in range(3))
+        pred_loss = st[1, 3].reshape(1, 1) if (A > 1 and use_aux) else torch.zeros(1, 1, device=dev)
+        return loss, policy_loss, value_loss, entropies, pred_loss
 
     def compute_grads(self, optimizer, training_mode):
         """loss -> backward into the flat gradient bucket (hipGraph-capturable: no host sync)."""

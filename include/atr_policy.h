@@ -77,6 +77,26 @@ int atr_lstm_cell_backward(const float *dh_out, long long dh_pstride, const floa
 int atr_gae_returns(const float *rewards, const float *values, const float *notdone, float gamma, float tau,
                     float *returns, float *gae, int T, int N, int A, void *stream);
 
+/* Heads + loss of ONE player over all stored steps (rows = T*N; R hidden units, R/4 in {16,32,64}; A <= 8 actions):
+ * critic/actor heads (model.py:24-52,120-126 of the reference), softmax statistics of the taken action and the loss
+ * terms of Agent.optimize (player_util.py:118-154) with analytic gradients.
+ *   atr_heads_values: values[row*vstride + voff] = h[row] . wc + bc   (needed first: returns/GAE use detached values)
+ *   atr_heads_loss:   ret/gae/val are read at [row*stride + off]; r_aux (nullable) at [row*aux_stride + aux_off] is
+ *     the reward the aux head (waux, baux; nullable) regresses with an L1 loss. Objective contribution of this player:
+ *       scale * sum_rows( -logp(a) gae - w_ent H + 0.5 * 0.5 (ret - v)^2 ) + scale_aux * sum_rows |pred - r_aux|
+ *     Outputs: dh [rows,R] = dL/dh; grads_and_sums = dWa [A*R] | dWc [R] | dWaux [R] | dba [A] | dbc | dbaux |
+ *     sum(-logp gae - w_ent H) | sum(0.5 (ret-v)^2) | sum(H) | sum|pred - r_aux| (the four sums are UNscaled) |
+ *     the objective contribution above (one float): (A+2)*R + (A+2) + 5 floats in all.
+ *     workspace: atr_heads_workspace_floats(rows, R, A) floats. Fixed reduction order (reproducible). */
+int atr_heads_values(const float *h, const float *wc, const float *bc, float *values, long long rows, int R, int vstride,
+                     int voff, void *stream);
+long long atr_heads_workspace_floats(long long rows, int R, int A);
+int atr_heads_loss(const float *h, const long long *actions, const float *ret, const float *gae, const float *val,
+                   int stride, int off, const float *r_aux, int aux_stride, int aux_off, const float *wa,
+                   const float *ba, const float *wc, const float *waux, const float *baux, float scale, float scale_aux,
+                   float w_ent, float *dh, float *grads_and_sums, float *workspace, long long rows, int R, int A,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -160,24 +160,31 @@ def test_cached_rollout_learner_matches_the_recompute_learner():
     rollout(player, args.num_steps, fast=True)
     assert player._cache is not None
     outs = []
-    for cached in (True, False):
-        cache = player._cache
-        if not cached:
-            player._cache = None
+    cache = player._cache
+    for cached, fused_heads in ((True, True), (True, False), (False, False)):
+        player._cache = cache if cached else None
+        player.fused_heads = fused_heads
         # the bootstrap value of the tracker-aware target depends on a freshly SAMPLED tracker action: pin the draw
         torch.manual_seed(5)
         if getattr(player.model, "_sampler", None) is not None:
             player.model._sampler.counter.zero_()
         loss, pl, vl, ent, pred = player.loss_recompute(args.train_mode)
-        player._cache = cache
+        player._cache, player.fused_heads = cache, True
         params = [p for p in player.model.parameters()]
         grads = torch.autograd.grad(loss, params, allow_unused=True)
-        outs.append((loss.detach(), pl.detach(), vl.detach(), ent, pred.detach(), grads, params))
-    (la, pla, vla, ea, pa, ga, params), (lb, plb, vlb, eb, pb, gb, _) = outs
-    torch.testing.assert_close(la, lb, rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(pla, plb, rtol=1e-3, atol=1e-4)
-    torch.testing.assert_close(vla, vlb, rtol=1e-3, atol=1e-4)
-    torch.testing.assert_close(ea, eb, rtol=1e-4, atol=1e-4)
+        outs.append((loss.detach(), pl.detach().mean(0), vl.detach().mean(0), ent.mean(0), pred.detach().mean(0), grads))
+    for k in (0, 1):                                      # fused heads, cached -- each against the recompute learner
+        la, pla, vla, ea, pa, ga = outs[k]
+        lb, plb, vlb, eb, pb, gb = outs[2]
+        torch.testing.assert_close(la, lb, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(pla, plb, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(vla, vlb, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(ea, eb, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(pa.reshape(-1), pb.reshape(-1), rtol=1e-4, atol=1e-4)
+        _check_grads(ga, gb)
+
+
+def _check_grads(ga, gb):
     n_checked = 0
     for a, b in zip(ga, gb):
         assert (a is None) == (b is None)
