@@ -67,21 +67,24 @@ def save_checkpoints(model, args, n_iter, best):
     return model_dir
 
 
-def test(args, shared_model, train_modes, n_iters, rounds=None):
+def test(args, shared_model, train_modes, n_iters, rounds=None, state=None):
     """Evaluator loop with the reference signature. `shared_model` is the (rank-0) replica being trained; call it
     between training iterations or from a side thread. `rounds` bounds the number of evaluation rounds (None = until
-    the stop rule fires, as in the reference)."""
+    the stop rule fires, as in the reference). `state`: a dict the caller keeps between bounded calls, so that the
+    elapsed time, the best score and the one-off flag dump continue across them as in the reference's single loop."""
     gpu_id = args.gpu_ids[-1]
     device = torch.device('cuda:%d' % gpu_id)
     check_path(args.log_dir)
     name = '{}_log'.format(args.env)
     setup_logger(name, os.path.join(args.log_dir, 'logger'))
     log = logging.getLogger(name)
-    for k, v in vars(args).items():
-        log.info('{0}: {1}'.format(k, v))
+    state = {} if state is None else state
+    if not state.get("started"):
+        for k, v in vars(args).items():
+            log.info('{0}: {1}'.format(k, v))
+        state.update(started=True, start_time=time.time(), max_score=-100)
     env_id = args.env if args.env_base is None else args.env_base
-    start_time = time.time()
-    max_score = -100
+    start_time, max_score = state["start_time"], state["max_score"]
     done_rounds = 0
     while rounds is None or done_rounds < rounds:
         rsum, length = evaluate(shared_model, env_id, args, device, args.test_eps)
@@ -98,7 +101,7 @@ def test(args, shared_model, train_modes, n_iters, rounds=None):
             time.strftime("%Hh %Mm %Ss", time.gmtime(time.time() - start_time)), ave_reward_sum, len_mean, reward_step))
         best = ave_reward_sum[0] >= max_score
         if best:
-            max_score = ave_reward_sum[0]
+            max_score = state["max_score"] = ave_reward_sum[0]
         save_checkpoints(shared_model, args, n_iter, best)
         done_rounds += 1
         if n_iter > args.max_step:                             # test.py:129-134

@@ -87,6 +87,7 @@ if __name__ == '__main__':
     train_modes, n_iters = [args.train_mode] * world, [0] * world
     step = GraphedIteration(player, optimizer, args).run if not args.no_graph else None
     it = 0
+    eval_state = {}
     while True:
         if step is not None:
             step()
@@ -98,7 +99,7 @@ if __name__ == '__main__':
         n_iters[:] = [it] * world
         if it % args.test_every == 0 or it > args.max_step:
             if rank == 0:
-                test(args, player.model, train_modes, n_iters, rounds=1)
+                test(args, player.model, train_modes, n_iters, rounds=1, state=eval_state)
             if world > 1:
                 dist.barrier()
         if it > args.max_step:
