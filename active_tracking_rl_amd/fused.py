@@ -41,6 +41,10 @@ def lib():
         L.atr_heads_loss.restype = i32
         L.atr_heads_loss.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, C.c_float, C.c_float,
                                      C.c_float, vp, vp, vp, ll, i32, i32, vp]
+        L.atr_gemm_tn_workspace_floats.restype = ll
+        L.atr_gemm_tn_workspace_floats.argtypes = [ll, i32, i32]
+        L.atr_gemm_tn.restype = i32
+        L.atr_gemm_tn.argtypes = [vp, vp, vp, vp, ll, i32, i32, vp]
         L.atr_gae_returns.restype = i32
         L.atr_gae_returns.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, i32, vp]
         _lib = L
@@ -162,7 +166,7 @@ class _LinearReluCached(torch.autograd.Function):
     def backward(ctx, df):
         x, w, f = ctx.saved_tensors
         dpre = torch.ops.aten.threshold_backward(df.contiguous(), f, 0.0)
-        return dpre @ w, dpre.t() @ x, dpre.sum(0), None
+        return dpre @ w, gemm_tn(dpre, x), dpre.sum(0), None
 
 
 def linear_relu_cached(x, linear, f):
@@ -325,7 +329,10 @@ def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs):
     kprev = torch.cat([torch.ones_like(keep[:1]), keep[:-1]], 0).view(1, T, N, 1)
     hm = (h_all[:, :T] * kprev).view(P, T * N, R)
     dG = dG.view(P, T * N, 4 * R)
-    dwhh = torch.bmm(hm.transpose(1, 2), dG)
+    if use_gemm_tn and R % 128 == 0 and T * N >= 4096:
+        dwhh = torch.stack([gemm_tn(hm[p], dG[p]) for p in range(P)], 0)
+    else:
+        dwhh = torch.bmm(hm.transpose(1, 2), dG)
     return dG, dhn, dcc, dwhh
 
 
@@ -350,7 +357,7 @@ class _LstmSeqCached(torch.autograd.Function):
         feats, wih = ctx.saved_tensors[5:5 + P], ctx.saved_tensors[5 + P:5 + 2 * P]
         dG, _, _, dwhh = _lstm_bptt(whh, keep, h_all, c_all, acts, dhs)
         dfeat = [dG[p] @ wih[p] for p in range(P)]
-        dwih = [dG[p].t() @ feats[p] for p in range(P)]
+        dwih = [gemm_tn(dG[p], feats[p]) for p in range(P)]
         dwhh_l = [dwhh[p].t() for p in range(P)]
         db = [dG[p].sum(0) for p in range(P)]
         return (None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + tuple(db)
@@ -467,3 +474,24 @@ def heads_loss(h, actor, critic, aux, actions, ret, gae, val, off, r_aux, aux_of
     return _HeadsLoss.apply(h, actor.weight, actor.bias, critic.weight, critic.bias,
                             aux.weight if aux is not None else None, aux.bias if aux is not None else None,
                             actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent)
+
+
+use_gemm_tn = True
+
+
+@torch.no_grad()
+def gemm_tn(x1, x2):
+    """x1.t() @ x2 for tall row-major x1 [K,M], x2 [K,N] — the weight-gradient GEMMs (csrc/gemm_tn_hip.hip) when the
+    shape fits the kernel (CUDA fp32, contiguous, M and N multiples of 128), otherwise the library GEMM."""
+    K, M = x1.shape
+    N = x2.shape[1]
+    if (use_gemm_tn and x1.is_cuda and x1.dtype == torch.float32 and x2.dtype == torch.float32 and M % 128 == 0
+            and N % 128 == 0 and K >= 4096 and x1.is_contiguous() and x2.is_contiguous()):
+        L = lib()
+        ws = torch.empty(L.atr_gemm_tn_workspace_floats(K, M, N), dtype=torch.float32, device=x1.device)
+        c = torch.empty((M, N), dtype=torch.float32, device=x1.device)
+        rc = L.atr_gemm_tn(_p(x1), _p(x2), _p(c), _p(ws), K, M, N, _stream(x1))
+        if rc != 0:
+            raise RuntimeError("atr_gemm_tn failed (%d)" % rc)
+        return c
+    return x1.t() @ x2

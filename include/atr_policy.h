@@ -97,6 +97,12 @@ int atr_heads_loss(const float *h, const long long *actions, const float *ret, c
                    float w_ent, float *dh, float *grads_and_sums, float *workspace, long long rows, int R, int A,
                    void *stream);
 
+/* C [M,N] = X1^T X2 for tall row-major X1 [K,M], X2 [K,N] (the learner's weight-gradient GEMMs: K = T*N_envs rows;
+ * M, N multiples of 128), fp32 on the f32 matrix cores with split-K and a fixed-order reduction (reproducible).
+ * workspace: atr_gemm_tn_workspace_floats(K, M, N) floats (-1 for unsupported shapes). */
+long long atr_gemm_tn_workspace_floats(long long K, int M, int N);
+int atr_gemm_tn(const float *x1, const float *x2, float *c, float *workspace, long long K, int M, int N, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,3 +233,18 @@ def test_actor_cell_kernel_cell_embedding_and_draw():
     sampler.end_block()
     h_ref, c_ref = fused.lstm_cell(ig, hg, c, done=done)
     torch.testing.assert_close(outs[0], h_ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("K,M,N", [(81920, 256, 512), (20480, 512, 256), (4099, 128, 384), (8192, 128, 128)])
+def test_gemm_tn_matches_float64_reference(K, M, N):
+    """atr_gemm_tn (x1^T x2 for tall operands, csrc/gemm_tn_hip.hip) against a float64 matmul; ragged K tail included.
+    Tolerance: fp32 accumulation over K products of N(0,1) operands."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(K + M)
+    x1, x2 = torch.randn(K, M, device="cuda"), torch.randn(K, N, device="cuda")
+    c = fused.gemm_tn(x1, x2)
+    ref = (x1.double().t() @ x2.double())
+    assert c.shape == (M, N)
+    assert float((c.double() - ref).abs().max()) < 3e-5 * K ** 0.5 * 4
+    c2 = fused.gemm_tn(x1, x2)
+    assert torch.equal(c, c2)                                   # fixed reduction order: bit-reproducible
