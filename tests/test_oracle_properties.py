@@ -101,3 +101,34 @@ def test_bfs_direction_field_descends_along_shortest_paths(seed, map_type):
         assert n == dist[s[0], s[1]]
         plan = orc.astar(m, s, goal)
         assert plan is not None and len(plan) == n
+
+
+@settings(max_examples=30, deadline=None)
+@given(seed=st.integers(0, 2**31 - 1), map_type=st.sampled_from(["Block", "Maze", "Empty"]), level=st.integers(0, 1),
+       rng=st.sampled_from([orc.RNG_NP, orc.RNG_PHILOX]))
+def test_rpf_reset_and_patrol_invariants(seed, map_type, level, rng):
+    """RPF ids (static goals): tracker spawn fixed at patrol cell 0 = (S/6, S/6) — even when the env's own copy of the
+    map has a wall there —, target in the 2x2 window up-left of it, both goals = patrol cell 1, the scripted target
+    only ever emits legal actions, and the env never moves an agent INTO a wall."""
+    env = orc.OracleEnv(map_type, "RPF", level, 500, rng, seed, env_id=seed % 331)
+    if rng == orc.RNG_NP:
+        env.seed_np(seed)
+    env.reset()
+    S, m = env.side, env.maze
+    s = env.state()
+    lo, hi = S // 6, S * 5 // 6
+    assert tuple(s["pos"][0]) == (lo, lo)
+    assert 0 <= s["pos"][0][0] - s["pos"][1][0] <= 1 and 0 <= s["pos"][0][1] - s["pos"][1][1] <= 1
+    assert [tuple(g) for g in s["goals"]] == [(hi, lo), (hi, lo)]
+    rs = np.random.RandomState(seed % 911)
+    for t in range(40):
+        before = env.state()["pos"].copy()
+        obs, rew, done, applied = env.step(rs.randint(0, 4, 2))
+        assert 0 <= applied[1] <= 3
+        after = env.state()["pos"]
+        for i in range(2):
+            d = np.abs(after[i] - before[i]).sum()
+            assert d in (0, 1)
+            if d == 1:
+                assert m[after[i][0], after[i][1]] == 0
+        assert set(np.unique(obs)) <= {0, 1, 2, 4}
