@@ -538,6 +538,24 @@ __device__ __forceinline__ void store_dir_field(uint32_t *gdir, const NavField &
         }
     }
 }
+// Prefetched plan of a Nav target (goal drawn ahead of time, field computed by the generator pass): the two direction
+// planes as above plus the visited plane at words 512..757, so that reachability of the target's position can be
+// checked when the plan is adopted.
+constexpr int kPlanWords = 768;
+__device__ __forceinline__ void store_plan_field(uint32_t *gp, const NavField &f, int side, int lane)
+{
+    store_dir_field(gp, f, side, lane);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        if (lane < side) gp[512 + lane * kRowWords + j] = f.visA.w[j];
+        if (lane + 64 < side) gp[512 + (lane + 64) * kRowWords + j] = f.visB.w[j];
+    }
+}
+__device__ __forceinline__ uint32_t load_vis(const uint32_t *gp, int r, int c)
+{
+    return (gp[512 + r * kRowWords + (c >> 5)] >> (c & 31)) & 1u;
+}
+
 __device__ __forceinline__ uint32_t load_dir(const uint32_t *gdir, int r, int c)
 {
     const int w = r * kRowWords + (c >> 5);

@@ -39,6 +39,11 @@ struct DevState {
     // ---- next episode, generated ahead of time by k_gen (episode[e] + 1) ----
     uint32_t *n_maps, *n_pos, *n_goals, *n_plan, *n_tctr, *n_navgoal, *n_nav2, *n_d2, *n_dirf;
     uint32_t *gen_req;  // [N] 0 = next slot valid; s > 0 = consumed at step stamp s, to be regenerated
+    // ---- Nav targets: the NEXT plan of the current episode, prepared ahead of time by the generator pass ----
+    uint32_t *p_field;  // [N][768] direction planes + visited plane of the BFS rooted at p_goal
+    uint32_t *p_goal;   // [N] r | c<<8
+    uint32_t *p_tctr;   // [N] TARGET stream word counter after drawing p_goal
+    uint32_t *p_state;  // [N] 1 = the three above are valid for the current episode and map
     uint32_t *faults;   // [1]
     const float2 *rew_lut;    // [3][kLutN] (r_track, r_target) as float32(float64 formula), by w_p class and d^2
     int n;
@@ -191,9 +196,28 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t upto, int forc
     const int e = (int)blockIdx.x * kWavesPerBlock + wave;
     if (e >= s.n) return;
     const uint32_t req = s.gen_req[e];
-    if (!force && (req == 0u || req > upto)) return;
-    uint32_t *tile = tiles[wave];
     const uint32_t cfg = s.cfg[e];
+    uint32_t *tile = tiles[wave];
+    const bool need_gen = force || (req != 0u && req <= upto);
+    if (NAV && !force && (int)((cfg >> 2) & 7u) == TGT_NAV && s.p_state[e] == 0u) {
+        // Prefetch the Nav target's next plan on the CURRENT map: draw the goal the Navigator will draw when its
+        // plan is exhausted (navigator.py:17 — the TARGET stream has no other consumer until then, so drawing it now
+        // keeps the stream order) and run the BFS for it here, off the step kernel's critical path. The step kernel
+        // adopts it if the target's position turns out reachable and different from the goal, else re-plans inline.
+        reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(s.maps + (size_t)e * kTileWords)[lane];
+        wave_lds_sync();
+        const int side = (int)(s.cnt[e] >> 24);
+        const FreeIndex fi = build_free_index(tile, side, lane);
+        Stream ts;
+        ts.init(s.k0, s.k1, s.episode[e], s.env_base + (uint32_t)e, STREAM_TARGET, s.tctr[e]);
+        const uint32_t g2 = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+        NavField nf;
+        bfs_dir_field(tile, side, lane, (int)(g2 & 0xffu), (int)(g2 >> 8), nf);
+        store_plan_field(s.p_field + (size_t)e * kPlanWords, nf, side, lane);
+        if (lane == 0) { s.p_goal[e] = g2; s.p_tctr[e] = ts.ctr; s.p_state[e] = 1u; }
+        wave_lds_sync();
+    }
+    if (!need_gen) return;
     uint32_t pos, goals, plan, tctr, navgoal, d2, nav2;
     uint32_t *gdir = NAV ? s.n_dirf + (size_t)e * kDirWords : nullptr;
     generate_episode<NAV>(s, e, tile, lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2, nav2);
@@ -349,17 +373,38 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
                                          : (r1 == (int)(navgoal & 0xffu) && c1 == (int)(navgoal >> 8));
             int qr = rpf ? (int)(nav2 & 0xffu) : r1, qc = rpf ? (int)((nav2 >> 8) & 0xffu) : c1;
             uint32_t dir = 0;
-            if (exhausted) {
+            bool adopted = false, have_goal = false;
+            if (exhausted && !rpf && s.p_state[e] == 1u) {
+                // a plan for the next goal was prepared by the generator pass (k_gen): adopt it if it is a valid plan
+                // from here (reachable, not already on the goal) — else fall through to the inline re-plan, which
+                // then starts from the same already-drawn goal
+                const uint32_t *pf = s.p_field + (size_t)e * kPlanWords;
+                const uint32_t g2 = s.p_goal[e];
+                ts.init(s.k0, s.k1, s.episode[e], genv, STREAM_TARGET, s.p_tctr[e]);
+                navgoal = g2;
+                have_goal = true;
+                if (load_vis(pf, r1, c1) != 0u && !(r1 == (int)(g2 & 0xffu) && c1 == (int)(g2 >> 8))) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(pf);
+                    uint4 *dst = reinterpret_cast<uint4 *>(gdir);
+                    dst[lane] = src[lane]; dst[lane + 64] = src[lane + 64];
+                    dir = load_dir(pf, r1, c1);
+                    plan = 0u; planb = false;
+                    adopted = true;
+                    navgoal_dirty = true;
+                }
+                if (lane == 0) s.p_state[e] = 0u;
+            }
+            if (exhausted && !adopted) {
                 const FreeIndex fi = build_free_index(tile, side, lane);
                 if (rpf) { nav2 = (nav2 & 0x3fffffffu) | ((((nav2 >> 30) + 1u) & 3u) << 30); navgoal = rpf_cell(side, (int)(nav2 >> 30)); }
-                else navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+                else if (!have_goal) navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
                 NavField nf;
                 nav_plan(tile, side, lane, r1, c1, fi, navgoal, ts, plan, nf, rpf ? &nav2 : nullptr);
                 planb = ((plan >> 28) & 1u) != 0u;
                 qr = r1; qc = c1;
                 if (!planb) { store_dir_field(gdir, nf, side, lane); dir = nav_dir_from_regs(nf, qr, qc); }
                 navgoal_dirty = true;
-            } else if (!planb) {
+            } else if (!planb && !adopted) {
                 dir = load_dir(gdir, qr, qc);
             }
             if (rpf && !planb) {   // advance the virtual position along the field, one planned step consumed
@@ -413,7 +458,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
             dst[lane] = src[lane]; dst[lane + 64] = src[lane + 64];
         }
         pos = s.n_pos[e]; plan = s.n_plan[e]; tctr = s.n_tctr[e]; navgoal = s.n_navgoal[e]; d2 = s.n_d2[e];
-        if (NAV && lane == 0) s.nav2[e] = s.n_nav2[e];
+        if (NAV && lane == 0) { s.nav2[e] = s.n_nav2[e]; s.p_state[e] = 0u; }   // new map: the prefetched plan is void
         cnt = (uint32_t)side_of_cfg(cfg) << 24;
         if (!MULTI) episode = s.episode[e];
         episode += 1u;
@@ -571,7 +616,11 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     uint32_t **arrs[] = {&s.pos, &s.goals, &s.cnt, &s.cfg, &s.episode, &s.plan, &s.tctr, &s.navgoal, &s.d2,
                          &s.n_pos, &s.n_goals, &s.n_plan, &s.n_tctr, &s.n_navgoal, &s.n_d2, &s.gen_req, &s.nav2, &s.n_nav2};
     for (auto a : arrs) alloc(a, nb);
-    if (has_nav) { alloc(&s.dirf, db); alloc(&s.n_dirf, db); }
+    if (has_nav) {
+        alloc(&s.dirf, db); alloc(&s.n_dirf, db);
+        alloc(&s.p_field, (size_t)n * kPlanWords * sizeof(uint32_t));
+        alloc(&s.p_goal, nb); alloc(&s.p_tctr, nb); alloc(&s.p_state, nb);
+    }
     alloc(&s.faults, sizeof(uint32_t));
     float2 *lut = nullptr;
     if (err == hipSuccess) err = hipMalloc((void **)&lut, (size_t)3 * kLutN * sizeof(float2));
@@ -597,7 +646,7 @@ extern "C" int t2d_destroy(t2d_handle *h)
     DevState &s = h->s;
     void *ptrs[] = {s.maps, s.n_maps, s.pos, s.goals, s.cnt, s.cfg, s.episode, s.plan, s.tctr, s.navgoal, s.d2,
                     s.n_pos, s.n_goals, s.n_plan, s.n_tctr, s.n_navgoal, s.n_d2, s.gen_req, s.dirf, s.n_dirf, s.faults,
-                    (void *)s.rew_lut, s.nav2, s.n_nav2};
+                    (void *)s.rew_lut, s.nav2, s.n_nav2, s.p_field, s.p_goal, s.p_tctr, s.p_state};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -822,6 +871,7 @@ extern "C" int t2d_inject(t2d_handle *h, int first, int count, int side, const u
     HIP_TRY(hipMemcpyAsync(s.navgoal + first, navgoal.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s.plan + first, zero.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s.nav2 + first, zero.data(), nb, hipMemcpyHostToDevice, st));   // RPF: re-plan to patrol cell 1
+    if (s.p_state) HIP_TRY(hipMemcpyAsync(s.p_state + first, zero.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (first == 0 && count == s.n) h->reset_done = true;
     return T2D_OK;

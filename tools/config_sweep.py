@@ -1,0 +1,42 @@
+"""End-to-end A3C throughput of the other BASELINE.json configurations at their per-GPU size on ONE MI355X (the
+headline configuration is bench.py's). Same driver as bench.py: GraphedIteration, 20-step rollouts, SharedAdam."""
+import time
+
+import numpy as np
+import torch
+
+from active_tracking_rl_amd import registry
+from active_tracking_rl_amd.environment import VecEnv
+from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player
+
+CASES = [
+    ("configs[1] BlockPartialRam, 1024 envs, maze-lstm, train-mode 0",
+     dict(env="Track2D-BlockPartialRam-v0", num_envs=1024, network="maze-lstm", aux="none", train_mode=0), None),
+    ("configs[2] BlockPartialPZR, 4096 envs, tat-maze-lstm, train-mode -1 (= bench.py)",
+     dict(env="Track2D-BlockPartialPZR-v0", num_envs=4096, network="tat-maze-lstm", aux="reward", train_mode=-1), None),
+    ("configs[3] MazePartialNav, 1024 envs per GPU (8192 over 8), maze-lstm, train-mode 0",
+     dict(env="Track2D-MazePartialNav-v0", num_envs=1024, network="maze-lstm", aux="none", train_mode=0), None),
+    ("configs[4] BlockPartialAdv, 2048 envs per GPU (16384 over 8), maze-lstm, train-mode -1, Block/Maze 50/50",
+     dict(env="Track2D-BlockPartialAdv-v0", num_envs=2048, network="maze-lstm", aux="none", train_mode=-1), "mixed"),
+]
+dev = torch.device("cuda:0")
+for name, over, special in CASES:
+    args = default_args(**over)
+    env = None
+    if special == "mixed":
+        n = args.num_envs
+        maps = np.array([registry.MAP_CODE["Block"] if i % 2 == 0 else registry.MAP_CODE["Maze"] for i in range(n)], np.uint8)
+        env = VecEnv(args.env, n, device="cuda:0", seed=args.seed, map_type_per_env=maps)
+    player, opt = make_player(args, dev, 0, 1, env=env)
+    g = GraphedIteration(player, opt, args)
+    for _ in range(5):
+        g.run()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    iters = 40
+    for _ in range(iters):
+        g.run()
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / iters
+    print("%-100s %7.3f ms/iter  %6.2f M env steps/s" % (name, dt * 1e3, args.num_envs * args.num_steps / dt / 1e6), flush=True)
+    player.env.close()
