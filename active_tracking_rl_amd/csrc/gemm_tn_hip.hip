@@ -5,9 +5,9 @@
 // TFLOP/s on all of them, 2.5% of an A3C iteration saved; also tighter error than the library's split-K order):
 //   * 128 x 128 output tile per workgroup (4 waves, each a 64 x 64 quadrant = 2 x 2 v_mfma_f32_32x32x2_f32 tiles,
 //     64 accumulator VGPRs), the K range split over many workgroups (split-K) so that ~512 workgroups exist;
-//   * both operands are consumed in their natural row-major layout: a 16-row chunk of X1 and of X2 is staged in LDS
-//     (rows padded to 160 floats so that the two k-rows an MFMA operand read touches fall into disjoint banks) and an
-//     MFMA operand is ONE ds_read_b32 per lane (A[i = m][k] = X1[k][m], B[k][j] = X2[k][n]: lane l reads row k0 + (l>>5),
+//   * both operands are consumed in their natural row-major layout: a 32-row chunk of X1 and of X2 is staged in LDS
+//     (unpadded rows: the two k-rows an MFMA operand read touches are served in different LDS passes; padding them
+//     apart was measured 3-10 % slower) and an MFMA operand is ONE ds_read_b32 per lane (A[i = m][k] = X1[k][m], B[k][j] = X2[k][n]: lane l reads row k0 + (l>>5),
 //     column base + (l & 31)); the next chunk's global loads are in flight while the current one is multiplied;
 //   * XCD-aware workgroup order: the output tiles of one K-slice run on the same XCD back to back, so each operand
 //     slice is fetched from HBM once and re-read from that XCD's L2 by the other tiles;
@@ -22,10 +22,10 @@ namespace atr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTile = 128, kKC = 16, kLd = 160;   // tile side, K-chunk rows, padded LDS row length (floats)
+constexpr int kTile = 128, kKC = 32, kLd = 128;   // tile side, K-chunk rows, LDS row length (floats)
 constexpr int kGemmThreads = 256;
 
-struct GemmLds { float a[2][kKC][kLd]; float b[2][kKC][kLd]; };   // 40 KB
+struct GemmLds { float a[2][kKC][kLd]; float b[2][kKC][kLd]; };   // 64 KB: two workgroups per CU
 
 __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const float *__restrict__ x1, const float *__restrict__ x2,
                                                              float *__restrict__ partial, long long K, int M, int N,
@@ -43,21 +43,23 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const float *__rest
     const long long k_begin = (long long)slice * chunks_per_slice * kKC;
     long long k_end = k_begin + (long long)chunks_per_slice * kKC;
     if (k_end > K) k_end = K;
-    // global -> LDS staging: thread t moves rows r and r + 8, 16 B at column c4 * 4 of each operand
+    // global -> LDS staging: thread t moves rows r, r + 8, r + 16, r + 24: 16 B at column c4 * 4 of each operand
     const int r = tid >> 5, c4 = tid & 31;
     // NB: predicated `if (in range) v = p[i]` loads, not `cond ? p[i] : zero` — the select form makes the compiler
     // merge the two sources into a generic pointer and emit flat_load, which also ticks lgkmcnt and so serialises
     // the global prefetch behind every LDS wait of the MFMA loop
     const float4 *g1 = reinterpret_cast<const float4 *>(x1 + m0 + c4 * 4), *g2 = reinterpret_cast<const float4 *>(x2 + n0 + c4 * 4);
     const long long ldm = M / 4, ldn = N / 4;                          // row strides in float4 units
-    float4 ra0, ra1, rb0, rb1;
+    float4 ra0, ra1, rb0, rb1, ra2, ra3, rb2, rb3;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define GEMM_TN_FETCH(k0_)                                                     \
     {                                                                          \
-        const long long ka_ = (k0_) + r, kb_ = (k0_) + r + 8;                  \
-        ra0 = zero4; ra1 = zero4; rb0 = zero4; rb1 = zero4;                    \
+        const long long ka_ = (k0_) + r, kb_ = (k0_) + r + 8, kc_ = (k0_) + r + 16, kd_ = (k0_) + r + 24;  \
+        ra0 = zero4; ra1 = zero4; rb0 = zero4; rb1 = zero4; ra2 = zero4; ra3 = zero4; rb2 = zero4; rb3 = zero4; \
         if (ka_ < k_end) { ra0 = g1[ka_ * ldm]; rb0 = g2[ka_ * ldn]; }         \
         if (kb_ < k_end) { ra1 = g1[kb_ * ldm]; rb1 = g2[kb_ * ldn]; }         \
+        if (kc_ < k_end) { ra2 = g1[kc_ * ldm]; rb2 = g2[kc_ * ldn]; }         \
+        if (kd_ < k_end) { ra3 = g1[kd_ * ldm]; rb3 = g2[kd_ * ldn]; }         \
     }
 #define GEMM_TN_STAGE(buf_)                                                    \
     {                                                                          \
@@ -65,6 +67,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const float *__rest
         *reinterpret_cast<float4 *>(&s.a[buf_][r + 8][c4 * 4]) = ra1;          \
         *reinterpret_cast<float4 *>(&s.b[buf_][r][c4 * 4]) = rb0;              \
         *reinterpret_cast<float4 *>(&s.b[buf_][r + 8][c4 * 4]) = rb1;          \
+        *reinterpret_cast<float4 *>(&s.a[buf_][r + 16][c4 * 4]) = ra2;         \
+        *reinterpret_cast<float4 *>(&s.a[buf_][r + 24][c4 * 4]) = ra3;         \
+        *reinterpret_cast<float4 *>(&s.b[buf_][r + 16][c4 * 4]) = rb2;         \
+        *reinterpret_cast<float4 *>(&s.b[buf_][r + 24][c4 * 4]) = rb3;         \
     }
     f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
