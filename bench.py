@@ -15,9 +15,12 @@ per GPU, independent shards keyed by global env id.
 Extra objects on the same JSON line:
   roofline     the step/observe kernel (k_env<OP_STEP>): algorithmic bytes (1723 B x envs per launch)
                / average launch duration, measured with HIP events on the launch stream over back-to-back
-               launches; peak 8 TB/s (HBM3E). `traffic` comes from a separate rocprofv3 --pmc pass (see
-               profiles/), so it is null in the line.
-  env_only     the same kernel driven with on-device random actions (no policy): launches/s -> env steps/s.
+               policy-shaped launches in a hipGraph (the kernel alone; the per-step figure with the generator pass
+               every 10th step is reported next to it); peak 8 TB/s (HBM3E). `traffic` is read from the committed
+               rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json).
+  env_only     the same kernel driven with on-device random actions (no policy): launches/s -> env steps/s, per
+               launch and in the persistent mode (t2d_rollout_random: up to 10 steps per launch).
+  policy_stem  informational f32-MFMA roofline of the conv-stem kernels (the largest single kernels of the iteration).
   cpu_baseline reference-shaped 16-worker CPU A3C on the oracle (oracle/cpu_a3c.py), rank 0, N=1 only.
 """
 import argparse
@@ -155,7 +158,27 @@ def main():
         g.replay()
     e1.record()
     torch.cuda.synchronize(device)
-    k_us = e0.elapsed_time(e1) * 1e3 / (M * REPS)
+    step_us = e0.elapsed_time(e1) * 1e3 / (M * REPS)          # per step incl. the generator pass every 10th step
+    # the step kernel alone: a graph of gen_every - 1 = 9 launches captured right after a generator pass holds no
+    # k_gen. (Timing only: replays do not advance the library's host-side window counter, so no pass runs between
+    # them and an env that finishes twice re-enters the same pre-generated episode; the env is reset afterwards.)
+    core.flush()
+    torch.cuda.synchronize(device)
+    g9 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g9, capture_error_mode="thread_local"):
+        for i in range(9):
+            core.step(acts[i, 0], acts[i, 1], out)
+    core.flush()
+    torch.cuda.synchronize(device)
+    tot = 0.0
+    for _ in range(40):
+        e0.record()
+        g9.replay()
+        e1.record()
+        torch.cuda.synchronize(device)
+        tot += e0.elapsed_time(e1)
+    k_us = tot * 1e3 / (40 * 9)
+    core.reset()
     achieved = B_STEP * n / (k_us * 1e-6) / 1e9
     # env-only loop with on-device random actions
     core.step_random(50, 7, out)
@@ -236,11 +259,13 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "t2d::k_env<OP_STEP> (step+observe, in-launch auto-reset)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": B_STEP * n,
-                     "avg_launch_us": k_us,
-                     "note": "avg_launch_us = hipGraph of 100 policy-shaped step launches replayed 5x, HIP events on the "
-                             "launch stream; it includes the generator launch every 10th step (k_gen) and the "
-                             "inter-kernel boundaries, so it sits ~1.5 us above rocprofv3's k_env-only average "
-                             "(profiles/r01_env_only_kernel_stats.txt)"},
+                     "avg_launch_us": k_us, "avg_step_us_incl_generator": step_us,
+                     "achieved_incl_generator": B_STEP * n / (step_us * 1e-6) / 1e9,
+                     "note": "avg_launch_us = the step kernel alone: hipGraph of 9 policy-shaped step launches (no "
+                             "generator pass inside) replayed 40x, HIP events on the launch stream around each replay; "
+                             "it still contains the in-graph kernel boundaries, so it sits a few tenths of a us above "
+                             "rocprofv3's k_env average (profiles/r01_*kernel_stats.txt). avg_step_us_incl_generator = "
+                             "100-launch graph replayed 5x, generator pass (k_gen) every 10th step included"},
         "env_only": {"value": n * world / (eo_us * 1e-6), "unit": "env steps/s", "us_per_launch": eo_us,
                      "note": "same kernel, on-device random actions, one launch per batched step, per-rank x ranks",
                      "fused_value": n * world / (eof_us * 1e-6), "fused_us_per_step": eof_us,
