@@ -29,7 +29,9 @@ struct GemmLds { float a[2][kKC][kLd]; float b[2][kKC][kLd]; };   // 64 KB: two 
 
 __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const float *__restrict__ x1, const float *__restrict__ x2,
                                                              float *__restrict__ partial, long long K, int M, int N,
-                                                             int slices, int chunks_per_slice)
+                                                             int slices, int chunks_per_slice,
+                                                             const float *__restrict__ row_scale,
+                                                             float *__restrict__ colsum_partial)
 {
     __shared__ __attribute__((aligned(16))) GemmLds s;
     const int tid = (int)threadIdx.x, l = tid & 63, wave = tid >> 6;
@@ -51,6 +53,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const float *__rest
     const float4 *g1 = reinterpret_cast<const float4 *>(x1 + m0 + c4 * 4), *g2 = reinterpret_cast<const float4 *>(x2 + n0 + c4 * 4);
     const long long ldm = M / 4, ldn = N / 4;                          // row strides in float4 units
     float4 ra0, ra1, rb0, rb1, ra2, ra3, rb2, rb3;
+    // optional extras: row_scale[k] multiplies row k of X1 on its way into LDS (dW_hh needs the episode mask on h);
+    // colsum_partial receives the column sums of X1 (the bias gradient that goes with a weight gradient) from the
+    // workgroups of the first tile column, which add up their staged chunks
+    const bool do_colsum = colsum_partial != nullptr && n0 == 0;
+    float cs = 0.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define GEMM_TN_FETCH(k0_)                                                     \
     {                                                                          \
@@ -60,6 +67,12 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const float *__rest
         if (kb_ < k_end) { ra1 = g1[kb_ * ldm]; rb1 = g2[kb_ * ldn]; }         \
         if (kc_ < k_end) { ra2 = g1[kc_ * ldm]; rb2 = g2[kc_ * ldn]; }         \
         if (kd_ < k_end) { ra3 = g1[kd_ * ldm]; rb3 = g2[kd_ * ldn]; }         \
+        if (row_scale) {                                                       \
+            const float s0_ = ka_ < k_end ? row_scale[ka_] : 0.f, s1_ = kb_ < k_end ? row_scale[kb_] : 0.f;   \
+            const float s2_ = kc_ < k_end ? row_scale[kc_] : 0.f, s3_ = kd_ < k_end ? row_scale[kd_] : 0.f;   \
+            ra0.x *= s0_; ra0.y *= s0_; ra0.z *= s0_; ra0.w *= s0_; ra1.x *= s1_; ra1.y *= s1_; ra1.z *= s1_; ra1.w *= s1_; \
+            ra2.x *= s2_; ra2.y *= s2_; ra2.z *= s2_; ra2.w *= s2_; ra3.x *= s3_; ra3.y *= s3_; ra3.z *= s3_; ra3.w *= s3_; \
+        }                                                                      \
     }
 #define GEMM_TN_STAGE(buf_)                                                    \
     {                                                                          \
@@ -100,8 +113,19 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const float *__rest
             acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
             a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
+        if (do_colsum) {                                 // thread = (column tid & 127, half of the chunk's rows)
+            const float *pc = &s.a[buf][(tid >> 7) * (kKC / 2)][tid & 127];
+#pragma unroll
+            for (int q = 0; q < kKC / 2; q++) cs += pc[q * kLd];
+        }
         if (more) GEMM_TN_STAGE(buf ^ 1);                // the other buffer was last read one iteration ago
         __syncthreads();
+    }
+    if (do_colsum) {
+        float *red = &s.a[0][0][0];
+        if (tid >= 128) red[tid - 128] = cs;
+        __syncthreads();
+        if (tid < 128) colsum_partial[(size_t)slice * M + m0 + tid] = cs + red[tid];
     }
 #undef GEMM_TN_FETCH
 #undef GEMM_TN_STAGE
@@ -132,6 +156,15 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float *__restrict_
     *reinterpret_cast<float4 *>(c + i) = acc;
 }
 
+__global__ __launch_bounds__(256) void k_gemm_tn_colsum(const float *__restrict__ partial, float *__restrict__ out, int slices, int M)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= M) return;
+    float acc = 0.f;
+    for (int z = 0; z < slices; z++) acc += partial[(size_t)z * M + i];
+    out[i] = acc;
+}
+
 static void gemm_tn_plan(long long K, int M, int N, int *slices, int *chunks_per_slice)
 {
     const int tiles = (M / kTile) * (N / kTile);
@@ -153,20 +186,23 @@ extern "C" long long atr_gemm_tn_workspace_floats(long long K, int M, int N)
     if (K <= 0 || M <= 0 || N <= 0 || M % kTile || N % kTile) return -1;
     int s, c;
     gemm_tn_plan(K, M, N, &s, &c);
-    return (long long)s * M * N;
+    return (long long)s * M * N + (long long)s * M;
 }
 
 extern "C" int atr_gemm_tn(const float *x1, const float *x2, float *c, float *workspace, long long K, int M, int N,
-                           void *stream)
+                           const float *row_scale, float *colsum, void *stream)
 {
     if (!x1 || !x2 || !c || !workspace || K <= 0 || M <= 0 || N <= 0 || M % kTile || N % kTile) return -1;
     int slices, cps;
     gemm_tn_plan(K, M, N, &slices, &cps);
     const int tiles = (M / kTile) * (N / kTile);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)(slices * tiles)), dim3(kGemmThreads), 0, st, x1, x2, workspace, K, M, N,
-                       slices, cps);
     const long long mn = (long long)M * N;
+    float *cs_partial = colsum ? workspace + (size_t)slices * mn : nullptr;
+    hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)(slices * tiles)), dim3(kGemmThreads), 0, st, x1, x2, workspace, K, M, N,
+                       slices, cps, row_scale, cs_partial);
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, workspace, c, slices, mn);
+    if (colsum)
+        hipLaunchKernelGGL(k_gemm_tn_colsum, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, cs_partial, colsum, slices, M);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -44,7 +44,7 @@ def lib():
         L.atr_gemm_tn_workspace_floats.restype = ll
         L.atr_gemm_tn_workspace_floats.argtypes = [ll, i32, i32]
         L.atr_gemm_tn.restype = i32
-        L.atr_gemm_tn.argtypes = [vp, vp, vp, vp, ll, i32, i32, vp]
+        L.atr_gemm_tn.argtypes = [vp, vp, vp, vp, ll, i32, i32, vp, vp, vp]
         L.atr_gae_returns.restype = i32
         L.atr_gae_returns.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, i32, vp]
         _lib = L
@@ -166,7 +166,8 @@ class _LinearReluCached(torch.autograd.Function):
     def backward(ctx, df):
         x, w, f = ctx.saved_tensors
         dpre = torch.ops.aten.threshold_backward(df.contiguous(), f, 0.0)
-        return dpre @ w, gemm_tn(dpre, x), dpre.sum(0), None
+        dw, db = gemm_tn(dpre, x, colsum=True)
+        return dpre @ w, dw, db, None
 
 
 def linear_relu_cached(x, linear, f):
@@ -326,12 +327,14 @@ def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs):
             raise RuntimeError("atr_lstm_cell_backward failed (%d)" % rc)
         torch.bmm(dG[:, t], whh_t, out=dhn)                                   # gradient into h_{t-1}
     # W_hh: sum_t (k_{t-1} h_{t-1})^T dG_t as one GEMM per player over all T*N rows
-    kprev = torch.cat([torch.ones_like(keep[:1]), keep[:-1]], 0).view(1, T, N, 1)
-    hm = (h_all[:, :T] * kprev).view(P, T * N, R)
+    kprev = torch.cat([torch.ones_like(keep[:1]), keep[:-1]], 0)              # [T, N]: mask on h_{t-1}
     dG = dG.view(P, T * N, 4 * R)
     if use_gemm_tn and R % 128 == 0 and T * N >= 4096:
-        dwhh = torch.stack([gemm_tn(hm[p], dG[p]) for p in range(P)], 0)
+        # the mask is applied to h's rows on their way into the GEMM kernel's LDS tiles
+        dwhh = torch.stack([gemm_tn(h_all[p, :T].reshape(T * N, R), dG[p], row_scale=kprev.reshape(T * N))
+                            for p in range(P)], 0)
     else:
+        hm = (h_all[:, :T] * kprev.view(1, T, N, 1)).view(P, T * N, R)
         dwhh = torch.bmm(hm.transpose(1, 2), dG)
     return dG, dhn, dcc, dwhh
 
@@ -357,9 +360,9 @@ class _LstmSeqCached(torch.autograd.Function):
         feats, wih = ctx.saved_tensors[5:5 + P], ctx.saved_tensors[5 + P:5 + 2 * P]
         dG, _, _, dwhh = _lstm_bptt(whh, keep, h_all, c_all, acts, dhs)
         dfeat = [dG[p] @ wih[p] for p in range(P)]
-        dwih = [gemm_tn(dG[p], feats[p]) for p in range(P)]
+        pairs = [gemm_tn(dG[p], feats[p], colsum=True) for p in range(P)]
+        dwih, db = [a for a, _ in pairs], [b for _, b in pairs]
         dwhh_l = [dwhh[p].t() for p in range(P)]
-        db = [dG[p].sum(0) for p in range(P)]
         return (None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + tuple(db)
 
 
@@ -480,9 +483,11 @@ use_gemm_tn = True
 
 
 @torch.no_grad()
-def gemm_tn(x1, x2):
+def gemm_tn(x1, x2, row_scale=None, colsum=False):
     """x1.t() @ x2 for tall row-major x1 [K,M], x2 [K,N] — the weight-gradient GEMMs (csrc/gemm_tn_hip.hip) when the
-    shape fits the kernel (CUDA fp32, contiguous, M and N multiples of 128), otherwise the library GEMM."""
+    shape fits the kernel (CUDA fp32, contiguous, M and N multiples of 128), otherwise the library GEMM.
+    row_scale [K]: x1's rows are multiplied by it first; colsum=True: also return (scaled x1).sum(0) — the bias
+    gradient that goes with the weight gradient — from the same pass."""
     K, M = x1.shape
     N = x2.shape[1]
     if (use_gemm_tn and x1.is_cuda and x1.dtype == torch.float32 and x2.dtype == torch.float32 and M % 128 == 0
@@ -490,8 +495,13 @@ def gemm_tn(x1, x2):
         L = lib()
         ws = torch.empty(L.atr_gemm_tn_workspace_floats(K, M, N), dtype=torch.float32, device=x1.device)
         c = torch.empty((M, N), dtype=torch.float32, device=x1.device)
-        rc = L.atr_gemm_tn(_p(x1), _p(x2), _p(c), _p(ws), K, M, N, _stream(x1))
+        cs = torch.empty(M, dtype=torch.float32, device=x1.device) if colsum else None
+        rs = row_scale.contiguous() if row_scale is not None else None
+        rc = L.atr_gemm_tn(_p(x1), _p(x2), _p(c), _p(ws), K, M, N, _pn(rs), _pn(cs), _stream(x1))
         if rc != 0:
             raise RuntimeError("atr_gemm_tn failed (%d)" % rc)
-        return c
-    return x1.t() @ x2
+        return (c, cs) if colsum else c
+    if row_scale is not None:
+        x1 = x1 * row_scale.unsqueeze(1)
+    c = x1.t() @ x2
+    return (c, x1.sum(0)) if colsum else c

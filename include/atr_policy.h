@@ -99,9 +99,12 @@ int atr_heads_loss(const float *h, const long long *actions, const float *ret, c
 
 /* C [M,N] = X1^T X2 for tall row-major X1 [K,M], X2 [K,N] (the learner's weight-gradient GEMMs: K = T*N_envs rows;
  * M, N multiples of 128), fp32 on the f32 matrix cores with split-K and a fixed-order reduction (reproducible).
+ * Optional: row_scale [K] (nullable) multiplies row k of X1 first (the episode mask of dW_hh = (k h)^T dG); colsum [M]
+ * (nullable) receives the column sums of the (scaled) X1 — the bias gradient that goes with the weight gradient.
  * workspace: atr_gemm_tn_workspace_floats(K, M, N) floats (-1 for unsupported shapes). */
 long long atr_gemm_tn_workspace_floats(long long K, int M, int N);
-int atr_gemm_tn(const float *x1, const float *x2, float *c, float *workspace, long long K, int M, int N, void *stream);
+int atr_gemm_tn(const float *x1, const float *x2, float *c, float *workspace, long long K, int M, int N,
+                const float *row_scale, float *colsum, void *stream);
 
 #ifdef __cplusplus
 }

@@ -248,3 +248,9 @@ def test_gemm_tn_matches_float64_reference(K, M, N):
     assert float((c.double() - ref).abs().max()) < 3e-5 * K ** 0.5 * 4
     c2 = fused.gemm_tn(x1, x2)
     assert torch.equal(c, c2)                                   # fixed reduction order: bit-reproducible
+    # fused extras: row scaling of x1 (the episode mask of dW_hh) and the column sums (the bias gradient)
+    scale = (torch.rand(K, device="cuda") > 0.2).float()
+    cs_, colsum = fused.gemm_tn(x1, x2, row_scale=scale, colsum=True)
+    xs = x1.double() * scale.double().unsqueeze(1)
+    assert float((cs_.double() - xs.t() @ x2.double()).abs().max()) < 3e-5 * K ** 0.5 * 4
+    assert float((colsum.double() - xs.sum(0)).abs().max()) < 3e-5 * K ** 0.5 * 4
