@@ -156,13 +156,15 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float *__restrict_
     *reinterpret_cast<float4 *>(c + i) = acc;
 }
 
+// one wavefront per column: lanes stride over the slices, then a fixed-order butterfly
 __global__ __launch_bounds__(256) void k_gemm_tn_colsum(const float *__restrict__ partial, float *__restrict__ out, int slices, int M)
 {
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= M) return;
+    const int col = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63u);
+    if (col >= M) return;
     float acc = 0.f;
-    for (int z = 0; z < slices; z++) acc += partial[(size_t)z * M + i];
-    out[i] = acc;
+    for (int z = lane; z < slices; z += 64) acc += partial[(size_t)z * M + col];
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) out[col] = acc;
 }
 
 static void gemm_tn_plan(long long K, int M, int N, int *slices, int *chunks_per_slice)
@@ -203,6 +205,6 @@ extern "C" int atr_gemm_tn(const float *x1, const float *x2, float *c, float *wo
                        slices, cps, row_scale, cs_partial);
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, workspace, c, slices, mn);
     if (colsum)
-        hipLaunchKernelGGL(k_gemm_tn_colsum, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, cs_partial, colsum, slices, M);
+        hipLaunchKernelGGL(k_gemm_tn_colsum, dim3((unsigned)((M * 64 + 255) / 256)), dim3(256), 0, st, cs_partial, colsum, slices, M);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
