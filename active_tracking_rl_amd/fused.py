@@ -1,8 +1,17 @@
-"""Fused policy-side HIP kernels (include/atr_policy.h) as autograd functions.
+"""ctypes + autograd bindings of the policy-side HIP kernels (include/atr_policy.h). GPU tensors only — on CPU tensors the
+model evaluates the same network with plain PyTorch ops (model.CNN_maze.forward_dense_stem / forward_conv2d, nn.LSTMCell).
 
-stem(x, conv1, conv2): CNN_maze's conv(1->16,k3,s2,p1)+ReLU+conv(16->32,k3,s2,p1)+ReLU on [M,169] frames in one
-launch forward and three launches backward (csrc/stem_hip.hip). Used on CUDA/ROCm tensors; on CPU tensors the
-model evaluates the same network with plain PyTorch ops (model.CNN_maze.forward_dense / forward_conv2d)."""
+  stem / stem_into / stem_into2 / stem_cached   CNN_maze's conv(1->16,k3,s2,p1)+ReLU+conv(16->32,k3,s2,p1)+ReLU on
+                                                13x13 frames: one launch forward, two backward (csrc/stem_hip.hip)
+  lstm_cell / lstm_cell_into / lstm_cell_act_into, lstm_sequence(_cached)
+                                                masked LSTMCell step(s), the actor's cell + head + draw in one launch,
+                                                the whole recurrence as one autograd node (csrc/lstm_hip.hip)
+  ActionSampler                                 actor head + categorical draw (csrc/policy_hip.hip)
+  gae_returns, heads_values, heads_loss         returns / GAE, critic values, heads + A3C loss terms with analytic
+                                                gradients (csrc/lstm_hip.hip, csrc/heads_hip.hip)
+  gemm_tn                                       weight-gradient GEMMs x1^T x2 (+ bias gradient, row mask) on the f32
+                                                matrix cores (csrc/gemm_tn_hip.hip)
+  linear_relu_cached, lstm_sequence_cached      cached-forward autograd nodes of the rollout cache (model.RolloutCache)"""
 import ctypes as C
 
 import torch
