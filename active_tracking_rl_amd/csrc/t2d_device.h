@@ -264,34 +264,40 @@ __device__ __forceinline__ void gen_block(uint32_t *tile, int lane, S &ms, doubl
 }
 
 // RandomMazeGenerator._generate_maze — G/envs/generators.py:115-145 (81x81). Inherently sequential (every step
-// depends on the walls laid so far), so it is one wave-uniform loop made as short as possible:
-//   * the algorithm only ever READS cells at even coordinates ("nodes", a 41x41 grid); their occupancy lives in
-//     registers — lane y holds node row y as 41 bits — and is read/updated with readlane/writelane, no LDS round trip;
-//   * the full-resolution tile (nodes + the carved midpoints) is write-only here: lane 0 fires LDS stores;
-//   * random words come from the 64-block VStream (one readlane per draw).
+// depends on the walls laid so far), so it is one wave-uniform loop made as short as possible. Walls are only ever
+// laid on three kinds of cells, each kept as a register bitmap with one row per lane for the whole loop:
+//   nodes  (y even, x even): lane y/2, bit x/2 — the only cells the algorithm READS (readlane, no LDS round trip);
+//   hmid   (y even, x odd) : lane y/2, bit (x-1)/2 — the midpoint carved by a horizontal move;
+//   vmid   (y odd, x even) : lane (y-1)/2, bit x/2 — the midpoint carved by a vertical move
+// (odd/odd cells stay free). A wall is a predicated OR into the owning lane's register; the bit-packed tile is
+// assembled once at the end by interleaving the bitmaps (bit i -> bit 2i). Random words come from the 64-block VStream
+// (one readlane per draw).
+__device__ __forceinline__ uint32_t spread16(uint32_t v)   // bit i of the low 16 bits -> bit 2i
+{
+    v &= 0xffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
 template <class S>
 __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double ratio)
 {
     const int SZ = 81;
-    tile_clear(tile, lane);
-    wave_lds_sync();
-    tile_border(tile, SZ, lane);
-    wave_lds_sync();
     const int complexity = (int)(ratio * 810.0);
     const int density = (int)(ratio * 1600.0);
-    // node rows: bit x/2 of row y/2; border nodes are walls
-    uint32_t nlo = 0u, nhi = 0u;
-    if (lane == 0 || lane == 40) { nlo = 0xffffffffu; nhi = 0x1ffu; }
+    // border walls (generators.py:127-128): rows 0 / 80 entirely, columns 0 / 80 of every row
+    uint32_t nlo = 0u, nhi = 0u, hlo = 0u, hhi = 0u, vlo = 0u, vhi = 0u;
+    if (lane == 0 || lane == 40) { nlo = 0xffffffffu; nhi = 0x1ffu; hlo = 0xffffffffu; hhi = 0xffu; }
     else if (lane < 40) { nlo = 1u; nhi = 0x100u; }
+    if (lane < 40) { vlo = 1u; vhi = 0x100u; }
     auto node_get = [&](int ny, int nx) -> uint32_t {
         const uint32_t lo = __builtin_amdgcn_readlane(nlo, ny), hi = __builtin_amdgcn_readlane(nhi, ny);
         return nx < 32 ? (lo >> nx) & 1u : (hi >> (nx - 32)) & 1u;
     };
-    auto node_set = [&](int ny, int nx) {
-        if (lane == ny) { if (nx < 32) nlo |= 1u << nx; else nhi |= 1u << (nx - 32); }
-    };
-    auto set = [&](int y, int x) { // fire-and-forget ds_or_b32: the loop never reads the tile back
-        if (lane == 0) atomicOr(&tile[y * kRowWords + (x >> 5)], 1u << (x & 31));
+    auto bit_set = [&](uint32_t &lo, uint32_t &hi, int row, int idx) {
+        if (lane == row) { if (idx < 32) lo |= 1u << idx; else hi |= 1u << (idx - 32); }
     };
     // k-th present candidate of the neighbour list [(y,x-2) if x>1, (y,x+2) if x<S-2, (y-2,x) if y>1, (y+2,x) if
     // y<S-2] (generators.py:135-138) as a table: entry (mask, k) = direction 0..3, 2 bits each.
@@ -310,8 +316,7 @@ __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double
     for (int i = 0; i < density; i++) {
         int x = (int)ms.bounded(40u) * 2;
         int y = (int)ms.bounded(40u) * 2;
-        set(y, x);
-        node_set(y >> 1, x >> 1);
+        bit_set(nlo, nhi, y >> 1, x >> 1);
         for (int j = 0; j < complexity; j++) {
             const int m = (int)(x > 1) | ((int)(x < SZ - 2) << 1) | ((int)(y > 1) << 2) | ((int)(y < SZ - 2) << 3);
             const int n = __popc((unsigned)m);
@@ -321,12 +326,27 @@ __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double
             const int step = (d & 1) * 4 - 2;                    // -2 for directions 0/2, +2 for 1/3
             const int x_ = x + ((d & 2) ? 0 : step), y_ = y + ((d & 2) ? step : 0);
             if (node_get(y_ >> 1, x_ >> 1) == 0u) {
-                set(y_, x_);
-                set(y_ + (y - y_) / 2, x_ + (x - x_) / 2);
-                node_set(y_ >> 1, x_ >> 1);
+                bit_set(nlo, nhi, y_ >> 1, x_ >> 1);             // Z[y_, x_] = 1
+                if (d & 2) bit_set(vlo, vhi, min(y, y_) >> 1, x >> 1);       // Z[y_ + (y - y_) // 2, x_ + (x - x_) // 2] = 1
+                else bit_set(hlo, hhi, y >> 1, min(x, x_) >> 1);
                 x = x_; y = y_;
             }
         }
+    }
+    // assemble the tile: even row 2j = nodes_j interleaved with hmid_j; odd row 2j+1 = vmid_j on the even columns
+    tile_clear(tile, lane);
+    wave_lds_sync();
+    if (lane <= 40) {
+        uint32_t *r = tile + (2 * lane) * kRowWords;
+        r[0] = spread16(nlo) | (spread16(hlo) << 1);
+        r[1] = spread16(nlo >> 16) | (spread16(hlo >> 16) << 1);
+        r[2] = spread16(nhi) | (spread16(hhi) << 1);
+    }
+    if (lane < 40) {
+        uint32_t *r = tile + (2 * lane + 1) * kRowWords;
+        r[0] = spread16(vlo);
+        r[1] = spread16(vlo >> 16);
+        r[2] = spread16(vhi);
     }
     wave_lds_sync();
 }
