@@ -23,9 +23,16 @@ constexpr int kHeadsBlock = 256;
 
 __device__ __forceinline__ float4 h_ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float dot4(const float4 &a, const float4 &b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+// sum over the L = 16 / 32 / 64 lanes that hold one row: within a 16-lane DPP row on the crossbar (quad permutes, then
+// row rotations by 4 and 8), across rows through the permute network
 __device__ __forceinline__ float row_sum(float v, int L)
 {
-    for (int m = 1; m < L; m <<= 1) v += __shfl_xor(v, m, 64);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124 /* row_ror:4 */, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, true));
+    if (L > 16) v += __shfl_xor(v, 16, 64);
+    if (L > 32) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
