@@ -19,35 +19,45 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-# ---- initialisers (utils.py:30-33,47-72) ---------------------------------------------------------------
+# ---- initialisers ---------------------------------------------------------------------------------------
+# Same numerics and the same consumption of torch's global RNG as utils.py:30-33,47-72 of the reference (one
+# randn / uniform_ / normal_ of the weight's shape per call, in the same order), so seeded inits agree.
+def _glorot_bound(fan_in, fan_out):
+    return float(np.sqrt(6.0 / (fan_in + fan_out)))
+
+
 def norm_col_init(weights, std=1.0):
-    x = torch.randn(weights.size())
-    x *= std / torch.sqrt((x ** 2).sum(1, keepdim=True))
-    return x
+    """Gaussian rows rescaled to Euclidean norm `std` (utils.py:30-33)."""
+    g = torch.randn(weights.size())
+    return g * (std / g.pow(2).sum(1, keepdim=True).sqrt())
 
 
+@torch.no_grad()
 def weights_init(m):
-    classname = m.__class__.__name__
-    if classname.find('Conv') != -1:
-        weight_shape = list(m.weight.data.size())
-        fan_in = np.prod(weight_shape[1:4])
-        fan_out = np.prod(weight_shape[2:4]) * weight_shape[0]
-        w_bound = np.sqrt(6. / (fan_in + fan_out))
-        m.weight.data.uniform_(-w_bound, w_bound)
-        m.bias.data.fill_(0)
-    elif classname.find('Linear') != -1:
-        weight_shape = list(m.weight.data.size())
-        w_bound = np.sqrt(6. / (weight_shape[1] + weight_shape[0]))
-        m.weight.data.uniform_(-w_bound, w_bound)
-        m.bias.data.fill_(0)
+    """Glorot-uniform weights, zero biases for every Conv* / *Linear* module (utils.py:47-62). For a conv kernel
+    [O, I, kh, kw] the fans are I*kh*kw and O*kh*kw; for a linear layer [O, I] they are I and O."""
+    kind = type(m).__name__
+    if 'Conv' in kind:
+        o, i, kh, kw = m.weight.shape
+        bound = _glorot_bound(i * kh * kw, o * kh * kw)
+    elif 'Linear' in kind:
+        o, i = m.weight.shape
+        bound = _glorot_bound(i, o)
+    else:
+        return
+    m.weight.uniform_(-bound, bound)
+    m.bias.zero_()
 
 
+@torch.no_grad()
 def weights_init_mlp(m):
-    if m.__class__.__name__.find('Linear') != -1:
-        m.weight.data.normal_(0, 1)
-        m.weight.data *= 1 / torch.sqrt(m.weight.data.pow(2).sum(1, keepdim=True))
-        if m.bias is not None:
-            m.bias.data.fill_(0)
+    """Unit-norm Gaussian rows, zero bias, Linear modules only (utils.py:65-72)."""
+    if 'Linear' not in type(m).__name__:
+        return
+    m.weight.normal_(0, 1)
+    m.weight.mul_(m.weight.pow(2).sum(1, keepdim=True).sqrt().reciprocal())
+    if m.bias is not None:
+        m.bias.zero_()
 
 
 def build_model(obs_space, action_space, args, device):

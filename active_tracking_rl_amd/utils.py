@@ -3,21 +3,21 @@ Weight initialisers live in model.py; ensure_shared_grads is replaced by Agent.a
 import logging
 import os
 
+_LOG_FORMAT = '%(asctime)s : %(message)s'
+
 
 def setup_logger(logger_name, log_file, level=logging.INFO):
-    l = logging.getLogger(logger_name)
-    if l.handlers:          # the evaluator is called once per round here (a forked process in the reference)
-        return
-    formatter = logging.Formatter('%(asctime)s : %(message)s')
-    fileHandler = logging.FileHandler(log_file, mode='w')
-    fileHandler.setFormatter(formatter)
-    streamHandler = logging.StreamHandler()
-    streamHandler.setFormatter(formatter)
-    l.setLevel(level)
-    l.addHandler(fileHandler)
-    l.addHandler(streamHandler)
+    """Named logger writing to `log_file` (truncated) and to stderr, one '<time> : <message>' line per record
+    (utils.py:11-21). Idempotent: the evaluator calls this once per round here (a forked process in the reference)."""
+    log = logging.getLogger(logger_name)
+    if log.handlers:
+        return log
+    log.setLevel(level)
+    for handler in (logging.FileHandler(log_file, mode='w'), logging.StreamHandler()):
+        handler.setFormatter(logging.Formatter(_LOG_FORMAT))
+        log.addHandler(handler)
+    return log
 
 
 def check_path(path):
-    if not os.path.exists(path):
-        os.makedirs(path, exist_ok=True)
+    os.makedirs(path, exist_ok=True)
