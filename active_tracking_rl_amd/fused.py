@@ -445,7 +445,8 @@ class _HeadsLoss(torch.autograd.Function):
     out. The output must enter the objective with coefficient 1 (Agent.loss_recompute adds the players' terms)."""
 
     @staticmethod
-    def forward(ctx, h, wa, ba, wc, bc, waux, baux, actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent):
+    def forward(ctx, h, wa, ba, wc, bc, waux, baux, actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent,
+                unit_coeff=False):
         L = lib()
         h = h.contiguous()
         rows, R = h.shape
@@ -466,6 +467,7 @@ class _HeadsLoss(torch.autograd.Function):
             raise RuntimeError("atr_heads_loss failed (%d)" % rc)
         ctx.save_for_backward(dh, gs)
         ctx.dims = (A, R, waux is not None)
+        ctx.unit_coeff = bool(unit_coeff)
         stats = gs[rec - 4:rec]
         ctx.mark_non_differentiable(stats)
         return gs[rec], stats
@@ -475,17 +477,23 @@ class _HeadsLoss(torch.autograd.Function):
         dh, gs = ctx.saved_tensors
         A, R, has_aux = ctx.dims
         o = (A + 2) * R
+        if not ctx.unit_coeff:          # the kernel's gradients are those of coefficient 1: apply the incoming one
+            dh, gs = dh * gloss, gs * gloss
         dwa, dwc, dwx = gs[:A * R].view(A, R), gs[A * R:(A + 1) * R].view(1, R), gs[(A + 1) * R:o].view(1, R)
         dba, dbc, dbx = gs[o:o + A], gs[o + A:o + A + 1], gs[o + A + 1:o + A + 2]
-        return (dh, dwa, dba, dwc, dbc, dwx if has_aux else None, dbx if has_aux else None) + (None,) * 10
+        return (dh, dwa, dba, dwc, dbc, dwx if has_aux else None, dbx if has_aux else None) + (None,) * 11
 
 
-def heads_loss(h, actor, critic, aux, actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent):
+def heads_loss(h, actor, critic, aux, actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent,
+               unit_coeff=False):
     """-> (objective contribution (0-dim, differentiable w.r.t. h and the head parameters),
-           stats [4] = unscaled sums: policy term, value term, entropy, |aux error|)."""
+           stats [4] = unscaled sums: policy term, value term, entropy, |aux error|).
+    unit_coeff=True promises that the contribution enters the differentiated objective with coefficient exactly 1
+    (Agent._loss_fused_heads adds the players' terms and differentiates the sum): backward then hands out the
+    kernel's gradients as they are instead of scaling them by the incoming gradient."""
     return _HeadsLoss.apply(h, actor.weight, actor.bias, critic.weight, critic.bias,
                             aux.weight if aux is not None else None, aux.bias if aux is not None else None,
-                            actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent)
+                            actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent, unit_coeff)
 
 
 use_gemm_tn = True

@@ -328,7 +328,7 @@ class Agent(object):
             lp, st = fused.heads_loss(h_seq[p].reshape(T * N, R_dim), players[p].actor.actor_linear,
                                       players[p].critic.critic_linear, aux, actions[:, :, p].reshape(T * N), R, gae, v, p,
                                       rew_c if aux is not None else None, 0, scale[p], scale_aux if aux is not None else 0.0,
-                                      w_ent[p])
+                                      w_ent[p], unit_coeff=True)   # summed and differentiated as is
             loss = loss + lp
             stats.append(st)
         st = torch.stack(stats, 0) / N                                       # [A, 4]: policy, value, entropy, |aux|

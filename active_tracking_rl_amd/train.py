@@ -94,7 +94,12 @@ class GraphedIteration(object):
     from the loop. The gradient all-reduce stays an eager RCCL call between the two graphs, so the captured
     regions contain no collective. State carried between iterations (obs, LSTM state, done, episode lengths) lives
     in static tensors that the captured region reads first and writes last; the env state itself is device-resident
-    inside the HIP library."""
+    inside the HIP library.
+
+    The training mode (which player's loss is differentiated, player_util.py:147-152) is a constant of the captured
+    loss, so there is ONE rollout graph PER MODE, captured the first time `run(mode)` sees it: the evaluator's
+    `train_modes[rank]` schedule (test.py:84-92: tracker-only until --init-step) selects the graph per iteration.
+    All graphs read and write the same carry tensors, so switching modes does not disturb the env/LSTM state."""
 
     def __init__(self, player, optimizer, args, warmup=2, fast=True):
         self.player, self.optimizer, self.args, self.fast = player, optimizer, args, fast
@@ -108,33 +113,63 @@ class GraphedIteration(object):
         torch.cuda.synchronize(dev)
         self.carry = dict(state=player.state.clone(), hxs=player.hxs.detach().clone(),
                           cxs=player.cxs.detach().clone(), done=player.done.clone(), eps_len=player.eps_len.clone())
-        self.g_roll, self.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.g_rolls, self.stats_by_mode = {}, {}
+        self._capture(args.train_mode)
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
+            optimizer.step()
+
+    def _bind_carry(self):
+        p = self.player
+        p.state, p.hxs, p.cxs = self.carry["state"], self.carry["hxs"], self.carry["cxs"]
+        p.done, p.eps_len = self.carry["done"], self.carry["eps_len"]
+
+    def _capture(self, mode):
+        player, args = self.player, self.args
+        torch.cuda.synchronize(player.device)
+        g = torch.cuda.CUDAGraph()
         # thread_local: an RCCL watchdog thread polling events must not invalidate the capture
-        with torch.cuda.graph(self.g_roll, capture_error_mode="thread_local"):
-            player.state, player.hxs, player.cxs = self.carry["state"], self.carry["hxs"], self.carry["cxs"]
-            player.done, player.eps_len = self.carry["done"], self.carry["eps_len"]
-            rollout(player, args.num_steps, fast=fast)
-            self.stats = player.compute_grads(optimizer, args.train_mode)
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self._bind_carry()
+            rollout(player, args.num_steps, fast=self.fast)
+            stats = player.compute_grads(self.optimizer, mode)
             self.carry["state"].copy_(player.state)
             self.carry["hxs"].copy_(player.hxs.detach())
             self.carry["cxs"].copy_(player.cxs.detach())
             self.carry["done"].copy_(player.done)
             self.carry["eps_len"].copy_(player.eps_len)
-        with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
-            optimizer.step()
-        player.state, player.hxs, player.cxs = self.carry["state"], self.carry["hxs"], self.carry["cxs"]
-        player.done, player.eps_len = self.carry["done"], self.carry["eps_len"]
+        self._bind_carry()
+        self.g_rolls[mode], self.stats_by_mode[mode] = g, stats
+        self.g_roll, self.stats = g, stats          # the most recently captured pair (kept for callers/tools)
+        return g
 
     def _eager(self):
         rollout(self.player, self.args.num_steps, fast=self.fast)
         self.player.optimize(None, self.optimizer, self.player.model, self.args.train_mode, self.player.device)
 
-    def run(self):
-        self.g_roll.replay()
+    def run(self, mode=None):
+        mode = self.args.train_mode if mode is None else int(mode)
+        g = self.g_rolls.get(mode)
+        if g is None:
+            g = self._capture(mode)
+        g.replay()
         self.player.allreduce_grads(self.optimizer)
         self.g_opt.replay()
         self.player.n_steps += self.args.num_steps
+        self.stats = self.stats_by_mode[mode]
         return self.stats
+
+
+def sync_train_modes(train_modes, device, src=0):
+    """Every rank must differentiate the same loss before the all-reduce: rank `src` (the only one running the
+    evaluator, which owns the schedule — test.py:84-92,129-134) broadcasts its train_modes list."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return train_modes
+    t = torch.tensor([int(m) for m in train_modes], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=src)
+    train_modes[:] = [int(v) for v in t.tolist()]
+    return train_modes
 
 
 def train(rank, args, shared_model, optimizer, train_modes, n_iters, env=None):

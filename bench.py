@@ -9,8 +9,14 @@ Workload (config.workload): BASELINE config 3 — Track2D-BlockPartialPZR-v0 (AD
 tat-maze-lstm tracker + target, train-mode -1, 20-step rollouts. A "step" is ONE batched env step of the full
 A3C path: policy forward for both players (PyTorch-ROCm) -> HIP step/observe kernel for all envs (in-launch
 auto-reset) -> every 20th step the n-step/GAE loss, backward, ONE all-reduce of the flat gradient bucket (RCCL)
-and the SharedAdam update. value = (K x envs over all ranks) / max-over-ranks wall time. Weak scaling: 4096 envs
-per GPU, independent shards keyed by global env id.
+and the SharedAdam update. value = (K x envs over all ranks) / max-over-ranks wall time of the MEDIAN of >= 5
+repeats of the K-step region. Weak scaling (`value`): 4096 envs per GPU, independent shards keyed by global env id;
+the strong form of the same metric (4096 envs GLOBAL, 4096/N per GPU — SURVEY §8d's headline) is measured in the same
+run and reported in the `strong` object of the same line.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (re-exec under
+torch.distributed.run on 127.0.0.1, the role main.py:102-116 plays in the reference); it refuses to report unless
+the process group really has N ranks (checked with an all-reduce of ones and an all-gather of the device ids).
 
 Extra objects on the same JSON line:
   roofline     the step/observe kernel (k_env<OP_STEP>): algorithmic bytes (1723 B x envs per launch)
@@ -39,6 +45,62 @@ B_STEP = 1723          # algorithmic bytes per env-step
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """Start `n` ranks of this script under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and return
+    the exit code. Rank 0 prints the JSON line; stdout/stderr are inherited."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def init_ranks(a):
+    """Join the process group (RCCL unless BENCH_DIST_BACKEND says otherwise) and PROVE it has a.gpus ranks.
+    Returns (world, rank, local_rank, info) where info goes into the JSON line."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d — refusing to report a %d-GPU number from %d rank(s)"
+                         % (a.gpus, world, a.gpus, world))
+    # test hooks (not used by the driver): run N ranks on ONE device over gloo to exercise the N>1 code path
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    use_cuda = torch.cuda.is_available()
+    info = {"backend": backend if world > 1 else None, "rccl_ranks": 1, "devices": [local_rank]}
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if use_cuda:
+            torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        dev = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                      # brings the communicator up; the sum counts its ranks
+        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([local_rank], dtype=torch.int64, device=dev))
+        n_comm = int(round(float(ones.item())))
+        if dist.get_world_size() != a.gpus or n_comm != a.gpus:
+            raise SystemExit("bench.py: communicator has %d ranks (world_size %d), expected %d"
+                             % (n_comm, dist.get_world_size(), a.gpus))
+        info.update(rccl_ranks=n_comm, devices=[int(t.item()) for t in ids])
+    return world, rank, local_rank, info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,24 +115,23 @@ def main():
                     help="reference-shaped learner (autograd graph built during the rollout) instead of the "
                          "actor/learner split with time-batched re-evaluation")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K-step region (median reported)")
+    ap.add_argument("--global-envs", type=int, default=4096, help="env count of the strong-scaling form")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, verify the communicator and print a stub line (runs without a GPU "
+                         "with BENCH_DIST_BACKEND=gloo; covers the launcher in the CPU test-suite)")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hooks (not used by the driver): run N ranks on ONE GPU over gloo to exercise the N>1 code path
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+    world, rank, local_rank, comm = init_ranks(a)
+    if a.launch_check:
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, **comm}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -84,48 +145,84 @@ def main():
     from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player, rollout
 
     T = 20
-    steps = max(T, (a.steps + T - 1) // T * T)
-    warm = (a.warmup + T - 1) // T * T
-    args = default_args(env=a.env, network=a.network, num_envs=a.envs_per_gpu, num_steps=T, gpu_ids=[local_rank],
-                        aux="reward" if "tat" in a.network else "none", train_mode=-1)
-    player, optimizer = make_player(args, device, rank, world)
-
-    def eager_iteration():
-        rollout(player, T, fast=not a.per_step_autograd)
-        player.optimize(None, optimizer, player.model, args.train_mode, device)
-
-    iteration, graphed = eager_iteration, False
-    if world > 1:   # bring the communicator up (and its first-call allocations) before any hipGraph capture
-        _w = torch.zeros(1, device=device)
-        dist.all_reduce(_w)
-        torch.cuda.synchronize(device)
-    if not a.no_graph:
-        try:
-            iteration = GraphedIteration(player, optimizer, args, fast=not a.per_step_autograd).run
-            graphed = True
-        except Exception as ex:  # fall back to eager, and say so in the JSON line
-            print("hipGraph capture failed, running eagerly: %r" % (ex,), file=sys.stderr)
-            torch.cuda.synchronize(device)
-    for _ in range(max(1, warm // T)):
-        iteration()
+    steps = max(T, (a.steps + T - 1) // T * T)          # an A3C iteration is T env steps + one update
+    warm = max(T, (a.warmup + T - 1) // T * T)
+    repeats = max(1, a.repeats)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(steps // T):
-        iteration()
-    fence()
-    dt = time.perf_counter() - t0
+    def measure(envs_per_gpu):
+        """Build the player for `envs_per_gpu` envs on this rank, warm up, then time `repeats` repeats of `steps` env
+        steps, each bracketed by barrier + synchronize; per repeat the MAX over ranks; returns the median repeat."""
+        args = default_args(env=a.env, network=a.network, num_envs=envs_per_gpu, num_steps=T, gpu_ids=[local_rank],
+                            aux="reward" if "tat" in a.network else "none", train_mode=-1)
+        player, optimizer = make_player(args, device, rank, world)
+
+        def eager_iteration():
+            rollout(player, T, fast=not a.per_step_autograd)
+            player.optimize(None, optimizer, player.model, args.train_mode, device)
+
+        iteration, graphed = eager_iteration, False
+        if not a.no_graph:
+            try:
+                iteration = GraphedIteration(player, optimizer, args, fast=not a.per_step_autograd).run
+                graphed = True
+            except Exception as ex:  # fall back to eager, and say so in the JSON line
+                print("hipGraph capture failed, running eagerly: %r" % (ex,), file=sys.stderr)
+                torch.cuda.synchronize(device)
+        for _ in range(warm // T):
+            iteration()
+        times = []
+        for _ in range(repeats):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps // T):
+                iteration()
+            fence()
+            times.append(time.perf_counter() - t0)
+        tt = torch.tensor(times, dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ts = sorted(tt.tolist())
+        med = ts[len(ts) // 2]
+        ar_us = None
+        if world > 1:   # the one collective of the path, timed alone: flat fp32 gradient bucket, eager, back to back
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(5):
+                player.allreduce_grads(optimizer)
+            fence()
+            e0.record()
+            for _ in range(50):
+                player.allreduce_grads(optimizer)
+            e1.record()
+            torch.cuda.synchronize(device)
+            tu = torch.tensor([e0.elapsed_time(e1) * 1e3 / 50], dtype=torch.float64, device=device)
+            dist.all_reduce(tu, op=dist.ReduceOp.MAX)
+            ar_us = float(tu.item())
+        res = {"value": steps * envs_per_gpu * world / med, "ms_per_step": med * 1e3 / steps,
+               "envs_per_gpu": envs_per_gpu, "global_envs": envs_per_gpu * world, "repeats": repeats,
+               "spread": {"min_ms_per_step": ts[0] * 1e3 / steps, "max_ms_per_step": ts[-1] * 1e3 / steps},
+               "hipgraph": graphed, "allreduce_us": ar_us,
+               "allreduce_elems": int(optimizer.bucket.grad.numel()) if hasattr(optimizer, "bucket") else None}
+        return res, player, optimizer, args
+
+    # strong form first (4096 envs GLOBAL, sharded), then the weak form whose player also serves the kernel sections
+    strong = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    n_total = a.envs_per_gpu * world
-    value = steps * n_total / dt
+        per = a.global_envs // world
+        strong, p_, o_, _ = measure(per)
+        strong["scaling"] = "strong"
+        p_.env.close()
+        del p_, o_
+        torch.cuda.empty_cache()
+    weak, player, optimizer, args = measure(a.envs_per_gpu)
+    graphed = weak["hipgraph"]
+    value, n_total = weak["value"], a.envs_per_gpu * world
+    if strong is None:
+        strong = dict(weak, scaling="strong", note="N=1: the strong and weak forms coincide")
 
     # ---- roofline of the step/observe kernel: HIP events on the launch stream --------------------------
     # M policy-shaped launches (int64 action tensors, fresh per launch) are captured once into a hipGraph and
@@ -248,8 +345,14 @@ def main():
         pass
     line = {
         "metric": "env steps/sec, Track2D-BlockPartialPZR-v0 @4096 envs, 1/2/4/8 GPU",
-        "value": value, "unit": "env steps/s", "n_gpus": world, "steps": steps, "warmup": warm,
-        "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": value, "unit": "env steps/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+        "warmup_effective": warm, "steps_requested": a.steps, "repeats": repeats, "spread": weak["spread"],
+        "ms_per_step": weak["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "rccl_ranks": comm["rccl_ranks"], "devices": comm["devices"], "dist_backend": comm["backend"],
+        "allreduce_us": weak["allreduce_us"], "allreduce_elems": weak["allreduce_elems"],
+        "weak": {k: weak[k] for k in ("value", "ms_per_step", "envs_per_gpu", "global_envs", "allreduce_us")},
+        "strong": {k: strong[k] for k in ("value", "ms_per_step", "envs_per_gpu", "global_envs", "allreduce_us",
+                                          "spread") if k in strong},
         "dtype": "u8 map bits / f64 reward -> f32 obs+reward; policy fp32", "data": "synthetic",
         "config": {"workload": "%s, %d envs/GPU x %d GPU, %s tracker+target, train-mode -1, 20-step A3C rollouts "
                                "(policy fwd + HIP env step + loss/backward + grad all-reduce + SharedAdam)"

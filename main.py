@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from active_tracking_rl_amd import build
 from active_tracking_rl_amd.test import test
-from active_tracking_rl_amd.train import GraphedIteration, make_player
+from active_tracking_rl_amd.train import GraphedIteration, make_player, sync_train_modes
 
 parser = argparse.ArgumentParser(description='A3C (MI355X data-parallel)')
 parser.add_argument('--lr', type=float, default=0.001, metavar='LR', help='learning rate (2D: 0.001, 3D: 0.0001)')
@@ -84,13 +84,21 @@ if __name__ == '__main__':
     if args.load_model_dir is not None:
         saved_state = torch.load(args.load_model_dir, map_location=lambda storage, loc: storage)
         player.model.load_state_dict(saved_state)
-    train_modes, n_iters = [args.train_mode] * world, [0] * world
+    if args.optimizer != 'Adam':
+        raise SystemExit("--optimizer %s: only Adam (SharedAdam numerics, shared_optim.py:90-175) is built; "
+                         "SharedRMSprop is out of the Track2D scope (DESIGN.md section 8)" % args.optimizer)
+    # until the evaluator first speaks, the schedule of test.py:84-92 applies from iteration 0: tracker only while
+    # n_iter < --init-step
+    first_mode = 0 if args.init_step > 0 else args.train_mode
+    train_modes, n_iters = [first_mode] * world, [0] * world
     step = GraphedIteration(player, optimizer, args).run if not args.no_graph else None
     it = 0
     eval_state = {}
     while True:
+        if train_modes[rank] == -100:                       # the evaluator's stop sentinel (test.py:129-134)
+            break
         if step is not None:
-            step()
+            step(train_modes[rank])                         # one hipGraph per training mode (test.py:84-92 schedule)
         else:
             from active_tracking_rl_amd.train import rollout
             rollout(player, args.num_steps)
@@ -100,8 +108,7 @@ if __name__ == '__main__':
         if it % args.test_every == 0 or it > args.max_step:
             if rank == 0:
                 test(args, player.model, train_modes, n_iters, rounds=1, state=eval_state)
-            if world > 1:
-                dist.barrier()
+            sync_train_modes(train_modes, device)           # rank 0 owns the schedule; a broadcast is also a barrier
         if it > args.max_step:
             break
     player.env.close()
