@@ -20,6 +20,10 @@
 #include "../../include/track2d.h"
 #include "t2d_device.h"
 
+#ifndef T2D_EXP
+#define T2D_EXP 0
+#endif
+
 namespace t2d {
 
 struct DevState {
@@ -482,6 +486,274 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
   }
 }
 
+// =====================================================================================================
+// k_step2 — the step + observe kernel of every handle without Nav/RPF targets and with 'Partial' observations
+// (all BASELINE configs but the Nav one). Same semantics as k_env<OP_STEP> (track_1v1.py:71-127,271-326), laid out
+// for the two limits k_env hit: VALU issue at large N (~450 instructions per env-wave) and latency at N = 4096.
+//
+//   * TWO envs per wavefront: lane = slot(1) | agent(1) | k(4). An env pair's observations are 2 x 1352 B = 169 x
+//     16 B, so every lane streams them out as three `global_store_dwordx4` (8-B stores run at 0.54-0.70x the 16-B
+//     rate on this chip).
+//   * Only the map rows the step can touch are fetched: lane k < 15 of an agent's group loads row r_old - 7 + k (12 B,
+//     one dwordx3 load; rows outside the map read as walls). Those 15 rows contain the four move targets AND the 13
+//     window rows of whichever cell the agent ends on, so the row loads depend on nothing but the state load: 360 B
+//     per env instead of the 1 KiB tile, and no second dependent round trip for the wall test.
+//   * The reward-table entries of the four possible outcomes (each agent moves or bumps) are fetched speculatively
+//     together with the rows; the wall test is one wave ballot.
+//   * Observation: the lane that HOLDS a row turns it into the 13 window bits (v_alignbit over the row words with
+//     ones outside the map) and parks them as one dword in LDS; agent colours go into a zeroed 676-byte mark plane.
+//     Each lane then builds its three 4-cell output groups straight from two row dwords and one mark dword
+//     (bit -> byte spread by one 24-bit multiply, v_cvt_f32_ubyteN): no per-cell staging pass.
+//   * The episode switch (rare) is a wave-uniform side path: whole-tile copy by all 64 lanes, then the rows are
+//     re-read for the first observation of the next episode.
+// OBS: 0 = f32 observations, 16-B stores (pointer and per-step stride 16-B aligned); 1 = f32, 4-B stores (any
+// alignment); 2 = u8 observations [N,2,13,13] (the B_step = 709 variant of SURVEY 8d; the policy stem decodes them).
+enum : int { OBS_F32_VEC4 = 0, OBS_F32_SCALAR = 1, OBS_U8 = 2 };
+constexpr int kStage2Rows = 56;                     // 52 window rows of the pair (+1 read past the end, +pad)
+constexpr int kStage2Words = kStage2Rows + 172;     // + 169 dwords of mark bytes
+
+template <bool RANDOM, bool MULTI, int ADT, int OBS, bool RAM>
+__global__ __launch_bounds__(256) void k_step2(DevState s, const void *act0, const void *act1, void *obs, float *rew,
+                                               uint8_t *done_out, uint32_t aseed_lo, uint32_t aseed_hi,
+                                               uint32_t step_idx, uint32_t stamp, int nsteps)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stage2[kWavesPerBlock][kStage2Words];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int e0 = ((int)blockIdx.x * kWavesPerBlock + wave) * 2;
+    if (e0 >= s.n) return;
+    const int sl = lane >> 5, ag = (lane >> 4) & 1, k = lane & 15;
+    const bool live = e0 + sl < s.n;            // false only for slot 1 of the last pair of an odd batch
+    const int e = live ? e0 + sl : e0;          // a dead slot shadows slot 0 (loads only; it never votes or stores)
+    const bool leader = live && ag == 0 && k == 15;   // one lane per env: reward table, rew/done, state write-back
+    uint32_t *st = stage2[wave];
+    uint32_t *mk = st + kStage2Rows;
+
+    // T2D_EXP (compile-time, 0 in the product build): latency probes behind the N = 4096 numbers in DESIGN.md section 3 —
+    // 5 = empty kernel (launch floor), 7 = state loads -> one store, 8 = state -> rows + reward table -> one store,
+    // 6 = s_memtime timeline (tools/timeline_probe.py); built and timed by tools/exp_variants.sh.
+    if (T2D_EXP == 5) { if (lane == 0) done_out[e0] = 0; return; }
+#if T2D_EXP == 6
+    // timeline probe: s_memtime stamps of this wave, parked in the spare words 246..253 of the env's tile
+    uint32_t *tstamp = s.maps + (size_t)(live ? e0 + sl : e0) * kTileWords + 246;
+#define T2D_STAMP(i) do { if (leader) tstamp[i] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define T2D_STAMP(i) do { } while (0)
+#endif
+    T2D_STAMP(0);
+    uint32_t pos = s.pos[e], cnt = s.cnt[e];
+    const uint32_t cfg = s.cfg[e];
+    long long act_raw0 = 0, act_raw1 = 0;
+    if (!RANDOM) {
+        act_raw0 = load_action_raw<ADT>(act0, e);
+        act_raw1 = load_action_raw<ADT>(act1, e);
+    }
+    if (T2D_EXP == 7) {   // latency probe: level-1 loads -> one store
+        if (leader) done_out[e] = (uint8_t)((pos ^ cnt ^ cfg ^ (uint32_t)act_raw0 ^ (uint32_t)act_raw1) & 1u);
+        return;
+    }
+    {   // every kernel argument the step needs, fetched NOW (one scalar round trip under the state loads' latency)
+        // instead of lazily at first use, where each would put its own s_load + wait on the critical path
+        const float2 *a0_ = s.rew_lut; const uint32_t *a1_ = s.maps, *a2_ = s.d2, *a3_ = s.faults;
+        const int a4_ = s.max_steps, a5_ = s.auto_reset; const uint32_t a6_ = s.env_base;
+        asm volatile("" ::"s"(a0_), "s"(a1_), "s"(a2_), "s"(a3_), "s"(a4_), "s"(a5_), "s"(a6_), "s"(obs), "s"(rew),
+                     "s"(done_out));
+    }
+    const int mode = (int)((cfg >> 2) & 7u);
+    // RAM = some env of the handle has the scripted Ram target; handles without one get a kernel without the plan /
+    // Philox code (the step kernel's duration at N = 4096 is partly instruction-fetch latency: code size matters)
+    const bool ram = RAM && mode == TGT_RAM;
+    uint32_t plan = 0, tctr = 0, episode = 0, d2 = 0;
+    if (MULTI || ram) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }
+    const uint32_t genv = s.env_base + (uint32_t)e;
+    const float2 *lut = s.rew_lut + (mode == TGT_PZR ? kLutN : (mode == TGT_FAR ? 2 * kLutN : 0));
+    const uint32_t *gmap = s.maps + (size_t)e * kTileWords;
+
+    // output groups of this lane: cells 4q .. 4q+3 of the pair's 676, q = lane + 64 i; cell p lives in window row
+    // p / 13 (52 rows: slot, agent, y), column p % 13
+    int rj[3], rx[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int p = 4 * (lane + 64 * i);
+        rj[i] = (p * 1261) >> 14;               // p / 13, exact for p < 676
+        rx[i] = p - 13 * rj[i];
+    }
+    const int cells = (e0 + 1 < s.n) ? 2 * kObsPerEnv : kObsPerEnv;
+
+  for (int it = 0; it < (MULTI ? nsteps : 1); it++) {
+    const int side = (int)(cnt >> 24);
+    int c_far = (int)(cnt & 0xffu), t = (int)((cnt >> 8) & 0xffffu);
+    int a_tr, a_tg;
+    if (RANDOM) {
+        u32x4 w = philox4x32_10(aseed_lo, aseed_hi, step_idx + (uint32_t)it, 0u, genv, STREAM_ACTION);
+        a_tr = (int)(w.x & 3u); a_tg = (int)(w.y & 3u);
+    } else {
+        if (leader && (act_raw0 < 0 || act_raw0 > 3 || act_raw1 < 0 || act_raw1 > 3)) atomicOr(s.faults, 1u);
+        a_tr = (int)(act_raw0 & 3); a_tg = (int)(act_raw1 & 3);
+    }
+    bool dirty = false;
+    if (ram) { // track_1v1.py:81-82
+        Stream ts;
+        ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, tctr);
+        a_tg = (int)ram_step(plan, ts);
+        tctr = ts.ctr;
+        dirty = true;
+    }
+    int r0 = (int)(pos & 0xffu), c0 = (int)((pos >> 8) & 0xffu);
+    int r1 = (int)((pos >> 16) & 0xffu), c1 = (int)(pos >> 24);
+    if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(1); }
+    const int dy0 = a_tr == 0 ? -1 : (a_tr == 1 ? 1 : 0), dx0 = a_tr == 2 ? -1 : (a_tr == 3 ? 1 : 0);
+    const int dy1 = a_tg == 0 ? -1 : (a_tg == 1 ? 1 : 0), dx1 = a_tg == 2 ? -1 : (a_tg == 3 ? 1 : 0);
+    // rows r_old - 7 .. r_old + 7 of this lane's agent: the move targets and every possible window row
+    int rowbase = (ag ? r1 : r0) - 7;
+    uint32_t w0 = 0xffffffffu, w1 = 0xffffffffu, w2 = 0xffffffffu;   // np.pad(..., 1): rows outside the map
+    if (k < 15 && (unsigned)(rowbase + k) < (unsigned)side) {
+        const uint32_t *rp = gmap + (rowbase + k) * kRowWords;
+        w0 = rp[0]; w1 = rp[1]; w2 = rp[2];
+    }
+    // the reward of each possible outcome (tracker moves / bumps) x (target moves / bumps): track_1v1.py:94-104
+    float2 rw_mm = make_float2(0.f, 0.f), rw_ms = rw_mm, rw_sm = rw_mm, rw_ss = rw_mm;
+    const int ddr = r1 - r0, ddc = c1 - c0;
+    if (leader) {
+        auto sq = [](int a, int b) { return a * a + b * b; };
+        rw_mm = lut[sq(ddr + dy1 - dy0, ddc + dx1 - dx0)];
+        rw_ms = lut[sq(ddr - dy0, ddc - dx0)];
+        rw_sm = lut[sq(ddr + dy1, ddc + dx1)];
+        rw_ss = lut[sq(ddr, ddc)];
+    }
+    // _next_state (track_1v1.py:271-285): the lane holding the destination row of its agent votes "wall"
+    const int mdy = ag ? dy1 : dy0, mcc = (ag ? c1 : c0) + (ag ? dx1 : dx0);
+    const uint32_t wsel = (mcc >> 5) == 0 ? w0 : ((mcc >> 5) == 1 ? w1 : w2);
+    const bool vote = live && k == 7 + mdy && ((wsel >> (mcc & 31)) & 1u) != 0u;
+    const unsigned long long bal = __ballot(vote);
+    const uint32_t half = sl ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+    const bool wall_tr = (half & 0xffffu) != 0u, wall_tg = (half >> 16) != 0u;
+    if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(2); }
+    if (T2D_EXP == 8) {   // latency probe: level-1 loads -> rows + reward table -> one store
+        if (leader) reinterpret_cast<float2 *>(rew)[e] = wall_tr ? (wall_tg ? rw_ss : rw_sm) : (wall_tg ? rw_ms : rw_mm);
+        return;
+    }
+    if (!wall_tr) { r0 += dy0; c0 += dx0; }
+    if (!wall_tg) { r1 += dy1; c1 += dx1; }
+    pos = (uint32_t)r0 | ((uint32_t)c0 << 8) | ((uint32_t)r1 << 16) | ((uint32_t)c1 << 24);
+    {
+        const int dr = r1 - r0, dc = c1 - c0;
+        d2 = (uint32_t)(dr * dr + dc * dc);
+    }
+    c_far = d2 <= 36u ? 0 : min(c_far + 1, 255);  // distance <= 6 (track_1v1.py:106-109)
+    int dn = c_far > 10;
+    t = min(t + 1, 65535);
+    if (s.max_steps > 0 && t >= s.max_steps) dn = 1; // gym TimeLimit
+    cnt = (uint32_t)c_far | ((uint32_t)t << 8) | ((uint32_t)side << 24);
+    if (leader) {
+        const float2 rwd = wall_tr ? (wall_tg ? rw_ss : rw_sm) : (wall_tg ? rw_ms : rw_mm);
+        reinterpret_cast<float2 *>(rew)[(size_t)it * s.n + e] = rwd;
+        done_out[(size_t)it * s.n + e] = (uint8_t)dn;
+    }
+    const bool consume = live && dn != 0 && s.auto_reset != 0;
+
+    const unsigned long long cm = __ballot(consume);
+    if (__builtin_expect(cm != 0ull, 0)) {
+        // Track1v1Env.reset(): switch to the pre-generated next episode (k_gen). Wave-uniform side path.
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (((cm >> (32 * q)) & 1ull) == 0ull) continue;
+            const uint4 nt = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)(e0 + q) * kTileWords)[lane];
+            reinterpret_cast<uint4 *>(s.maps + (size_t)(e0 + q) * kTileWords)[lane] = nt;
+        }
+        if (consume) {
+            pos = s.n_pos[e]; plan = s.n_plan[e]; tctr = s.n_tctr[e]; d2 = s.n_d2[e];
+            cnt = (uint32_t)side_of_cfg(cfg) << 24;
+            if (!MULTI && !ram) episode = s.episode[e];
+            episode += 1u;
+            if (leader) {
+                s.goals[e] = s.n_goals[e]; s.episode[e] = episode; s.navgoal[e] = s.n_navgoal[e];
+                s.gen_req[e] = stamp + (uint32_t)it;
+            }
+            r0 = (int)(pos & 0xffu); c0 = (int)((pos >> 8) & 0xffu);
+            r1 = (int)((pos >> 16) & 0xffu); c1 = (int)(pos >> 24);
+            rowbase = (ag ? r1 : r0) - 7;
+            const int nside = (int)(cnt >> 24);
+            w0 = w1 = w2 = 0xffffffffu;
+            // rows of the NEW map are read from its n_maps slot, which nobody writes during this launch (the copy into
+            // `maps` above is for later launches): no store -> load hazard through the vector L1
+            gmap = s.n_maps + (size_t)e * kTileWords;
+            if (k < 15 && (unsigned)(rowbase + k) < (unsigned)nside) {
+                const uint32_t *rp = gmap + (rowbase + k) * kRowWords;
+                w0 = rp[0]; w1 = rp[1]; w2 = rp[2];
+            }
+        }
+    }
+    if (leader) {
+        s.pos[e] = pos; s.cnt[e] = cnt; s.d2[e] = d2;
+        if (consume || dirty) { s.plan[e] = plan; s.tctr[e] = tctr; }
+    }
+
+    T2D_STAMP(3);
+    if (obs != nullptr) {
+        // _get_obs / _get_partial_obs (track_1v1.py:287-326) in closed form: own cell = own colour, the other agent's
+        // colour where it falls in the window, else the map bit, outside the map 1
+        const int oside = (int)(cnt >> 24);
+        const int my_r = ag ? r1 : r0, my_c = ag ? c1 : c0, ot_r = ag ? r0 : r1, ot_c = ag ? c0 : c1;
+        const int rr = rowbase + k, y = rr - (my_r - T2D_POB);
+        if (k < 15 && (unsigned)y < (unsigned)T2D_WIN) {
+            const uint32_t W2 = w2 | ~valid_mask_w2(oside);           // columns >= side read as 1
+            const int sp = my_c - T2D_POB + 32;                        // window start in [ones | w0 | w1 | W2 | ones]
+            const int j = sp >> 5;
+            const uint32_t lo = j == 0 ? 0xffffffffu : (j == 1 ? w0 : (j == 2 ? w1 : W2));
+            const uint32_t hi = j == 0 ? w0 : (j == 1 ? w1 : (j == 2 ? W2 : 0xffffffffu));
+            uint32_t bits = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(sp & 31)) & 0x1fffu;
+            if (y == T2D_POB) bits &= ~(1u << T2D_POB);                 // coloured cells carry no map bit
+            const int xo = ot_c - (my_c - T2D_POB);
+            if (rr == ot_r && (unsigned)xo < (unsigned)T2D_WIN) bits &= ~(1u << xo);
+            st[sl * 26 + ag * 13 + y] = bits;
+        }
+        mk[lane] = 0u; mk[lane + 64] = 0u;
+        if (lane < 169 - 128) mk[lane + 128] = 0u;
+        if (k == 0) {   // the four (slot, agent) windows: own colour at the centre (:313), the other agent if inside
+            uint8_t *mb = reinterpret_cast<uint8_t *>(mk) + sl * kObsPerEnv + ag * (T2D_WIN * T2D_WIN)
+                          + T2D_POB * T2D_WIN + T2D_POB;
+            const int dr = ot_r - my_r, dc = ot_c - my_c;
+            if ((unsigned)(dr + T2D_POB) < (unsigned)T2D_WIN && (unsigned)(dc + T2D_POB) < (unsigned)T2D_WIN)
+                mb[dr * T2D_WIN + dc] = ag ? 2 : 4;
+            mb[0] = ag ? 4 : 2;                                         // written last: own colour wins when co-located
+        }
+        wave_lds_sync();
+        T2D_STAMP(4);
+        const size_t ebase = ((size_t)it * s.n + e0) * kObsPerEnv;   // first cell of the pair in the output
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int q = lane + 64 * i, p = 4 * q;
+            if (p >= cells) continue;
+            const uint32_t lo = st[rj[i]], hi = st[rj[i] + 1];
+            const uint32_t nib = ((lo | (hi << 13)) >> rx[i]) & 0xfu;
+            const uint32_t bytes = (__umul24(nib, 0x204081u) & 0x01010101u) | mk[q];   // bit c -> byte c, then colours
+            const int nvalid = min(4, cells - p);
+            if (OBS == OBS_U8) {
+                uint8_t *o = reinterpret_cast<uint8_t *>(obs) + ebase + p;
+                if (nvalid == 4) *reinterpret_cast<uint32_t *>(o) = bytes;
+                else for (int c = 0; c < nvalid; c++) o[c] = (uint8_t)(bytes >> (8 * c));
+            } else {
+                float *o = reinterpret_cast<float *>(obs) + ebase + p;
+                const float f0 = (float)(bytes & 0xffu), f1 = (float)((bytes >> 8) & 0xffu);
+                const float f2 = (float)((bytes >> 16) & 0xffu), f3 = (float)(bytes >> 24);
+                if (OBS == OBS_F32_VEC4 && nvalid == 4) {
+                    *reinterpret_cast<float4 *>(o) = make_float4(f0, f1, f2, f3);
+                } else {
+                    o[0] = f0;
+                    if (nvalid > 1) o[1] = f1;
+                    if (nvalid > 2) o[2] = f2;
+                    if (nvalid > 3) o[3] = f3;
+                }
+            }
+        }
+        if (MULTI) wave_lds_sync();   // the next step overwrites the stage
+        T2D_STAMP(5);
+        if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(6); }
+    }
+  }
+}
+
 __global__ void k_build_reward_lut(float2 *lut)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -514,6 +786,7 @@ struct t2d_handle {
     bool reset_done;   // every env has a current episode
     bool primed;       // every env has a valid next slot
     bool has_nav;
+    bool has_ram;      // some env has the scripted Ram target (selects the step kernel variant with the plan code)
     bool has_rpf;      // some env has the RPF patrol target (an agent may then stand on a wall of the env's own map)
     uint32_t random_step;
     uint32_t gen_every; // generator launch period in steps (see step_impl)
@@ -570,7 +843,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         return fail(T2D_ERR_INVALID, "t2d_create: device %d out of range (%d visible)", cfg->device, ndev);
     const int n = cfg->num_envs;
     std::vector<uint32_t> hcfg((size_t)n);
-    bool has_nav = false, has_rpf = false;
+    bool has_nav = false, has_rpf = false, has_ram = false;
     int n_maze = 0;
     if (cfg->obs_type > T2D_OBS_FULL) return fail(T2D_ERR_INVALID, "t2d_create: obs_type %u", cfg->obs_type);
     for (int i = 0; i < n; i++) {
@@ -581,6 +854,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         if (tm > T2D_TGT_RPF) return fail(T2D_ERR_INVALID, "t2d_create: target_mode %u (env %d)", tm, i);
         has_nav = has_nav || tm == T2D_TGT_NAV || tm == T2D_TGT_RPF;
         has_rpf = has_rpf || tm == T2D_TGT_RPF;
+        has_ram = has_ram || tm == T2D_TGT_RAM;
         n_maze += mt == T2D_MAP_MAZE;
         if (lv > 15) return fail(T2D_ERR_INVALID, "t2d_create: level %u (env %d)", lv, i);
         hcfg[(size_t)i] = mt | (tm << 2) | (lv << 5);
@@ -592,7 +866,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     if (!h) return fail(T2D_ERR_INVALID, "t2d_create: out of host memory");
     std::memset(&h->s, 0, sizeof(h->s));
     h->device = cfg->device;
-    h->reset_done = false; h->primed = false; h->has_nav = has_nav; h->has_rpf = has_rpf;
+    h->reset_done = false; h->primed = false; h->has_nav = has_nav; h->has_rpf = has_rpf; h->has_ram = has_ram;
     h->random_step = 0; h->phase = 0;
     // A slot consumed at step q cannot be needed again before step q + min(11, max_episode_steps): done needs 11
     // consecutive far steps (track_1v1.py:106-111) or the TimeLimit. Launching the generator every G <= that many
@@ -661,10 +935,51 @@ static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t upto, int force)
     else hipLaunchKernelGGL((k_gen<false>), env_grid(h->s.n), dim3(256), 0, st, h->s, upto, force);
 }
 
+static inline dim3 pair_grid(int n) { return dim3((unsigned)(((n + 1) / 2 + kWavesPerBlock - 1) / kWavesPerBlock)); }
+static inline bool use_step2(const t2d_handle *h) { return !h->has_nav && !h->s.obs_full; }
+
+// k_step2 launcher. obs_kind: OBS_F32_* picked from the pointer / stride alignment, or OBS_U8.
+template <bool RANDOM, bool MULTI>
+static void launch_step2(t2d_handle *h, hipStream_t st, const void *a0, const void *a1, int adt, void *obs, bool u8,
+                         float *rew, uint8_t *done, uint32_t slo, uint32_t shi, uint32_t sidx, uint32_t stamp, int nsteps)
+{
+    if (a1 == nullptr) a1 = a0;
+    const bool vec4 = ((uintptr_t)obs & 15u) == 0u && (!MULTI || (h->s.n & 1) == 0);
+    const int kind = u8 ? OBS_U8 : (vec4 ? OBS_F32_VEC4 : OBS_F32_SCALAR);
+#define T2D_LAUNCH2(ADTV, KIND)                                                                                         \
+    do {                                                                                                                \
+        if (h->has_ram)                                                                                                 \
+            hipLaunchKernelGGL((k_step2<RANDOM, MULTI, ADTV, KIND, true>), pair_grid(h->s.n), dim3(256), 0, st, h->s,   \
+                               a0, a1, obs, rew, done, slo, shi, sidx, stamp, nsteps);                                  \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_step2<RANDOM, MULTI, ADTV, KIND, false>), pair_grid(h->s.n), dim3(256), 0, st, h->s,  \
+                               a0, a1, obs, rew, done, slo, shi, sidx, stamp, nsteps);                                  \
+    } while (0)
+#define T2D_LAUNCH2K(ADTV)                                                                                              \
+    do {                                                                                                                \
+        if (kind == OBS_U8) T2D_LAUNCH2(ADTV, OBS_U8);                                                                  \
+        else if (kind == OBS_F32_VEC4) T2D_LAUNCH2(ADTV, OBS_F32_VEC4);                                                 \
+        else T2D_LAUNCH2(ADTV, OBS_F32_SCALAR);                                                                         \
+    } while (0)
+    if constexpr (RANDOM) {
+        T2D_LAUNCH2K(T2D_ACT_I64);
+    } else {
+        if (adt == T2D_ACT_I64) T2D_LAUNCH2K(T2D_ACT_I64);
+        else if (adt == T2D_ACT_I32) T2D_LAUNCH2K(T2D_ACT_I32);
+        else T2D_LAUNCH2K(T2D_ACT_U8);
+    }
+#undef T2D_LAUNCH2K
+#undef T2D_LAUNCH2
+}
+
 template <int OP, bool RANDOM>
 static void launch_env(t2d_handle *h, hipStream_t st, const void *a0, const void *a1, int adt, const uint8_t *mask,
                        float *obs, float *rew, uint8_t *done, uint32_t slo, uint32_t shi, uint32_t sidx, uint32_t stamp)
 {
+    if (OP == OP_STEP && use_step2(h)) {
+        launch_step2<RANDOM, false>(h, st, a0, a1, adt, obs, false, rew, done, slo, shi, sidx, stamp, 1);
+        return;
+    }
     if (a1 == nullptr) a1 = a0;   // scripted target: the value is overridden in the kernel
 #define T2D_LAUNCH(NAVF, ADTV)                                                                                          \
     hipLaunchKernelGGL((k_env<OP, RANDOM, NAVF, false, ADTV>), env_grid(h->s.n), dim3(256), 0, st, h->s, a0, a1, adt,   \
@@ -741,6 +1056,27 @@ extern "C" int t2d_step(t2d_handle *h, const void *act_tracker_dev, const void *
                             done_dev, 0u, 0u, 0u);
 }
 
+extern "C" int t2d_step_u8(t2d_handle *h, const void *act_tracker_dev, const void *act_target_dev, int act_dtype,
+                           uint8_t *obs_u8_dev, float *rew_dev, uint8_t *done_dev, void *stream)
+{
+    if (!h) return fail(T2D_ERR_INVALID, "t2d_step_u8: null handle");
+    if (!act_tracker_dev || !rew_dev || !done_dev) return fail(T2D_ERR_INVALID, "t2d_step_u8: null buffer");
+    if (act_dtype < T2D_ACT_U8 || act_dtype > T2D_ACT_I64) return fail(T2D_ERR_INVALID, "t2d_step_u8: act_dtype %d", act_dtype);
+    if (!use_step2(h))
+        return fail(T2D_ERR_INVALID, "t2d_step_u8: u8 observations exist for 'Partial' ids without Nav/RPF targets");
+    if (((uintptr_t)obs_u8_dev & 3u) != 0u) return fail(T2D_ERR_INVALID, "t2d_step_u8: obs buffer must be 4-byte aligned");
+    if (!h->reset_done) return fail(T2D_ERR_STATE, "t2d_step_u8: call t2d_reset (all envs) or t2d_inject first");
+    if (h->s.auto_reset && !h->primed) return fail(T2D_ERR_STATE, "t2d_step_u8: auto_reset needs one t2d_reset before stepping");
+    DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->s.auto_reset) h->phase++;
+    launch_step2<false, false>(h, st, act_tracker_dev, act_target_dev, act_dtype, obs_u8_dev, true, rew_dev, done_dev, 0u,
+                               0u, 0u, h->phase, 1);
+    HIP_TRY(hipGetLastError());
+    if (h->s.auto_reset && h->phase >= h->gen_every) return flush_impl(h, st);
+    return T2D_OK;
+}
+
 extern "C" int t2d_step_random(t2d_handle *h, int steps, uint64_t action_seed, float *obs_dev, float *rew_dev,
                                uint8_t *done_dev, void *stream)
 {
@@ -780,9 +1116,13 @@ extern "C" int t2d_rollout_random(t2d_handle *h, int steps, uint64_t action_seed
         // up to the next generator pass (at most one episode switch per env in between)
         int chunk = steps - done_steps;
         if (h->s.auto_reset && chunk > (int)(h->gen_every - h->phase)) chunk = (int)(h->gen_every - h->phase);
-        hipLaunchKernelGGL((k_env<OP_STEP, true, false, true>), env_grid(h->s.n), dim3(256), 0, st, h->s, nullptr, nullptr,
-                           0, nullptr, o, r, d, (uint32_t)action_seed, (uint32_t)(action_seed >> 32), h->random_step,
-                           h->phase + 1u, chunk);
+        if (use_step2(h))
+            launch_step2<true, true>(h, st, nullptr, nullptr, 0, o, false, r, d, (uint32_t)action_seed,
+                                     (uint32_t)(action_seed >> 32), h->random_step, h->phase + 1u, chunk);
+        else
+            hipLaunchKernelGGL((k_env<OP_STEP, true, false, true>), env_grid(h->s.n), dim3(256), 0, st, h->s, nullptr,
+                               nullptr, 0, nullptr, o, r, d, (uint32_t)action_seed, (uint32_t)(action_seed >> 32),
+                               h->random_step, h->phase + 1u, chunk);
         HIP_TRY(hipGetLastError());
         h->random_step += (uint32_t)chunk;
         done_steps += chunk;
@@ -978,6 +1318,16 @@ extern "C" int t2d_get_target(t2d_handle *h, int first, int count, int32_t *plan
     }
     return T2D_OK;
 }
+
+#if T2D_EXP == 6
+extern "C" int t2d_debug_tile_words(t2d_handle *h, uint32_t *out_host /* [n][256] */)
+{
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_host, h->s.maps, (size_t)h->s.n * kTileWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return T2D_OK;
+}
+#endif
 
 extern "C" int t2d_get_faults(t2d_handle *h, uint32_t *faults_host, void *stream)
 {

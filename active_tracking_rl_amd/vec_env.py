@@ -17,7 +17,7 @@ import torch
 from . import registry
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrack2d_hip.so")
+LIB_PATH = os.environ.get("T2D_LIB_PATH") or os.path.join(_HERE, "libtrack2d_hip.so")   # override: kernel experiments
 ABI_VERSION = 1
 
 ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2
@@ -43,7 +43,7 @@ _lib = None
 ABI_SYMBOLS = (
     "t2d_last_error", "t2d_abi_version", "t2d_create", "t2d_destroy", "t2d_num_envs", "t2d_reset", "t2d_step",
     "t2d_observe", "t2d_inject", "t2d_inject_plan", "t2d_get_state", "t2d_get_maps", "t2d_get_target",
-    "t2d_get_faults", "t2d_step_random", "t2d_rollout_random", "t2d_reward_table", "t2d_flush",
+    "t2d_get_faults", "t2d_step_u8", "t2d_step_random", "t2d_rollout_random", "t2d_reward_table", "t2d_flush",
 )
 
 
@@ -69,6 +69,8 @@ def load_library():
     L.t2d_reset.argtypes = [vp, vp, vp, vp]
     L.t2d_step.restype = i32
     L.t2d_step.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
+    L.t2d_step_u8.restype = i32
+    L.t2d_step_u8.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     L.t2d_observe.restype = i32
     L.t2d_observe.argtypes = [vp, vp, vp]
     L.t2d_flush.restype = i32
@@ -213,6 +215,28 @@ class VecTrack2D(object):
         _check(self.L.t2d_step(self.h, C.c_void_p(a0.data_ptr()), a1p, _ACT_DTYPE[a0.dtype],
                                C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()),
                                C.c_void_p(done.data_ptr()), self._stream()))
+        return obs, rew, done
+
+    def step_u8(self, act_tracker, act_target=None, out=None):
+        """step() with the observations left as bytes: obs u8 [N,2,13,13] (t2d_step_u8)."""
+        if out is None:
+            out = (torch.empty((self.num_envs, 2) + self.obs_hw, dtype=torch.uint8, device=self.device),
+                   torch.empty((self.num_envs, 2), dtype=torch.float32, device=self.device),
+                   torch.empty((self.num_envs,), dtype=torch.uint8, device=self.device))
+        obs, rew, done = out
+        a0 = act_tracker.reshape(-1)
+        assert obs.dtype == torch.uint8 and obs.is_contiguous()
+        assert a0.is_cuda and a0.is_contiguous() and a0.numel() == self.num_envs and a0.dtype in _ACT_DTYPE
+        a1p = None
+        if act_target is not None:
+            a1 = act_target.reshape(-1)
+            assert a1.is_cuda and a1.is_contiguous() and a1.numel() == self.num_envs and a1.dtype == a0.dtype
+            a1p = C.c_void_p(a1.data_ptr())
+        elif not self.scripted_target:
+            raise T2DError("act_target is required unless every env has a scripted (Ram/Nav/RPF) target")
+        _check(self.L.t2d_step_u8(self.h, C.c_void_p(a0.data_ptr()), a1p, _ACT_DTYPE[a0.dtype],
+                                  C.c_void_p(obs.data_ptr()), C.c_void_p(rew.data_ptr()),
+                                  C.c_void_p(done.data_ptr()), self._stream()))
         return obs, rew, done
 
     def step_random(self, steps, action_seed=1, out=None):

@@ -96,6 +96,13 @@ int t2d_reset(t2d_handle *h, const uint8_t *mask_dev, float *obs_dev, void *stre
 int t2d_step(t2d_handle *h, const void *act_tracker_dev, const void *act_target_dev, int act_dtype,
              float *obs_dev, float *rew_dev, uint8_t *done_dev, void *stream);
 
+/* The same step with the observations left as bytes: obs u8 [N,2,13,13] (values 0,1,2,4), i.e. the step before
+ * frame_stack's np.float32(obs) cast (environment.py:138,146); the consumer (the policy's conv stem, perception.py:86-92)
+ * decodes them in its first layer. SURVEY 8(d): B_step = 709 B for this variant. Only for 'Partial' observations and
+ * handles without Nav/RPF targets; obs_u8_dev must be 4-byte aligned. */
+int t2d_step_u8(t2d_handle *h, const void *act_tracker_dev, const void *act_target_dev, int act_dtype,
+                uint8_t *obs_u8_dev, float *rew_dev, uint8_t *done_dev, void *stream);
+
 /* With auto_reset, finished envs switch to a pre-generated "next episode" slot inside the step launch; the
  * library refills consumed slots with a generator launch every <= 10 steps on the caller's stream (a slot
  * cannot be needed again sooner: done needs 11 consecutive far steps). t2d_flush runs the generator now for

@@ -489,3 +489,49 @@ def test_rpf_patrol_replans_and_bumps_into_walled_patrol_cells(vec):
     # the patrol really went round: env 1 (nothing walled) stood on at least three patrol cells
     assert sum(((1, c) in visited) for c in ((13, 13), (68, 13), (68, 68), (13, 68))) >= 3
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,n", [("Track2D-BlockPartialPZR-v0", 4096), ("Track2D-BlockPartialRam-v0", 333),
+                                      ("Track2D-MazePartialAdv-v0", 2)])
+def test_u8_observations_equal_the_f32_ones(env_id, n):
+    """t2d_step_u8 (obs left as bytes, SURVEY 8(d) B_step = 709 variant) against t2d_step from the same seed with the
+    same actions: identical rewards / done flags and obs_u8 == obs_f32 cell for cell, across episode switches."""
+    import torch
+    from active_tracking_rl_amd.vec_env import VecTrack2D
+    a = VecTrack2D(env_id, num_envs=n, seed=11, max_episode_steps=30)
+    b = VecTrack2D(env_id, num_envs=n, seed=11, max_episode_steps=30)
+    assert torch.equal(a.reset(), b.reset())
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(70):
+        acts = torch.randint(0, 4, (2, n), device="cuda", generator=g, dtype=torch.uint8 if t % 2 else torch.int64)
+        of, rf, df = a.step(acts[0], acts[1])
+        ou, ru, du = b.step_u8(acts[0], acts[1])
+        assert ou.dtype == torch.uint8 and torch.equal(of, ou.float()), (env_id, t)
+        assert torch.equal(rf, ru) and torch.equal(df, du), (env_id, t)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_unaligned_observation_buffer_takes_the_scalar_store_path():
+    """An obs pointer that is only 4-byte aligned (a view at an odd float offset) must give the same observations."""
+    import torch
+    from active_tracking_rl_amd.vec_env import VecTrack2D
+    n = 65
+    a = VecTrack2D("Track2D-BlockPartialPZR-v0", num_envs=n, seed=2)
+    b = VecTrack2D("Track2D-BlockPartialPZR-v0", num_envs=n, seed=2)
+    a.reset(); b.reset()
+    raw = torch.zeros(n * 338 + 8, device="cuda")
+    view = raw[1:1 + n * 338].view(n, 2, 13, 13)
+    assert view.data_ptr() % 16 != 0
+    rew, done = torch.empty((n, 2), device="cuda"), torch.empty((n,), dtype=torch.uint8, device="cuda")
+    for t in range(15):
+        acts = torch.randint(0, 4, (2, n), device="cuda")
+        o1, r1, d1 = a.step(acts[0], acts[1])
+        o2, r2, d2 = b.step(acts[0], acts[1], out=(view, rew, done))
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), t
+    assert float(raw[0]) == 0.0 and float(raw[1 + n * 338:].abs().sum()) == 0.0      # nothing written outside the view
+    a.close(); b.close()
