@@ -54,15 +54,18 @@ __device__ __forceinline__ float xor_sum(float v, int mask) { return v + __shfl_
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // A frame's 169 floats: lane l holds elements l, l+64, l+128.
+// XT = float, or uint8_t: the env's u8 observations (t2d_step_u8, values 0/1/2/4) decoded here, in the first layer
+// (the np.float32(obs) cast of frame_stack, environment.py:138,146, fused into conv1: SURVEY 8f rank 1).
 struct XRegs { float v[3]; };
-__device__ __forceinline__ XRegs load_x(const float *__restrict__ x, long long m, long long M, long long xs, int l)
+template <typename XT>
+__device__ __forceinline__ XRegs load_x(const XT *__restrict__ x, long long m, long long M, long long xs, int l)
 {
     XRegs r;
-    const float *p = x + m * xs;
+    const XT *p = x + m * xs;
     const bool ok = m < M;
-    r.v[0] = ok ? p[l] : 0.f;
-    r.v[1] = ok ? p[l + 64] : 0.f;
-    r.v[2] = (ok && l < 41) ? p[l + 128] : 0.f;
+    r.v[0] = ok ? (float)p[l] : 0.f;
+    r.v[1] = ok ? (float)p[l + 64] : 0.f;
+    r.v[2] = (ok && l < 41) ? (float)p[l + 128] : 0.f;
     return r;
 }
 __device__ __forceinline__ int xpad_addr(int i) { const int r = i / 13; return (r + 1) * kXS + (i - r * 13) + 1; }
@@ -123,7 +126,8 @@ __device__ __forceinline__ void zero_wave(float *p, int n, int l)
 // forward: D[pos][co] = sum_k im2col(a1)[pos][k] * W2[co][k]; step s = t*4 + cq covers tap t = kh*3+kw of the
 // input channels 4cq..4cq+3 (k within the step = ci & 3).
 struct StemProblem {
-    const float *x, *w1, *b1, *w2, *b2;
+    const void *x;
+    const float *w1, *b1, *w2, *b2;
     float *y;
     long long M, xs;
 };
@@ -131,6 +135,7 @@ struct StemProblem {
 // step): workgroups [0, split) work on p[0], the rest on p[1], so the chip is filled by one launch.
 struct StemPair { StemProblem p[2]; int split; };
 
+template <typename XT>
 __global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
 {
     __shared__ __attribute__((aligned(16))) LdsF lds[kWaves];
@@ -138,8 +143,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
     LdsF &s = lds[wave];
     const bool second = (int)blockIdx.x >= pr.split;
     const StemProblem &pb = pr.p[second ? 1 : 0];
-    const float *__restrict__ x = pb.x, *__restrict__ w1 = pb.w1, *__restrict__ b1 = pb.b1, *__restrict__ w2 = pb.w2,
-                             *__restrict__ b2 = pb.b2;
+    const XT *__restrict__ x = reinterpret_cast<const XT *>(pb.x);
+    const float *__restrict__ w1 = pb.w1, *__restrict__ b1 = pb.b1, *__restrict__ w2 = pb.w2, *__restrict__ b2 = pb.b2;
     float *__restrict__ y = pb.y;
     const long long M = pb.M, xs = pb.xs;
     const int blk = second ? (int)blockIdx.x - pr.split : (int)blockIdx.x;
@@ -216,7 +221,8 @@ __device__ __forceinline__ float4 relu_mask(const float4 &yv, const float4 &dv)
 //      to a1pad[ci][2oh+kh][2ow+kw] in registers: lane (ci = l&15, oh = l>>4) ends up with the a1-gradient of the
 //      real rows 2oh (tap row kh=1) and 2oh+1 (kh=2 of its own output row + kh=0 of the next one, fetched from lane
 //      l+16); dz1 = da1 * (a1 > 0) -> dW1 / db1 against the frame's input rows.
-__global__ __launch_bounds__(kThreads, 2) void k_stem_bwd(const float *__restrict__ x, const float *__restrict__ y,
+template <typename XT>
+__global__ __launch_bounds__(kThreads, 2) void k_stem_bwd(const XT *__restrict__ x, const float *__restrict__ y,
                                                           const float *__restrict__ dy, const float *__restrict__ w1,
                                                           const float *__restrict__ b1, const float *__restrict__ w2,
                                                           float *__restrict__ partial, long long M, long long xs)
@@ -424,7 +430,7 @@ constexpr int kFwdBlocksPerCu = 3, kBwdBlocksPerCu = 2;
 
 extern "C" long long atr_stem_workspace_floats(long long M) { return (long long)stem_grid(M, kBwdBlocksPerCu) * kPartial; }
 
-static StemProblem make_problem(const float *x, long long x_stride, const float *w1, const float *b1, const float *w2,
+static StemProblem make_problem(const void *x, long long x_stride, const float *w1, const float *b1, const float *w2,
                                 const float *b2, float *y, long long M)
 {
     StemProblem p;
@@ -432,22 +438,24 @@ static StemProblem make_problem(const float *x, long long x_stride, const float 
     return p;
 }
 
-extern "C" int atr_stem_forward(const float *x, long long x_stride, const float *w1, const float *b1, const float *w2,
-                                const float *b2, float *y, long long M, void *stream)
+template <typename XT>
+static int stem_forward_impl(const XT *x, long long x_stride, const float *w1, const float *b1, const float *w2,
+                             const float *b2, float *y, long long M, void *stream)
 {
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || M < 0 || x_stride < 169) return -1;
     if (M == 0) return 0;
     StemPair pr;
     pr.p[0] = pr.p[1] = make_problem(x, x_stride, w1, b1, w2, b2, y, M);
     pr.split = stem_grid(M, kFwdBlocksPerCu);
-    hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)pr.split), dim3(kThreads), 0, (hipStream_t)stream, pr);
+    hipLaunchKernelGGL((k_stem_fwd<XT>), dim3((unsigned)pr.split), dim3(kThreads), 0, (hipStream_t)stream, pr);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern "C" int atr_stem_forward2(const float *x0, long long x0_stride, const float *w1_0, const float *b1_0,
-                                 const float *w2_0, const float *b2_0, float *y0, long long M0, const float *x1,
-                                 long long x1_stride, const float *w1_1, const float *b1_1, const float *w2_1,
-                                 const float *b2_1, float *y1, long long M1, void *stream)
+template <typename XT>
+static int stem_forward2_impl(const XT *x0, long long x0_stride, const float *w1_0, const float *b1_0, const float *w2_0,
+                              const float *b2_0, float *y0, long long M0, const XT *x1, long long x1_stride,
+                              const float *w1_1, const float *b1_1, const float *w2_1, const float *b2_1, float *y1,
+                              long long M1, void *stream)
 {
     if (!x0 || !w1_0 || !b1_0 || !w2_0 || !b2_0 || !y0 || M0 <= 0 || x0_stride < 169 || !x1 || !w1_1 || !b1_1 ||
         !w2_1 || !b2_1 || !y1 || M1 <= 0 || x1_stride < 169)
@@ -465,19 +473,60 @@ extern "C" int atr_stem_forward2(const float *x0, long long x0_stride, const flo
     if (g1 < 1) g1 = 1;
     if (g1 > need1) g1 = need1;
     pr.split = g0;
-    hipLaunchKernelGGL(k_stem_fwd, dim3((unsigned)(g0 + g1)), dim3(kThreads), 0, (hipStream_t)stream, pr);
+    hipLaunchKernelGGL((k_stem_fwd<XT>), dim3((unsigned)(g0 + g1)), dim3(kThreads), 0, (hipStream_t)stream, pr);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-extern "C" int atr_stem_backward(const float *x, long long x_stride, const float *y, const float *dy, const float *w1,
-                                 const float *b1, const float *w2, float *dw1, float *db1, float *dw2, float *db2,
-                                 float *workspace, long long M, void *stream)
+template <typename XT>
+static int stem_backward_impl(const XT *x, long long x_stride, const float *y, const float *dy, const float *w1,
+                              const float *b1, const float *w2, float *dw1, float *db1, float *dw2, float *db2,
+                              float *workspace, long long M, void *stream)
 {
     if (!x || !y || !dy || !w1 || !b1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !workspace || M <= 0 || x_stride < 169)
         return -1;
     const int grid = stem_grid(M, kBwdBlocksPerCu);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_stem_bwd, dim3((unsigned)grid), dim3(kThreads), 0, st, x, y, dy, w1, b1, w2, workspace, M, x_stride);
+    hipLaunchKernelGGL((k_stem_bwd<XT>), dim3((unsigned)grid), dim3(kThreads), 0, st, x, y, dy, w1, b1, w2, workspace, M,
+                       x_stride);
     hipLaunchKernelGGL(k_stem_reduce, dim3((kPartial + 15) / 16), dim3(1024), 0, st, workspace, grid, dw1, db1, dw2, db2);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int atr_stem_forward(const float *x, long long x_stride, const float *w1, const float *b1, const float *w2,
+                                const float *b2, float *y, long long M, void *stream)
+{
+    return stem_forward_impl<float>(x, x_stride, w1, b1, w2, b2, y, M, stream);
+}
+extern "C" int atr_stem_forward_u8(const unsigned char *x, long long x_stride, const float *w1, const float *b1,
+                                   const float *w2, const float *b2, float *y, long long M, void *stream)
+{
+    return stem_forward_impl<uint8_t>(x, x_stride, w1, b1, w2, b2, y, M, stream);
+}
+extern "C" int atr_stem_forward2(const float *x0, long long x0_stride, const float *w1_0, const float *b1_0,
+                                 const float *w2_0, const float *b2_0, float *y0, long long M0, const float *x1,
+                                 long long x1_stride, const float *w1_1, const float *b1_1, const float *w2_1,
+                                 const float *b2_1, float *y1, long long M1, void *stream)
+{
+    return stem_forward2_impl<float>(x0, x0_stride, w1_0, b1_0, w2_0, b2_0, y0, M0, x1, x1_stride, w1_1, b1_1, w2_1, b2_1,
+                                     y1, M1, stream);
+}
+extern "C" int atr_stem_forward2_u8(const unsigned char *x0, long long x0_stride, const float *w1_0, const float *b1_0,
+                                    const float *w2_0, const float *b2_0, float *y0, long long M0,
+                                    const unsigned char *x1, long long x1_stride, const float *w1_1, const float *b1_1,
+                                    const float *w2_1, const float *b2_1, float *y1, long long M1, void *stream)
+{
+    return stem_forward2_impl<uint8_t>(x0, x0_stride, w1_0, b1_0, w2_0, b2_0, y0, M0, x1, x1_stride, w1_1, b1_1, w2_1,
+                                       b2_1, y1, M1, stream);
+}
+extern "C" int atr_stem_backward(const float *x, long long x_stride, const float *y, const float *dy, const float *w1,
+                                 const float *b1, const float *w2, float *dw1, float *db1, float *dw2, float *db2,
+                                 float *workspace, long long M, void *stream)
+{
+    return stem_backward_impl<float>(x, x_stride, y, dy, w1, b1, w2, dw1, db1, dw2, db2, workspace, M, stream);
+}
+extern "C" int atr_stem_backward_u8(const unsigned char *x, long long x_stride, const float *y, const float *dy,
+                                    const float *w1, const float *b1, const float *w2, float *dw1, float *db1, float *dw2,
+                                    float *db2, float *workspace, long long M, void *stream)
+{
+    return stem_backward_impl<uint8_t>(x, x_stride, y, dy, w1, b1, w2, dw1, db1, dw2, db2, workspace, M, stream);
 }

@@ -48,7 +48,7 @@ class VecEnv(object):
     step([a_tracker [N], a_target [N]]) -> (obs, rewards [N, A] f32, done [N] uint8, info)."""
 
     def __init__(self, env_id, num_envs, device="cuda:0", seed=1, stack_frames=1, env_id_base=0, auto_reset=True,
-                 rescale=False, **overrides):
+                 rescale=False, obs_u8=False, **overrides):
         self.env_id = env_id
         self.num_envs = num_envs
         self.stack_frames = int(stack_frames)
@@ -56,6 +56,10 @@ class VecEnv(object):
         self.core = VecTrack2D(env_id, num_envs=num_envs, device=device, seed=seed, env_id_base=env_id_base,
                                auto_reset=auto_reset, **overrides)
         self.observation_space, self.action_space = _spaces(self.core.obs_hw)
+        # obs_u8: observations stay bytes between the step kernel and the policy's conv stem (t2d_step_u8 ->
+        # atr_stem_*_u8), i.e. frame_stack's np.float32 cast (environment.py:138,146) is fused into conv1. Only where
+        # the kernels exist ('Partial' ids without Nav/RPF targets) and no host-side frame processing is asked for.
+        self.obs_u8 = bool(obs_u8) and self.stack_frames == 1 and not self.rescale and self.core.supports_u8
         if self.rescale:
             for box in self.observation_space:
                 box.low, box.high = -1.0, 1.0
@@ -86,14 +90,17 @@ class VecEnv(object):
         return self._frames
 
     def reset(self):
-        return self._stack(self.core.reset(), fill=True)
+        obs = self.core.reset()
+        if self.obs_u8:
+            obs = obs.to(torch.uint8)        # values 0/1/2/4: exact
+        return self._stack(obs, fill=True)
 
     def step(self, actions, out=None):
-        """out: optional (obs [N,A,h,w] f32, rew [N,A] f32, done [N] u8) device tensors the kernel writes directly
-        (a slot of rollout_buffers)."""
+        """out: optional (obs [N,A,h,w] f32 (u8 with obs_u8), rew [N,A] f32, done [N] u8) device tensors the kernel
+        writes directly (a slot of rollout_buffers)."""
         a0 = actions[0]
         a1 = actions[1] if len(actions) > 1 else None
-        obs, rew, done = self.core.step(a0, a1, out=out)
+        obs, rew, done = (self.core.step_u8 if self.obs_u8 else self.core.step)(a0, a1, out=out)
         return self._stack(obs, done), rew, done, {}
 
     def rollout_buffers(self, num_steps):
@@ -104,7 +111,8 @@ class VecEnv(object):
             return None
         h, w = self.core.obs_hw
         dev = self.device
-        return (torch.empty((num_steps + 1, self.num_envs, 2, h, w), dtype=torch.float32, device=dev),
+        return (torch.empty((num_steps + 1, self.num_envs, 2, h, w), device=dev,
+                            dtype=torch.uint8 if self.obs_u8 else torch.float32),
                 torch.empty((num_steps, self.num_envs, 2), dtype=torch.float32, device=dev),
                 torch.empty((num_steps, self.num_envs), dtype=torch.uint8, device=dev))
 
@@ -153,7 +161,7 @@ class Track2DEnv(object):
         return self.vec.render()
 
 
-def create_env(env_id, args, num_envs=None, device=None, env_id_base=0):
+def create_env(env_id, args, num_envs=None, device=None, env_id_base=0, obs_u8=None):
     """environment.create_env (environment.py:11-32) for the Track2D ids.
 
     args carries the reference's flags (stack_frames, seed, ...) plus optionally `num_envs` and `gpu_ids`.
@@ -173,6 +181,9 @@ def create_env(env_id, args, num_envs=None, device=None, env_id_base=0):
         device = "cuda:%d" % max(int(gid), 0)
     stack = getattr(args, "stack_frames", 1)
     seed = getattr(args, "seed", 1)
+    if obs_u8 is None:
+        obs_u8 = bool(getattr(args, "obs_u8", False))
     if n > 1:
-        return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base, rescale=rescale)
+        return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base, rescale=rescale,
+                      obs_u8=obs_u8)
     return Track2DEnv(env_id, device=device, seed=seed, stack_frames=stack, rescale=rescale)

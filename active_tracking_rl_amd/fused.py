@@ -34,6 +34,9 @@ def lib():
         L.atr_stem_workspace_floats.argtypes = [ll]
         L.atr_stem_backward.restype = C.c_int
         L.atr_stem_backward.argtypes = [vp, ll] + [vp] * 10 + [ll, vp]
+        for name in ("atr_stem_forward", "atr_stem_forward2", "atr_stem_backward"):      # the u8-frame twins
+            f = getattr(L, name + "_u8")
+            f.restype, f.argtypes = C.c_int, getattr(L, name).argtypes
         L.atr_sample_actions.restype = C.c_int
         L.atr_sample_actions.argtypes = [vp, vp, vp, vp, vp, C.c_ulonglong, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         i32 = C.c_int
@@ -64,6 +67,15 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _stem_fn(name, x):
+    """The stem entry point for x's element type: float32 frames, or the env's u8 observations (decoded inside conv1)."""
+    if x.dtype == torch.uint8:
+        return getattr(lib(), name + "_u8")
+    if x.dtype != torch.float32:
+        raise TypeError("stem frames must be float32 or uint8, got %s" % x.dtype)
+    return getattr(lib(), name)
+
+
 def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -76,7 +88,7 @@ class _Stem(torch.autograd.Function):
         w1c, b1c, w2c, b2c = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
         M = x.shape[0]
         y = torch.empty((M, 512), dtype=torch.float32, device=x.device)
-        rc = lib().atr_stem_forward(_p(x), x.stride(0), _p(w1c), _p(b1c), _p(w2c), _p(b2c), _p(y), M, _stream(x))
+        rc = _stem_fn("atr_stem_forward", x)(_p(x), x.stride(0), _p(w1c), _p(b1c), _p(w2c), _p(b2c), _p(y), M, _stream(x))
         if rc != 0:
             raise RuntimeError("atr_stem_forward failed (%d)" % rc)
         ctx.save_for_backward(x, y, w1c, b1c, w2c)
@@ -96,8 +108,8 @@ def _stem_backward(x, y, dy, w1, b1, w2, shapes):
     ws = torch.empty(L.atr_stem_workspace_floats(M), dtype=torch.float32, device=x.device)
     dw1, db1 = torch.empty(144, device=x.device), torch.empty(16, device=x.device)
     dw2, db2 = torch.empty(4608, device=x.device), torch.empty(32, device=x.device)
-    rc = L.atr_stem_backward(_p(x), x.stride(0), _p(y), _p(dy), _p(w1), _p(b1), _p(w2), _p(dw1), _p(db1), _p(dw2),
-                             _p(db2), _p(ws), M, _stream(x))
+    rc = _stem_fn("atr_stem_backward", x)(_p(x), x.stride(0), _p(y), _p(dy), _p(w1), _p(b1), _p(w2), _p(dw1), _p(db1),
+                                          _p(dw2), _p(db2), _p(ws), M, _stream(x))
     if rc != 0:
         raise RuntimeError("atr_stem_backward failed (%d)" % rc)
     return dw1.view(shapes[0]), db1, dw2.view(shapes[1]), db2
@@ -128,8 +140,8 @@ def stem_into(x, conv1, conv2, out):
         x = x.contiguous()
     M = x.shape[0]
     assert out.is_contiguous() and out.numel() == M * 512
-    rc = lib().atr_stem_forward(_p(x), x.stride(0), _p(conv1.weight), _p(conv1.bias), _p(conv2.weight), _p(conv2.bias),
-                                _p(out), M, _stream(x))
+    rc = _stem_fn("atr_stem_forward", x)(_p(x), x.stride(0), _p(conv1.weight), _p(conv1.bias), _p(conv2.weight),
+                                         _p(conv2.bias), _p(out), M, _stream(x))
     if rc != 0:
         raise RuntimeError("atr_stem_forward failed (%d)" % rc)
     return out
@@ -149,7 +161,8 @@ def stem_into2(xa, enc_a, out_a, xb, enc_b, out_b):
         assert out.is_contiguous() and out.numel() == x.shape[0] * 512
         args += [_p(x), x.stride(0), _p(enc.conv1.weight), _p(enc.conv1.bias), _p(enc.conv2.weight), _p(enc.conv2.bias),
                  _p(out), x.shape[0]]
-    rc = lib().atr_stem_forward2(*(args + [_stream(xs[0])]))
+    assert xs[0].dtype == xs[1].dtype
+    rc = _stem_fn("atr_stem_forward2", xs[0])(*(args + [_stream(xs[0])]))
     if rc != 0:
         raise RuntimeError("atr_stem_forward2 failed (%d)" % rc)
     return out_a, out_b

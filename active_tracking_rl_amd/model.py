@@ -285,9 +285,12 @@ class CNN_maze(nn.Module):
 
     def forward(self, x, fc=True):
         n, f = x.shape[0], x.shape[1]
+        fused_ok = x.is_cuda and self.small and self.use_fused and self.conv1.in_channels == 1 and x.shape[-1] == 13
+        if not x.is_floating_point() and not fused_ok:
+            x = x.float()            # u8 observations: only the fused stem decodes them inside conv1
         if not self.small:
             return self.forward_conv2d(x, fc)
-        if x.is_cuda and self.use_fused and self.conv1.in_channels == 1 and x.shape[-1] == 13:
+        if fused_ok:
             from . import fused
             x = fused.stem(x, self.conv1, self.conv2)       # strided views of the obs tensor are read in place
         else:
@@ -496,7 +499,7 @@ class A3C_Dueling(nn.Module):
             return self._to_ref(out) if ref_layout else out
         R_pred = 0
         if self.tat:
-            action2target = F.one_hot(action_0, self.action_dim_tracker).to(states.dtype)   # model.py:253-254
+            action2target = F.one_hot(action_0, self.action_dim_tracker).to(hx.dtype)       # model.py:253-254
             state_target = states.reshape(n, -1, states.shape[3], states.shape[4], states.shape[5])  # :255
             value1, action_1, entropy_1, log_prob_1, (hx1, cx1), R_pred = self.player1(
                 (state_target, (hx[:, 1], cx[:, 1]), action2target), test)
@@ -564,7 +567,7 @@ class A3C_Dueling(nn.Module):
         also evaluates the forward pass once, inside the rollout (player_util.py:46-73). None when the fused GPU path
         does not apply (CPU tensors, non-maze encoders, fused kernels switched off)."""
         p0, p1 = self.player0, self.player1
-        ok = (states.is_cuda and states.dtype == torch.float32 and fused_lstm and not self.single
+        ok = (states.is_cuda and states.dtype in (torch.float32, torch.uint8) and fused_lstm and not self.single
               and all(isinstance(p.encoder, CNN_maze) and p.encoder.small and p.encoder.use_fused
                       and p.encoder.conv1.in_channels == 1 for p in (p0, p1))
               and states.shape[-1] == 13 and states.shape[-2] == 13 and p0.lstm.hidden_size % 4 == 0
@@ -677,7 +680,7 @@ class A3C_Dueling(nn.Module):
         p0, p1 = self.player0, self.player1
         f0 = p0.sequence_features(states_seq[:, :, 0])
         if self.tat:
-            a2t = F.one_hot(actions_seq[:, :, 0], self.action_dim_tracker).to(states_seq.dtype)
+            a2t = F.one_hot(actions_seq[:, :, 0], self.action_dim_tracker).to(hx.dtype)
             x1 = states_seq.reshape(T, N, -1, states_seq.shape[4], states_seq.shape[5], states_seq.shape[6])
             f1 = p1.sequence_features(x1, a2t)
         else:

@@ -24,14 +24,15 @@ from .shared_optim import SharedAdam
 
 
 def default_args(**over):
-    """The flag defaults of main.py:16-50 as a namespace (plus num_envs / max_grad_norm)."""
+    """The flag defaults of main.py:16-50 as a namespace (plus num_envs / max_grad_norm / obs_u8: keep the training
+    env's observations as bytes up to the policy's conv stem where the kernels allow it, see environment.VecEnv)."""
     import argparse
     d = dict(lr=0.001, gamma=0.9, tau=1.00, entropy=0.01, entropy_target=0.2, seed=1, workers=1, num_steps=20,
              test_eps=100, env='Track2D-BlockPartialPZR-v0', env_base='Track2D-BlockPartialNav-v0', optimizer='Adam',
              amsgrad=True, load_model_dir=None, log_dir='logs/', network='tat-maze-lstm', aux='reward', gpu_ids=[0],
              obs='img', single=False, gray=False, crop=False, inv=False, rescale=False, render=False,
              shared_optimizer=True, split=False, train_mode=-1, stack_frames=1, input_size=80, rnn_out=128,
-             sleep_time=0, max_step=150000, init_step=-1, num_envs=4096, max_grad_norm=None)
+             sleep_time=0, max_step=150000, init_step=-1, num_envs=4096, max_grad_norm=None, obs_u8=True)
     d.update(over)
     return argparse.Namespace(**d)
 

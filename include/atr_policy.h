@@ -33,6 +33,20 @@ int atr_stem_backward(const float *x, long long x_stride, const float *y, const 
                       const float *b1, const float *w2, float *dw1, float *db1, float *dw2, float *db2,
                       float *workspace, long long M, void *stream);
 
+/* The same three entry points on u8 frames (the env's t2d_step_u8 observations, one byte per cell, values 0/1/2/4;
+ * x_stride in bytes): the float32 cast frame_stack applies (environment.py:138,146 of the reference) happens inside
+ * conv1's load, so the observation crosses HBM once, as bytes. Bit-identical results to the float entry points on
+ * float(x). */
+int atr_stem_forward_u8(const unsigned char *x, long long x_stride, const float *w1, const float *b1, const float *w2,
+                        const float *b2, float *y, long long M, void *stream);
+int atr_stem_forward2_u8(const unsigned char *x0, long long x0_stride, const float *w1_0, const float *b1_0,
+                         const float *w2_0, const float *b2_0, float *y0, long long M0, const unsigned char *x1,
+                         long long x1_stride, const float *w1_1, const float *b1_1, const float *w2_1,
+                         const float *b2_1, float *y1, long long M1, void *stream);
+int atr_stem_backward_u8(const unsigned char *x, long long x_stride, const float *y, const float *dy, const float *w1,
+                         const float *b1, const float *w2, float *dw1, float *db1, float *dw2, float *db2,
+                         float *workspace, long long M, void *stream);
+
 /* Actor head of the rollout in one launch (replaces actor_linear -> softmax -> multinomial, model.py:41-49 of the
  * reference): logits = w h + b with h [n,R] (R <= 256, multiple of 4), w [A,R], b [A], A <= 8; one categorical draw
  * per row by inverse CDF on a Philox4x32-10 uniform keyed (seed; row, *counter, ordinal). `counter` is a device-side

@@ -60,6 +60,7 @@ parser.add_argument('--sleep-time', type=int, default=0, metavar='ST', help='acc
 parser.add_argument('--max-step', type=int, default=150000, metavar='MS', help='max learning steps (iterations)')
 parser.add_argument('--init-step', type=int, default=-1, metavar='IS', help='steps not update target at beginning')
 parser.add_argument('--max-grad-norm', type=float, default=None, help='clip (off by default, as the reference effectively is)')
+parser.add_argument('--f32-obs', dest='obs_u8', action='store_false', help='float32 observations between env and policy (default: bytes, decoded in conv1)')
 parser.add_argument('--no-graph', action='store_true', help='run iterations eagerly instead of as hipGraphs')
 
 if __name__ == '__main__':

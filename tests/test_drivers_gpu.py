@@ -212,3 +212,30 @@ def test_rescale_wrapper_matches_the_reference_formula():
     assert np.array_equal(oa, want.astype(np.float32))
     assert a.rollout_buffers(5) is None
     a.close(); b.close()
+
+
+def test_byte_observations_train_exactly_like_float_observations():
+    """obs_u8 (t2d_step_u8 -> atr_stem_*_u8: the observation crosses HBM as bytes and is decoded in conv1) against
+    the float32 path from the same seeds: same trajectories, same loss, same gradients, bit for bit, through the
+    cached-rollout learner and a hipGraph-replayed iteration."""
+    from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player, rollout
+    dev = torch.device("cuda:0")
+    res = []
+    for u8 in (True, False):
+        args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=192, num_steps=8, seed=4, obs_u8=u8)
+        player, opt = make_player(args, dev)
+        assert player.env.obs_u8 == u8 and player.state.dtype == (torch.uint8 if u8 else torch.float32)
+        rollout(player, args.num_steps)
+        assert player._buf[0].dtype == player.state.dtype
+        obs_seq = player._buf[0].float().clone()
+        stats = player.optimize(None, opt, player.model, -1, dev)
+        it = GraphedIteration(player, opt, args)
+        for _ in range(2):
+            it.run()
+        torch.cuda.synchronize()
+        res.append((obs_seq, [s.clone() for s in stats], opt.bucket.flat.clone(), player.state.float().clone()))
+        player.env.close()
+    (oa, sa, wa, xa), (ob, sb, wb, xb) = res
+    assert torch.equal(oa, ob) and torch.equal(xa, xb)
+    assert all(torch.equal(a, b) for a, b in zip(sa, sb))
+    assert torch.equal(wa, wb)

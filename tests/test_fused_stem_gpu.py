@@ -254,3 +254,29 @@ def test_gemm_tn_matches_float64_reference(K, M, N):
     xs = x1.double() * scale.double().unsqueeze(1)
     assert float((cs_.double() - xs.t() @ x2.double()).abs().max()) < 3e-5 * K ** 0.5 * 4
     assert float((colsum.double() - xs.sum(0)).abs().max()) < 3e-5 * K ** 0.5 * 4
+
+
+@pytest.mark.parametrize("M", [5, 4096])
+def test_u8_frames_give_the_float_results_bit_for_bit(M):
+    """atr_stem_*_u8 (the env's byte observations decoded inside conv1's load) against the float entry points on
+    float(x): the same arithmetic on the same values, so forward and all four gradients are identical, also on a
+    strided view (one agent's frames of an [N,2,13,13] observation tensor)."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(M)
+    dev = "cuda"
+    conv1 = torch.nn.Conv2d(1, 16, 3, 2, 1).to(dev)
+    conv2 = torch.nn.Conv2d(16, 32, 3, 2, 1).to(dev)
+    obs = torch.tensor(np.random.RandomState(M).choice([0, 1, 2, 4], size=(M, 2, 13, 13)).astype(np.uint8), device=dev)
+    params = [conv1.weight, conv1.bias, conv2.weight, conv2.bias]
+    for view in (obs[:, 1], obs):                       # strided (stride 338 bytes) and dense
+        yu = fused.stem(view, conv1, conv2)
+        yf = fused.stem(view.float(), conv1, conv2)
+        assert torch.equal(yu, yf)
+        g = torch.randn_like(yf)
+        gu = torch.autograd.grad((yu * g).sum(), params)
+        gf = torch.autograd.grad((yf * g).sum(), params)
+        assert all(torch.equal(a, b) for a, b in zip(gu, gf))
+    out_u, out_f = torch.empty((M, 512), device=dev), torch.empty((M, 512), device=dev)
+    fused.stem_into(obs[:, 0], conv1, conv2, out_u)
+    fused.stem_into(obs[:, 0].float(), conv1, conv2, out_f)
+    assert torch.equal(out_u, out_f)
