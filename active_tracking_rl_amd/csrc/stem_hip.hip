@@ -56,24 +56,43 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __buil
 // A frame's 169 floats: lane l holds elements l, l+64, l+128.
 // XT = float, or uint8_t: the env's u8 observations (t2d_step_u8, values 0/1/2/4) decoded here, in the first layer
 // (the np.float32(obs) cast of frame_stack, environment.py:138,146, fused into conv1: SURVEY 8f rank 1).
-struct XRegs { float v[3]; };
+// A frame is fetched one loop iteration ahead of its use, so XRegs carries the RAW loaded words across the loop
+// back-edge and the decode happens in store_x: converting at load time would make the prefetch a blocking load.
+// Bytes are fetched as the aligned dword that holds them (never leaves the byte's own 4-byte granule): lanes l, l+64
+// and l+128 of a frame share the same byte offset within their dwords.
+struct XRegs { uint32_t w[3]; uint32_t sh; };
 template <typename XT>
 __device__ __forceinline__ XRegs load_x(const XT *__restrict__ x, long long m, long long M, long long xs, int l)
 {
     XRegs r;
-    const XT *p = x + m * xs;
-    const bool ok = m < M;
-    r.v[0] = ok ? (float)p[l] : 0.f;
-    r.v[1] = ok ? (float)p[l + 64] : 0.f;
-    r.v[2] = (ok && l < 41) ? (float)p[l + 128] : 0.f;
+    r.w[0] = r.w[1] = r.w[2] = 0u;
+    r.sh = 0u;
+    if (m < M) {
+        if (sizeof(XT) == 4) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(x + m * xs);
+            r.w[0] = p[l]; r.w[1] = p[l + 64];
+            if (l < 41) r.w[2] = p[l + 128];
+        } else {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(x + m * xs) + (uintptr_t)l;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+            r.sh = 8u * (uint32_t)(a & 3u);
+            r.w[0] = p[0]; r.w[1] = p[16];
+            if (l < 41) r.w[2] = p[32];
+        }
+    }
     return r;
 }
+template <typename XT> __device__ __forceinline__ float decode_x(uint32_t w, uint32_t sh)
+{
+    return sizeof(XT) == 4 ? __uint_as_float(w) : (float)((w >> sh) & 0xffu);
+}
 __device__ __forceinline__ int xpad_addr(int i) { const int r = i / 13; return (r + 1) * kXS + (i - r * 13) + 1; }
+template <typename XT>
 __device__ __forceinline__ void store_x(float *xpad, const XRegs &r, int l)
 {
-    xpad[xpad_addr(l)] = r.v[0];
-    xpad[xpad_addr(l + 64)] = r.v[1];
-    if (l < 41) xpad[xpad_addr(l + 128)] = r.v[2];
+    xpad[xpad_addr(l)] = decode_x<XT>(r.w[0], r.sh);
+    xpad[xpad_addr(l + 64)] = decode_x<XT>(r.w[1], r.sh);
+    if (l < 41) xpad[xpad_addr(l + 128)] = decode_x<XT>(r.w[2], r.sh);
 }
 
 // conv1 + ReLU of the wave's frame on packed f32 FMAs (v_pk_fma_f32: two channels per lane). Lane = (channel pair
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
     const float *ap = s.a1 + q * kA1Ch + (2 * (c >> 2)) * kA1Row + 2 * (c & 3);
     wave_lds_sync();
     for (; m < M; m += stride) {
-        store_x(s.x, xv, l);
+        store_x<XT>(s.x, xv, l);
         xv = load_x(x, m + stride, M, xs, l);        // prefetch the next frame under this one's math
         wave_lds_sync();
         conv1_wave(s.x, s.a1, cw, l);
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_bwd(const XT *__restrict__
     const float *bp = s.a1 + c * kA1Ch + 2 * q;       // B operand of (1): input channel c, output column q of row s
     __syncthreads();
     for (; m < M; m += stride) {
-        store_x(s.x, xv, l);
+        store_x<XT>(s.x, xv, l);
         const float4 z0 = relu_mask(zv.y0, zv.d0), z1 = relu_mask(zv.y1, zv.d1);
         gb0 += (z0.x + z0.y) + (z0.z + z0.w);
         gb1 += (z1.x + z1.y) + (z1.z + z1.w);

@@ -19,11 +19,11 @@ torch.distributed.run on 127.0.0.1, the role main.py:102-116 plays in the refere
 the process group really has N ranks (checked with an all-reduce of ones and an all-gather of the device ids).
 
 Extra objects on the same JSON line:
-  roofline     the step/observe kernel (k_env<OP_STEP>): algorithmic bytes (1723 B x envs per launch)
+  roofline     the step/observe kernel (k_step2): algorithmic bytes (1723 B x envs per launch)
                / average launch duration, measured with HIP events on the launch stream over back-to-back
                policy-shaped launches in a hipGraph (the kernel alone; the per-step figure with the generator pass
                every 10th step is reported next to it); peak 8 TB/s (HBM3E). `traffic` is read from the committed
-               rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json).
+               rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json).
   env_only     the same kernel driven with on-device random actions (no policy): launches/s -> env steps/s, per
                launch and in the persistent mode (t2d_rollout_random: up to 10 steps per launch).
   policy_stem  informational f32-MFMA roofline of the conv-stem kernels (the largest single kernels of the iteration).
@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B_STEP = 1723          # algorithmic bytes per env-step
+B_STEP_U8 = 709        # ... of the u8-observation variant (obs 338 B instead of 1352 B)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -115,6 +116,8 @@ def main():
                     help="reference-shaped learner (autograd graph built during the rollout) instead of the "
                          "actor/learner split with time-batched re-evaluation")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--f32-obs", action="store_true", help="float32 observations between env and policy (default: bytes, "
+                                                          "decoded in the stem's conv1)")
     ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K-step region (median reported)")
     ap.add_argument("--global-envs", type=int, default=4096, help="env count of the strong-scaling form")
     ap.add_argument("--launch-check", action="store_true",
@@ -158,7 +161,7 @@ def main():
         """Build the player for `envs_per_gpu` envs on this rank, warm up, then time `repeats` repeats of `steps` env
         steps, each bracketed by barrier + synchronize; per repeat the MAX over ranks; returns the median repeat."""
         args = default_args(env=a.env, network=a.network, num_envs=envs_per_gpu, num_steps=T, gpu_ids=[local_rank],
-                            aux="reward" if "tat" in a.network else "none", train_mode=-1)
+                            aux="reward" if "tat" in a.network else "none", train_mode=-1, obs_u8=not a.f32_obs)
         player, optimizer = make_player(args, device, rank, world)
 
         def eager_iteration():
@@ -275,6 +278,26 @@ def main():
         torch.cuda.synchronize(device)
         tot += e0.elapsed_time(e1)
     k_us = tot * 1e3 / (40 * 9)
+    # the u8-observation variant of the same kernel (t2d_step_u8; SURVEY 8(d): B_step = 709 B, reported under its own name)
+    k8_us = None
+    if getattr(core, "supports_u8", False):
+        out8 = (torch.empty((n, 2, 13, 13), dtype=torch.uint8, device=device), out[1], out[2])
+        core.flush()
+        torch.cuda.synchronize(device)
+        g8 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g8, capture_error_mode="thread_local"):
+            for i in range(9):
+                core.step_u8(acts[i, 0], acts[i, 1], out8)
+        core.flush()
+        torch.cuda.synchronize(device)
+        tot = 0.0
+        for _ in range(40):
+            e0.record()
+            g8.replay()
+            e1.record()
+            torch.cuda.synchronize(device)
+            tot += e0.elapsed_time(e1)
+        k8_us = tot * 1e3 / (40 * 9)
     core.reset()
     achieved = B_STEP * n / (k_us * 1e-6) / 1e9
     # env-only loop with on-device random actions
@@ -338,9 +361,9 @@ def main():
 
     traffic, traffic_src = None, None
     try:   # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (cannot be taken inside this run)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
         if pm.get("n_envs") == n:
-            traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     except Exception:
         pass
     line = {
@@ -358,8 +381,9 @@ def main():
                                "(policy fwd + HIP env step + loss/backward + grad all-reduce + SharedAdam)"
                                % (a.env, n, world, a.network),
                    "global_envs": n_total, "rollout": T, "hipgraph": graphed,
+                   "obs": "u8 (t2d_step_u8 -> atr_stem_*_u8)" if getattr(player.env, "obs_u8", False) else "f32",
                    "gemm_algos": "TunableOp picks from tunableop_gfx950.csv" if tuned else "library default", "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},
-        "roofline": {"bound": "hbm", "kernel": "t2d::k_env<OP_STEP> (step+observe, in-launch auto-reset)",
+        "roofline": {"bound": "hbm", "kernel": "t2d::k_step2 (step+observe, f32 observations, in-launch auto-reset)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": B_STEP * n,
                      "avg_launch_us": k_us, "avg_step_us_incl_generator": step_us,
@@ -367,14 +391,22 @@ def main():
                      "note": "avg_launch_us = the step kernel alone: hipGraph of 9 policy-shaped step launches (no "
                              "generator pass inside) replayed 40x, HIP events on the launch stream around each replay; "
                              "it still contains the in-graph kernel boundaries, so it sits a few tenths of a us above "
-                             "rocprofv3's k_env average (profiles/r01_*kernel_stats.txt). avg_step_us_incl_generator = "
+                             "rocprofv3's k_step2 average (profiles/r02_*kernel_stats*.txt). avg_step_us_incl_generator = "
                              "100-launch graph replayed 5x, generator pass (k_gen) every 10th step included"},
+        "roofline_u8": None if k8_us is None else {
+            "bound": "hbm", "kernel": "t2d::k_step2<..., OBS_U8> (t2d_step_u8: observations left as bytes, decoded by "
+                                      "the policy stem's conv1 load)",
+            "achieved": B_STEP_U8 * n / (k8_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": B_STEP_U8 * n / (k8_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": B_STEP_U8 * n,
+            "avg_launch_us": k8_us,
+            "note": "SURVEY 8(d) B_step = 709 B variant (obs 338 B instead of 1352 B), same measurement as `roofline`; "
+                    "this is the kernel the end-to-end `value` uses when config.obs is u8"},
         "env_only": {"value": n * world / (eo_us * 1e-6), "unit": "env steps/s", "us_per_launch": eo_us,
                      "note": "same kernel, on-device random actions, one launch per batched step, per-rank x ranks",
                      "fused_value": n * world / (eof_us * 1e-6), "fused_us_per_step": eof_us,
                      "fused_gbs": B_STEP * n / (eof_us * 1e-6) / 1e9,
-                     "fused_note": "t2d_rollout_random: up to 10 env steps per launch (state in registers, map tile in "
-                                   "LDS), all %d steps' observations/rewards/done written; bit-identical to the "
+                     "fused_note": "t2d_rollout_random: up to 10 env steps per launch (state in registers, map rows re-read "
+                                   "through L1/L2), all %d steps' observations/rewards/done written; bit-identical to the "
                                    "per-step launches" % T},
         "policy_stem": stem_roof,
     }
