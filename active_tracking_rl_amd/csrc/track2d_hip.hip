@@ -851,9 +851,9 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         uint32_t tm = cfg->target_mode_per_env ? cfg->target_mode_per_env[i] : cfg->target_mode;
         uint32_t lv = cfg->level_per_env ? cfg->level_per_env[i] : cfg->level;
         if (mt > T2D_MAP_EMPTY) return fail(T2D_ERR_INVALID, "t2d_create: map_type %u (env %d)", mt, i);
-        if (tm > T2D_TGT_RPF) return fail(T2D_ERR_INVALID, "t2d_create: target_mode %u (env %d)", tm, i);
+        if (tm > T2D_TGT_EXT) return fail(T2D_ERR_INVALID, "t2d_create: target_mode %u (env %d)", tm, i);
         has_nav = has_nav || tm == T2D_TGT_NAV || tm == T2D_TGT_RPF;
-        has_rpf = has_rpf || tm == T2D_TGT_RPF;
+        has_rpf = has_rpf || tm == T2D_TGT_RPF || tm == T2D_TGT_EXT;   // agents may stand on walls
         has_ram = has_ram || tm == T2D_TGT_RAM;
         n_maze += mt == T2D_MAP_MAZE;
         if (lv > 15) return fail(T2D_ERR_INVALID, "t2d_create: level %u (env %d)", lv, i);

@@ -131,24 +131,54 @@ class VecEnv(object):
 
 
 class Track2DEnv(object):
-    """One env behind the reference's exact gym protocol (TimeLimit + frame_stack included)."""
+    """One env behind the reference's exact gym protocol (TimeLimit + frame_stack included).
 
-    def __init__(self, env_id, device="cuda:0", seed=1, stack_frames=1, rescale=False):
+    rng="philox" (default): maps / spawns / scripted targets come from the device generators (Philox streams).
+    rng="numpy": the reference-exact mode — np.random.seed(seed) semantics: maps, spawns, goals and the scripted
+    Ram / Nav / RPF targets are produced on the host by the numpy-legacy stream + heapq-faithful A* of
+    include/track2d_np.h (np_mode.NpEpisodeSource) in the reference's draw order and injected (t2d_inject; the target's
+    action as the step's target action), so an episode is the reference's, bit for bit, from the seed alone. The
+    argument-less np.random.seed() calls inside generators.py:41,56 are NOT replayed (they make the reference itself
+    irreproducible; the golden vectors were captured with them neutralised)."""
+
+    def __init__(self, env_id, device="cuda:0", seed=1, stack_frames=1, rescale=False, rng="philox"):
+        if rng not in ("philox", "numpy"):
+            raise ValueError("rng must be 'philox' or 'numpy'")
+        self.rng = rng
+        self._np = None
+        over = {}
+        if rng == "numpy":
+            from .np_mode import NpEpisodeSource
+            sp = registry.spec(env_id)
+            self._np = NpEpisodeSource(sp["map_type"], sp["target_mode"], sp["level"], seed)
+            if self._np.scripted:      # the host drives the target; rewards use w_p = 0 either way (track_1v1.py:147-152)
+                over = dict(target_mode_per_env=np.array([registry.TARGET_CODE["Ext"]], np.uint8))
         self.vec = VecEnv(env_id, 1, device=device, seed=seed, stack_frames=stack_frames, auto_reset=False,
-                          rescale=rescale)
+                          rescale=rescale, **over)
         self.observation_space, self.action_space = self.vec.observation_space, self.vec.action_space
 
     def seed(self, seed=None):
+        """rng="numpy": np.random.seed(seed) on the env's stream (what actually determines the reference's episodes;
+        the reference's own env.seed() is a no-op for them, track_1v1.py:129-132)."""
+        if self._np is not None and seed is not None:
+            self._np.seed(seed)
         return self.vec.seed(seed)
 
     def reset(self):
-        return self.vec.reset()[0].cpu().numpy()
+        if self._np is None:
+            return self.vec.reset()[0].cpu().numpy()
+        maze, pos, goals = self._np.reset()
+        core = self.vec.core
+        core.inject(maze, pos, goals)                      # also zeroes the step / far counters (Track1v1Env.reset)
+        return self.vec._stack(core.observe(), fill=True)[0].cpu().numpy()
 
     def step(self, action):
-        a = [torch.tensor([int(np.asarray(x).reshape(-1)[0])], dtype=torch.int64, device=self.vec.device)
-             for x in list(action)[:2]]
+        a = [int(np.asarray(x).reshape(-1)[0]) for x in list(action)[:2]]
         if len(a) == 1:
-            a.append(torch.zeros_like(a[0]))
+            a.append(0)
+        if self._np is not None and self._np.scripted:
+            a[1] = self._np.target_action()                # track_1v1.py:80-84: the scripted target overrides action[1]
+        a = [torch.tensor([x], dtype=torch.int64, device=self.vec.device) for x in a]
         obs, rew, done, _ = self.vec.step(a)
         d2 = int(self.vec.core.get_state()["d2"][0])
         info = {"distance": float(np.sqrt(float(d2)))}           # track_1v1.py:118
@@ -156,12 +186,14 @@ class Track2DEnv(object):
 
     def close(self):
         self.vec.close()
+        if self._np is not None:
+            self._np.close()
 
     def render(self, *a, **k):
         return self.vec.render()
 
 
-def create_env(env_id, args, num_envs=None, device=None, env_id_base=0, obs_u8=None):
+def create_env(env_id, args, num_envs=None, device=None, env_id_base=0, obs_u8=None, rng=None):
     """environment.create_env (environment.py:11-32) for the Track2D ids.
 
     args carries the reference's flags (stack_frames, seed, ...) plus optionally `num_envs` and `gpu_ids`.
@@ -186,4 +218,5 @@ def create_env(env_id, args, num_envs=None, device=None, env_id_base=0, obs_u8=N
     if n > 1:
         return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base, rescale=rescale,
                       obs_u8=obs_u8)
-    return Track2DEnv(env_id, device=device, seed=seed, stack_frames=stack, rescale=rescale)
+    rng = rng if rng is not None else getattr(args, "rng", "philox")
+    return Track2DEnv(env_id, device=device, seed=seed, stack_frames=stack, rescale=rescale, rng=rng)

@@ -1,0 +1,114 @@
+"""ctypes binding of include/track2d_np.h: the reference-exact episode source (numpy-legacy MT19937 stream +
+heapq-faithful A*, host side of libtrack2d_hip.so). Used by environment.Track2DEnv(rng="numpy"): what it generates
+goes to the device through t2d_inject, the scripted target's action through t2d_step."""
+import ctypes as C
+
+import numpy as np
+
+from . import registry, vec_env
+
+NP_SYMBOLS = ("t2d_np_create", "t2d_np_destroy", "t2d_np_last_error", "t2d_np_seed", "t2d_np_reset",
+              "t2d_np_target_action", "t2d_np_get_plan", "t2d_np_astar", "t2d_np_draw")
+_ready = False
+
+
+def _lib():
+    global _ready
+    L = vec_env.load_library()
+    if not _ready:
+        vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
+        L.t2d_np_last_error.restype = C.c_char_p
+        L.t2d_np_create.restype = i32
+        L.t2d_np_create.argtypes = [i32, i32, i32, u32, C.POINTER(vp)]
+        L.t2d_np_destroy.restype = i32
+        L.t2d_np_destroy.argtypes = [vp]
+        L.t2d_np_seed.restype = i32
+        L.t2d_np_seed.argtypes = [vp, u32]
+        L.t2d_np_reset.restype = i32
+        L.t2d_np_reset.argtypes = [vp, vp, vp, vp, vp]
+        L.t2d_np_target_action.restype = i32
+        L.t2d_np_target_action.argtypes = [vp, vp]
+        L.t2d_np_get_plan.restype = i32
+        L.t2d_np_get_plan.argtypes = [vp, vp, i32, vp, vp, vp]
+        L.t2d_np_astar.restype = i32
+        L.t2d_np_astar.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp]
+        L.t2d_np_draw.restype = i32
+        L.t2d_np_draw.argtypes = [vp, i32, u32, u32, vp]
+        _ready = True
+    return L
+
+
+class NpError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise NpError("track2d_np error %d: %s" % (rc, _lib().t2d_np_last_error().decode()))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class NpEpisodeSource(object):
+    """One env's random side: np.random.seed(seed), then reset() / target_action() in the reference's draw order."""
+
+    def __init__(self, map_type, target_mode, level=0, seed=0):
+        self.L = _lib()
+        self.map_type, self.target_mode, self.level = map_type, target_mode, int(level)
+        h = C.c_void_p()
+        _check(self.L.t2d_np_create(registry.MAP_CODE[map_type], registry.TARGET_CODE[target_mode], int(level),
+                                    int(seed) & 0xFFFFFFFF, C.byref(h)))
+        self.h = h
+        self.scripted = target_mode in ("Ram", "Nav", "RPF")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.t2d_np_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def seed(self, seed):
+        _check(self.L.t2d_np_seed(self.h, int(seed) & 0xFFFFFFFF))
+
+    def reset(self):
+        """-> (maze u8 [side, side], pos int32 [2, 2] (tracker, target), goals int32 [2, 2])."""
+        maze = np.zeros((82, 82), np.uint8)
+        side = np.zeros(1, np.int32)
+        pos, goals = np.zeros(4, np.int32), np.zeros(4, np.int32)
+        _check(self.L.t2d_np_reset(self.h, _ptr(maze), _ptr(side), _ptr(pos), _ptr(goals)))
+        s = int(side[0])
+        return np.ascontiguousarray(maze[:s, :s]), pos.reshape(2, 2), goals.reshape(2, 2)
+
+    def target_action(self):
+        a = np.zeros(1, np.int32)
+        _check(self.L.t2d_np_target_action(self.h, _ptr(a)))
+        return int(a[0])
+
+    def plan(self):
+        """-> (plan_actions int32 [len], a_i, navgoal int32 [2])."""
+        ln, cur, ng = np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(2, np.int32)
+        _check(self.L.t2d_np_get_plan(self.h, None, 0, _ptr(ln), _ptr(cur), _ptr(ng)))
+        plan = np.zeros(max(int(ln[0]), 1), np.int32)
+        _check(self.L.t2d_np_get_plan(self.h, _ptr(plan), int(ln[0]), _ptr(ln), _ptr(cur), _ptr(ng)))
+        return plan[:int(ln[0])], int(cur[0]), ng
+
+    def draw(self, kind, arg=0, count=1):
+        out = np.zeros(max(int(arg) if kind == 2 else int(count), 1), np.float64)
+        _check(self.L.t2d_np_draw(self.h, int(kind), int(arg), int(count), _ptr(out)))
+        return out[:int(arg) if kind == 2 else int(count)]
+
+
+def astar(maze, start, goal, max_len=8192):
+    """AstarSolver(start, [0, 1, 2, 3], maze, goal): -> (solvable, actions int32 [n])."""
+    maze = np.ascontiguousarray(maze, np.uint8)
+    side = maze.shape[0]
+    assert maze.shape == (side, side)
+    st, gl = np.asarray(start, np.int32).reshape(2).copy(), np.asarray(goal, np.int32).reshape(2).copy()
+    acts = np.zeros(max_len, np.int32)
+    n, ok = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    _check(_lib().t2d_np_astar(_ptr(maze), side, _ptr(st), _ptr(gl), _ptr(acts), max_len, _ptr(n), _ptr(ok)))
+    assert int(n[0]) <= max_len
+    return bool(ok[0]), acts[:int(n[0])].copy()

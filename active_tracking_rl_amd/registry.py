@@ -9,7 +9,8 @@ TARGET_MODES = ("Adv", "PZR", "Far", "Nav", "Ram", "RPF")
 MAX_EPISODE_STEPS = 500
 
 MAP_CODE = {"Block": 0, "Maze": 1, "Empty": 2}
-TARGET_CODE = {"Adv": 0, "PZR": 1, "Far": 2, "Nav": 3, "Ram": 4, "RPF": 5}
+TARGET_CODE = {"Adv": 0, "PZR": 1, "Far": 2, "Nav": 3, "Ram": 4, "RPF": 5,
+               "Ext": 6}   # not an id: target action supplied by the caller (include/track2d.h T2D_TGT_EXT)
 
 REGISTRY = {}
 for _m in MAP_TYPES:

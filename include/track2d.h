@@ -37,7 +37,11 @@ typedef enum {
 
 /* map_type / target_mode values: the kwargs of the registry, G/__init__.py:3-18 */
 enum { T2D_MAP_BLOCK = 0, T2D_MAP_MAZE = 1, T2D_MAP_EMPTY = 2 };
-enum { T2D_TGT_ADV = 0, T2D_TGT_PZR = 1, T2D_TGT_FAR = 2, T2D_TGT_NAV = 3, T2D_TGT_RAM = 4, T2D_TGT_RPF = 5 };
+enum { T2D_TGT_ADV = 0, T2D_TGT_PZR = 1, T2D_TGT_FAR = 2, T2D_TGT_NAV = 3, T2D_TGT_RAM = 4, T2D_TGT_RPF = 5,
+       /* not a registry mode: the target's action always comes from the caller (w_p = 0 like Adv/Nav/Ram/RPF) and the
+        * agents may be injected on wall cells, as the reference's RPF spawn can be (track_1v1.py:233-236). Used by the
+        * reference-exact mode, whose scripted targets run on the host (include/track2d_np.h). */
+       T2D_TGT_EXT = 6 };
 /* dtype codes for action arrays */
 enum { T2D_ACT_U8 = 0, T2D_ACT_I32 = 1, T2D_ACT_I64 = 2 };
 /* obs_type of the registry kwargs (G/__init__.py:11), define_observation at G/envs/track_1v1.py:251-262 */

@@ -1,0 +1,66 @@
+/*
+ * track2d_np.h — C ABI of the reference-exact episode source: the part of the Track2D env that draws random numbers
+ * (maps, spawns, goals, the scripted Ram / Nav / RPF targets), restated on the HOST with numpy's legacy global
+ * stream (MT19937, RandomState.random_sample / randint / choice / permutation) and a heapq-faithful A*, so that an env
+ * seeded like the reference (np.random.seed(s)) produces the reference's episodes draw for draw. The device keeps
+ * doing the per-step work (moves, rewards, done, observations): what this library generates goes in through
+ * t2d_inject (include/track2d.h) and the scripted target's action goes in as the target action of t2d_step.
+ * SURVEY.md section 8(f) rank 3. Host-only code (active_tracking_rl_amd/csrc/np_mode.cpp); no device memory is touched.
+ *
+ * Reference lines restated (G/ = envs/gym-track2d/gym_track2d/): G/envs/track_1v1.py:134-168,218-240 (reset,
+ * init_maze), G/envs/generators.py:12-94,115-176 (static_goals, sample_state, sample_goal, sample_close_states,
+ * get_around, the two map generators), G/envs/navigator.py:5-93 (Navigator, RamAgent), G/envs/Astar_solver.py:42-173.
+ * numpy (not vendored; legacy stream frozen by NEP 19): mt19937 seeding by an integer, random_sample = (a >> 5,
+ * b >> 6) / 2^53, bounded integers by masked rejection on 32-bit words, shuffle = Fisher-Yates from the top,
+ * choice(n, k, replace=False) = permutation(n)[:k].
+ */
+#ifndef TRACK2D_NP_H
+#define TRACK2D_NP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct t2d_np t2d_np;
+
+/* One env's host-side state: the kwargs of the registry entry (G/__init__.py:3-18; codes as in track2d.h:
+ * map_type 0 Block / 1 Maze / 2 Empty, target_mode 0 Adv / 1 PZR / 2 Far / 3 Nav / 4 Ram / 5 RPF) and its own
+ * MT19937 stream seeded like np.random.seed(seed). Returns 0 or a negative code (t2d_np_last_error has the text). */
+int t2d_np_create(int map_type, int target_mode, int level, uint32_t seed, t2d_np **out);
+int t2d_np_destroy(t2d_np *e);
+const char *t2d_np_last_error(void);
+/* np.random.seed(seed) — restarts the stream (the reference's env.seed() has no effect on it, track_1v1.py:129-132). */
+int t2d_np_seed(t2d_np *e, uint32_t seed);
+
+/* Track1v1Env.reset() up to (not including) the observation: init_maze (new map, goals, spawns, the goal_test loop),
+ * then the scripted target's reset (Ram plan / Navigator A* plan with its retries and plan B).
+ * maze: u8 [82*82] row-major with row stride 82, the ENV's map (track_1v1.py:233; for RPF it keeps the walls the
+ * generator cleared on the patrol cells); *side = 81 (Maze) or 82; pos = tracker r, c, target r, c (init_states);
+ * goals = goal_states flattened. Feed them to t2d_inject. */
+int t2d_np_reset(t2d_np *e, uint8_t *maze, int32_t *side, int32_t pos[4], int32_t goals[4]);
+
+/* The scripted target's action for the next env step — RamAgent.step() (navigator.py:77-88) or Navigator.step(
+ * old_state[1], maze_generator, None) (navigator.py:11-41), including the draws it consumes — and the host-side mirror
+ * of the target's own position advanced by it (_next_state on the env's map, track_1v1.py:271-285: the target's motion
+ * does not depend on the tracker). Error for the policy-driven modes (Adv / PZR / Far). */
+int t2d_np_target_action(t2d_np *e, int32_t *action);
+
+/* The target's current plan (plan_actions, a_i) and, for Nav / RPF, its goal: for tests against the reference's
+ * plan0 / navgoal0. plan: caller buffer of max_len ints; *len = full length (may exceed max_len). */
+int t2d_np_get_plan(const t2d_np *e, int32_t *plan, int32_t max_len, int32_t *len, int32_t *cursor, int32_t navgoal[2]);
+
+/* AstarSolver(start, [0,1,2,3], maze, goal) (Astar_solver.py:86-173) alone: maze u8 [side*side] row-major (non-zero =
+ * wall). *solvable = solution_node is not None; actions = get_actions() (caller buffer of max_len ints, *n = length). */
+int t2d_np_astar(const uint8_t *maze, int32_t side, const int32_t start[2], const int32_t goal[2], int32_t *actions,
+                 int32_t max_len, int32_t *n, int32_t *solvable);
+
+/* Primitives of the stream, exposed for the known-answer tests against the installed numpy. */
+int t2d_np_draw(t2d_np *e, int kind, uint32_t arg, uint32_t count, double *out);
+/* kind 0: random_sample() x count; 1: randint(0, arg) x count; 2: permutation(arg) (count ignored, arg values out). */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -11,9 +11,9 @@ import pytest
 from conftest import GOLDEN, ROOT
 
 
-def _header_symbols():
-    txt = open(os.path.join(ROOT, "include", "track2d.h")).read()
-    return sorted(set(re.findall(r"\b(t2d_[a-z_0-9]+)\s*\(", txt)))
+def _header_symbols(header="track2d.h", prefix="t2d_"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    return sorted(set(re.findall(r"\b(%s[a-z_0-9]+)\s*\(" % prefix, txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -27,6 +27,14 @@ def test_library_exports_every_declared_symbol():
     assert sorted(vec_env.ABI_SYMBOLS) == syms
     lib.t2d_abi_version.restype = ctypes.c_int
     assert lib.t2d_abi_version() == vec_env.ABI_VERSION
+    # the other two headers of the boundary: policy-side kernels and the reference-exact episode source
+    from active_tracking_rl_amd import np_mode
+    np_syms = _header_symbols("track2d_np.h", "t2d_np_")
+    assert sorted(np_mode.NP_SYMBOLS) == np_syms and len(np_syms) >= 9
+    atr_syms = _header_symbols("atr_policy.h", "atr_")
+    assert len(atr_syms) >= 16 and "atr_stem_forward_u8" in atr_syms
+    for s in np_syms + atr_syms:
+        assert hasattr(lib, s), s
 
 
 def test_registry_matches_reference():

@@ -1,0 +1,80 @@
+"""The reference-exact episode source (include/track2d_np.h, csrc/np_mode.cpp — host code of the PRODUCT library,
+independent of oracle/) on CPU: its numpy-legacy stream against the installed numpy, its heapq-faithful A* against the
+reference's AstarSolver fixtures, and whole multi-episode golden cases replayed FROM THE SEED ALONE: maps, spawns,
+goals, the scripted targets' first plans / goals and every action they emitted (tests/golden/*.npz were captured
+from the reference env by tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, unpack_maze
+
+
+@pytest.fixture(scope="module")
+def npm():
+    from active_tracking_rl_amd import build, np_mode
+    build.build()
+    return np_mode
+
+
+def test_stream_primitives_match_numpy_legacy_randomstate(npm):
+    for seed in (0, 1, 1234, 2 ** 32 - 1):
+        src = npm.NpEpisodeSource("Block", "PZR", 0, seed)
+        rs = np.random.RandomState(seed)
+        assert np.array_equal(src.draw(0, count=9), rs.random_sample(9))
+        for high in (2, 4, 10, 41, 6400):
+            assert np.array_equal(src.draw(1, arg=high, count=11), rs.randint(0, high, size=11))
+        assert np.array_equal(src.draw(2, arg=6400), rs.permutation(6400))
+        assert np.array_equal(src.draw(2, arg=5), rs.choice(5, size=5, replace=False))   # choice == permutation prefix
+        assert np.array_equal(src.draw(0, count=3), rs.random_sample(3))                 # streams still aligned
+        src.seed(seed + 7)
+        assert np.array_equal(src.draw(0, count=2), np.random.RandomState((seed + 7) & 0xFFFFFFFF).random_sample(2))
+        src.close()
+
+
+def test_astar_matches_the_reference_solver(npm):
+    d = np.load(os.path.join(GOLDEN, "astar.npz"))
+    names = sorted(set(k.split("/")[0] for k in d.keys() if "/" in k))
+    assert len(names) >= 40
+    n_unsolvable = 0
+    for nme in names:
+        ok, acts = npm.astar(unpack_maze(d[nme + "/maze"], d[nme + "/side"]), d[nme + "/start"], d[nme + "/goal"])
+        assert ok == bool(d[nme + "/solvable"]), nme
+        n_unsolvable += not ok
+        if ok:
+            assert np.array_equal(acts, d[nme + "/actions"]), nme          # tie-breaks included, not just the length
+    assert n_unsolvable >= 1
+
+
+@pytest.mark.parametrize("fixture", ["episodes.npz", "episodes_rpf.npz", "episodes_full.npz"])
+def test_golden_episodes_from_the_seed_alone(npm, fixture):
+    g = np.load(os.path.join(GOLDEN, fixture))
+    n_scripted = 0
+    for name in [str(n) for n in g["names"]]:
+        mp, mode, lvl, seed, _ = [str(x) for x in g[name + "/meta"]]
+        src = npm.NpEpisodeSource(mp, mode, int(lvl), int(seed))
+        for ep in range(int(g[name + "/n_eps"])):          # consecutive episodes of ONE stream
+            p = "%s/ep%d_" % (name, ep)
+            maze, pos, goals = src.reset()
+            assert np.array_equal(maze, unpack_maze(g[p + "maze"], g[p + "side"])), p
+            assert np.array_equal(pos, g[p + "init"]) and np.array_equal(goals, g[p + "goals"]), p
+            if mode in ("Ram", "Nav", "RPF"):
+                plan, cur, navgoal = src.plan()
+                assert cur == 0 and np.array_equal(plan, g[p + "plan0"]), p
+                if mode != "Ram":
+                    assert np.array_equal(navgoal, g[p + "navgoal0"]), p
+                want = g[p + "act_applied"][:, 1]
+                got = np.array([src.target_action() for _ in range(len(want))])
+                assert np.array_equal(got, want), (p, np.nonzero(got != want)[0][:5])
+                n_scripted += 1
+        src.close()
+    assert n_scripted >= 2
+
+
+def test_policy_driven_modes_have_no_scripted_action(npm):
+    src = npm.NpEpisodeSource("Block", "PZR", 0, 3)
+    src.reset()
+    with pytest.raises(npm.NpError):
+        src.target_action()
+    src.close()
