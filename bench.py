@@ -27,7 +27,8 @@ Extra objects on the same JSON line:
   env_only     the same kernel driven with on-device random actions (no policy): launches/s -> env steps/s, per
                launch and in the persistent mode (t2d_rollout_random: up to 10 steps per launch).
   policy_stem  informational f32-MFMA roofline of the conv-stem kernels (the largest single kernels of the iteration).
-  cpu_baseline reference-shaped 16-worker CPU A3C on the oracle (oracle/cpu_a3c.py), rank 0, N=1 only.
+  cpu_baseline reference-shaped 16-worker (+1 evaluator) CPU A3C on the oracle (oracle/cpu_a3c.py --suite), rank 0, N=1
+               only: the headline workload; `cpu_baselines` adds BASELINE config 1 and the env-only 1/16-process rates.
 """
 import argparse
 import json
@@ -115,7 +116,7 @@ def main():
     ap.add_argument("--per-step-autograd", action="store_true",
                     help="reference-shaped learner (autograd graph built during the rollout) instead of the "
                          "actor/learner split with time-batched re-evaluation")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--f32-obs", action="store_true", help="float32 observations between env and policy (default: bytes, "
                                                           "decoded in the stem's conv1)")
     ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K-step region (median reported)")
@@ -412,19 +413,27 @@ def main():
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            # separate process: the baseline forks Hogwild workers, which must not inherit autograd/HIP state
+            # separate process: the baseline forks Hogwild workers, which must not inherit autograd/HIP state.
+            # --suite = BASELINE.md section 3: the headline config and config 1 (BlockPartialRam, maze-lstm, --aux none,
+            # train-mode 0), each 16 workers + 1 evaluator pinned one per physical core, + the env alone on 1 / 16 procs
             import subprocess
-            r = subprocess.run([sys.executable, "-m", "oracle.cpu_a3c", "--json", "--env", a.env, "--network", a.network,
-                                "--aux", args.aux, "--workers", "16", "--seconds", str(a.cpu_seconds)],
-                               cwd=ROOT, capture_output=True, text=True, timeout=600,
+            r = subprocess.run([sys.executable, "-m", "oracle.cpu_a3c", "--suite", "--workers", "16", "--seconds",
+                                str(a.cpu_seconds)], cwd=ROOT, capture_output=True, text=True, timeout=900,
                                env=dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES=""))
-            cb = json.loads(r.stdout.strip().splitlines()[-1])
-            line["cpu_baseline"] = {
-                "value": cb["value"], "unit": "env steps/s", "cores": cb["cores"], "kind": "port",
-                "sample": "%d Hogwild workers x %.0f s of reference-shaped A3C (1 oracle env + batch-1 %s on torch-CPU "
-                          "per worker, <=20-step rollouts, SharedAdam), host has %d logical CPUs; oracle env alone "
-                          "%.0f steps/s on 1 core" % (cb["cores"], cb["seconds"], a.network, cb["host_cpus"],
-                                                       cb["env_only"])}
+            rows = json.loads(r.stdout.strip().splitlines()[-1])
+
+            def entry(cb):
+                return {"value": cb["value"], "unit": "env steps/s", "cores": cb["cores"], "kind": "port",
+                        "config": cb["config"], "cpu_model": cb["cpu_model"], "physical_cores": cb["physical_cores"],
+                        "logical_cpus": cb["host_cpus"], "evaluator_cores": cb["evaluator_cores"], "pinning": cb["pinning"],
+                        "env_only_1proc": cb["env_only_1proc"], "env_only_16proc": cb["env_only_16proc"],
+                        "sample": "%d Hogwild workers + %d evaluator x %.0f s of reference-shaped A3C (%s, %s, --aux %s, "
+                                  "train-mode %d; 1 oracle env + batch-1 policy on torch-CPU per worker, <=20-step "
+                                  "rollouts, SharedAdam); env alone (random actions): %.0f steps/s on 1 process, %.0f on 16"
+                                  % (cb["cores"], cb["evaluator_cores"], cb["seconds"], cb["env"], cb["network"], cb["aux"],
+                                     cb["train_mode"], cb["env_only_1proc"], cb["env_only_16proc"])}
+            line["cpu_baseline"] = entry(rows[0])              # the headline workload's CPU form
+            line["cpu_baselines"] = [entry(cb) for cb in rows]  # + BASELINE config 1
         except Exception as ex:  # the GPU numbers must still be printed
             line["cpu_baseline"] = {"value": None, "error": repr(ex)}
     if rank == 0:
