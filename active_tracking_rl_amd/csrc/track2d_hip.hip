@@ -42,6 +42,7 @@ struct DevState {
     uint32_t *dirf;     // [N][512] Nav direction planes (only if some env has a Nav target)
     // ---- next episode, generated ahead of time by k_gen (episode[e] + 1) ----
     uint32_t *n_maps, *n_pos, *n_goals, *n_plan, *n_tctr, *n_navgoal, *n_nav2, *n_d2, *n_dirf;
+    uint32_t *n_win;    // [N][32] the 2 x 13 window rows (13 map bits each) of the next episode's FIRST observation
     uint32_t *gen_req;  // [N] 0 = next slot valid; s > 0 = consumed at step stamp s, to be regenerated
     // ---- Nav targets: the NEXT plan of the current episode, prepared ahead of time by the generator pass ----
     uint32_t *p_field;  // [N][768] direction planes + visited plane of the BFS rooted at p_goal
@@ -187,6 +188,18 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
     d2 = (uint32_t)(dr * dr + dc * dc);
 }
 
+// The 13 map bits [c - 6, c + 6] of one row given as its three words (ones outside the map: np.pad(..., 1),
+// track_1v1.py:316-322): one v_alignbit over the window [ones | w0 | w1 | w2' | ones].
+__device__ __forceinline__ uint32_t window_row_bits(uint32_t w0, uint32_t w1, uint32_t w2, int side, int c)
+{
+    const uint32_t W2 = w2 | ~valid_mask_w2(side);           // columns >= side read as 1
+    const int sp = c - T2D_POB + 32;
+    const int j = sp >> 5;
+    const uint32_t lo = j == 0 ? 0xffffffffu : (j == 1 ? w0 : (j == 2 ? w1 : W2));
+    const uint32_t hi = j == 0 ? w0 : (j == 1 ? w1 : (j == 2 ? W2 : 0xffffffffu));
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(sp & 31)) & 0x1fffu;
+}
+
 // Generator kernel: fills the "next episode" slot (episode[e] + 1) of every env whose slot was consumed at a step
 // stamp <= upto (or of every env when force != 0). Launched by the host every `gen_every` steps (<= 10): a
 // consumed slot cannot be needed again for 11 steps (done needs 11 consecutive far steps, track_1v1.py:106-111),
@@ -227,6 +240,20 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t upto, int forc
     generate_episode<NAV>(s, e, tile, lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2, nav2);
     wave_lds_sync();
     reinterpret_cast<uint4 *>(s.n_maps + (size_t)e * kTileWords)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
+    if (lane < 2 * T2D_WIN) {
+        // the window rows of the episode's first observation, so that the step kernel that switches to this episode
+        // needs no dependent map fetch (k_step2 reads them speculatively when a done is possible)
+        const int ag = lane >= T2D_WIN ? 1 : 0, y = lane - ag * T2D_WIN;
+        const int gside = side_of_cfg(cfg);
+        const int ar = (int)((pos >> (16 * ag)) & 0xffu), ac = (int)((pos >> (16 * ag + 8)) & 0xffu);
+        const int rr = ar - T2D_POB + y;
+        uint32_t bits = 0x1fffu;
+        if ((unsigned)rr < (unsigned)gside) {
+            const uint32_t *w = tile + rr * kRowWords;
+            bits = window_row_bits(w[0], w[1], w[2], gside, ac);
+        }
+        s.n_win[(size_t)e * 32 + lane] = bits;
+    }
     if (lane == 0) {
         s.n_pos[e] = pos; s.n_goals[e] = goals; s.n_plan[e] = plan; s.n_tctr[e] = tctr;
         s.n_navgoal[e] = navgoal; s.n_d2[e] = d2; s.gen_req[e] = 0u;
@@ -511,16 +538,20 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
 enum : int { OBS_F32_VEC4 = 0, OBS_F32_SCALAR = 1, OBS_U8 = 2 };
 constexpr int kStage2Rows = 56;                     // 52 window rows of the pair (+1 read past the end, +pad)
 constexpr int kStage2Words = kStage2Rows + 172;     // + 169 dwords of mark bytes
+#ifndef T2D_STEP2_WAVES
+#define T2D_STEP2_WAVES 4
+#endif
+constexpr int kStep2Waves = T2D_STEP2_WAVES;        // waves (env pairs) per workgroup of k_step2
 
 template <bool RANDOM, bool MULTI, int ADT, int OBS, bool RAM>
-__global__ __launch_bounds__(256) void k_step2(DevState s, const void *act0, const void *act1, void *obs, float *rew,
+__global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const void *act0, const void *act1, void *obs, float *rew,
                                                uint8_t *done_out, uint32_t aseed_lo, uint32_t aseed_hi,
                                                uint32_t step_idx, uint32_t stamp, int nsteps)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t stage2[kWavesPerBlock][kStage2Words];
+    __shared__ __attribute__((aligned(16))) uint32_t stage2[kStep2Waves][kStage2Words];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = uni((int)(threadIdx.x >> 6));
-    const int e0 = ((int)blockIdx.x * kWavesPerBlock + wave) * 2;
+    const int e0 = ((int)blockIdx.x * kStep2Waves + wave) * 2;
     if (e0 >= s.n) return;
     const int sl = lane >> 5, ag = (lane >> 4) & 1, k = lane & 15;
     const bool live = e0 + sl < s.n;            // false only for slot 1 of the last pair of an odd batch
@@ -621,6 +652,24 @@ __global__ __launch_bounds__(256) void k_step2(DevState s, const void *act0, con
         rw_sm = lut[sq(ddr + dy1, ddc + dx1)];
         rw_ss = lut[sq(ddr, ddc)];
     }
+    // A done is only possible this step if the far counter stands at 10 or the time limit is one step away (:106-111,
+    // TimeLimit): for those envs the next episode's scalars, the window rows of its first observation (n_win) and its map
+    // tile are fetched NOW, beside the rows, so that the episode switch below adds no dependent memory round trip.
+    const bool maybe = live && s.auto_reset != 0 && (c_far >= 10 || (s.max_steps > 0 && t + 1 >= s.max_steps));
+    const unsigned long long mb = __ballot(maybe);
+    uint32_t sp_pos = 0, sp_plan = 0, sp_tctr = 0, sp_d2 = 0, sp_goals = 0, sp_navgoal = 0, sp_episode = 0, sp_win = 0x1fffu;
+    uint4 sp_tile0 = make_uint4(0u, 0u, 0u, 0u), sp_tile1 = sp_tile0;
+    if (__builtin_expect(mb != 0ull, 0)) {
+        if (maybe) {
+            sp_pos = s.n_pos[e]; sp_plan = s.n_plan[e]; sp_tctr = s.n_tctr[e]; sp_d2 = s.n_d2[e];
+            sp_goals = s.n_goals[e]; sp_navgoal = s.n_navgoal[e]; sp_episode = s.episode[e];
+            if (k >= 1 && k <= T2D_WIN) sp_win = s.n_win[(size_t)e * 32 + ag * T2D_WIN + (k - 1)];
+        }
+        if ((mb & 0xffffffffull) != 0ull)
+            sp_tile0 = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)e0 * kTileWords)[lane];
+        if ((mb >> 32) != 0ull)
+            sp_tile1 = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)(e0 + 1) * kTileWords)[lane];
+    }
     // _next_state (track_1v1.py:271-285): the lane holding the destination row of its agent votes "wall"
     const int mdy = ag ? dy1 : dy0, mcc = (ag ? c1 : c0) + (ag ? dx1 : dx0);
     const uint32_t wsel = (mcc >> 5) == 0 ? w0 : ((mcc >> 5) == 1 ? w1 : w2);
@@ -653,35 +702,29 @@ __global__ __launch_bounds__(256) void k_step2(DevState s, const void *act0, con
     const bool consume = live && dn != 0 && s.auto_reset != 0;
 
     const unsigned long long cm = __ballot(consume);
+    bool switched = false;
     if (__builtin_expect(cm != 0ull, 0)) {
-        // Track1v1Env.reset(): switch to the pre-generated next episode (k_gen). Wave-uniform side path.
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            if (((cm >> (32 * q)) & 1ull) == 0ull) continue;
-            const uint4 nt = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)(e0 + q) * kTileWords)[lane];
-            reinterpret_cast<uint4 *>(s.maps + (size_t)(e0 + q) * kTileWords)[lane] = nt;
-        }
+        // Track1v1Env.reset(): switch to the pre-generated next episode (k_gen). Everything it needs is already in
+        // registers (fetched speculatively above); the tile copy into `maps` is a fire-and-forget store.
+        if ((cm & 0xffffffffull) != 0ull)
+            reinterpret_cast<uint4 *>(s.maps + (size_t)e0 * kTileWords)[lane] = sp_tile0;
+        if ((cm >> 32) != 0ull)
+            reinterpret_cast<uint4 *>(s.maps + (size_t)(e0 + 1) * kTileWords)[lane] = sp_tile1;
         if (consume) {
-            pos = s.n_pos[e]; plan = s.n_plan[e]; tctr = s.n_tctr[e]; d2 = s.n_d2[e];
+            switched = true;
+            pos = sp_pos; plan = sp_plan; tctr = sp_tctr; d2 = sp_d2;
             cnt = (uint32_t)side_of_cfg(cfg) << 24;
-            if (!MULTI && !ram) episode = s.episode[e];
-            episode += 1u;
+            episode = sp_episode + 1u;
             if (leader) {
-                s.goals[e] = s.n_goals[e]; s.episode[e] = episode; s.navgoal[e] = s.n_navgoal[e];
+                s.goals[e] = sp_goals; s.episode[e] = episode; s.navgoal[e] = sp_navgoal;
                 s.gen_req[e] = stamp + (uint32_t)it;
             }
             r0 = (int)(pos & 0xffu); c0 = (int)((pos >> 8) & 0xffu);
             r1 = (int)((pos >> 16) & 0xffu); c1 = (int)(pos >> 24);
             rowbase = (ag ? r1 : r0) - 7;
-            const int nside = (int)(cnt >> 24);
-            w0 = w1 = w2 = 0xffffffffu;
-            // rows of the NEW map are read from its n_maps slot, which nobody writes during this launch (the copy into
-            // `maps` above is for later launches): no store -> load hazard through the vector L1
+            // later steps of a multi-step launch read the NEW map from its n_maps slot, which nobody writes during this
+            // launch (the copy into `maps` above is for later launches): no store -> load hazard through the vector L1
             gmap = s.n_maps + (size_t)e * kTileWords;
-            if (k < 15 && (unsigned)(rowbase + k) < (unsigned)nside) {
-                const uint32_t *rp = gmap + (rowbase + k) * kRowWords;
-                w0 = rp[0]; w1 = rp[1]; w2 = rp[2];
-            }
         }
     }
     if (leader) {
@@ -697,12 +740,9 @@ __global__ __launch_bounds__(256) void k_step2(DevState s, const void *act0, con
         const int my_r = ag ? r1 : r0, my_c = ag ? c1 : c0, ot_r = ag ? r0 : r1, ot_c = ag ? c0 : c1;
         const int rr = rowbase + k, y = rr - (my_r - T2D_POB);
         if (k < 15 && (unsigned)y < (unsigned)T2D_WIN) {
-            const uint32_t W2 = w2 | ~valid_mask_w2(oside);           // columns >= side read as 1
-            const int sp = my_c - T2D_POB + 32;                        // window start in [ones | w0 | w1 | W2 | ones]
-            const int j = sp >> 5;
-            const uint32_t lo = j == 0 ? 0xffffffffu : (j == 1 ? w0 : (j == 2 ? w1 : W2));
-            const uint32_t hi = j == 0 ? w0 : (j == 1 ? w1 : (j == 2 ? W2 : 0xffffffffu));
-            uint32_t bits = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(sp & 31)) & 0x1fffu;
+            // the lane that holds a row extracts its 13 window bits; after an episode switch they come ready-made from
+            // the next-episode slot (n_win, lane k <-> window row k - 1)
+            uint32_t bits = switched ? sp_win : window_row_bits(w0, w1, w2, oside, my_c);
             if (y == T2D_POB) bits &= ~(1u << T2D_POB);                 // coloured cells carry no map bit
             const int xo = ot_c - (my_c - T2D_POB);
             if (rr == ot_r && (unsigned)xo < (unsigned)T2D_WIN) bits &= ~(1u << xo);
@@ -887,6 +927,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         if (err == hipSuccess) err = hipMemset(*p, 0, bytes);
     };
     alloc(&s.maps, tb); alloc(&s.n_maps, tb);
+    alloc(&s.n_win, (size_t)n * 32 * sizeof(uint32_t));
     uint32_t **arrs[] = {&s.pos, &s.goals, &s.cnt, &s.cfg, &s.episode, &s.plan, &s.tctr, &s.navgoal, &s.d2,
                          &s.n_pos, &s.n_goals, &s.n_plan, &s.n_tctr, &s.n_navgoal, &s.n_d2, &s.gen_req, &s.nav2, &s.n_nav2};
     for (auto a : arrs) alloc(a, nb);
@@ -920,7 +961,7 @@ extern "C" int t2d_destroy(t2d_handle *h)
     DevState &s = h->s;
     void *ptrs[] = {s.maps, s.n_maps, s.pos, s.goals, s.cnt, s.cfg, s.episode, s.plan, s.tctr, s.navgoal, s.d2,
                     s.n_pos, s.n_goals, s.n_plan, s.n_tctr, s.n_navgoal, s.n_d2, s.gen_req, s.dirf, s.n_dirf, s.faults,
-                    (void *)s.rew_lut, s.nav2, s.n_nav2, s.p_field, s.p_goal, s.p_tctr, s.p_state};
+                    (void *)s.rew_lut, s.nav2, s.n_nav2, s.p_field, s.p_goal, s.p_tctr, s.p_state, s.n_win};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -935,7 +976,7 @@ static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t upto, int force)
     else hipLaunchKernelGGL((k_gen<false>), env_grid(h->s.n), dim3(256), 0, st, h->s, upto, force);
 }
 
-static inline dim3 pair_grid(int n) { return dim3((unsigned)(((n + 1) / 2 + kWavesPerBlock - 1) / kWavesPerBlock)); }
+static inline dim3 pair_grid(int n) { return dim3((unsigned)(((n + 1) / 2 + kStep2Waves - 1) / kStep2Waves)); }
 static inline bool use_step2(const t2d_handle *h) { return !h->has_nav && !h->s.obs_full; }
 
 // k_step2 launcher. obs_kind: OBS_F32_* picked from the pointer / stride alignment, or OBS_U8.
@@ -949,10 +990,12 @@ static void launch_step2(t2d_handle *h, hipStream_t st, const void *a0, const vo
 #define T2D_LAUNCH2(ADTV, KIND)                                                                                         \
     do {                                                                                                                \
         if (h->has_ram)                                                                                                 \
-            hipLaunchKernelGGL((k_step2<RANDOM, MULTI, ADTV, KIND, true>), pair_grid(h->s.n), dim3(256), 0, st, h->s,   \
+            hipLaunchKernelGGL((k_step2<RANDOM, MULTI, ADTV, KIND, true>), pair_grid(h->s.n), dim3(64 * kStep2Waves), 0, \
+                               st, h->s,   \
                                a0, a1, obs, rew, done, slo, shi, sidx, stamp, nsteps);                                  \
         else                                                                                                            \
-            hipLaunchKernelGGL((k_step2<RANDOM, MULTI, ADTV, KIND, false>), pair_grid(h->s.n), dim3(256), 0, st, h->s,  \
+            hipLaunchKernelGGL((k_step2<RANDOM, MULTI, ADTV, KIND, false>), pair_grid(h->s.n), dim3(64 * kStep2Waves), 0, \
+                               st, h->s,  \
                                a0, a1, obs, rew, done, slo, shi, sidx, stamp, nsteps);                                  \
     } while (0)
 #define T2D_LAUNCH2K(ADTV)                                                                                              \
