@@ -44,6 +44,8 @@ def lib():
         L.atr_lstm_cell_forward.argtypes = [vp, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp]
         L.atr_lstm_cell_forward_act.restype = i32
         L.atr_lstm_cell_forward_act.argtypes = [vp] * 11 + [i32, vp, vp, C.c_ulonglong, C.c_uint, i32, i32, vp]
+        L.atr_actor_step.restype = i32
+        L.atr_actor_step.argtypes = [vp] * 12 + [i32, i32, i32, vp]
         L.atr_lstm_cell_backward.restype = i32
         L.atr_lstm_cell_backward.argtypes = [vp, ll, vp, vp, vp, vp, vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, i32, vp]
         L.atr_heads_values.restype = i32
@@ -421,6 +423,25 @@ def lstm_cell_act_into(ig, hg, c_prev, done, h_out, c_out, acts, sampler, actor,
     if rc != 0:
         raise RuntimeError("atr_lstm_cell_forward_act failed (%d)" % rc)
     return actions_out
+
+
+def actor_step_supported(F, R):
+    return F == 256 and R == 128
+
+
+@torch.no_grad()
+def actor_step_into(f, h_prev, c_prev, done, lstm, bias, h_out, c_out, acts, emb=None, act_in=None):
+    """The actor's LSTMCell step as ONE MFMA kernel (csrc/actor_step_hip.hip): gates = f W_ih^T + (k h_prev) W_hh^T + bias
+    [+ emb[act_in]] run straight into the cell; h', c' and the activated gates are written into the given (rollout
+    cache) slots. f [N,256], h_prev / c_prev [N,128] contiguous; k = (done == 0)."""
+    N, F = f.shape
+    R = h_prev.shape[1]
+    assert f.is_contiguous() and h_prev.is_contiguous() and c_prev.is_contiguous() and h_out.is_contiguous() and c_out.is_contiguous()
+    rc = lib().atr_actor_step(_p(f), _p(h_prev), _p(c_prev), _pn(done), _p(lstm.weight_ih), _p(lstm.weight_hh), _p(bias),
+                              _pn(emb), _pn(act_in), _p(h_out), _p(c_out), _pn(acts), N, F, R, _stream(f))
+    if rc != 0:
+        raise RuntimeError("atr_actor_step failed (%d)" % rc)
+    return h_out, c_out
 
 
 def lstm_sequence(ig0, ig1, whh, h0, c0, keep):

@@ -512,6 +512,7 @@ class A3C_Dueling(nn.Module):
         return self._to_ref(out) if ref_layout else out
 
     fused_sampling = True   # GPU rollouts draw actions with the fused HIP head (csrc/policy_hip.hip)
+    fused_actor_step = True  # ... and run the LSTMCell step as one MFMA kernel (csrc/actor_step_hip.hip)
 
     @torch.no_grad()
     def begin_act(self):
@@ -611,14 +612,24 @@ class A3C_Dueling(nn.Module):
         acts_out = []
         # both players' stems in one launch, both hidden GEMMs in one bmm (neither depends on the tracker's action)
         ys = fused.stem_into2(x_in[0], p0.encoder, cache.y[0][t], x_in[1], p1.encoder, cache.y[1][t])
-        hgs = torch.bmm(cache.h_all[:, t], cache.whh_t)
         R = cache.h_all.shape[-1]
+        # the whole LSTMCell step (both GEMMs + cell) as one MFMA kernel per player (csrc/actor_step_hip.hip), the draw as
+        # a second small launch; else hidden GEMMs as one bmm + per-player input GEMM + fused cell/head/draw kernel
+        mfma_step = (self.fused_actor_step and cache.actions is not None and self._sampler._ordinal is not None
+                     and fused.actor_step_supported(p0.encoder.outdim, R) and p1.encoder.outdim == p0.encoder.outdim)
+        hgs = None if mfma_step else torch.bmm(cache.h_all[:, t], cache.whh_t)
         one_launch = (cache.actions is not None and self._sampler._ordinal is not None and R // 4 in (16, 32, 64)
                       and p0.actor.actor_linear.weight.shape[0] <= 8 and p1.actor.actor_linear.weight.shape[0] <= 8)
         for i, p in enumerate((p0, p1)):
             enc = p.encoder
             f = _addmm_relu(enc.fc.bias, ys[i].view(n, -1), enc.fc.weight.t(), cache.f[i][t])
             tat = i == 1 and self.tat
+            if mfma_step:
+                fused.actor_step_into(f, cache.h_all[i, t], cache.c_all[i, t], done, p.lstm, cache.bsum[i],
+                                      cache.h_all[i, t + 1], cache.c_all[i, t + 1], cache.acts[i, t],
+                                      emb=cache.emb_ih if tat else None, act_in=acts_out[0] if tat else None)
+                acts_out.append(sample(cache.h_all[i, t + 1], p.actor.actor_linear, out=cache.actions[t, i]))
+                continue
             if tat and not one_launch:
                 f = torch.add(f, cache.emb[acts_out[0]], out=cache.feat1[t])
             ig = torch.addmm(cache.bsum[i], f, p.lstm.weight_ih.t())

@@ -117,6 +117,9 @@ def main():
                     help="reference-shaped learner (autograd graph built during the rollout) instead of the "
                          "actor/learner split with time-batched re-evaluation")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--actor-step", choices=("mfma", "gemm"), default=None,
+                    help="A/B switch of the actor's LSTM step: one MFMA kernel (csrc/actor_step_hip.hip) or library GEMMs + "
+                         "fused cell kernel (default: the model's setting)")
     ap.add_argument("--f32-obs", action="store_true", help="float32 observations between env and policy (default: bytes, "
                                                           "decoded in the stem's conv1)")
     ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K-step region (median reported)")
@@ -164,6 +167,8 @@ def main():
         args = default_args(env=a.env, network=a.network, num_envs=envs_per_gpu, num_steps=T, gpu_ids=[local_rank],
                             aux="reward" if "tat" in a.network else "none", train_mode=-1, obs_u8=not a.f32_obs)
         player, optimizer = make_player(args, device, rank, world)
+        if a.actor_step is not None:
+            player.model.fused_actor_step = a.actor_step == "mfma"
 
         def eager_iteration():
             rollout(player, T, fast=not a.per_step_autograd)

@@ -78,6 +78,17 @@ int atr_lstm_cell_forward_act(const float *ig, const float *hg, const float *c_p
                               const float *actor_w, const float *actor_b, int A, long long *actions_out,
                               const unsigned long long *counter, unsigned long long seed, unsigned ordinal, int N,
                               int R, void *stream);
+/* The actor's whole LSTMCell step for ONE player as one f32-MFMA kernel (csrc/actor_step_hip.hip): both GEMMs of
+ * nn.LSTMCell (model.py:110,172 of the reference) and the cell, without materialising the gate pre-activations:
+ *   gates = f W_ih^T + (k h_prev) W_hh^T + bias [+ emb[act_in[n]]],  k[n] = (done[n] == 0) (1 if done is NULL)
+ *   c' = sigm(f) (k c_prev) + sigm(i) tanh(g),  h' = sigm(o) tanh(c')        (gate order i, f, g, o)
+ * f [N,F], h_prev / c_prev / h_out / c_out [N,R] (out must not alias prev), w_ih [4R,F], w_hh [4R,R], bias [4R]
+ * (= b_ih + b_hh), emb (nullable) [*,4R] rows selected by act_in [N] (the tracker-action embedding projected through
+ * W_ih, model.py:178), acts (nullable) [N,4R] receives the activated gates for atr_lstm_cell_backward.
+ * Only F = 256, R = 128 (the maze policies); -1 otherwise. Follow with atr_sample_actions on h_out for the draw. */
+int atr_actor_step(const float *f, const float *h_prev, const float *c_prev, const unsigned char *done,
+                   const float *w_ih, const float *w_hh, const float *bias, const float *emb, const long long *act_in,
+                   float *h_out, float *c_out, float *acts, int N, int F, int R, void *stream);
 /* One step of back-propagation through time for the cell above. dh_out: dL/dh' from the heads; dh_next [P,N,R]:
  * dg_{t+1} W_hh (gradient arriving through the next step's hidden GEMM, unmasked); dc_carry [P,N,R]: in = dc f of step
  * t+1, out = dc f of this step; both are scaled by keep_out (this step's mask k_t) when has_next != 0 and ignored

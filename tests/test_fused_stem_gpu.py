@@ -280,3 +280,44 @@ def test_u8_frames_give_the_float_results_bit_for_bit(M):
     fused.stem_into(obs[:, 0], conv1, conv2, out_u)
     fused.stem_into(obs[:, 0].float(), conv1, conv2, out_f)
     assert torch.equal(out_u, out_f)
+
+
+@pytest.mark.parametrize("N", [1, 130, 4096])
+def test_actor_step_mfma_kernel_matches_lstmcell(N):
+    """atr_actor_step (both LSTMCell GEMMs + the cell as one f32-MFMA kernel) against torch.nn.LSTMCell in float64 on
+    the masked state, with and without the tracker-action embedding; activated gates checked against the same
+    reference. Tolerance 2e-5: an fp32 sum over 384 products in a different order (exact-f32 MFMA, no reduced precision)."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(N)
+    F_, R = 256, 128
+    lstm = torch.nn.LSTMCell(F_, R).cuda()
+    with torch.no_grad():
+        lstm.bias_ih.normal_(0, 0.3); lstm.bias_hh.normal_(0, 0.3)
+    f = torch.relu(torch.randn(N, F_, device="cuda"))
+    h, c = torch.randn(N, R, device="cuda") * 0.5, torch.randn(N, R, device="cuda")
+    done = (torch.rand(N, device="cuda") < 0.3).to(torch.uint8)
+    emb = torch.randn(4, 4 * R, device="cuda") * 0.2
+    a_in = torch.randint(0, 4, (N,), device="cuda")
+    bsum = (lstm.bias_ih + lstm.bias_hh).detach()
+    for use_emb in (False, True):
+        h_out, c_out, acts = torch.empty_like(h), torch.empty_like(c), torch.empty(N, 4 * R, device="cuda")
+        fused.actor_step_into(f, h, c, done, lstm, bsum, h_out, c_out, acts, emb=emb if use_emb else None,
+                              act_in=a_in if use_emb else None)
+        k = (done == 0).double().unsqueeze(1)
+        pre = f.double() @ lstm.weight_ih.double().t() + (k * h.double()) @ lstm.weight_hh.double().t() + bsum.double()
+        if use_emb:
+            pre = pre + emb.double()[a_in]
+        gi, gf, gg, go = pre.chunk(4, 1)
+        c_ref = torch.sigmoid(gf) * (k * c.double()) + torch.sigmoid(gi) * torch.tanh(gg)
+        h_ref = torch.sigmoid(go) * torch.tanh(c_ref)
+        torch.testing.assert_close(c_out.double(), c_ref, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(h_out.double(), h_ref, rtol=2e-5, atol=2e-5)
+        acts_ref = torch.cat([torch.sigmoid(gi), torch.sigmoid(gf), torch.tanh(gg), torch.sigmoid(go)], 1)
+        torch.testing.assert_close(acts.double(), acts_ref, rtol=2e-5, atol=2e-5)
+    # no mask, no gate store
+    h_out, c_out = torch.empty_like(h), torch.empty_like(c)
+    fused.actor_step_into(f, h, c, None, lstm, bsum, h_out, c_out, None)
+    with torch.no_grad():
+        h_t, c_t = lstm(f, (h, c))
+    torch.testing.assert_close(h_out, h_t, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(c_out, c_t, rtol=2e-5, atol=2e-5)
