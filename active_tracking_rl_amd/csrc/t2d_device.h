@@ -264,14 +264,20 @@ __device__ __forceinline__ void gen_block(uint32_t *tile, int lane, S &ms, doubl
 }
 
 // RandomMazeGenerator._generate_maze — G/envs/generators.py:115-145 (81x81). Inherently sequential (every step
-// depends on the walls laid so far), so it is one wave-uniform loop made as short as possible. Walls are only ever
-// laid on three kinds of cells, each kept as a register bitmap with one row per lane for the whole loop:
-//   nodes  (y even, x even): lane y/2, bit x/2 — the only cells the algorithm READS (readlane, no LDS round trip);
-//   hmid   (y even, x odd) : lane y/2, bit (x-1)/2 — the midpoint carved by a horizontal move;
-//   vmid   (y odd, x even) : lane (y-1)/2, bit x/2 — the midpoint carved by a vertical move
-// (odd/odd cells stay free). A wall is a predicated OR into the owning lane's register; the bit-packed tile is
-// assembled once at the end by interleaving the bitmaps (bit i -> bit 2i). Random words come from the 64-block VStream
-// (one readlane per draw).
+// depends on the walls laid so far): one wave-uniform loop whose cost is the number of instructions per growth step
+// times the ~5 cycles a lone wave needs per dependent instruction. Restated for a short step (round 2: ~45 instructions,
+// was ~100):
+//   * the walk lives on the 41x41 node grid (cells with even coordinates — the only cells the algorithm READS); the
+//     position is ONE scalar p = y * 128 + x, a move is p += delta[d] from a 4-lane register table;
+//   * the neighbour list [(y,x-2) if x>1, (y,x+2) if x<S-2, (y-2,x) if y>1, (y+2,x) if y<S-2] (generators.py:135-138)
+//     is ONE lane-parallel compare: lane d < 4 extracts its coordinate of p (v_bfe with a per-lane offset) and compares
+//     it with its own limit; the ballot is the 4-bit presence mask m; the k-th present direction comes from a 64-lane
+//     register table indexed m * 4 + k (one v_readlane);
+//   * node bits: one register pair with a row per lane (read: two v_readlane; write: one predicated OR per half);
+//   * the carved mid-points are not written in the loop: every successful move is appended to a log in LDS (one
+//     ds_write by lane 0) and all mid-point walls are set in parallel afterwards;
+//   * random words: the 64-block VStream (one readlane per draw).
+// Same draws in the same order as before, hence the same mazes bit for bit (oracle PHILOX mode).
 __device__ __forceinline__ uint32_t spread16(uint32_t v)   // bit i of the low 16 bits -> bit 2i
 {
     v &= 0xffffu;
@@ -281,72 +287,82 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v)   // bit i of the low 1
     v = (v | (v << 1)) & 0x55555555u;
     return v;
 }
+constexpr int kMazeLogMax = 47 * 24;     // density <= int(0.03 * 1600) = 47 seeds x complexity <= int(0.03 * 810) = 24 moves
 template <class S>
-__device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double ratio)
+__device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double ratio, uint32_t *log)
 {
-    const int SZ = 81;
+#ifdef T2D_EXP_NOMAZE
+    const int complexity = 0, density = 0;        // timing probe: everything but the growth loop
+#else
     const int complexity = (int)(ratio * 810.0);
     const int density = (int)(ratio * 1600.0);
-    // border walls (generators.py:127-128): rows 0 / 80 entirely, columns 0 / 80 of every row
-    uint32_t nlo = 0u, nhi = 0u, hlo = 0u, hhi = 0u, vlo = 0u, vhi = 0u;
-    if (lane == 0 || lane == 40) { nlo = 0xffffffffu; nhi = 0x1ffu; hlo = 0xffffffffu; hhi = 0xffu; }
+#endif
+    // border walls (generators.py:127-128): node rows 0 / 40 entirely, node columns 0 / 40 of every row
+    uint32_t nlo = 0u, nhi = 0u;
+    if (lane == 0 || lane == 40) { nlo = 0xffffffffu; nhi = 0x1ffu; }
     else if (lane < 40) { nlo = 1u; nhi = 0x100u; }
-    if (lane < 40) { vlo = 1u; vhi = 0x100u; }
-    auto node_get = [&](int ny, int nx) -> uint32_t {
-        const uint32_t lo = __builtin_amdgcn_readlane(nlo, ny), hi = __builtin_amdgcn_readlane(nhi, ny);
-        return nx < 32 ? (lo >> nx) & 1u : (hi >> (nx - 32)) & 1u;
-    };
-    auto bit_set = [&](uint32_t &lo, uint32_t &hi, int row, int idx) {
-        if (lane == row) { if (idx < 32) lo |= 1u << idx; else hi |= 1u << (idx - 32); }
-    };
-    // k-th present candidate of the neighbour list [(y,x-2) if x>1, (y,x+2) if x<S-2, (y-2,x) if y>1, (y+2,x) if
-    // y<S-2] (generators.py:135-138) as a table: entry (mask, k) = direction 0..3, 2 bits each.
-    unsigned long long tbl_lo = 0ull, tbl_hi = 0ull;
-#pragma unroll
-    for (int m = 0; m < 16; m++) {
+    // per-lane constants of the 4 direction lanes: which coordinate of p decides the presence of direction d, and its limit
+    const uint32_t coord_off = (lane & 2) ? 7u : 0u;                 // d = 0, 1 look at x (bits 0..6), d = 2, 3 at y (bits 7..13)
+    const uint32_t coord_lim = (lane & 1) ? 40u : 0u;                // d even: coordinate != 0; d odd: coordinate != 40
+    const int delta = lane == 0 ? -1 : (lane == 1 ? 1 : (lane == 2 ? -128 : 128));
+    // table lane (m * 4 + k) -> the k-th set bit of m
+    uint32_t kth = 0u;
+    {
+        const int m = lane >> 2, k = lane & 3;
         int seen = 0;
 #pragma unroll
         for (int d = 0; d < 4; d++)
-            if (m & (1 << d)) {
-                const int e = (m * 4 + seen) * 2;
-                if (e < 64) tbl_lo |= (unsigned long long)d << e; else tbl_hi |= (unsigned long long)d << (e - 64);
+            if ((m >> d) & 1) {
+                if (seen == k) kth = (uint32_t)d;
                 seen++;
             }
     }
+    int nlog = 0;
     for (int i = 0; i < density; i++) {
-        int x = (int)ms.bounded(40u) * 2;
-        int y = (int)ms.bounded(40u) * 2;
-        bit_set(nlo, nhi, y >> 1, x >> 1);
+        const int sx = (int)ms.bounded(40u);                          // x's draw first (the tuple on generators.py:131)
+        const int sy = (int)ms.bounded(40u);
+        int p = sy * 128 + sx;
+        {   // Z[y, x] = 1
+            const uint32_t bit = 1u << (sx & 31);
+            if (lane == sy) { if (sx < 32) nlo |= bit; else nhi |= bit; }
+        }
         for (int j = 0; j < complexity; j++) {
-            const int m = (int)(x > 1) | ((int)(x < SZ - 2) << 1) | ((int)(y > 1) << 2) | ((int)(y < SZ - 2) << 3);
-            const int n = __popc((unsigned)m);
-            const int k = (int)ms.bounded((uint32_t)(n - 1));
-            const int e = (m * 4 + k) * 2;
-            const int d = (int)((e < 64 ? tbl_lo >> e : tbl_hi >> (e - 64)) & 3ull);
-            const int step = (d & 1) * 4 - 2;                    // -2 for directions 0/2, +2 for 1/3
-            const int x_ = x + ((d & 2) ? 0 : step), y_ = y + ((d & 2) ? step : 0);
-            if (node_get(y_ >> 1, x_ >> 1) == 0u) {
-                bit_set(nlo, nhi, y_ >> 1, x_ >> 1);             // Z[y_, x_] = 1
-                if (d & 2) bit_set(vlo, vhi, min(y, y_) >> 1, x >> 1);       // Z[y_ + (y - y_) // 2, x_ + (x - x_) // 2] = 1
-                else bit_set(hlo, hhi, y >> 1, min(x, x_) >> 1);
-                x = x_; y = y_;
+            const uint32_t coord = __builtin_amdgcn_ubfe((uint32_t)p, coord_off, 7u);
+            const uint32_t m = (uint32_t)__ballot(coord != coord_lim) & 0xfu;
+            const uint32_t k = ms.bounded((uint32_t)__popc(m) - 1u);
+            const int d = (int)__builtin_amdgcn_readlane(kth, (int)(m * 4u + k));
+            const int q = p + (int)__builtin_amdgcn_readlane((uint32_t)delta, d);
+            const int qy = q >> 7, qx = q & 127;
+            const uint32_t lo = __builtin_amdgcn_readlane(nlo, qy), hi = __builtin_amdgcn_readlane(nhi, qy);
+            const uint32_t word = qx < 32 ? lo : hi;
+            if (((word >> (qx & 31)) & 1u) == 0u) {                   // Z[y_, x_] == 0: carve
+                const uint32_t bit = 1u << (qx & 31);
+                if (lane == qy) { if (qx < 32) nlo |= bit; else nhi |= bit; }
+                if (lane == 0) log[nlog] = (uint32_t)(p + q);          // mid-point (y + y_) * 128 + (x + x_), full-resolution cells
+                nlog++;
+                p = q;
             }
         }
     }
-    // assemble the tile: even row 2j = nodes_j interleaved with hmid_j; odd row 2j+1 = vmid_j on the even columns
+    // assemble the tile: even row 2j = the node bits at the even columns; then the logged mid-points
     tile_clear(tile, lane);
     wave_lds_sync();
     if (lane <= 40) {
         uint32_t *r = tile + (2 * lane) * kRowWords;
-        r[0] = spread16(nlo) | (spread16(hlo) << 1);
-        r[1] = spread16(nlo >> 16) | (spread16(hlo >> 16) << 1);
-        r[2] = spread16(nhi) | (spread16(hhi) << 1);
+        const bool edge = lane == 0 || lane == 40;                    // rows 0 / 80 are walls at the odd columns too
+        r[0] = edge ? 0xffffffffu : spread16(nlo);
+        r[1] = edge ? 0xffffffffu : spread16(nlo >> 16);
+        r[2] = edge ? 0x1ffffu : spread16(nhi);
     }
-    if (lane < 40) {
+    if (lane < 40) {      // odd rows: the border columns 0 and 80
         uint32_t *r = tile + (2 * lane + 1) * kRowWords;
-        r[0] = spread16(vlo);
-        r[1] = spread16(vlo >> 16);
-        r[2] = spread16(vhi);
+        r[0] = 1u; r[2] = 0x10000u;
+    }
+    wave_lds_sync();
+    for (int i = lane; i < nlog; i += 64) {
+        const uint32_t e = log[i];                                    // (y + y_) * 128 + (x + x_): row and column of the wall
+        const uint32_t row = e >> 7, col = e & 127u;
+        atomicOr(&tile[row * kRowWords + (col >> 5)], 1u << (col & 31u));
     }
     wave_lds_sync();
 }
@@ -456,7 +472,10 @@ __device__ __forceinline__ uint32_t rpf_cell(int side, int i)
 }
 
 // clear_rpf: plan on the GENERATOR's map of an RPF env, i.e. the env's tile with the four patrol cells free
-// (track_1v1.py:233-236). (qr, qc) / dist: optional BFS distance of one query cell (-1 if unreachable).
+// (track_1v1.py:233-236). (qr, qc): the cell the plan will be followed FROM (-1: none); dist (optional): its BFS distance
+// (-1 if unreachable). The flood stops at the level that reaches (qr, qc): every cell of a shortest path from there to the
+// goal is closer to the goal, hence already labelled — the rest of the field would never be read (about half the levels
+// on average).
 __device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, int lane, int gr, int gc, NavField &f,
                                               bool clear_rpf = false, int qr = -1, int qc = -1, int *dist = nullptr)
 {
@@ -531,7 +550,7 @@ __device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, in
             }
         }
         level++;
-        if (dist != nullptr && found < 0) {   // did this level reach the query cell?
+        if (qr >= 0 && found < 0) {           // did this level reach the cell the plan starts from?
             uint32_t hit = 0u;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -540,6 +559,7 @@ __device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, in
             }
             if (__ballot(hit != 0u) != 0ull) found = level;
         }
+        if (found >= 0) break;                // everything a path from (qr, qc) can touch is labelled
         if (__ballot(any != 0u) == 0ull) break;
     }
     if (dist != nullptr) *dist = found;

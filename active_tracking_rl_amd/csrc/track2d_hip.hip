@@ -94,7 +94,7 @@ __device__ __forceinline__ void nav_plan(const uint32_t *tile, int side, int lan
     int dist = -1;
     for (;;) {
         const int gr = (int)(navgoal & 0xffu), gc = (int)(navgoal >> 8);
-        bfs_dir_field(tile, side, lane, gr, gc, f, rpf, fr, fc, rpf ? &dist : nullptr);
+        bfs_dir_field(tile, side, lane, gr, gc, f, rpf, fr, fc, rpf ? &dist : nullptr);   // stops once (fr, fc) is reached
         const bool ok = rowbits_get(f.visA, f.visB, fr, fc) != 0u && !(fr == gr && fc == gc);
         if (ok) break;
         if (++count_res > 5) { planb = true; break; }
@@ -115,7 +115,7 @@ __device__ __forceinline__ int side_of_cfg(uint32_t cfg) { return (cfg & 3u) == 
 // Track1v1Env.reset -> init_maze (track_1v1.py:134-168,218-240) for one env and one episode number, executed by
 // one wave on an LDS tile. All arguments are wave-uniform. `gdir` receives the Nav direction planes.
 template <bool NAV>
-__device__ __forceinline__ void generate_episode(const DevState &s, int e, uint32_t *tile, int lane, uint32_t cfg,
+__device__ __forceinline__ void generate_episode(const DevState &s, int e, uint32_t *tile, uint32_t *mlog, int lane, uint32_t cfg,
                                                  uint32_t episode, uint32_t *gdir, uint32_t &pos, uint32_t &goals,
                                                  uint32_t &plan, uint32_t &tctr, uint32_t &navgoal, uint32_t &d2,
                                                  uint32_t &nav2)
@@ -128,7 +128,7 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
     const int side = side_of_cfg(cfg);
     if (map_type == MAP_MAZE) {
         double r = level > 0 ? (double)level * 0.02 : .03 * ms.next_double();
-        gen_maze(tile, lane, ms, r);
+        gen_maze(tile, lane, ms, r, mlog);
     } else if (map_type == MAP_BLOCK) {
         double r = level > 0 ? (double)level * 0.05 : 0.15 * ms.next_double();
         gen_block(tile, lane, ms, r);
@@ -208,6 +208,7 @@ template <bool NAV>
 __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t upto, int force)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tiles[kWavesPerBlock][kTileWords];
+    __shared__ uint32_t mlogs[kWavesPerBlock][kMazeLogMax];     // move log of the maze generator (t2d_device.h gen_maze)
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = uni((int)(threadIdx.x >> 6));
     const int e = (int)blockIdx.x * kWavesPerBlock + wave;
@@ -229,7 +230,11 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t upto, int forc
         ts.init(s.k0, s.k1, s.episode[e], s.env_base + (uint32_t)e, STREAM_TARGET, s.tctr[e]);
         const uint32_t g2 = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
         NavField nf;
-        bfs_dir_field(tile, side, lane, (int)(g2 & 0xffu), (int)(g2 >> 8), nf);
+        // the target will stand on its CURRENT goal when this plan is needed (navigator.py:15: a plan is exhausted exactly
+        // there), so the flood may stop once it has reached that cell; if the target is elsewhere (plan B), the adoption
+        // test in the step kernel (visited plane) sends it to the inline re-plan
+        const uint32_t cur = s.navgoal[e];
+        bfs_dir_field(tile, side, lane, (int)(g2 & 0xffu), (int)(g2 >> 8), nf, false, (int)(cur & 0xffu), (int)(cur >> 8));
         store_plan_field(s.p_field + (size_t)e * kPlanWords, nf, side, lane);
         if (lane == 0) { s.p_goal[e] = g2; s.p_tctr[e] = ts.ctr; s.p_state[e] = 1u; }
         wave_lds_sync();
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t upto, int forc
     if (!need_gen) return;
     uint32_t pos, goals, plan, tctr, navgoal, d2, nav2;
     uint32_t *gdir = NAV ? s.n_dirf + (size_t)e * kDirWords : nullptr;
-    generate_episode<NAV>(s, e, tile, lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2, nav2);
+    generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2, nav2);
     wave_lds_sync();
     reinterpret_cast<uint4 *>(s.n_maps + (size_t)e * kTileWords)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
     if (lane < 2 * T2D_WIN) {

@@ -615,7 +615,9 @@ class A3C_Dueling(nn.Module):
         R = cache.h_all.shape[-1]
         # the whole LSTMCell step (both GEMMs + cell) as one MFMA kernel per player (csrc/actor_step_hip.hip), the draw as
         # a second small launch; else hidden GEMMs as one bmm + per-player input GEMM + fused cell/head/draw kernel
-        mfma_step = (self.fused_actor_step and cache.actions is not None and self._sampler._ordinal is not None
+        # (only from 3072 rows up: one wave tile per SIMD of the chip needs 4096 rows; at 1024 rows its 22 us per call lose to
+        # the library GEMMs + cell kernel, measured with tools/config_sweep.py)
+        mfma_step = (self.fused_actor_step and n >= 3072 and cache.actions is not None and self._sampler._ordinal is not None
                      and fused.actor_step_supported(p0.encoder.outdim, R) and p1.encoder.outdim == p0.encoder.outdim)
         hgs = None if mfma_step else torch.bmm(cache.h_all[:, t], cache.whh_t)
         one_launch = (cache.actions is not None and self._sampler._ordinal is not None and R // 4 in (16, 32, 64)
