@@ -20,6 +20,8 @@ for e in Track2D-BlockPartialRam-v0 Track2D-MazePartialNav-v0 Track2D-BlockParti
 timeout 300 python $R/tools/hbm_ceiling.py > $O/hbm_ceiling.txt 2>&1
 timeout 300 python $R/tools/stem_bench.py > $O/stem_bench.txt 2>&1
 timeout 300 python $R/tools/stem_u8_ab.py > $O/stem_u8_ab.txt 2>&1
+timeout 300 python $R/tools/actor_step_bench.py > $O/actor_step_bench.txt 2>&1
+bash $R/tools/prof_nav.sh > $O/nav_profile.txt 2>&1
 timeout 600 python $R/tools/config_sweep.py > $O/config_sweep.txt 2>&1
 if [ -f $R/scratch_exp/libexp6.so ]; then
   T2D_LIB_PATH=$R/scratch_exp/libexp6.so timeout 120 python $R/tools/timeline_probe.py 4096 > $O/step_kernel_timeline_4096.txt 2>&1
