@@ -13,13 +13,16 @@
 //   * a wave owns 32 rows x 16 hidden units = two 32x32 output tiles whose 32 columns are [gate i | gate f] and
 //     [gate g | gate o] of those 16 units: 1024 wave tiles at 4096 rows = one per SIMD of the chip, 384 MFMAs each, on
 //     four accumulators (tile x parity of the MFMA step) so that same-accumulator MFMAs are three others apart.
-//   * both operands are streamed as float4s along K straight from memory (A: the lane's row of [f | h_prev], B: the
-//     lane's gate column of [W_ih | W_hh]), eight K chunks ahead; MFMA step t of an 8-wide K chunk consumes component t of
-//     both, so the k <-> slot assignment is the same permutation on both sides. No LDS: the four waves of a workgroup
-//     take four row tiles of the SAME unit slice, so the weight columns are shared through the CU's L1, and the 8 unit
-//     slices of a row block run on one XCD (block b runs on XCD b % 8), so the rows are fetched from memory once and
-//     re-read out of that XCD's L2. (Variants measured and dropped: weights resident in LDS with 16x16x4 tiles, 25 us;
-//     with 32x32x2 tiles and block-wise LDS fill, 28 us and register spills.)
+//   * operands: per 32-wide K block a wave fetches its A rows ([f | h_prev], 32 x 128 B) and its two weight tiles
+//     (2 x 32 gate columns x 128 B) with COALESCED loads — 8 lanes x 16 B cover one 128-B line, 8 lines per load
+//     instruction — parks them in its own LDS slice (wave-private: no barrier, DS ops of a wave are ordered) and reads
+//     them back in the MFMA operand layout (lane = row / column, K slot), conflict-free with a 36-float row stride.
+//     Loads run two blocks ahead of the MFMAs. MFMA step t of an 8-wide K chunk consumes component t of the A and B
+//     float4s, so the k <-> slot assignment is the same permutation on both sides. Reading the operands in MFMA layout
+//     straight from memory (32 B used per 128-B line and instruction) made the L1 tag pipe, not the matrix pipe, set the
+//     pace: 24 us per 4096-row call against 11.7 us of MFMA time. The 8 unit slices of a row block run on one XCD
+//     (block b runs on XCD b % 8), so the rows are fetched from memory once and re-read out of that XCD's L2; the four
+//     waves of a workgroup share their weight tiles through the CU's L1.
 //   * lanes j < 16 end up with gates (i, g), lanes j + 16 with (f, o) of the same unit: 16 ds_bpermute exchanges later
 //     every lane holds all four gates of 8 (row, unit) pairs and evaluates the cell in registers; h', c' and the
 //     activated gates (for the backward pass) are stored once.
@@ -38,7 +41,9 @@ constexpr int kF = 256, kR = 128, kK = kF + kR;          // feature width, hidde
 constexpr int kUnits = 16;                                // hidden units per workgroup (x 4 gates = two 32-column tiles)
 constexpr int kRowsPerWg = 128;                           // 4 waves x one 32-row tile
 constexpr int kChunks = kK / 8, kChunksIh = kF / 8;       // 48 K-chunks of 8 (4 MFMA steps each); the first 32 are W_ih
-constexpr int kDepth = 8;                                 // operand prefetch depth in chunks (8 x 512 MFMA cycles of cover)
+constexpr int kBlk = 32, kBlocks = kK / kBlk, kBlocksIh = kF / kBlk;   // K blocks of 32 (4 chunks); the first 8 are W_ih
+constexpr int kLs = kBlk + 4;                             // LDS row stride (floats): 16-lane float4 reads hit 64 distinct banks
+constexpr int kOpFloats = 32 * kLs;                       // one staged operand (32 rows / columns x 32 k)
 
 // sigmoid / tanh on the hardware exp and reciprocal (v_exp_f32, v_rcp_f32): ~1e-7 relative, far inside the 2e-5 the
 // summation order of a 384-term fp32 dot product already costs
@@ -57,6 +62,7 @@ struct ActorStep {
 
 __global__ __launch_bounds__(256, 1) void k_actor_step(ActorStep a)
 {
+    __shared__ __attribute__((aligned(16))) float lds[4][2 * 3 * kOpFloats];   // per wave: 2 buffers x {A, B0, B1}: 27 KB
     const int tid = (int)threadIdx.x, l = tid & 63, wave = tid >> 6;
     const int jj = l & 31, kk = l >> 5;                    // MFMA lane coordinates: row / column index, K slot
     // workgroup -> (row block, unit slice): the 8 slices of a row block on one XCD (see the header)
@@ -85,33 +91,60 @@ __global__ __launch_bounds__(256, 1) void k_actor_step(ActorStep a)
 #pragma unroll
     for (int i = 0; i < 8; i++) ain[i] = ainp[has_emb ? rws[i] : 0];
 
-    // ---- A: lane (row jj, K slot kk) reads float4 A[row][8 c + 4 kk] of [f | h_prev] (the episode mask of the h_prev
-    // part is applied when a chunk is CONSUMED: multiplying at load time would turn the prefetch into a blocking load)
-    const int arow = min(row0 + jj, a.N - 1);              // tail rows shadow the last one (never stored)
-    const float *fa = a.f + (size_t)arow * kF + 4 * kk, *ha = a.h_prev + (size_t)arow * kR + 4 * kk;
-    auto load_a = [&](int c) -> float4 {
-        return c < kChunksIh ? *reinterpret_cast<const float4 *>(fa + 8 * c)
-                             : *reinterpret_cast<const float4 *>(ha + 8 * (c - kChunksIh));
-    };
-    // ---- B: lane (column jj of tile T, K slot kk): gate 2 T + (jj >> 4), unit u0 + (jj & 15); float4 W[col][8 c + 4 kk]
-    const float *wi[2], *wh[2];
+    // ---- coalesced staging loads: lane (sub-row rs = l >> 3, k4 = l & 7) fetches float4 X[rs + 8 i][32 blk + 4 k4],
+    // i = 0..3, for X = A rows, weight tile 0, weight tile 1
+    const int rs = l >> 3, k4 = l & 7;
+    const float *pf[4], *ph[4], *pwi[2][4], *pwh[2][4];
 #pragma unroll
-    for (int T = 0; T < 2; T++) {
-        const size_t col = (size_t)(2 * T + half) * kR + u;
-        wi[T] = a.w_ih + col * kF + 4 * kk;
-        wh[T] = a.w_hh + col * kR + 4 * kk;
-    }
-    auto load_b = [&](int c, int T) -> float4 {
-        return c < kChunksIh ? *reinterpret_cast<const float4 *>(wi[T] + 8 * c)
-                             : *reinterpret_cast<const float4 *>(wh[T] + 8 * (c - kChunksIh));
-    };
-    float4 ra[kDepth], rbv[kDepth][2];
+    for (int i = 0; i < 4; i++) {
+        const int ar = min(row0 + rs + 8 * i, a.N - 1);    // tail rows shadow the last one (never stored)
+        pf[i] = a.f + (size_t)ar * kF + 4 * k4;
+        ph[i] = a.h_prev + (size_t)ar * kR + 4 * k4;
+        const int cj = rs + 8 * i;                         // column of the tile: gate 2 T + (cj >> 4), unit u0 + (cj & 15)
 #pragma unroll
-    for (int c = 0; c < kDepth; c++) {
-        ra[c] = load_a(c);
-        rbv[c][0] = load_b(c, 0);
-        rbv[c][1] = load_b(c, 1);
+        for (int T = 0; T < 2; T++) {
+            const size_t col = (size_t)(2 * T + (cj >> 4)) * kR + u0 + (cj & 15);
+            pwi[T][i] = a.w_ih + col * kF + 4 * k4;
+            pwh[T][i] = a.w_hh + col * kR + 4 * k4;
+        }
     }
+    // (written out per operand with constant indices: with lambdas over a 3 x 4 array the compiler kept the staging
+    // registers in memory — promoted to LDS — and every load became load -> wait -> ds_write)
+    float4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3, sc0, sc1, sc2, sc3;
+#define ATR_LOAD_BLOCK(blk)                                                                                            \
+    do {                                                                                                               \
+        if ((blk) < kBlocksIh) {                                                                                       \
+            const int o_ = kBlk * (blk);                                                                               \
+            sa0 = *reinterpret_cast<const float4 *>(pf[0] + o_); sa1 = *reinterpret_cast<const float4 *>(pf[1] + o_);   \
+            sa2 = *reinterpret_cast<const float4 *>(pf[2] + o_); sa3 = *reinterpret_cast<const float4 *>(pf[3] + o_);   \
+            sb0 = *reinterpret_cast<const float4 *>(pwi[0][0] + o_); sb1 = *reinterpret_cast<const float4 *>(pwi[0][1] + o_); \
+            sb2 = *reinterpret_cast<const float4 *>(pwi[0][2] + o_); sb3 = *reinterpret_cast<const float4 *>(pwi[0][3] + o_); \
+            sc0 = *reinterpret_cast<const float4 *>(pwi[1][0] + o_); sc1 = *reinterpret_cast<const float4 *>(pwi[1][1] + o_); \
+            sc2 = *reinterpret_cast<const float4 *>(pwi[1][2] + o_); sc3 = *reinterpret_cast<const float4 *>(pwi[1][3] + o_); \
+        } else {                                                                                                       \
+            const int o_ = kBlk * ((blk) - kBlocksIh);                                                                 \
+            sa0 = *reinterpret_cast<const float4 *>(ph[0] + o_); sa1 = *reinterpret_cast<const float4 *>(ph[1] + o_);   \
+            sa2 = *reinterpret_cast<const float4 *>(ph[2] + o_); sa3 = *reinterpret_cast<const float4 *>(ph[3] + o_);   \
+            sb0 = *reinterpret_cast<const float4 *>(pwh[0][0] + o_); sb1 = *reinterpret_cast<const float4 *>(pwh[0][1] + o_); \
+            sb2 = *reinterpret_cast<const float4 *>(pwh[0][2] + o_); sb3 = *reinterpret_cast<const float4 *>(pwh[0][3] + o_); \
+            sc0 = *reinterpret_cast<const float4 *>(pwh[1][0] + o_); sc1 = *reinterpret_cast<const float4 *>(pwh[1][1] + o_); \
+            sc2 = *reinterpret_cast<const float4 *>(pwh[1][2] + o_); sc3 = *reinterpret_cast<const float4 *>(pwh[1][3] + o_); \
+        }                                                                                                              \
+    } while (0)
+    float *mybuf = lds[wave];
+    float *stp = mybuf + rs * kLs + 4 * k4;
+#define ATR_ST4(dst, v) (*reinterpret_cast<float4 *>(dst) = (v))
+#define ATR_STORE_BLOCK(blk)                                                                                           \
+    do {                                                                                                               \
+        float *d_ = stp + ((blk) & 1) * 3 * kOpFloats;                                                                 \
+        ATR_ST4(d_, sa0); ATR_ST4(d_ + 8 * kLs, sa1); ATR_ST4(d_ + 16 * kLs, sa2); ATR_ST4(d_ + 24 * kLs, sa3);        \
+        d_ += kOpFloats;                                                                                               \
+        ATR_ST4(d_, sb0); ATR_ST4(d_ + 8 * kLs, sb1); ATR_ST4(d_ + 16 * kLs, sb2); ATR_ST4(d_ + 24 * kLs, sb3);        \
+        d_ += kOpFloats;                                                                                               \
+        ATR_ST4(d_, sc0); ATR_ST4(d_ + 8 * kLs, sc1); ATR_ST4(d_ + 16 * kLs, sc2); ATR_ST4(d_ + 24 * kLs, sc3);        \
+    } while (0)
+    ATR_LOAD_BLOCK(0);
+
     // ---- per-row inputs, second half. Raw loads only (results are first touched after the main loop): any arithmetic on
     // a loaded value here makes the compiler wait for it on the spot.
     float bias[4], cp[8], eb[8][4];
@@ -123,6 +156,7 @@ __global__ __launch_bounds__(256, 1) void k_actor_step(ActorStep a)
         cp[i] = a.c_prev[(size_t)rws[i] * kR + u];
         dn[i] = donep[has_done ? rws[i] : 0];
     }
+    const int arow = min(row0 + jj, a.N - 1);              // the row this lane supplies as MFMA operand A
     const unsigned char adone = donep[has_done ? arow : 0];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -132,6 +166,8 @@ __global__ __launch_bounds__(256, 1) void k_actor_step(ActorStep a)
         for (int g = 0; g < 4; g++) eb[i][g] = e[g * kR];
     }
     __builtin_amdgcn_sched_barrier(0);
+    ATR_STORE_BLOCK(0);
+    ATR_LOAD_BLOCK(1);
 
     // Four accumulators (tile T x parity of the MFMA step): same-accumulator MFMAs are three others apart.
     f32x16 acc[2][2];
@@ -142,28 +178,33 @@ __global__ __launch_bounds__(256, 1) void k_actor_step(ActorStep a)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[T][p2][r] = 0.0f;
 
+    const float akeep = (has_done && adone != 0) ? 0.0f : 1.0f;
+    const float *rd = mybuf + jj * kLs + 4 * kk;           // MFMA layout: lane (row / column jj, K slot kk)
 #pragma unroll
-    for (int c = 0; c < kChunks; c++) {
-        float4 av = ra[c % kDepth];
-        const float4 b0 = rbv[c % kDepth][0], b1 = rbv[c % kDepth][1];
-        if (c >= kChunksIh) {                  // (k h) W == k (h W): the mask rides on A
-            const float akeep = (has_done && adone != 0) ? 0.0f : 1.0f;
-            av.x *= akeep; av.y *= akeep; av.z *= akeep; av.w *= akeep;
+    for (int blk = 0; blk < kBlocks; blk++) {
+        if (blk + 1 < kBlocks) ATR_STORE_BLOCK(blk + 1);   // block blk + 1 (in registers since the previous iteration) -> LDS
+        if (blk + 2 < kBlocks) ATR_LOAD_BLOCK(blk + 2);    // block blk + 2: memory -> registers, under this block's MFMAs
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_sched_barrier(0);
+        const float *src = rd + (blk & 1) * 3 * kOpFloats;
+#pragma unroll
+        for (int cc = 0; cc < kBlk / 8; cc++) {
+            float4 av = *reinterpret_cast<const float4 *>(src + 8 * cc);
+            const float4 b0 = *reinterpret_cast<const float4 *>(src + kOpFloats + 8 * cc);
+            const float4 b1 = *reinterpret_cast<const float4 *>(src + 2 * kOpFloats + 8 * cc);
+            if (blk >= kBlocksIh) {            // (k h) W == k (h W): the mask rides on A
+                av.x *= akeep; av.y *= akeep; av.z *= akeep; av.w *= akeep;
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc[1][1], 0, 0, 0);
         }
-        if (c + kDepth < kChunks) {
-            ra[c % kDepth] = load_a(c + kDepth);
-            rbv[c % kDepth][0] = load_b(c + kDepth, 0);
-            rbv[c % kDepth][1] = load_b(c + kDepth, 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch above this chunk's MFMAs
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc[1][1], 0, 0, 0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     f32x16 accs[2];
 #pragma unroll
