@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
 // alignment); 2 = u8 observations [N,2,13,13] (the B_step = 709 variant of SURVEY 8d; the policy stem decodes them).
 enum : int { OBS_F32_VEC4 = 0, OBS_F32_SCALAR = 1, OBS_U8 = 2 };
 constexpr int kStage2Rows = 56;                     // 52 window rows of the pair (+1 read past the end, +pad)
-constexpr int kStage2Words = kStage2Rows + 172;     // + 169 dwords of mark bytes
+constexpr int kStage2Words = kStage2Rows + 192;     // + 169 dwords of mark bytes (padded: every lane reads 3 of them)
 #ifndef T2D_STEP2_WAVES
 #define T2D_STEP2_WAVES 4
 #endif
@@ -766,13 +766,19 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const vo
         wave_lds_sync();
         T2D_STAMP(4);
         const size_t ebase = ((size_t)it * s.n + e0) * kObsPerEnv;   // first cell of the pair in the output
+        // all LDS reads of the three groups first (independent: their latencies overlap), then the math, then the stores
+        uint32_t glo[3], ghi[3], gmk[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            glo[i] = st[rj[i]]; ghi[i] = st[rj[i] + 1];
+            gmk[i] = mk[lane + 64 * i];                      // (the mark plane is padded to 192 dwords: always in bounds)
+        }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const int q = lane + 64 * i, p = 4 * q;
+            const uint32_t nib = ((glo[i] | (ghi[i] << 13)) >> rx[i]) & 0xfu;
+            const uint32_t bytes = (__umul24(nib, 0x204081u) & 0x01010101u) | gmk[i];   // bit c -> byte c, then colours
             if (p >= cells) continue;
-            const uint32_t lo = st[rj[i]], hi = st[rj[i] + 1];
-            const uint32_t nib = ((lo | (hi << 13)) >> rx[i]) & 0xfu;
-            const uint32_t bytes = (__umul24(nib, 0x204081u) & 0x01010101u) | mk[q];   // bit c -> byte c, then colours
             const int nvalid = min(4, cells - p);
             if (OBS == OBS_U8) {
                 uint8_t *o = reinterpret_cast<uint8_t *>(obs) + ebase + p;
