@@ -272,3 +272,35 @@ def test_numpy_rng_mode_replays_the_reference_from_the_seed_alone(fixture):
                 n_steps += 1
         env.close()
     assert n_steps > 100
+
+
+def test_graphed_iteration_selects_the_training_mode_per_call():
+    """One rollout graph per training mode (the evaluator's train_modes schedule, test.py:84-92): replaying mode 0 (tracker
+    only, --init-step phase) must leave the target's weights untouched, mode -1 must move both players, and switching
+    back and forth keeps the env / LSTM carry consistent (finite weights, env invariants)."""
+    from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player
+    dev = torch.device("cuda:0")
+    args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=128, seed=9)
+    player, opt = make_player(args, dev)
+    it = GraphedIteration(player, opt, args)                 # captures mode -1; two eager warm-up updates happened
+    snap = lambda m: torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+    # fresh moments so that a zero gradient means a zero Adam step for the target in mode 0
+    for st in (opt.exp_avg, opt.exp_avg_sq, opt.max_exp_avg_sq):
+        st.zero_()
+    t0, g0 = snap(player.model.player0), snap(player.model.player1)
+    it.run(0)
+    torch.cuda.synchronize()
+    t1, g1 = snap(player.model.player0), snap(player.model.player1)
+    assert not torch.equal(t0, t1) and torch.equal(g0, g1)
+    it.run(-1)
+    it.run(0)
+    it.run(-1)
+    torch.cuda.synchronize()
+    t2, g2 = snap(player.model.player0), snap(player.model.player1)
+    assert not torch.equal(g1, g2) and not torch.equal(t1, t2)
+    assert sorted(it.g_rolls.keys()) == [-1, 0]
+    assert torch.isfinite(opt.bucket.flat).all()
+    st = player.env.core.get_state()
+    maps = player.env.core.get_maps()
+    assert (maps[np.arange(128), st["pos"][:, 0, 0], st["pos"][:, 0, 1]] == 0).all()
+    player.env.close()
