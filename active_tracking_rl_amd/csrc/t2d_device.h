@@ -472,12 +472,12 @@ __device__ __forceinline__ uint32_t rpf_cell(int side, int i)
 }
 
 // clear_rpf: plan on the GENERATOR's map of an RPF env, i.e. the env's tile with the four patrol cells free
-// (track_1v1.py:233-236). (qr, qc): the cell the plan will be followed FROM (-1: none); dist (optional): its BFS distance
-// (-1 if unreachable). The flood stops at the level that reaches (qr, qc): every cell of a shortest path from there to the
+// (track_1v1.py:233-236). (qr, qc): the cell the plan will be followed FROM (-1: none); returns its BFS distance (-1 if
+// unreachable or not asked for; by value — a nullable out-pointer kept the caller's variable in scratch memory). The flood stops at the level that reaches (qr, qc): every cell of a shortest path from there to the
 // goal is closer to the goal, hence already labelled — the rest of the field would never be read (about half the levels
 // on average).
-__device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, int lane, int gr, int gc, NavField &f,
-                                              bool clear_rpf = false, int qr = -1, int qc = -1, int *dist = nullptr)
+__device__ __forceinline__ int bfs_dir_field(const uint32_t *tile, int side, int lane, int gr, int gc, NavField &f,
+                                              bool clear_rpf = false, int qr = -1, int qc = -1)
 {
     RowBits freeA, freeB, frA, frB;
     const uint32_t m2 = valid_mask_w2(side);
@@ -562,7 +562,7 @@ __device__ __forceinline__ void bfs_dir_field(const uint32_t *tile, int side, in
         if (found >= 0) break;                // everything a path from (qr, qc) can touch is labelled
         if (__ballot(any != 0u) == 0ull) break;
     }
-    if (dist != nullptr) *dist = found;
+    return found;
 }
 
 // direction-plane tile in HBM: plane 0 = words 0..245, plane 1 = words 256..501 (same row layout as the map)

@@ -80,21 +80,20 @@ __device__ __forceinline__ int check_action(long long v, uint32_t *faults)
 
 // Navigator.reset / the re-plan branch of Navigator.step (navigator.py:43-63, :15-38): plan from (fr, fc) to navgoal;
 // unreachable or empty plan -> resample the goal, the 6th failure -> plan B (10 random actions).
-// RPF (nav2 != nullptr): goals cycle the four patrol cells without random draws (generators.py:48-50), the plan is made
-// on the generator's map (patrol cells free) and *nav2 receives the open-loop plan: virtual position = (fr, fc),
-// remaining = BFS distance, vector.
+// RPF: goals cycle the four patrol cells without random draws (generators.py:48-50), the plan is made on the
+// generator's map (patrol cells free) and nav2 receives the open-loop plan: virtual position = (fr, fc), remaining =
+// BFS distance, vector. (rpf + reference instead of a nullable pointer: the latter kept nav2 in scratch memory.)
 template <class S>
 __device__ __forceinline__ void nav_plan(const uint32_t *tile, int side, int lane, int fr, int fc, const FreeIndex &fi,
-                                         uint32_t &navgoal, S &ts, uint32_t &plan, NavField &f, uint32_t *nav2 = nullptr)
+                                         uint32_t &navgoal, S &ts, uint32_t &plan, NavField &f, bool rpf, uint32_t &nav2)
 {
     int count_res = 0;
     bool planb = false;
-    const bool rpf = nav2 != nullptr;
-    uint32_t vector = rpf ? (*nav2 >> 30) : 0u;
+    uint32_t vector = rpf ? (nav2 >> 30) : 0u;
     int dist = -1;
     for (;;) {
         const int gr = (int)(navgoal & 0xffu), gc = (int)(navgoal >> 8);
-        bfs_dir_field(tile, side, lane, gr, gc, f, rpf, fr, fc, rpf ? &dist : nullptr);   // stops once (fr, fc) is reached
+        dist = bfs_dir_field(tile, side, lane, gr, gc, f, rpf, fr, fc);   // stops once (fr, fc) is reached
         const bool ok = rowbits_get(f.visA, f.visB, fr, fc) != 0u && !(fr == gr && fc == gc);
         if (ok) break;
         if (++count_res > 5) { planb = true; break; }
@@ -103,7 +102,7 @@ __device__ __forceinline__ void nav_plan(const uint32_t *tile, int side, int lan
     }
     plan = planb ? (plan_random(ts, 10u) | (1u << 28)) : 0u;
     if (rpf)
-        *nav2 = (uint32_t)fr | ((uint32_t)fc << 8) | ((planb ? 0u : ((uint32_t)dist & 0x3fffu)) << 16) | (vector << 30);
+        nav2 = (uint32_t)fr | ((uint32_t)fc << 8) | ((planb ? 0u : ((uint32_t)dist & 0x3fffu)) << 16) | (vector << 30);
 }
 __device__ __forceinline__ uint32_t nav_dir_from_regs(const NavField &f, int r, int c)
 {
@@ -179,7 +178,7 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
     if (NAV && (mode == TGT_NAV || rpf)) { // Navigator.reset (navigator.py:43-63): plan from the target spawn to goal_states[1]
         NavField nf;
         nav2 = 1u << 30;                   // RPF: sample_goal(2) at reset advanced the patrol vector to 1
-        nav_plan(tile, side, lane, (int)(tg & 0xffu), (int)(tg >> 8), fi, navgoal, ts, plan, nf, rpf ? &nav2 : nullptr);
+        nav_plan(tile, side, lane, (int)(tg & 0xffu), (int)(tg >> 8), fi, navgoal, ts, plan, nf, rpf, nav2);
         if (!rpf) nav2 = 0u;
         if (((plan >> 28) & 1u) == 0u) store_dir_field(gdir, nf, side, lane);
     }
@@ -435,7 +434,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
                 if (rpf) { nav2 = (nav2 & 0x3fffffffu) | ((((nav2 >> 30) + 1u) & 3u) << 30); navgoal = rpf_cell(side, (int)(nav2 >> 30)); }
                 else if (!have_goal) navgoal = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
                 NavField nf;
-                nav_plan(tile, side, lane, r1, c1, fi, navgoal, ts, plan, nf, rpf ? &nav2 : nullptr);
+                nav_plan(tile, side, lane, r1, c1, fi, navgoal, ts, plan, nf, rpf, nav2);
                 planb = ((plan >> 28) & 1u) != 0u;
                 qr = r1; qc = c1;
                 if (!planb) { store_dir_field(gdir, nf, side, lane); dir = nav_dir_from_regs(nf, qr, qc); }

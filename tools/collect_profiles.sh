@@ -27,4 +27,5 @@ if [ -f $R/scratch_exp/libexp6.so ]; then
   T2D_LIB_PATH=$R/scratch_exp/libexp6.so timeout 120 python $R/tools/timeline_probe.py 4096 > $O/step_kernel_timeline_4096.txt 2>&1
   (bash $R/tools/exp_variants.sh 5 7 8; N=65536 bash $R/tools/exp_variants.sh 5 7 8) > $O/step_kernel_latency_probes.txt 2>&1
 fi
+timeout 300 bash $R/tools/prof_iter.sh
 ls -la $O
