@@ -104,16 +104,21 @@ struct VStream {
         k0 = k0_; k1 = k1_; episode = ep; env = env_; stream = s; ctr = ctr_; base = 0xffffffffu; lane = lane_;
         wv = 0u;
     }
-    __device__ __forceinline__ uint32_t next()
+    // make the 64-word block that holds word `i` the one in the lanes
+    __device__ __forceinline__ void ensure(uint32_t i)
     {
-        const uint32_t i = uni(ctr);
-        ctr = i + 1u;
         if ((i & ~63u) != base) {
             base = i & ~63u;
             const u32x4 w = philox4x32_10(k0, k1, (base >> 2) + (uint32_t)(lane >> 2), episode, env, stream);
             const int j = lane & 3;
             wv = j == 0 ? w.x : (j == 1 ? w.y : (j == 2 ? w.z : w.w));
         }
+    }
+    __device__ __forceinline__ uint32_t next()
+    {
+        const uint32_t i = uni(ctr);
+        ctr = i + 1u;
+        ensure(i);
         return __builtin_amdgcn_readlane(wv, (int)(i & 63u));
     }
     __device__ __forceinline__ double next_double()
@@ -265,17 +270,19 @@ __device__ __forceinline__ void gen_block(uint32_t *tile, int lane, S &ms, doubl
 
 // RandomMazeGenerator._generate_maze — G/envs/generators.py:115-145 (81x81). Inherently sequential (every step
 // depends on the walls laid so far): one wave-uniform loop whose cost is the number of instructions per growth step
-// times the ~5 cycles a lone wave needs per dependent instruction. Restated for a short step (round 2: ~45 instructions,
-// was ~100):
+// times the ~5 cycles a lone wave needs per dependent instruction, plus every hand-over between the vector and the
+// scalar unit. Restated for a short, almost purely scalar step:
 //   * the walk lives on the 41x41 node grid (cells with even coordinates — the only cells the algorithm READS); the
-//     position is ONE scalar p = y * 128 + x, a move is p += delta[d] from a 4-lane register table;
-//   * the neighbour list [(y,x-2) if x>1, (y,x+2) if x<S-2, (y-2,x) if y>1, (y+2,x) if y<S-2] (generators.py:135-138)
-//     is ONE lane-parallel compare: lane d < 4 extracts its coordinate of p (v_bfe with a per-lane offset) and compares
-//     it with its own limit; the ballot is the 4-bit presence mask m; the k-th present direction comes from a 64-lane
-//     register table indexed m * 4 + k (one v_readlane);
-//   * node bits: one register pair with a row per lane (read: two v_readlane; write: one predicated OR per half);
+//     position is ONE scalar p = y * 41 + x, which is also the BIT INDEX of the node in a 1681-bit map held by ONE
+//     vector register (lane L = bits [32 L, 32 L + 32)): a node test is one v_readlane + a scalar bit test, a carve
+//     is one predicated OR;
+//   * an INTERIOR node has all four neighbours (generators.py:135-138 drops a neighbour only at x <= 1, x >= S - 2,
+//     y <= 1, y >= S - 2, i.e. on the border nodes), the draw over 4 candidates is the low two bits of ONE random word
+//     (masked rejection never rejects for max = 3) and the move is p += delta[d] from a byte table in a scalar
+//     constant. The walk can only stand on a border node at its seed (border nodes are walls, so it never MOVES onto
+//     one): those steps take the general path (presence mask by arithmetic, k-th present direction by a small loop);
 //   * the carved mid-points are not written in the loop: every successful move is appended to a log in LDS (one
-//     ds_write by lane 0) and all mid-point walls are set in parallel afterwards;
+//     ds_write by lane 0, never waited for) as p | d << 11, and all mid-point walls are set in parallel afterwards;
 //   * random words: the 64-block VStream (one readlane per draw).
 // Same draws in the same order as before, hence the same mazes bit for bit (oracle PHILOX mode).
 __device__ __forceinline__ uint32_t spread16(uint32_t v)   // bit i of the low 16 bits -> bit 2i
@@ -288,71 +295,82 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v)   // bit i of the low 1
     return v;
 }
 constexpr int kMazeLogMax = 47 * 24;     // density <= int(0.03 * 1600) = 47 seeds x complexity <= int(0.03 * 810) = 24 moves
+constexpr uint32_t kMazeDelta = 0x29d701ffu;   // bytes -1, +1, -41, +41: node (y, x-2), (y, x+2), (y-2, x), (y+2, x)
 template <class S>
 __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double ratio, uint32_t *log)
 {
 #ifdef T2D_EXP_NOMAZE
     const int complexity = 0, density = 0;        // timing probe: everything but the growth loop
 #else
-    const int complexity = (int)(ratio * 810.0);
-    const int density = (int)(ratio * 1600.0);
+    const int complexity = uni((int)(ratio * 810.0));
+    const int density = uni((int)(ratio * 1600.0));
 #endif
-    // border walls (generators.py:127-128): node rows 0 / 40 entirely, node columns 0 / 40 of every row
-    uint32_t nlo = 0u, nhi = 0u;
-    if (lane == 0 || lane == 40) { nlo = 0xffffffffu; nhi = 0x1ffu; }
-    else if (lane < 40) { nlo = 1u; nhi = 0x100u; }
-    // per-lane constants of the 4 direction lanes: which coordinate of p decides the presence of direction d, and its limit
-    const uint32_t coord_off = (lane & 2) ? 7u : 0u;                 // d = 0, 1 look at x (bits 0..6), d = 2, 3 at y (bits 7..13)
-    const uint32_t coord_lim = (lane & 1) ? 40u : 0u;                // d even: coordinate != 0; d odd: coordinate != 40
-    const int delta = lane == 0 ? -1 : (lane == 1 ? 1 : (lane == 2 ? -128 : 128));
-    // table lane (m * 4 + k) -> the k-th set bit of m
-    uint32_t kth = 0u;
-    {
-        const int m = lane >> 2, k = lane & 3;
-        int seen = 0;
-#pragma unroll
-        for (int d = 0; d < 4; d++)
-            if ((m >> d) & 1) {
-                if (seen == k) kth = (uint32_t)d;
-                seen++;
-            }
+    // node bit map, bit b = y * 41 + x in lane b >> 5: border walls (generators.py:127-128) = node rows / columns 0 and 40
+    uint32_t zb = 0u;
+#pragma unroll 1
+    for (int k = 0; k < 32; k++) {
+        const int b = lane * 32 + k, y = b / 41, x = b - y * 41;
+        if (b < 1681 && (y == 0 || y == 40 || x == 0 || x == 40)) zb |= 1u << k;
     }
     int nlog = 0;
+    // one growth step from node p in direction d: test the node bit, carve + log + move on a free node
+#define T2D_MAZE_MOVE(D)                                                                                               \
+    do {                                                                                                               \
+        const uint32_t d_ = (D);                                                                                       \
+        const int q = p + (int)(int8_t)(kMazeDelta >> (8u * d_));                                                      \
+        const uint32_t word = __builtin_amdgcn_readlane(zb, q >> 5);                                                   \
+        if (((word >> (q & 31)) & 1u) == 0u) {                        /* Z[y_, x_] == 0: carve */                      \
+            zb |= lane == (q >> 5) ? 1u << (q & 31) : 0u;                                                              \
+            log[nlog] = (uint32_t)p | (d_ << 11);                     /* by every lane: same word, no exec juggling */ \
+            nlog++;                                                                                                    \
+            p = q;                                                                                                     \
+            interior = true;                                          /* a free node is never on the border */         \
+        }                                                                                                              \
+    } while (0)
     for (int i = 0; i < density; i++) {
         const int sx = (int)ms.bounded(40u);                          // x's draw first (the tuple on generators.py:131)
         const int sy = (int)ms.bounded(40u);
-        int p = sy * 128 + sx;
-        {   // Z[y, x] = 1
-            const uint32_t bit = 1u << (sx & 31);
-            if (lane == sy) { if (sx < 32) nlo |= bit; else nhi |= bit; }
+        int p = uni(sy * 41 + sx);
+        zb |= lane == (p >> 5) ? 1u << (p & 31) : 0u;                 // Z[y, x] = 1
+        bool interior = sx != 0 && sx != 40 && sy != 0 && sy != 40;
+        // presence mask of the seed's neighbours, in the order of the list on generators.py:135-138
+        const uint32_t m0 = (uint32_t)(sx != 0) | ((uint32_t)(sx != 40) << 1) | ((uint32_t)(sy != 0) << 2) | ((uint32_t)(sy != 40) << 3);
+        int j = 0;
+        for (; j < complexity && !interior; j++) {                    // border seed: general draw until the walk leaves it
+            uint32_t k = ms.bounded((uint32_t)__popc(m0) - 1u);
+            uint32_t d = 0u;
+            for (uint32_t mm = m0; ; mm >>= 1, d++)
+                if (mm & 1u) { if (k == 0u) break; k--; }
+            T2D_MAZE_MOVE(d);
         }
-        for (int j = 0; j < complexity; j++) {
-            const uint32_t coord = __builtin_amdgcn_ubfe((uint32_t)p, coord_off, 7u);
-            const uint32_t m = (uint32_t)__ballot(coord != coord_lim) & 0xfu;
-            const uint32_t k = ms.bounded((uint32_t)__popc(m) - 1u);
-            const int d = (int)__builtin_amdgcn_readlane(kth, (int)(m * 4u + k));
-            const int q = p + (int)__builtin_amdgcn_readlane((uint32_t)delta, d);
-            const int qy = q >> 7, qx = q & 127;
-            const uint32_t lo = __builtin_amdgcn_readlane(nlo, qy), hi = __builtin_amdgcn_readlane(nhi, qy);
-            const uint32_t word = qx < 32 ? lo : hi;
-            if (((word >> (qx & 31)) & 1u) == 0u) {                   // Z[y_, x_] == 0: carve
-                const uint32_t bit = 1u << (qx & 31);
-                if (lane == qy) { if (qx < 32) nlo |= bit; else nhi |= bit; }
-                if (lane == 0) log[nlog] = (uint32_t)(p + q);          // mid-point (y + y_) * 128 + (x + x_), full-resolution cells
-                nlog++;
-                p = q;
-            }
+        while (j < complexity) {                                       // interior: one word per move, block by block
+            const uint32_t c = uni(ms.ctr);
+            ms.ensure(c);
+            const int c0 = (int)(c & 63u), n = min(64 - c0, complexity - j);
+            for (int k = 0; k < n; k++) T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k) & 3u);
+            ms.ctr = c + (uint32_t)n;
+            j += n;
         }
     }
-    // assemble the tile: even row 2j = the node bits at the even columns; then the logged mid-points
+#undef T2D_MAZE_MOVE
+    // assemble the tile: even row 2y = node row y at the even columns (rows 0 / 80 are walls at the odd columns too);
+    // then the logged mid-points
     tile_clear(tile, lane);
     wave_lds_sync();
-    if (lane <= 40) {
-        uint32_t *r = tile + (2 * lane) * kRowWords;
-        const bool edge = lane == 0 || lane == 40;                    // rows 0 / 80 are walls at the odd columns too
-        r[0] = edge ? 0xffffffffu : spread16(nlo);
-        r[1] = edge ? 0xffffffffu : spread16(nlo >> 16);
-        r[2] = edge ? 0x1ffffu : spread16(nhi);
+    // node row y = bits [41 y, 41 y + 41) of the register bit map: up to three lanes' words (shuffles by every lane:
+    // a source lane must be active)
+    {
+        const int yl = min(lane, 40), b0 = yl * 41, l0 = b0 >> 5, sh = b0 & 31;
+        const uint32_t w0 = __shfl(zb, l0, 64), w1 = __shfl(zb, min(l0 + 1, 63), 64), w2 = __shfl(zb, min(l0 + 2, 63), 64);
+        uint64_t row = (((uint64_t)w1 << 32) | w0) >> sh;
+        if (sh != 0) row |= (uint64_t)w2 << (64 - sh);
+        if (lane <= 40) {
+            const bool edge = lane == 0 || lane == 40;
+            uint32_t *r = tile + (2 * lane) * kRowWords;
+            r[0] = edge ? 0xffffffffu : spread16((uint32_t)row);
+            r[1] = edge ? 0xffffffffu : spread16((uint32_t)(row >> 16));
+            r[2] = edge ? 0x1ffffu : (spread16((uint32_t)(row >> 32)) & 0x1ffffu);
+        }
     }
     if (lane < 40) {      // odd rows: the border columns 0 and 80
         uint32_t *r = tile + (2 * lane + 1) * kRowWords;
@@ -360,8 +378,10 @@ __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double
     }
     wave_lds_sync();
     for (int i = lane; i < nlog; i += 64) {
-        const uint32_t e = log[i];                                    // (y + y_) * 128 + (x + x_): row and column of the wall
-        const uint32_t row = e >> 7, col = e & 127u;
+        const uint32_t e = log[i];                                    // node p = y * 41 + x and the direction of the move
+        const uint32_t pp = e & 0x7ffu, d = e >> 11;
+        const uint32_t y = pp / 41u, x = pp - y * 41u;
+        const uint32_t row = 2u * y + (d == 2u ? -1 : (d == 3u ? 1 : 0)), col = 2u * x + (d == 0u ? -1 : (d == 1u ? 1 : 0));
         atomicOr(&tile[row * kRowWords + (col >> 5)], 1u << (col & 31u));
     }
     wave_lds_sync();

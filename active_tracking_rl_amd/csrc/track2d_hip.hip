@@ -199,12 +199,41 @@ __device__ __forceinline__ uint32_t window_row_bits(uint32_t w0, uint32_t w1, ui
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(sp & 31)) & 0x1fffu;
 }
 
+// Nav targets: prefetch the next plan on the CURRENT map, by the env's wave when no prefetched plan is pending. Draws
+// the goal the Navigator will draw when its plan is exhausted (navigator.py:17 — the TARGET stream has no other
+// consumer until then, so drawing it now keeps the stream order) and runs the BFS for it here, off the step kernel's
+// critical path. The step kernel adopts it if the target's position turns out reachable and different from the goal,
+// else re-plans inline. Reads the env's live state: only ever runs in order on the caller's stream, between two step
+// launches (inside the in-order generator launch, or as its own launch when the generator is forked).
+__device__ __forceinline__ void nav_prefetch(const DevState &s, int e, uint32_t *tile, int lane)
+{
+    reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(s.maps + (size_t)e * kTileWords)[lane];
+    wave_lds_sync();
+    const int side = (int)(s.cnt[e] >> 24);
+    const FreeIndex fi = build_free_index(tile, side, lane);
+    Stream ts;
+    ts.init(s.k0, s.k1, s.episode[e], s.env_base + (uint32_t)e, STREAM_TARGET, s.tctr[e]);
+    const uint32_t g2 = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+    NavField nf;
+    // the target will stand on its CURRENT goal when this plan is needed (navigator.py:15: a plan is exhausted exactly
+    // there), so the flood may stop once it has reached that cell; if the target is elsewhere (plan B), the adoption
+    // test in the step kernel (visited plane) sends it to the inline re-plan
+    const uint32_t cur = s.navgoal[e];
+    bfs_dir_field(tile, side, lane, (int)(g2 & 0xffu), (int)(g2 >> 8), nf, false, (int)(cur & 0xffu), (int)(cur >> 8));
+    store_plan_field(s.p_field + (size_t)e * kPlanWords, nf, side, lane);
+    if (lane == 0) { s.p_goal[e] = g2; s.p_tctr[e] = ts.ctr; s.p_state[e] = 1u; }
+    wave_lds_sync();
+}
+
 // Generator kernel: fills the "next episode" slot (episode[e] + 1) of every env whose slot was consumed at a step
-// stamp <= upto (or of every env when force != 0). Launched by the host every `gen_every` steps (<= 10): a
-// consumed slot cannot be needed again for 11 steps (done needs 11 consecutive far steps, track_1v1.py:106-111),
-// so generation is off the step kernel's critical path and its cost is amortised over the period.
-template <bool NAV>
-__global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t upto, int force)
+// stamp in [lo, hi] (or of every env when force != 0). Launched by the host once per stamp window: a consumed slot
+// cannot be needed again for 11 steps (done needs 11 consecutive far steps, track_1v1.py:106-111), so generation is
+// off the step kernel's critical path. Everything it reads (gen_req, cfg, episode of the envs it serves) was written
+// before its launch and is not touched by the step launches of the following window; everything it writes is read
+// only after the window's join (t2d_handle::gen_*): it may therefore run on the library's side stream, under the
+// step launches and policy kernels of the next window.
+template <bool NAV, bool PREFETCH>
+__global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t lo, uint32_t hi, int force)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tiles[kWavesPerBlock][kTileWords];
     __shared__ uint32_t mlogs[kWavesPerBlock][kMazeLogMax];     // move log of the maze generator (t2d_device.h gen_maze)
@@ -215,29 +244,8 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t upto, int forc
     const uint32_t req = s.gen_req[e];
     const uint32_t cfg = s.cfg[e];
     uint32_t *tile = tiles[wave];
-    const bool need_gen = force || (req != 0u && req <= upto);
-    if (NAV && !force && (int)((cfg >> 2) & 7u) == TGT_NAV && s.p_state[e] == 0u) {
-        // Prefetch the Nav target's next plan on the CURRENT map: draw the goal the Navigator will draw when its
-        // plan is exhausted (navigator.py:17 — the TARGET stream has no other consumer until then, so drawing it now
-        // keeps the stream order) and run the BFS for it here, off the step kernel's critical path. The step kernel
-        // adopts it if the target's position turns out reachable and different from the goal, else re-plans inline.
-        reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(s.maps + (size_t)e * kTileWords)[lane];
-        wave_lds_sync();
-        const int side = (int)(s.cnt[e] >> 24);
-        const FreeIndex fi = build_free_index(tile, side, lane);
-        Stream ts;
-        ts.init(s.k0, s.k1, s.episode[e], s.env_base + (uint32_t)e, STREAM_TARGET, s.tctr[e]);
-        const uint32_t g2 = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
-        NavField nf;
-        // the target will stand on its CURRENT goal when this plan is needed (navigator.py:15: a plan is exhausted exactly
-        // there), so the flood may stop once it has reached that cell; if the target is elsewhere (plan B), the adoption
-        // test in the step kernel (visited plane) sends it to the inline re-plan
-        const uint32_t cur = s.navgoal[e];
-        bfs_dir_field(tile, side, lane, (int)(g2 & 0xffu), (int)(g2 >> 8), nf, false, (int)(cur & 0xffu), (int)(cur >> 8));
-        store_plan_field(s.p_field + (size_t)e * kPlanWords, nf, side, lane);
-        if (lane == 0) { s.p_goal[e] = g2; s.p_tctr[e] = ts.ctr; s.p_state[e] = 1u; }
-        wave_lds_sync();
-    }
+    const bool need_gen = force || (req >= lo && req <= hi && req != 0u);
+    if (PREFETCH && !force && (int)((cfg >> 2) & 7u) == TGT_NAV && s.p_state[e] == 0u) nav_prefetch(s, e, tile, lane);
     if (!need_gen) return;
     uint32_t pos, goals, plan, tctr, navgoal, d2, nav2;
     uint32_t *gdir = NAV ? s.n_dirf + (size_t)e * kDirWords : nullptr;
@@ -263,6 +271,17 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t upto, int forc
         s.n_navgoal[e] = navgoal; s.n_d2[e] = d2; s.gen_req[e] = 0u;
         if (NAV) s.n_nav2[e] = nav2;
     }
+}
+
+__global__ __launch_bounds__(256) void k_nav_prefetch(DevState s)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kWavesPerBlock][kTileWords];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int e = (int)blockIdx.x * kWavesPerBlock + wave;
+    if (e >= s.n) return;
+    if ((int)((s.cfg[e] >> 2) & 7u) != TGT_NAV || s.p_state[e] != 0u) return;
+    nav_prefetch(s, e, tiles[wave], lane);
 }
 
 // _get_obs / _get_partial_obs (track_1v1.py:287-326) for ONE env by ONE wave. Lanes 0..51 each expand one half
@@ -839,8 +858,18 @@ struct t2d_handle {
     bool has_ram;      // some env has the scripted Ram target (selects the step kernel variant with the plan code)
     bool has_rpf;      // some env has the RPF patrol target (an agent may then stand on a wall of the env's own map)
     uint32_t random_step;
-    uint32_t gen_every; // generator launch period in steps (see step_impl)
-    uint32_t phase;     // steps since the last generator launch = stamp of the last step launch
+    bool has_navmode;  // some env has the Nav target (its next plan is prefetched once per stamp window)
+    uint32_t gen_every; // shortest possible episode = longest admissible generator period, in steps
+    // Step stamps run 1..cycle; the cycle is one window of gen_every steps (generator in order on the caller's
+    // stream) or, with the asynchronous generator, two windows of gen_every / 2: the slots consumed in window w are
+    // refilled by a launch forked onto gen_stream after w's last step and joined before w's next first step — one
+    // full window later, which is still sooner than any of those slots can be needed again (2 * win <= gen_every).
+    uint32_t win, cycle;
+    uint32_t phase;     // steps launched in the current cycle = stamp of the last step launch
+    bool gen_async;
+    bool pending[2];    // a forked generator launch of window w has not been joined yet
+    hipStream_t gen_stream;
+    hipEvent_t ev_fork, ev_join[2];
 };
 
 static thread_local char g_err[512] = "";
@@ -893,7 +922,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         return fail(T2D_ERR_INVALID, "t2d_create: device %d out of range (%d visible)", cfg->device, ndev);
     const int n = cfg->num_envs;
     std::vector<uint32_t> hcfg((size_t)n);
-    bool has_nav = false, has_rpf = false, has_ram = false;
+    bool has_nav = false, has_rpf = false, has_ram = false, has_navmode = false;
     int n_maze = 0;
     if (cfg->obs_type > T2D_OBS_FULL) return fail(T2D_ERR_INVALID, "t2d_create: obs_type %u", cfg->obs_type);
     for (int i = 0; i < n; i++) {
@@ -905,6 +934,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         has_nav = has_nav || tm == T2D_TGT_NAV || tm == T2D_TGT_RPF;
         has_rpf = has_rpf || tm == T2D_TGT_RPF || tm == T2D_TGT_EXT;   // agents may stand on walls
         has_ram = has_ram || tm == T2D_TGT_RAM;
+        has_navmode = has_navmode || tm == T2D_TGT_NAV;
         n_maze += mt == T2D_MAP_MAZE;
         if (lv > 15) return fail(T2D_ERR_INVALID, "t2d_create: level %u (env %d)", lv, i);
         hcfg[(size_t)i] = mt | (tm << 2) | (lv << 5);
@@ -917,12 +947,16 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     std::memset(&h->s, 0, sizeof(h->s));
     h->device = cfg->device;
     h->reset_done = false; h->primed = false; h->has_nav = has_nav; h->has_rpf = has_rpf; h->has_ram = has_ram;
+    h->has_navmode = has_navmode;
     h->random_step = 0; h->phase = 0;
+    h->gen_async = false; h->pending[0] = h->pending[1] = false;
+    h->gen_stream = nullptr; h->ev_fork = nullptr; h->ev_join[0] = h->ev_join[1] = nullptr;
     // A slot consumed at step q cannot be needed again before step q + min(11, max_episode_steps): done needs 11
     // consecutive far steps (track_1v1.py:106-111) or the TimeLimit. Launching the generator every G <= that many
     // steps, in order on the caller's stream, therefore always refills a slot before its next use.
     h->gen_every = 10u;
     if (cfg->max_episode_steps > 0 && (uint32_t)cfg->max_episode_steps < h->gen_every) h->gen_every = (uint32_t)cfg->max_episode_steps;
+    h->win = h->cycle = h->gen_every;
     DevState &s = h->s;
     s.n = n; s.env_base = cfg->env_id_base;
     s.k0 = (uint32_t)cfg->seed; s.k1 = (uint32_t)(cfg->seed >> 32);
@@ -972,6 +1006,11 @@ extern "C" int t2d_destroy(t2d_handle *h)
     void *ptrs[] = {s.maps, s.n_maps, s.pos, s.goals, s.cnt, s.cfg, s.episode, s.plan, s.tctr, s.navgoal, s.d2,
                     s.n_pos, s.n_goals, s.n_plan, s.n_tctr, s.n_navgoal, s.n_d2, s.gen_req, s.dirf, s.n_dirf, s.faults,
                     (void *)s.rew_lut, s.nav2, s.n_nav2, s.p_field, s.p_goal, s.p_tctr, s.p_state, s.n_win};
+    if (h->gen_stream) {
+        (void)hipStreamSynchronize(h->gen_stream);
+        (void)hipStreamDestroy(h->gen_stream);
+        (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join[0]); (void)hipEventDestroy(h->ev_join[1]);
+    }
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -980,10 +1019,54 @@ extern "C" int t2d_destroy(t2d_handle *h)
 
 static inline dim3 env_grid(int n) { return dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)); }
 
-static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t upto, int force)
+static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t lo, uint32_t hi, int force, bool prefetch = false)
 {
-    if (h->has_nav) hipLaunchKernelGGL((k_gen<true>), env_grid(h->s.n), dim3(256), 0, st, h->s, upto, force);
-    else hipLaunchKernelGGL((k_gen<false>), env_grid(h->s.n), dim3(256), 0, st, h->s, upto, force);
+    if (h->has_nav && prefetch) hipLaunchKernelGGL((k_gen<true, true>), env_grid(h->s.n), dim3(256), 0, st, h->s, lo, hi, force);
+    else if (h->has_nav) hipLaunchKernelGGL((k_gen<true, false>), env_grid(h->s.n), dim3(256), 0, st, h->s, lo, hi, force);
+    else hipLaunchKernelGGL((k_gen<false, false>), env_grid(h->s.n), dim3(256), 0, st, h->s, lo, hi, force);
+}
+
+// Make `st` wait for every forked generator launch.
+static int join_generator(t2d_handle *h, hipStream_t st)
+{
+    for (int w = 0; w < 2; w++)
+        if (h->pending[w]) {
+            HIP_TRY(hipStreamWaitEvent(st, h->ev_join[w], 0));
+            h->pending[w] = false;
+        }
+    return T2D_OK;
+}
+
+// Before a step launch: at the first step of a window, the slots consumed in that window one cycle ago must be back.
+static int window_begin(t2d_handle *h, hipStream_t st)
+{
+    if (!h->gen_async || h->phase % h->win != 0u) return T2D_OK;
+    const int w = (int)(h->phase / h->win);
+    if (h->pending[w]) {
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_join[w], 0));
+        h->pending[w] = false;
+    }
+    return T2D_OK;
+}
+
+// After the step launches (phase already advanced): at the last step of a window, refill what the window consumed.
+static int window_end(t2d_handle *h, hipStream_t st)
+{
+    if (h->phase == 0u || h->phase % h->win != 0u) return T2D_OK;
+    const uint32_t w = h->phase / h->win - 1u, lo = w * h->win + 1u, hi = (w + 1u) * h->win;
+    if (!h->gen_async) {
+        launch_gen(h, st, lo, hi, 0, h->has_navmode);   // the Nav plan prefetch rides in the same launch (other waves)
+    } else {
+        if (h->has_navmode) hipLaunchKernelGGL(k_nav_prefetch, env_grid(h->s.n), dim3(256), 0, st, h->s);
+        HIP_TRY(hipEventRecord(h->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(h->gen_stream, h->ev_fork, 0));
+        launch_gen(h, h->gen_stream, lo, hi, 0);
+        HIP_TRY(hipEventRecord(h->ev_join[w], h->gen_stream));
+        h->pending[w] = true;
+    }
+    HIP_TRY(hipGetLastError());
+    if (h->phase >= h->cycle) h->phase = 0;
+    return T2D_OK;
 }
 
 static inline dim3 pair_grid(int n) { return dim3((unsigned)(((n + 1) / 2 + kStep2Waves - 1) / kStep2Waves)); }
@@ -1047,11 +1130,14 @@ static void launch_env(t2d_handle *h, hipStream_t st, const void *a0, const void
 #undef T2D_LAUNCH
 }
 
-// Regenerate every consumed next-episode slot, in order on `st`, and restart the stamps.
+// Regenerate every consumed next-episode slot, in order on `st` (after joining the forked launches), and restart
+// the stamps.
 static int flush_impl(t2d_handle *h, hipStream_t st)
 {
-    if (h->s.auto_reset && h->phase != 0u) {
-        launch_gen(h, st, h->phase, 0);
+    int rc = join_generator(h, st);
+    if (rc) return rc;
+    if (h->s.auto_reset && h->phase % h->win != 0u) {
+        launch_gen(h, st, 1u, h->cycle, 0);
         HIP_TRY(hipGetLastError());
     }
     h->phase = 0;
@@ -1065,14 +1151,47 @@ extern "C" int t2d_flush(t2d_handle *h, void *stream)
     return flush_impl(h, (hipStream_t)stream);
 }
 
+extern "C" int t2d_generator_async(t2d_handle *h, int enable, void *stream)
+{
+    if (!h) return fail(T2D_ERR_INVALID, "t2d_generator_async: null handle");
+    DeviceGuard guard(h->device);
+    int rc = flush_impl(h, (hipStream_t)stream);
+    if (rc) return rc;
+    if (enable && h->gen_every < 2u)
+        return fail(T2D_ERR_INVALID, "t2d_generator_async: episodes of %u step(s) leave no window to overlap", h->gen_every);
+    if (enable && !h->gen_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->gen_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_join[1], hipEventDisableTiming));
+    }
+    h->gen_async = enable != 0;
+    h->win = h->gen_async ? h->gen_every / 2u : h->gen_every;
+    h->cycle = h->gen_async ? 2u * h->win : h->win;
+    return T2D_OK;
+}
+
+extern "C" int t2d_generator_join(t2d_handle *h, void *stream)
+{
+    if (!h) return fail(T2D_ERR_INVALID, "t2d_generator_join: null handle");
+    DeviceGuard guard(h->device);
+    return join_generator(h, (hipStream_t)stream);
+}
+
+extern "C" int t2d_generator_cycle(const t2d_handle *h) { return h ? (int)h->cycle : T2D_ERR_INVALID; }
+
 template <bool RANDOM>
 static int step_impl(t2d_handle *h, hipStream_t st, const void *a0, const void *a1, int adt, float *obs, float *rew,
                      uint8_t *done, uint32_t slo, uint32_t shi, uint32_t sidx)
 {
-    if (h->s.auto_reset) h->phase++;
+    if (h->s.auto_reset) {
+        int rc = window_begin(h, st);
+        if (rc) return rc;
+        h->phase++;
+    }
     launch_env<OP_STEP, RANDOM>(h, st, a0, a1, adt, nullptr, obs, rew, done, slo, shi, sidx, h->phase);
     HIP_TRY(hipGetLastError());
-    if (h->s.auto_reset && h->phase >= h->gen_every) return flush_impl(h, st);
+    if (h->s.auto_reset) return window_end(h, st);
     return T2D_OK;
 }
 
@@ -1084,13 +1203,13 @@ extern "C" int t2d_reset(t2d_handle *h, const uint8_t *mask_dev, float *obs_dev,
     int rc = flush_impl(h, st);
     if (rc) return rc;
     if (!h->primed) { // first use: generate episode 1 into every next slot
-        launch_gen(h, st, 0u, 1);
+        launch_gen(h, st, 0u, 0u, 1);
         h->primed = true;
     }
     if (mask_dev != nullptr && !h->reset_done)
         return fail(T2D_ERR_STATE, "t2d_reset: the first reset must cover every env (mask == NULL)");
     launch_env<OP_RESET, false>(h, st, nullptr, nullptr, 0, mask_dev, obs_dev, nullptr, nullptr, 0u, 0u, 0u, 1u);
-    launch_gen(h, st, 1u, 0); // refill the consumed next slots, in order on the caller's stream
+    launch_gen(h, st, 1u, 1u, 0); // refill the consumed next slots, in order on the caller's stream
     HIP_TRY(hipGetLastError());
     if (mask_dev == nullptr) h->reset_done = true;
     return T2D_OK;
@@ -1122,11 +1241,15 @@ extern "C" int t2d_step_u8(t2d_handle *h, const void *act_tracker_dev, const voi
     if (h->s.auto_reset && !h->primed) return fail(T2D_ERR_STATE, "t2d_step_u8: auto_reset needs one t2d_reset before stepping");
     DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
-    if (h->s.auto_reset) h->phase++;
+    if (h->s.auto_reset) {
+        int rc = window_begin(h, st);
+        if (rc) return rc;
+        h->phase++;
+    }
     launch_step2<false, false>(h, st, act_tracker_dev, act_target_dev, act_dtype, obs_u8_dev, true, rew_dev, done_dev, 0u,
                                0u, 0u, h->phase, 1);
     HIP_TRY(hipGetLastError());
-    if (h->s.auto_reset && h->phase >= h->gen_every) return flush_impl(h, st);
+    if (h->s.auto_reset) return window_end(h, st);
     return T2D_OK;
 }
 
@@ -1166,9 +1289,14 @@ extern "C" int t2d_rollout_random(t2d_handle *h, int steps, uint64_t action_seed
             done_steps++;
             continue;
         }
-        // up to the next generator pass (at most one episode switch per env in between)
+        // up to the end of the stamp window (at most one episode switch per env in between)
         int chunk = steps - done_steps;
-        if (h->s.auto_reset && chunk > (int)(h->gen_every - h->phase)) chunk = (int)(h->gen_every - h->phase);
+        if (h->s.auto_reset) {
+            const int left = (int)(h->win - h->phase % h->win);
+            if (chunk > left) chunk = left;
+            int rc = window_begin(h, st);
+            if (rc) return rc;
+        }
         if (use_step2(h))
             launch_step2<true, true>(h, st, nullptr, nullptr, 0, o, false, r, d, (uint32_t)action_seed,
                                      (uint32_t)(action_seed >> 32), h->random_step, h->phase + 1u, chunk);
@@ -1181,10 +1309,8 @@ extern "C" int t2d_rollout_random(t2d_handle *h, int steps, uint64_t action_seed
         done_steps += chunk;
         if (h->s.auto_reset) {
             h->phase += (uint32_t)chunk;
-            if (h->phase >= h->gen_every) {
-                int rc = flush_impl(h, st);
-                if (rc) return rc;
-            }
+            int rc = window_end(h, st);
+            if (rc) return rc;
         }
     }
     return T2D_OK;

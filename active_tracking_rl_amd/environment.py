@@ -13,6 +13,8 @@ frame_stack (environment.py:128-156) is folded in: obs are float32, `stack_frame
 agent, the deque filled with the first frame on reset. Rescale / listspace / UnrealPreprocess belong to the
 image envs and are not built.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -48,13 +50,18 @@ class VecEnv(object):
     step([a_tracker [N], a_target [N]]) -> (obs, rewards [N, A] f32, done [N] uint8, info)."""
 
     def __init__(self, env_id, num_envs, device="cuda:0", seed=1, stack_frames=1, env_id_base=0, auto_reset=True,
-                 rescale=False, obs_u8=False, **overrides):
+                 rescale=False, obs_u8=False, async_gen=None, **overrides):
         self.env_id = env_id
         self.num_envs = num_envs
         self.stack_frames = int(stack_frames)
         self.rescale = bool(rescale)    # environment.Rescale (environment.py:35-79) without --inv: [0,255] -> [-1,1]
+        # t2d_generator_async (map generation forked onto the library's stream, under the following steps) is opt-in:
+        # inside a captured hipGraph every fork/join of a side branch costs ~200 us on this ROCm (measured,
+        # profiles/r02_async_generator_ab.txt), more than the generator launch it hides
+        if async_gen is None:
+            async_gen = os.environ.get("T2D_ASYNC_GEN", "0") == "1"
         self.core = VecTrack2D(env_id, num_envs=num_envs, device=device, seed=seed, env_id_base=env_id_base,
-                               auto_reset=auto_reset, **overrides)
+                               auto_reset=auto_reset, async_gen=async_gen, **overrides)
         self.observation_space, self.action_space = _spaces(self.core.obs_hw)
         # obs_u8: observations stay bytes between the step kernel and the policy's conv stem (t2d_step_u8 ->
         # atr_stem_*_u8), i.e. frame_stack's np.float32 cast (environment.py:138,146) is fused into conv1. Only where
@@ -118,6 +125,13 @@ class VecEnv(object):
 
     def flush(self):
         self.core.flush()
+
+    def generator_join(self):
+        self.core.generator_join()
+
+    @property
+    def generator_cycle(self):
+        return self.core.generator_cycle
 
     def core_max_steps(self):
         """Upper bound on the episode length (TimeLimit, gym_track2d/__init__.py:17)."""

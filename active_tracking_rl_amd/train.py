@@ -84,8 +84,10 @@ def rollout(player, num_steps, fast=True):
         player.update_rnn_hiden()
         for _ in range(num_steps):
             player.action_train()
-    if hasattr(player.env, "flush"):
-        player.env.flush()               # join the env's generator stream (required before a hipGraph capture ends)
+    # A rollout that is not a whole number of generator stamp cycles restarts the stamps (so that a captured rollout
+    # replays consistently); otherwise forked generator launches stay in flight under the learner's kernels.
+    if hasattr(player.env, "flush") and num_steps % getattr(player.env, "generator_cycle", 1) != 0:
+        player.env.flush()
 
 
 class GraphedIteration(object):
@@ -127,6 +129,8 @@ class GraphedIteration(object):
 
     def _capture(self, mode):
         player, args = self.player, self.args
+        if hasattr(player.env, "flush"):
+            player.env.flush()           # no generator launch in flight and stamp 0 when the capture starts
         torch.cuda.synchronize(player.device)
         g = torch.cuda.CUDAGraph()
         # thread_local: an RCCL watchdog thread polling events must not invalidate the capture
@@ -134,6 +138,8 @@ class GraphedIteration(object):
             self._bind_carry()
             rollout(player, args.num_steps, fast=self.fast)
             stats = player.compute_grads(self.optimizer, mode)
+            if hasattr(player.env, "generator_join"):
+                player.env.generator_join()   # the env's forked generator launches end inside the captured region
             self.carry["state"].copy_(player.state)
             self.carry["hxs"].copy_(player.hxs.detach())
             self.carry["cxs"].copy_(player.cxs.detach())

@@ -44,6 +44,7 @@ ABI_SYMBOLS = (
     "t2d_last_error", "t2d_abi_version", "t2d_create", "t2d_destroy", "t2d_num_envs", "t2d_reset", "t2d_step",
     "t2d_observe", "t2d_inject", "t2d_inject_plan", "t2d_get_state", "t2d_get_maps", "t2d_get_target",
     "t2d_get_faults", "t2d_step_u8", "t2d_step_random", "t2d_rollout_random", "t2d_reward_table", "t2d_flush",
+    "t2d_generator_async", "t2d_generator_join", "t2d_generator_cycle",
 )
 
 
@@ -75,6 +76,12 @@ def load_library():
     L.t2d_observe.argtypes = [vp, vp, vp]
     L.t2d_flush.restype = i32
     L.t2d_flush.argtypes = [vp, vp]
+    L.t2d_generator_async.restype = i32
+    L.t2d_generator_async.argtypes = [vp, i32, vp]
+    L.t2d_generator_join.restype = i32
+    L.t2d_generator_join.argtypes = [vp, vp]
+    L.t2d_generator_cycle.restype = i32
+    L.t2d_generator_cycle.argtypes = [vp]
     L.t2d_inject.restype = i32
     L.t2d_inject.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.t2d_inject_plan.restype = i32
@@ -119,7 +126,8 @@ class VecTrack2D(object):
 
     def __init__(self, env_id=None, num_envs=1, device="cuda:0", seed=1, env_id_base=0, auto_reset=True,
                  map_type=None, target_mode=None, level=0, max_episode_steps=None,
-                 map_type_per_env=None, target_mode_per_env=None, level_per_env=None, obs_type="Partial"):
+                 map_type_per_env=None, target_mode_per_env=None, level_per_env=None, obs_type="Partial",
+                 async_gen=False):
         if not torch.cuda.is_available():
             raise T2DError("VecTrack2D needs an MI355X visible to PyTorch-ROCm (no CPU fallback)")
         self.L = load_library()
@@ -169,6 +177,9 @@ class VecTrack2D(object):
         _check(self.L.t2d_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.auto_reset = bool(auto_reset)
+        self.async_gen = False
+        if async_gen and auto_reset and min(10, int(max_episode_steps) or 10) >= 2:
+            self.generator_async(True)
 
     # -- lifecycle ------------------------------------------------------------------------------------
     def close(self):
@@ -267,8 +278,23 @@ class VecTrack2D(object):
         return obs, rew, done
 
     def flush(self):
-        """Join the library's generator stream into the current stream (see t2d_flush in include/track2d.h)."""
+        """Run the generator now for every consumed slot, in order on the current stream, and restart the step stamps
+        (see t2d_flush in include/track2d.h)."""
         _check(self.L.t2d_flush(self.h, self._stream()))
+
+    def generator_async(self, enable=True):
+        """Refill consumed next-episode slots on a library-owned side stream, overlapped with the following steps
+        (t2d_generator_async). Same results as the in-order generator."""
+        _check(self.L.t2d_generator_async(self.h, 1 if enable else 0, self._stream()))
+        self.async_gen = bool(enable)
+
+    def generator_join(self):
+        """Make the current stream wait for every forked generator launch (required before a hipGraph capture ends)."""
+        _check(self.L.t2d_generator_join(self.h, self._stream()))
+
+    @property
+    def generator_cycle(self):
+        return int(self.L.t2d_generator_cycle(self.h))
 
     def observe(self, out=None):
         obs = out if out is not None else self._new_obs()

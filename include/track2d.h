@@ -113,6 +113,21 @@ int t2d_step_u8(t2d_handle *h, const void *act_tracker_dev, const void *act_targ
  * whatever is pending (used before state readback; t2d_reset / t2d_inject / t2d_get_* flush implicitly). */
 int t2d_flush(t2d_handle *h, void *stream);
 
+/* Asynchronous generator (off by default). The reference builds the next map inside reset(), on the worker's
+ * critical path (G/envs/track_1v1.py:134-168); here the refill of consumed slots can leave the caller's stream
+ * altogether: with enable != 0 the step stamps run in two windows of 5 steps, the slots consumed in one window are
+ * regenerated by a launch forked onto a library-owned stream after the window's last step, and the caller's stream
+ * waits for it (event) one window later, before the first step that could need such a slot again. Results are
+ * identical to the in-order generator; only where the generator kernel runs changes. Inside a stream capture
+ * (hipGraph) the fork/join becomes a parallel branch of the graph; the capture must end with no fork open:
+ * call t2d_generator_join(h, stream) (or t2d_flush) before ending it, and capture a whole number of stamp cycles
+ * (t2d_generator_cycle steps) so that replays line up. Switching modes flushes first. */
+int t2d_generator_async(t2d_handle *h, int enable, void *stream);
+/* Make `stream` wait for every forked generator launch (no generator work is added, the stamps keep running). */
+int t2d_generator_join(t2d_handle *h, void *stream);
+/* Steps per stamp cycle (10, or min(10, max_episode_steps) rounded to an even number when asynchronous). */
+int t2d_generator_cycle(const t2d_handle *h);
+
 /* _get_obs() of the current state without stepping (G/envs/track_1v1.py:287-293). */
 int t2d_observe(t2d_handle *h, float *obs_dev, void *stream);
 

@@ -535,3 +535,47 @@ def test_unaligned_observation_buffer_takes_the_scalar_store_path():
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), t
     assert float(raw[0]) == 0.0 and float(raw[1 + n * 338:].abs().sum()) == 0.0      # nothing written outside the view
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,max_steps", [("Track2D-BlockPartialPZR-v0", 25), ("Track2D-MazePartialNav-v0", 25),
+                                              ("Track2D-BlockPartialRam-v0", 11), ("Track2D-MazePartialFar-v0", 7),
+                                              ("Track2D-BlockPartialRPF-v0", 500)])
+def test_async_generator_is_bit_identical_to_the_in_order_one(env_id, max_steps):
+    """t2d_generator_async: consumed next-episode slots refilled on the library's side stream, one 5-step stamp window
+    behind the steps, against the in-order generator from the same seed — every observation, reward and done flag of
+    single-step launches and of the fused multi-step launches, the final state and maps. Episode lengths down to 7
+    (odd windows of 3 steps) and the far rule's 11-step minimum are both exercised."""
+    import torch
+    from active_tracking_rl_amd.vec_env import VecTrack2D
+    n = 515
+    a = VecTrack2D(env_id, num_envs=n, seed=11, max_episode_steps=max_steps, async_gen=True)
+    b = VecTrack2D(env_id, num_envs=n, seed=11, max_episode_steps=max_steps)
+    assert a.async_gen and not b.async_gen
+    assert a.generator_cycle == 2 * (min(10, max_steps) // 2) and b.generator_cycle == min(10, max_steps)
+    assert torch.equal(a.reset(), b.reset())
+    ndone = 0
+    for t in range(83):
+        oa, ra, da = a.step_random(1, 3)
+        ob, rb, db = b.step_random(1, 3)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), (env_id, t)
+        ndone += int(da.sum())
+    obs, rew, done = a.rollout_random(38, 4)
+    obs2, rew2, done2 = b.rollout_random(38, 4)
+    assert torch.equal(obs, obs2) and torch.equal(rew, rew2) and torch.equal(done, done2)
+    assert ndone + int(done.sum()) > (2 * n if max_steps <= 25 else 0)
+    # masked reset and a mode switch in mid-window flush the forked launches first
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    mask[::3] = 1
+    assert torch.equal(a.reset(mask), b.reset(mask))
+    a.generator_async(False)
+    b.generator_async(True)
+    for t in range(27):
+        oa, ra, da = a.step_random(1, 5)
+        ob, rb, db = b.step_random(1, 5)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), (env_id, t)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(a.get_maps(), b.get_maps())
+    a.close(); b.close()
