@@ -1,0 +1,160 @@
+// driver_hip.hip — the rollout driver's bookkeeping between the big kernels, one launch each (C ABI in
+// include/atr_policy.h). In the reference these are a few Python statements per worker (player_util.py:98-106 LSTM state
+// reset / detach, train.py:73-76 episode-length counters, shared_optim.py:80-134 SharedAdam.step); batched over N envs
+// as tensor expressions each of them became a string of 5-20 tiny launches, which at ~5 us per launch added up to
+// ~0.3 ms of a 6.7 ms iteration.
+//
+//   atr_rollout_begin   LSTM state [N,A,R] -> slot 0 of the per-player rollout cache [A,T+1,N,R]; the current observation
+//                       -> row 0 of the rollout's observation store
+//   atr_rollout_end     masked final LSTM state of slot T -> [N,A,R]; episode-length counters; the done flags of the whole
+//                       rollout as the float keep-mask the learner's kernels read
+//   atr_adam_step       SharedAdam.step (Adam + AMSGrad, float64 step / beta powers on the device) over the flat bucket
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/atr_policy.h"
+
+namespace atr {
+
+struct RolloutBegin {
+    const float *hxs, *cxs;          // [N, A, R]
+    float *h0, *c0;                  // slot 0 of player 0; player p at + p * pstride
+    long long pstride;
+    const uint32_t *obs_src;         // nullable: current observation, obs_words dwords
+    uint32_t *obs_dst;
+    long long obs_words;
+    int N, A, R;
+};
+
+__global__ __launch_bounds__(256) void k_rollout_begin(RolloutBegin a)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nstate = (long long)a.N * a.A * (a.R / 4);
+    if (i < nstate) {
+        const int r4 = (int)(i % (a.R / 4));
+        const long long na = i / (a.R / 4);
+        const int p = (int)(na % a.A);
+        const long long n = na / a.A;
+        const float4 h = reinterpret_cast<const float4 *>(a.hxs)[i], c = reinterpret_cast<const float4 *>(a.cxs)[i];
+        const long long o = (long long)p * a.pstride + n * a.R + 4 * r4;
+        *reinterpret_cast<float4 *>(a.h0 + o) = h;
+        *reinterpret_cast<float4 *>(a.c0 + o) = c;
+    }
+    if (a.obs_src != nullptr)
+        for (long long j = i; j < a.obs_words; j += (long long)gridDim.x * blockDim.x) a.obs_dst[j] = a.obs_src[j];
+}
+
+struct RolloutEnd {
+    const float *hT, *cT;            // slot T of player 0; player p at + p * pstride
+    long long pstride;
+    const uint8_t *dones;            // [T, N]; row T-1 masks the final state
+    float *hxs, *cxs;                // [N, A, R]
+    int *eps_len;                    // [N], in place
+    float *keep;                     // [T, N] = (dones == 0)
+    int T, N, A, R;
+};
+
+__global__ __launch_bounds__(256) void k_rollout_end(RolloutEnd a)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nstate = (long long)a.N * a.A * (a.R / 4);
+    if (i < nstate) {
+        const int r4 = (int)(i % (a.R / 4));
+        const long long na = i / (a.R / 4);
+        const int p = (int)(na % a.A);
+        const long long n = na / a.A;
+        const float k = a.dones[(long long)(a.T - 1) * a.N + n] == 0 ? 1.f : 0.f;
+        const long long o = (long long)p * a.pstride + n * a.R + 4 * r4;
+        float4 h = *reinterpret_cast<const float4 *>(a.hT + o), c = *reinterpret_cast<const float4 *>(a.cT + o);
+        h.x *= k; h.y *= k; h.z *= k; h.w *= k;
+        c.x *= k; c.y *= k; c.z *= k; c.w *= k;
+        reinterpret_cast<float4 *>(a.hxs)[i] = h;
+        reinterpret_cast<float4 *>(a.cxs)[i] = c;
+    }
+    if (i < a.N) {
+        // train.py:73-76 per env: the counter restarts at a done and counts the steps since; over T stored steps that is
+        // eps_len * [no done in the rollout] + the number of steps after the last done
+        int run = 0;
+        bool alive = true;
+        for (int t = a.T - 1; t >= 0; t--) {
+            const bool nd = a.dones[(long long)t * a.N + i] == 0;
+            a.keep[(long long)t * a.N + i] = nd ? 1.f : 0.f;
+            alive = alive && nd;
+            run += alive ? 1 : 0;
+        }
+        a.eps_len[i] = (alive ? a.eps_len[i] : 0) + run;
+    }
+}
+
+// state: [0] step, [1] beta1^step, [2] beta2^step (float64, as SharedAdam keeps them); step_size: one float
+__global__ void k_adam_scalars(double *state, float *step_size, double lr, double beta1, double beta2)
+{
+    const double t = state[0] + 1.0, b1 = state[1] * beta1, b2 = state[2] * beta2;
+    state[0] = t; state[1] = b1; state[2] = b2;
+    *step_size = (float)(lr * sqrt(1.0 - b2) / (1.0 - b1));      // shared_optim.py:127-129
+}
+
+__global__ __launch_bounds__(256) void k_adam_update(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                     float *__restrict__ v, float *__restrict__ vmax,
+                                                     const float *__restrict__ step_size, float beta1, float beta2,
+                                                     float omb1, float omb2, float eps, float wd, long long n)
+{
+    const float ss = *step_size;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = fmaf(omb1, gi, m[i] * beta1);            // exp_avg.mul_(beta1).add_(grad, alpha=1-beta1)
+        const float vi = fmaf(omb2 * gi, gi, v[i] * beta2);       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+        m[i] = mi; v[i] = vi;
+        float d = vi;
+        if (vmax != nullptr) { d = fmaxf(vmax[i], vi); vmax[i] = d; }   // AMSGrad: max of all second-moment estimates so far
+        p[i] = pi - mi / (sqrtf(d) + eps) * ss;
+    }
+}
+
+} // namespace atr
+
+using namespace atr;
+
+extern "C" int atr_rollout_begin(const float *hxs, const float *cxs, float *h0, float *c0, long long pstride,
+                                 const void *obs_src, void *obs_dst, long long obs_bytes, int N, int A, int R, void *stream)
+{
+    if (!hxs || !cxs || !h0 || !c0 || N <= 0 || A <= 0 || R <= 0 || (R & 3) || (obs_bytes & 3) || (pstride & 3)) return 1;
+    if (((uintptr_t)hxs | (uintptr_t)cxs | (uintptr_t)h0 | (uintptr_t)c0) & 15u) return 1;
+    if (obs_src && (((uintptr_t)obs_src | (uintptr_t)obs_dst) & 3u)) return 1;
+    RolloutBegin a{hxs, cxs, h0, c0, pstride, (const uint32_t *)obs_src, (uint32_t *)obs_dst, obs_bytes / 4, N, A, R};
+    const long long work = (long long)N * A * (R / 4);
+    long long blocks = (work + 255) / 256;
+    if (obs_src && blocks < 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_rollout_begin, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" int atr_rollout_end(const float *hT, const float *cT, long long pstride, const uint8_t *dones, float *hxs,
+                               float *cxs, int *eps_len, float *keep, int T, int N, int A, int R, void *stream)
+{
+    if (!hT || !cT || !dones || !hxs || !cxs || !eps_len || !keep || T <= 0 || N <= 0 || A <= 0 || R <= 0 || (R & 3) || (pstride & 3))
+        return 1;
+    if (((uintptr_t)hxs | (uintptr_t)cxs | (uintptr_t)hT | (uintptr_t)cT) & 15u) return 1;
+    RolloutEnd a{hT, cT, pstride, dones, hxs, cxs, eps_len, keep, T, N, A, R};
+    long long work = (long long)N * A * (R / 4);
+    if (work < N) work = N;
+    hipLaunchKernelGGL(k_rollout_end, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" int atr_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
+                             double *state, float *step_size, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, long long n, void *stream)
+{
+    if (!params || !grad || !exp_avg || !exp_avg_sq || !state || !step_size || n <= 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_adam_scalars, dim3(1), dim3(1), 0, st, state, step_size, lr, beta1, beta2);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adam_update, dim3((unsigned)blocks), dim3(256), 0, st, params, grad, exp_avg, exp_avg_sq,
+                       max_exp_avg_sq, step_size, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
+                       (float)eps, (float)weight_decay, n);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}

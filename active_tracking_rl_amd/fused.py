@@ -61,6 +61,12 @@ def lib():
         L.atr_gemm_tn.argtypes = [vp, vp, vp, vp, ll, i32, i32, vp, vp, vp]
         L.atr_gae_returns.restype = i32
         L.atr_gae_returns.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, i32, vp]
+        L.atr_rollout_begin.restype = i32
+        L.atr_rollout_begin.argtypes = [vp, vp, vp, vp, ll, vp, vp, ll, i32, i32, i32, vp]
+        L.atr_rollout_end.restype = i32
+        L.atr_rollout_end.argtypes = [vp, vp, ll, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.atr_adam_step.restype = i32
+        L.atr_adam_step.argtypes = [vp] * 7 + [C.c_double] * 5 + [ll, vp]
         _lib = L
     return _lib
 
@@ -241,7 +247,14 @@ class ActionSampler(object):
         self._ordinal = 0
 
     def end_block(self):
+        if self._ordinal is not None:
+            self._last = self._ordinal
         self._ordinal = None
+
+    def reopen_block(self):
+        """Continue the ordinals of the block that end_block() closed last (the learner's bootstrap step draws once more
+        after the rollout, under the same counter value)."""
+        self._ordinal = getattr(self, "_last", None)
 
     @torch.no_grad()
     def __call__(self, h, linear, out=None):
@@ -556,3 +569,44 @@ def gemm_tn(x1, x2, row_scale=None, colsum=False):
         x1 = x1 * row_scale.unsqueeze(1)
     c = x1.t() @ x2
     return (c, x1.sum(0)) if colsum else c
+
+
+@torch.no_grad()
+def rollout_begin(hxs, cxs, h_all, c_all, obs_src=None, obs_dst=None):
+    """hxs/cxs [N,A,R] -> h_all/c_all[:, 0] ([A,T+1,N,R] rollout stores); optionally obs_src -> obs_dst (same bytes)."""
+    N, A, R = hxs.shape
+    assert hxs.is_contiguous() and cxs.is_contiguous() and h_all.is_contiguous() and c_all.is_contiguous()
+    assert h_all.shape[0] == A and h_all.shape[2] == N and h_all.shape[3] == R and hxs.dtype == torch.float32
+    nbytes = 0
+    if obs_src is not None:
+        assert obs_src.is_contiguous() and obs_dst.is_contiguous()
+        nbytes = obs_src.numel() * obs_src.element_size()
+        assert nbytes == obs_dst.numel() * obs_dst.element_size() and nbytes % 4 == 0
+    rc = lib().atr_rollout_begin(_p(hxs), _p(cxs), _p(h_all), _p(c_all), h_all.stride(0), _pn(obs_src), _pn(obs_dst), nbytes,
+                                 N, A, R, _stream(hxs))
+    if rc != 0:
+        raise RuntimeError("atr_rollout_begin failed (%d)" % rc)
+
+
+@torch.no_grad()
+def rollout_end(h_all, c_all, dones, hxs, cxs, eps_len, keep):
+    """Slot T of h_all/c_all [A,T+1,N,R], masked by dones[T-1], -> hxs/cxs [N,A,R] (in place); eps_len [N] int32 advanced
+    over the rollout's dones [T,N] uint8 (in place); keep [T,N] float32 = (dones == 0)."""
+    A, T1, N, R = h_all.shape
+    T = T1 - 1
+    assert dones.shape == (T, N) and dones.dtype == torch.uint8 and dones.is_contiguous()
+    assert hxs.shape == (N, A, R) and hxs.is_contiguous() and cxs.is_contiguous() and keep.is_contiguous()
+    assert eps_len.dtype == torch.int32 and eps_len.is_contiguous() and keep.shape == (T, N)
+    rc = lib().atr_rollout_end(_p(h_all[0, T]), _p(c_all[0, T]), h_all.stride(0), _p(dones), _p(hxs), _p(cxs), _p(eps_len),
+                               _p(keep), T, N, A, R, _stream(hxs))
+    if rc != 0:
+        raise RuntimeError("atr_rollout_end failed (%d)" % rc)
+
+
+@torch.no_grad()
+def adam_step(p, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, scalars, step_size, lr, beta1, beta2, eps, weight_decay):
+    """SharedAdam.step over the flat bucket (csrc/driver_hip.hip): scalars = [step, beta1^step, beta2^step] float64."""
+    rc = lib().atr_adam_step(_p(p), _p(grad), _p(exp_avg), _p(exp_avg_sq), _pn(max_exp_avg_sq), _p(scalars), _p(step_size),
+                             float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), p.numel(), _stream(p))
+    if rc != 0:
+        raise RuntimeError("atr_adam_step failed (%d)" % rc)

@@ -600,53 +600,84 @@ class A3C_Dueling(nn.Module):
     def act_cached(self, states, cache, t, done=None):
         """act() for step t of a cached rollout: same sampling and state update, every intermediate written into the
         cache's slot t (LSTM state of step t lives in cache.h_all/c_all[:, t], the new one goes to slot t+1)."""
+        return self._act_step(states, cache, [cache.y[0][t], cache.y[1][t]], [cache.f[0][t], cache.f[1][t]],
+                              cache.feat1[t] if cache.feat1 is not None else None,
+                              cache.h_all[:, t], cache.c_all[:, t], cache.h_all[:, t + 1], cache.c_all[:, t + 1],
+                              cache.acts[:, t], cache.actions[t] if cache.actions is not None else None, done)
+
+    @torch.no_grad()
+    def boot_values(self, states, cache, done, v_out):
+        """The bootstrap forward of Agent.loss (player_util.py:109-117: one more model call on the state after the last
+        step, of which only the values are used) with the rollout's fused kernels: one more actor step from the LSTM
+        state of slot T into scratch buffers (the tracker's action is drawn, as the reference's forward draws it, because
+        the tracker-aware target's features depend on it), then the critic heads. v_out [N, A, 1] float32 contiguous."""
+        from . import fused
+        b = getattr(cache, "boot", None)
+        if b is None:
+            b = cache.boot = RolloutCache()
+            dev, N, R = states.device, cache.N, cache.h_all.shape[-1]
+            b.y = [torch.empty_like(cache.y[i][0]) for i in range(2)]
+            b.f = [torch.empty_like(cache.f[i][0]) for i in range(2)]
+            b.feat1 = torch.empty_like(cache.feat1[0]) if cache.feat1 is not None else None
+            b.h, b.c = torch.empty((2, N, R), device=dev), torch.empty((2, N, R), device=dev)
+            b.acts = torch.empty((2, N, 4 * R), device=dev)
+            b.actions = torch.empty((2, N), dtype=torch.int64, device=dev) if cache.actions is not None else None
+        T = cache.T
+        self._act_step(states, cache, b.y, b.f, b.feat1, cache.h_all[:, T], cache.c_all[:, T], b.h, b.c, b.acts, b.actions,
+                       done)
+        for i, p in enumerate((self.player0, self.player1)):
+            fused.heads_values(b.h[i], p.critic.critic_linear, v_out, i)
+        return v_out
+
+    def _act_step(self, states, cache, y, f_out, feat1, h_prev, c_prev, h_out, c_out, acts, actions, done):
+        """One actor step of both players on explicit buffers: y / f_out per-player stem and fc outputs, h_prev / c_prev
+        [2,N,R] (un-masked; `done` [N] uint8 of the previous step is applied inside), h_out / c_out [2,N,R], acts
+        [2,N,4R] (activated gates), actions [2,N] int64 or None."""
         from . import fused
         n = states.shape[0]
         p0, p1 = self.player0, self.player1
         if getattr(self, "_sampler", None) is None:
             self._sampler = fused.ActionSampler(states.device)
         sample = self._sampler if self.fused_sampling else \
-            (lambda h, lin: F.softmax(lin(h), dim=1).multinomial(1).squeeze(1))
+            (lambda h, lin, out=None: F.softmax(lin(h), dim=1).multinomial(1).squeeze(1))
         x_in = [states[:, 0], states.reshape(n, -1, states.shape[3], states.shape[4], states.shape[5])
                 if self.tat else states[:, 1]]
         acts_out = []
         # both players' stems in one launch, both hidden GEMMs in one bmm (neither depends on the tracker's action)
-        ys = fused.stem_into2(x_in[0], p0.encoder, cache.y[0][t], x_in[1], p1.encoder, cache.y[1][t])
-        R = cache.h_all.shape[-1]
+        ys = fused.stem_into2(x_in[0], p0.encoder, y[0], x_in[1], p1.encoder, y[1])
+        R = h_prev.shape[-1]
         # the whole LSTMCell step (both GEMMs + cell) as one MFMA kernel per player (csrc/actor_step_hip.hip), the draw as
         # a second small launch; else hidden GEMMs as one bmm + per-player input GEMM + fused cell/head/draw kernel
         # (only from 3072 rows up: one wave tile per SIMD of the chip needs 4096 rows; at 1024 rows its 22 us per call lose to
         # the library GEMMs + cell kernel, measured with tools/config_sweep.py)
-        mfma_step = (self.fused_actor_step and n >= 3072 and cache.actions is not None and self._sampler._ordinal is not None
+        mfma_step = (self.fused_actor_step and n >= 3072 and actions is not None and self._sampler._ordinal is not None
                      and fused.actor_step_supported(p0.encoder.outdim, R) and p1.encoder.outdim == p0.encoder.outdim)
-        hgs = None if mfma_step else torch.bmm(cache.h_all[:, t], cache.whh_t)
-        one_launch = (cache.actions is not None and self._sampler._ordinal is not None and R // 4 in (16, 32, 64)
+        hgs = None if mfma_step else torch.bmm(h_prev, cache.whh_t)
+        one_launch = (actions is not None and self._sampler._ordinal is not None and R // 4 in (16, 32, 64)
                       and p0.actor.actor_linear.weight.shape[0] <= 8 and p1.actor.actor_linear.weight.shape[0] <= 8)
         for i, p in enumerate((p0, p1)):
             enc = p.encoder
-            f = _addmm_relu(enc.fc.bias, ys[i].view(n, -1), enc.fc.weight.t(), cache.f[i][t])
+            f = _addmm_relu(enc.fc.bias, ys[i].view(n, -1), enc.fc.weight.t(), f_out[i])
             tat = i == 1 and self.tat
             if mfma_step:
-                fused.actor_step_into(f, cache.h_all[i, t], cache.c_all[i, t], done, p.lstm, cache.bsum[i],
-                                      cache.h_all[i, t + 1], cache.c_all[i, t + 1], cache.acts[i, t],
+                fused.actor_step_into(f, h_prev[i], c_prev[i], done, p.lstm, cache.bsum[i], h_out[i], c_out[i], acts[i],
                                       emb=cache.emb_ih if tat else None, act_in=acts_out[0] if tat else None)
-                acts_out.append(sample(cache.h_all[i, t + 1], p.actor.actor_linear, out=cache.actions[t, i]))
+                acts_out.append(sample(h_out[i], p.actor.actor_linear, out=actions[i]))
                 continue
             if tat and not one_launch:
-                f = torch.add(f, cache.emb[acts_out[0]], out=cache.feat1[t])
+                f = torch.add(f, cache.emb[acts_out[0]], out=feat1)
             ig = torch.addmm(cache.bsum[i], f, p.lstm.weight_ih.t())
             if one_launch:   # cell (+ tracker-action embedding, projected through W_ih once per rollout) + actor head + draw
                 acts_out.append(fused.lstm_cell_act_into(
-                    ig, hgs[i], cache.c_all[i, t], done, cache.h_all[i, t + 1], cache.c_all[i, t + 1], cache.acts[i, t],
-                    self._sampler, p.actor.actor_linear, cache.actions[t, i],
+                    ig, hgs[i], c_prev[i], done, h_out[i], c_out[i], acts[i],
+                    self._sampler, p.actor.actor_linear, actions[i],
                     emb=cache.emb_ih if tat else None, act_in=acts_out[0] if tat else None))
                 continue
-            fused.lstm_cell_into(ig, hgs[i], cache.c_all[i, t], done, cache.h_all[i, t + 1], cache.c_all[i, t + 1],
-                                 cache.acts[i, t])
-            if cache.actions is not None:
-                acts_out.append(sample(cache.h_all[i, t + 1], p.actor.actor_linear, out=cache.actions[t, i]))
+            fused.lstm_cell_into(ig, hgs[i], c_prev[i], done, h_out[i], c_out[i], acts[i])
+            if actions is not None:
+                acts_out.append(sample(h_out[i], p.actor.actor_linear, out=actions[i]))
             else:
-                acts_out.append(sample(cache.h_all[i, t + 1], p.actor.actor_linear))
+                acts_out.append(sample(h_out[i], p.actor.actor_linear))
         return acts_out
 
     def cached_hidden(self, cache, states_seq, actions_seq, keep):

@@ -37,6 +37,8 @@ class Agent(object):
         self._buf, self._pending_done, self._cache, self._actions_buf = None, None, None, None
         self.cache_rollout = True   # fast path on the GPU: learner back-propagates through the actor's forward pass
         self.fused_heads = True     # ... and evaluates heads + loss terms as one fused HIP node per player
+        self.fused_bookkeeping = True   # rollout prologue / epilogue as one launch each (csrc/driver_hip.hip)
+        self._keep = None
         self.done = torch.ones(self.num_envs, dtype=torch.uint8, device=device)
         self.info = None
         self.reward = 0
@@ -123,23 +125,33 @@ class Agent(object):
         self._buf = None
         if num_steps is not None and hasattr(self.env, "rollout_buffers"):
             self._buf = self.env.rollout_buffers(num_steps)
-            if self._buf is not None:
-                self._buf[0][0].copy_(self.state.reshape(self._buf[0][0].shape))
         self.update_rnn_hiden()
         self.h0, self.c0 = self.hxs, self.cxs
         self.states, self.actions = [], []
         self._pending_done = None
         self._cache = None
+        self._keep = None
         sampler = getattr(self.model, "_sampler", None)
         if sampler is not None:
             sampler.begin_block()                                 # one counter bump per rollout, ordinals inside
         if num_steps is not None and self.cache_rollout and hasattr(self.model, "new_cache") and self.num_agents == 2:
             self._cache = self.model.new_cache(num_steps, self.state)
         self._actions_buf = getattr(self._cache, "actions", None)
+        obs0 = self.state.reshape(self._buf[0][0].shape) if self._buf is not None else None
         if self._cache is not None:                               # LSTM state lives in the cache: slot t -> t+1
+            if (self.fused_bookkeeping and self.hxs.is_cuda and self.hxs.is_contiguous() and self.cxs.is_contiguous()
+                    and (obs0 is None or (obs0.dtype == self._buf[0].dtype and obs0.is_contiguous()))):
+                from . import fused                               # both copies + the observation's in one launch
+                fused.rollout_begin(self.hxs, self.cxs, self._cache.h_all, self._cache.c_all, obs0,
+                                    self._buf[0][0] if obs0 is not None else None)
+                return
             self._cache.h_all[:, 0].copy_(self.hxs.transpose(0, 1))
             self._cache.c_all[:, 0].copy_(self.cxs.transpose(0, 1))
+            if obs0 is not None:
+                self._buf[0][0].copy_(obs0)
             return
+        if obs0 is not None:
+            self._buf[0][0].copy_(obs0)
         self._hs = [h.contiguous() for h in self.hxs.unbind(1)]
         self._cs = [c.contiguous() for c in self.cxs.unbind(1)]
         if hasattr(self.model, "begin_act"):
@@ -147,6 +159,23 @@ class Agent(object):
 
     def end_rollout(self):
         """Publish the per-player LSTM states back as hxs/cxs [N,A,R] and the episode-length counters."""
+        T = len(self.states)
+        if (self._cache is not None and self._buf is not None and self.fused_bookkeeping and T == self._cache.T
+                and T == self._buf[2].shape[0] and self._cache.h_all.is_cuda and self.eps_len.dtype == torch.int32):
+            from . import fused   # final state masked by the last done, episode lengths, the keep mask: one launch
+            if getattr(self.model, "_sampler", None) is not None:
+                self.model._sampler.end_block()
+            if hasattr(self.model, "_bsum"):
+                self.model._bsum = None
+            N, R = self.num_envs, self._cache.h_all.shape[-1]
+            self.hxs = torch.empty((N, 2, R), device=self.device)
+            self.cxs = torch.empty((N, 2, R), device=self.device)
+            self.eps_len = self.eps_len.contiguous()
+            self._keep = torch.empty((T, N), device=self.device)
+            fused.rollout_end(self._cache.h_all, self._cache.c_all, self._buf[2], self.hxs, self.cxs, self.eps_len,
+                              self._keep)
+            self._pending_done = None
+            return
         self._apply_pending_done()
         if getattr(self.model, "_sampler", None) is not None:
             self.model._sampler.end_block()
@@ -250,7 +279,7 @@ class Agent(object):
         if self._buf is not None and T == self._buf[1].shape[0]:
             states = self._buf[0][:T].unsqueeze(3).unsqueeze(4)              # [T, N, A, 1, 1, h, w] views
             rewards = self._buf[1].unsqueeze(3)
-            nd = (self._buf[2] == 0).to(rewards.dtype)
+            nd = self._keep if self._keep is not None else (self._buf[2] == 0).to(rewards.dtype)
         else:
             states = torch.stack(self.states, 0)
             rewards = torch.stack(self.rewards, 0)                           # [T, N, A, 1]
@@ -312,8 +341,14 @@ class Agent(object):
         with torch.no_grad():
             for p in range(A):
                 fused.heads_values(h_seq[p].detach().reshape(T * N, R_dim), players[p].critic.critic_linear, v, p)
-            boot, _, _, _, _, _ = model((self.state, (self.hxs, self.cxs)))
-            v[T].copy_(boot)
+            sampler = getattr(model, "_sampler", None)
+            if hasattr(model, "boot_values") and sampler is not None and getattr(sampler, "_last", None) is not None:
+                sampler.reopen_block()       # V(s_T) with the rollout's kernels: one more actor step + the critic heads
+                model.boot_values(self.state, self._cache, self.done, v[T])
+                sampler.end_block()
+            else:
+                boot, _, _, _, _, _ = model((self.state, (self.hxs, self.cxs)))
+                v[T].copy_(boot)
             R, gae = fused.gae_returns(rewards.contiguous(), v, nd, args.gamma, args.tau)
         use_aux = 'reward' in args.aux and getattr(model, "tat", False) and getattr(model.player1, "sub_task", False)
         w_ent = [float(args.entropy)] + [float(self.w_entropy_target)] * (A - 1)

@@ -74,10 +74,11 @@ class SharedAdam(torch.optim.Optimizer):
         dev = self.bucket.flat.device
         z = lambda: torch.zeros_like(self.bucket.flat)
         self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq = z(), z(), z()
-        # float64 scalars on the device: step, beta1^t, beta2^t
-        self.step_t = torch.zeros((), dtype=torch.float64, device=dev)
-        self.b1_pow = torch.ones((), dtype=torch.float64, device=dev)
-        self.b2_pow = torch.ones((), dtype=torch.float64, device=dev)
+        # float64 scalars on the device: step, beta1^t, beta2^t (one 3-vector, so that the fused step sees them together)
+        self._scalars = torch.tensor([0.0, 1.0, 1.0], dtype=torch.float64, device=dev)
+        self.step_t, self.b1_pow, self.b2_pow = self._scalars[0], self._scalars[1], self._scalars[2]
+        self._step_size = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.fused = True       # on the GPU: the whole update as one elementwise launch (csrc/driver_hip.hip)
 
     def share_memory(self):
         """API compatibility with main.py:93 — there is no shared-memory state in the data-parallel design."""
@@ -92,6 +93,11 @@ class SharedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         beta1, beta2 = g['betas']
         grad, p = self.bucket.grad, self.bucket.flat
+        if self.fused and p.is_cuda:
+            from . import fused
+            fused.adam_step(p, grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq if g['amsgrad'] else None,
+                            self._scalars, self._step_size, g['lr'], beta1, beta2, g['eps'], g['weight_decay'])
+            return loss
         if g['weight_decay'] != 0:
             grad = grad.add(p, alpha=g['weight_decay'])
         self.step_t += 1

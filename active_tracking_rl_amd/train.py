@@ -140,11 +140,10 @@ class GraphedIteration(object):
             stats = player.compute_grads(self.optimizer, mode)
             if hasattr(player.env, "generator_join"):
                 player.env.generator_join()   # the env's forked generator launches end inside the captured region
-            self.carry["state"].copy_(player.state)
-            self.carry["hxs"].copy_(player.hxs.detach())
-            self.carry["cxs"].copy_(player.cxs.detach())
-            self.carry["done"].copy_(player.done)
-            self.carry["eps_len"].copy_(player.eps_len)
+            for k, src in (("state", player.state), ("hxs", player.hxs.detach()), ("cxs", player.cxs.detach()),
+                           ("done", player.done), ("eps_len", player.eps_len)):
+                if self.carry[k].data_ptr() != src.data_ptr():    # (the epilogue kernel advances eps_len in place)
+                    self.carry[k].copy_(src)
         self._bind_carry()
         self.g_rolls[mode], self.stats_by_mode[mode] = g, stats
         self.g_roll, self.stats = g, stats          # the most recently captured pair (kept for callers/tools)

@@ -131,6 +131,24 @@ long long atr_gemm_tn_workspace_floats(long long K, int M, int N);
 int atr_gemm_tn(const float *x1, const float *x2, float *c, float *workspace, long long K, int M, int N,
                 const float *row_scale, float *colsum, void *stream);
 
+/* The rollout driver's bookkeeping, one launch each (csrc/driver_hip.hip).
+ *   atr_rollout_begin: what Agent keeps between rollouts (player_util.py:98-106: hxs/cxs [N,A,R]) -> slot 0 of the
+ *     per-player rollout stores h0/c0 (player p at + p*pstride floats, rows [N,R]); optionally the current observation
+ *     (obs_bytes bytes, multiple of 4) -> row 0 of the rollout's observation store.
+ *   atr_rollout_end: the final state (slot T, same addressing) -> hxs/cxs [N,A,R], zeroed for envs whose last step
+ *     finished an episode (the reset() of train.py:73-74); eps_len [N] int32 advanced as train.py:75-76 would have step by
+ *     step (restart at a done, +1 per step); keep [T,N] float = (dones == 0), the episode mask the learner's kernels read.
+ *   atr_adam_step: SharedAdam.step (shared_optim.py:80-134 of the reference: Adam with AMSGrad when max_exp_avg_sq != NULL,
+ *     eps added to the square root, bias correction through step_size) over a flat fp32 bucket of n elements.
+ *     state = {step, beta1^step, beta2^step} float64 on the device (advanced here); step_size: one float of scratch. */
+int atr_rollout_begin(const float *hxs, const float *cxs, float *h0, float *c0, long long pstride, const void *obs_src,
+                      void *obs_dst, long long obs_bytes, int N, int A, int R, void *stream);
+int atr_rollout_end(const float *hT, const float *cT, long long pstride, const uint8_t *dones, float *hxs, float *cxs,
+                    int *eps_len, float *keep, int T, int N, int A, int R, void *stream);
+int atr_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq, double *state,
+                  float *step_size, double lr, double beta1, double beta2, double eps, double weight_decay, long long n,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

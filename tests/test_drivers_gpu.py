@@ -165,9 +165,11 @@ def test_cached_rollout_learner_matches_the_recompute_learner():
         player._cache = cache if cached else None
         player.fused_heads = fused_heads
         # the bootstrap value of the tracker-aware target depends on a freshly SAMPLED tracker action: pin the draw
+        # (and take the bootstrap forward all three learners share: the fused one is checked in the next test)
         torch.manual_seed(5)
         if getattr(player.model, "_sampler", None) is not None:
             player.model._sampler.counter.zero_()
+            player.model._sampler._last = None
         loss, pl, vl, ent, pred = player.loss_recompute(args.train_mode)
         player._cache, player.fused_heads = cache, True
         params = [p for p in player.model.parameters()]
@@ -182,6 +184,79 @@ def test_cached_rollout_learner_matches_the_recompute_learner():
         torch.testing.assert_close(ea, eb, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(pa.reshape(-1), pb.reshape(-1), rtol=1e-4, atol=1e-4)
         _check_grads(ga, gb)
+
+
+def test_bootstrap_values_and_rollout_bookkeeping_kernels():
+    """The learner's bootstrap V(s_T) through the rollout's fused kernels (model.boot_values: one more actor step into
+    scratch + critic heads) against the plain model pieces evaluated with the tracker action it drew; the rollout
+    prologue / epilogue kernels (LSTM state hand-over, episode lengths, keep mask) against the tensor expressions they
+    replace — on a rollout with episode ends (max_episode_steps=7)."""
+    import torch.nn.functional as F
+    from active_tracking_rl_amd.environment import VecEnv
+    from active_tracking_rl_amd.train import default_args, make_player, rollout
+    for n in (256, 3072):                                  # below / above the MFMA actor-step threshold
+        args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=n, num_steps=7, network="tat-maze-lstm", seed=3)
+        env = VecEnv(args.env, n, device="cuda:0", seed=3, obs_u8=True, max_episode_steps=7)   # time limit at every 7th step
+        player, _ = make_player(args, torch.device("cuda:0"), 0, 1, env=env)
+        rollout(player, args.num_steps, fast=True)         # a first rollout so that the LSTM state is non-trivial
+        eps0, hx0, cx0 = player.eps_len.clone(), player.hxs.clone(), player.cxs.clone()
+        rollout(player, args.num_steps, fast=True)
+        cache, buf, T = player._cache, player._buf, args.num_steps
+        dones = buf[2]
+        assert int(dones.sum()) > 0 and int(dones[-1].sum()) > 0
+        # prologue: slot 0 of the cache = the state the rollout started from
+        assert torch.equal(cache.h_all[:, 0], hx0.transpose(0, 1)) and torch.equal(cache.c_all[:, 0], cx0.transpose(0, 1))
+        # epilogue
+        k = (dones[-1] == 0).float().view(-1, 1, 1)
+        assert torch.equal(player.hxs, cache.h_all[:, T].transpose(0, 1) * k)
+        assert torch.equal(player.cxs, cache.c_all[:, T].transpose(0, 1) * k)
+        nd = (dones == 0).to(torch.int32)
+        alive = torch.flip(torch.cumprod(torch.flip(nd, [0]), 0), [0])
+        assert torch.equal(player.eps_len, eps0 * alive[0] + alive.sum(0))
+        assert torch.equal(player._keep, (dones == 0).float())
+        # bootstrap values
+        model = player.model
+        v = torch.zeros((n, 2, 1), device="cuda")
+        model._sampler.reopen_block()
+        model.boot_values(player.state, cache, player.done, v)
+        model._sampler.end_block()
+        a0 = cache.boot.actions[0]
+        with torch.no_grad():
+            x = player.state.float()
+            p0, p1 = model.player0, model.player1
+            f0 = p0.encoder(x[:, 0])
+            f1 = p1.encoder(x.reshape(n, -1, *x.shape[3:])) + p1.fc_action_tracker(F.one_hot(a0, 4).float())
+            ref = []
+            for i, (p, f) in enumerate(((p0, f0), (p1, f1))):
+                h, _ = p.lstm(f, (player.hxs[:, i], player.cxs[:, i]))
+                ref.append(p.critic(h))
+            ref = torch.stack(ref, 1)
+        torch.testing.assert_close(v, ref, rtol=1e-4, atol=1e-5)
+        assert int(a0.min()) >= 0 and int(a0.max()) <= 3 and len(torch.unique(a0)) == 4
+        env.close()
+
+
+def test_fused_adam_step_matches_the_tensor_expression():
+    """atr_adam_step (SharedAdam.step as one elementwise launch + one scalar launch) against the same optimizer with the
+    fused path off, over several steps: parameters and all moments to fp32 round-off, step counter / beta powers exact."""
+    from active_tracking_rl_amd.shared_optim import SharedAdam
+    torch.manual_seed(0)
+    ws = [torch.randn(1000, 37, device="cuda"), torch.randn(4097, device="cuda")]
+    pa = [torch.nn.Parameter(w.clone()) for w in ws]
+    pb = [torch.nn.Parameter(w.clone()) for w in ws]
+    oa, ob = SharedAdam(pa, lr=1e-3, amsgrad=True), SharedAdam(pb, lr=1e-3, amsgrad=True)
+    ob.fused = False
+    for step in range(6):
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * (10.0 if step == 2 else 1.0)
+            a.grad.copy_(g); b.grad.copy_(g)
+        oa.step(); ob.step()
+        assert torch.equal(oa._scalars, ob._scalars)
+        torch.testing.assert_close(oa.bucket.flat, ob.bucket.flat, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(oa.exp_avg, ob.exp_avg, rtol=1e-6, atol=1e-9)
+        torch.testing.assert_close(oa.exp_avg_sq, ob.exp_avg_sq, rtol=1e-6, atol=1e-12)
+        torch.testing.assert_close(oa.max_exp_avg_sq, ob.max_exp_avg_sq, rtol=1e-6, atol=1e-12)
+    assert float(oa.step_t) == 6.0
 
 
 def _check_grads(ga, gb):
