@@ -347,7 +347,14 @@ __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double
             const uint32_t c = uni(ms.ctr);
             ms.ensure(c);
             const int c0 = (int)(c & 63u), n = min(64 - c0, complexity - j);
-            for (int k = 0; k < n; k++) T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k) & 3u);
+            int k = 0;
+            for (; k + 4 <= n; k += 4) {                               // (unrolled by hand: one loop branch per four moves)
+                T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k) & 3u);
+                T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k + 1) & 3u);
+                T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k + 2) & 3u);
+                T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k + 3) & 3u);
+            }
+            for (; k < n; k++) T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k) & 3u);
             ms.ctr = c + (uint32_t)n;
             j += n;
         }

@@ -384,8 +384,12 @@ class Agent(object):
         self.clear_actions()
         if hasattr(self.model, "cache_dense"):
             self.model.cache_dense(False)
-        return (policy_loss.detach().mean(0), value_loss.detach().mean(0), entropies.mean(0),
-                pred_loss.detach().mean(0, keepdim=True))
+        def env_mean(x, keepdim=False):      # the fused loss already reports means over envs (leading dim 1): no launch
+            x = x.detach()
+            if x.shape[0] == 1:
+                return x if keepdim else x[0]
+            return x.mean(0, keepdim=keepdim)
+        return env_mean(policy_loss), env_mean(value_loss), env_mean(entropies), env_mean(pred_loss, keepdim=True)
 
     def allreduce_grads(self, optimizer):
         """The ONE collective of the path: flat fp32 gradient bucket, mean over ranks (RCCL over xGMI). Replaces

@@ -56,7 +56,9 @@ class FlatParams(object):
         kernel at a time."""
         if getattr(self, "_views", None) is None:
             self._views = self.grad_views()
-        flat = [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(grads, self.params)]
+        if any(g is None for g in grads) and getattr(self, "_zeros", None) is None:
+            self._zeros = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=self.grad.device)
+        flat = [g.reshape(-1) if g is not None else self._zeros[:p.numel()] for g, p in zip(grads, self.params)]
         torch.cat(flat, out=self.grad)
         for p, v in zip(self.params, self._views):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
