@@ -54,6 +54,7 @@ struct DevState {
     int n;
     uint32_t env_base, k0, k1;
     int max_steps, auto_reset;
+    int amask;                // highest action: 3 ('VonNeumann') or 7 ('Moore', track_1v1.py:243-249)
     int obs_full, obs_side;   // obs_type 'Full': every env writes [2][obs_side][obs_side] floats
 };
 
@@ -72,11 +73,15 @@ template <int ADT> __device__ __forceinline__ long long load_action_raw(const vo
     if (ADT == T2D_ACT_I32) return reinterpret_cast<const int32_t *>(p)[e];
     return reinterpret_cast<const long long *>(p)[e];
 }
-__device__ __forceinline__ int check_action(long long v, uint32_t *faults)
+__device__ __forceinline__ int check_action(long long v, int amask, uint32_t *faults)
 {
-    if (v < 0 || v > 3) { atomicOr(faults, 1u); v &= 3; }
+    if (v < 0 || v > amask) { atomicOr(faults, 1u); v &= amask; }
     return (int)v;
 }
+// _next_state's transition table (track_1v1.py:275-279): the four VonNeumann moves are the first four of the Moore
+// table {0:(-1,0) 1:(+1,0) 2:(0,-1) 3:(0,+1) 4:(-1,+1) 5:(+1,+1) 6:(-1,-1) 7:(+1,-1)}; two bits per action and axis.
+__device__ __forceinline__ int move_dy(int a) { return (int)((0x8858u >> (2 * a)) & 3u) - 1; }
+__device__ __forceinline__ int move_dx(int a) { return (int)((0x0a85u >> (2 * a)) & 3u) - 1; }
 
 // Navigator.reset / the re-plan branch of Navigator.step (navigator.py:43-63, :15-38): plan from (fr, fc) to navgoal;
 // unreachable or empty plan -> resample the goal, the 6th failure -> plan B (10 random actions).
@@ -397,10 +402,10 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         int a_tr, a_tg;
         if (RANDOM) {
             u32x4 w = philox4x32_10(aseed_lo, aseed_hi, step_idx + (uint32_t)k, 0u, genv, STREAM_ACTION);
-            a_tr = (int)(w.x & 3u); a_tg = (int)(w.y & 3u);
+            a_tr = (int)(w.x & (uint32_t)s.amask); a_tg = (int)(w.y & (uint32_t)s.amask);
         } else {
-            a_tr = check_action(act_raw0, s.faults);
-            a_tg = check_action(act_raw1, s.faults);
+            a_tr = check_action(act_raw0, s.amask, s.faults);
+            a_tg = check_action(act_raw1, s.amask, s.faults);
         }
         if (mode == TGT_RAM) { // track_1v1.py:81-82
             if (!MULTI) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }
@@ -479,9 +484,9 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         }
         // _next_state (track_1v1.py:271-285): stay put iff the destination cell is a wall
         {
-            int nr = r0 + (a_tr == 0 ? -1 : (a_tr == 1 ? 1 : 0)), nc = c0 + (a_tr == 2 ? -1 : (a_tr == 3 ? 1 : 0));
+            int nr = r0 + move_dy(a_tr), nc = c0 + move_dx(a_tr);
             if (tile_bit(tile, nr, nc) == 0u) { r0 = nr; c0 = nc; }
-            nr = r1 + (a_tg == 0 ? -1 : (a_tg == 1 ? 1 : 0)); nc = c1 + (a_tg == 2 ? -1 : (a_tg == 3 ? 1 : 0));
+            nr = r1 + move_dy(a_tg); nc = c1 + move_dx(a_tg);
             if (tile_bit(tile, nr, nc) == 0u) { r1 = nr; c1 = nc; }
         }
         pos = (uint32_t)r0 | ((uint32_t)c0 << 8) | ((uint32_t)r1 << 16) | ((uint32_t)c1 << 24);
@@ -640,10 +645,10 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const vo
     int a_tr, a_tg;
     if (RANDOM) {
         u32x4 w = philox4x32_10(aseed_lo, aseed_hi, step_idx + (uint32_t)it, 0u, genv, STREAM_ACTION);
-        a_tr = (int)(w.x & 3u); a_tg = (int)(w.y & 3u);
+        a_tr = (int)(w.x & (uint32_t)s.amask); a_tg = (int)(w.y & (uint32_t)s.amask);
     } else {
-        if (leader && (act_raw0 < 0 || act_raw0 > 3 || act_raw1 < 0 || act_raw1 > 3)) atomicOr(s.faults, 1u);
-        a_tr = (int)(act_raw0 & 3); a_tg = (int)(act_raw1 & 3);
+        if (leader && (act_raw0 < 0 || act_raw0 > s.amask || act_raw1 < 0 || act_raw1 > s.amask)) atomicOr(s.faults, 1u);
+        a_tr = (int)(act_raw0 & s.amask); a_tg = (int)(act_raw1 & s.amask);
     }
     bool dirty = false;
     if (ram) { // track_1v1.py:81-82
@@ -656,8 +661,8 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const vo
     int r0 = (int)(pos & 0xffu), c0 = (int)((pos >> 8) & 0xffu);
     int r1 = (int)((pos >> 16) & 0xffu), c1 = (int)(pos >> 24);
     if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(1); }
-    const int dy0 = a_tr == 0 ? -1 : (a_tr == 1 ? 1 : 0), dx0 = a_tr == 2 ? -1 : (a_tr == 3 ? 1 : 0);
-    const int dy1 = a_tg == 0 ? -1 : (a_tg == 1 ? 1 : 0), dx1 = a_tg == 2 ? -1 : (a_tg == 3 ? 1 : 0);
+    const int dy0 = move_dy(a_tr), dx0 = move_dx(a_tr);
+    const int dy1 = move_dy(a_tg), dx1 = move_dx(a_tg);
     // rows r_old - 7 .. r_old + 7 of this lane's agent: the move targets and every possible window row
     int rowbase = (ag ? r1 : r0) - 7;
     uint32_t w0 = 0xffffffffu, w1 = 0xffffffffu, w2 = 0xffffffffu;   // np.pad(..., 1): rows outside the map
@@ -925,6 +930,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     bool has_nav = false, has_rpf = false, has_ram = false, has_navmode = false;
     int n_maze = 0;
     if (cfg->obs_type > T2D_OBS_FULL) return fail(T2D_ERR_INVALID, "t2d_create: obs_type %u", cfg->obs_type);
+    if (cfg->action_type > T2D_ACTIONS_MOORE) return fail(T2D_ERR_INVALID, "t2d_create: action_type %u", cfg->action_type);
     for (int i = 0; i < n; i++) {
         uint32_t mt = cfg->map_type_per_env ? cfg->map_type_per_env[i] : cfg->map_type;
         uint32_t tm = cfg->target_mode_per_env ? cfg->target_mode_per_env[i] : cfg->target_mode;
@@ -937,6 +943,10 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         has_navmode = has_navmode || tm == T2D_TGT_NAV;
         n_maze += mt == T2D_MAP_MAZE;
         if (lv > 15) return fail(T2D_ERR_INVALID, "t2d_create: level %u (env %d)", lv, i);
+        // the scripted targets plan in the four-move table: RamAgent would draw from 8 actions (navigator.py:74-75) and the
+        // Navigator's A* fails outright in the reference (Astar_solver.py:138,163-169 index a 4-entry table with 8 actions)
+        if (cfg->action_type == T2D_ACTIONS_MOORE && (tm == T2D_TGT_RAM || tm == T2D_TGT_NAV || tm == T2D_TGT_RPF))
+            return fail(T2D_ERR_INVALID, "t2d_create: action_type Moore with a scripted target (env %d)", i);
         hcfg[(size_t)i] = mt | (tm << 2) | (lv << 5);
     }
     if (cfg->obs_type == T2D_OBS_FULL && n_maze != 0 && n_maze != n)
@@ -962,6 +972,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     s.k0 = (uint32_t)cfg->seed; s.k1 = (uint32_t)(cfg->seed >> 32);
     s.max_steps = cfg->max_episode_steps; s.auto_reset = cfg->auto_reset ? 1 : 0;
     s.obs_full = cfg->obs_type == T2D_OBS_FULL ? 1 : 0;
+    s.amask = cfg->action_type == T2D_ACTIONS_MOORE ? 7 : 3;
     s.obs_side = n_maze == n ? 81 : 82;
     const size_t nb = (size_t)n * sizeof(uint32_t), tb = (size_t)n * kTileWords * sizeof(uint32_t),
                  db = (size_t)n * kDirWords * sizeof(uint32_t);

@@ -39,9 +39,9 @@ class Box(object):
         self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
 
 
-def _spaces(obs_hw=(13, 13)):
+def _spaces(obs_hw=(13, 13), num_actions=4):
     obs = [Box(0, 6, (1,) + tuple(obs_hw), np.float32) for _ in range(2)]
-    act = [Discrete(4) for _ in range(2)]
+    act = [Discrete(num_actions) for _ in range(2)]       # define_action, track_1v1.py:242-249: 4, or 8 with 'Moore'
     return obs, act
 
 
@@ -62,7 +62,7 @@ class VecEnv(object):
             async_gen = os.environ.get("T2D_ASYNC_GEN", "0") == "1"
         self.core = VecTrack2D(env_id, num_envs=num_envs, device=device, seed=seed, env_id_base=env_id_base,
                                auto_reset=auto_reset, async_gen=async_gen, **overrides)
-        self.observation_space, self.action_space = _spaces(self.core.obs_hw)
+        self.observation_space, self.action_space = _spaces(self.core.obs_hw, self.core.num_actions)
         # obs_u8: observations stay bytes between the step kernel and the policy's conv stem (t2d_step_u8 ->
         # atr_stem_*_u8), i.e. frame_stack's np.float32 cast (environment.py:138,146) is fused into conv1. Only where
         # the kernels exist ('Partial' ids without Nav/RPF targets) and no host-side frame processing is asked for.

@@ -33,6 +33,7 @@ class _Config(C.Structure):
         ("abi_version", C.c_uint32), ("device", C.c_int32), ("num_envs", C.c_int32), ("env_id_base", C.c_uint32),
         ("seed", C.c_uint64), ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32),
         ("map_type", C.c_uint8), ("target_mode", C.c_uint8), ("level", C.c_uint8), ("obs_type", C.c_uint8),
+        ("action_type", C.c_uint8), ("reserved_", C.c_uint8 * 3),
         ("map_type_per_env", C.c_void_p), ("target_mode_per_env", C.c_void_p), ("level_per_env", C.c_void_p),
     ]
 
@@ -127,7 +128,7 @@ class VecTrack2D(object):
     def __init__(self, env_id=None, num_envs=1, device="cuda:0", seed=1, env_id_base=0, auto_reset=True,
                  map_type=None, target_mode=None, level=0, max_episode_steps=None,
                  map_type_per_env=None, target_mode_per_env=None, level_per_env=None, obs_type="Partial",
-                 async_gen=False):
+                 async_gen=False, action_type="VonNeumann"):
         if not torch.cuda.is_available():
             raise T2DError("VecTrack2D needs an MI355X visible to PyTorch-ROCm (no CPU fallback)")
         self.L = load_library()
@@ -155,6 +156,10 @@ class VecTrack2D(object):
         cfg.target_mode = registry.TARGET_CODE[target_mode]
         cfg.level = int(level)
         cfg.obs_type = 1 if obs_type == "Full" else 0
+        if action_type not in ("VonNeumann", "Moore"):      # track_1v1.py:243-249
+            raise TypeError("Action type must be either 'VonNeumann' or 'Moore'")
+        cfg.action_type = 1 if action_type == "Moore" else 0
+        self.action_type, self.num_actions = action_type, 8 if action_type == "Moore" else 4
         self.obs_type = obs_type
         if obs_type == "Full":   # track_1v1.py:254-256: Box(shape=(1, S, S)); S = 81 for Maze maps, else 82
             all_maze = (map_type == "Maze") if map_type_per_env is None else bool((np.asarray(map_type_per_env) == 1).all())

@@ -46,6 +46,7 @@ enum { T2D_TGT_ADV = 0, T2D_TGT_PZR = 1, T2D_TGT_FAR = 2, T2D_TGT_NAV = 3, T2D_T
 enum { T2D_ACT_U8 = 0, T2D_ACT_I32 = 1, T2D_ACT_I64 = 2 };
 /* obs_type of the registry kwargs (G/__init__.py:11), define_observation at G/envs/track_1v1.py:251-262 */
 enum { T2D_OBS_PARTIAL = 0, T2D_OBS_FULL = 1 };
+enum { T2D_ACTIONS_VONNEUMANN = 0, T2D_ACTIONS_MOORE = 1 };   /* t2d_config.action_type */
 
 #define T2D_NUM_AGENTS 2
 #define T2D_POB 6          /* pob_size, G/envs/track_1v1.py:16 */
@@ -71,6 +72,11 @@ typedef struct {
     uint8_t map_type, target_mode, level;
     uint8_t obs_type;          /* 0 'Partial': obs [N,2,13,13]; 1 'Full': obs [N,2,S,S], S = 82 (Block/Empty) or 81
                                   (Maze), every env of the handle must then have the same S */
+    uint8_t action_type;       /* Track1v1Env(action_type=...) (G/envs/track_1v1.py:17,243-249,275-279): 0 'VonNeumann'
+                                  (actions 0..3, every registered id), 1 'Moore' (actions 0..7: 4..7 are the diagonals; only
+                                  the destination cell is tested). Moore with a scripted target (Ram/Nav/RPF) is refused.
+                                  (Occupies former padding: the layout is unchanged and 0 is the old behaviour.) */
+    uint8_t reserved_[3];
     /* optional per-env overrides (host pointers, num_envs bytes each, NULL = uniform): BASELINE config 5
      * mixes Block and Maze maps in one batch */
     const uint8_t *map_type_per_env;

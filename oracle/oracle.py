@@ -41,6 +41,7 @@ def lib():
         L.orc_destroy.argtypes = [vp]
         L.orc_seed_np.argtypes = [vp, u32]
         L.orc_set_obs_full.argtypes = [vp, i32]
+        L.orc_set_action_type.argtypes = [vp, i32]
         L.orc_obs_size.restype = i32
         L.orc_obs_size.argtypes = [vp]
         L.orc_reset.argtypes = [vp, pu8]
@@ -88,13 +89,14 @@ class OracleEnv(object):
     """One scalar Track2D env (obs u8[2,13,13], rewards f64[2], done bool)."""
 
     def __init__(self, map_type="Block", target_mode="PZR", level=0, max_steps=500,
-                 rng_mode=RNG_NP, seed=0, env_id=0, obs_type="Partial"):
+                 rng_mode=RNG_NP, seed=0, env_id=0, obs_type="Partial", action_type="VonNeumann"):
         self.L = lib()
         self.map_type, self.target_mode = map_type, target_mode
         self.h = self.L.orc_create(MAP[map_type], TGT[target_mode], level, max_steps, rng_mode,
                                    int(seed), int(env_id))
         self.full = obs_type == "Full"
         self.L.orc_set_obs_full(self.h, 1 if self.full else 0)
+        self.L.orc_set_action_type(self.h, 1 if action_type == "Moore" else 0)
         s = self.L.orc_side(self.h)
         self._obs = np.zeros((2, s, s) if self.full else (2, 13, 13), np.uint8)
         self._rew = np.zeros(2, np.float64)

@@ -144,6 +144,7 @@ struct orc_env {
     int cand[4][2], vector;
     int vpos[2], remaining;                   /* philox-mode RPF: open-loop plan = field descent of a virtual position */
     int obs_full;                             /* obs_type: 0 'Partial' (13x13 crops), 1 'Full' (whole map) */
+    int moore;                                /* action_type: 0 'VonNeumann' (4 actions), 1 'Moore' (8) — track_1v1.py:243-249 */
 };
 
 static uint32_t next_u32(orc_env *e, int stream)
@@ -489,11 +490,13 @@ void orc_bfs_field(int S, const uint8_t *maze, const int *goal, uint8_t *dir, in
 
 /* ---- scripted targets ---- */
 
-/* RamAgent.reset — navigator.py:90-93: randint(1,10) is evaluated before choice(4, n). */
+/* RamAgent.reset — navigator.py:90-93: randint(1,10) is evaluated before choice(all_actions, n); all_actions =
+ * range(action_space.n) (navigator.py:74-75), i.e. 4 or, with action_type 'Moore', 8 actions. */
+static uint32_t ram_amax(const orc_env *e) { return e->moore ? 7u : 3u; }
 static void ram_reset(orc_env *e)
 {
     int n = 1 + (int)bounded(e, STREAM_TARGET, 8);
-    for (int i = 0; i < n; i++) e->plan[i] = (int)bounded(e, STREAM_TARGET, 3);
+    for (int i = 0; i < n; i++) e->plan[i] = (int)bounded(e, STREAM_TARGET, ram_amax(e));
     e->plan_len = n; e->plan_cur = 0;
 }
 /* RamAgent.step — navigator.py:77-88. */
@@ -502,13 +505,13 @@ static int ram_step(orc_env *e)
     int action = e->plan[e->plan_cur++];
     if (e->plan_cur >= e->plan_len) {
         if (bounded(e, STREAM_TARGET, 1) == 0) {
-            action = (int)bounded(e, STREAM_TARGET, 3);
+            action = (int)bounded(e, STREAM_TARGET, ram_amax(e));
             int n = 1 + (int)bounded(e, STREAM_TARGET, 8);
             for (int i = 0; i < n; i++) e->plan[i] = action;
             e->plan_len = n;
         } else {
             int n = 1 + (int)bounded(e, STREAM_TARGET, 8);
-            for (int i = 0; i < n; i++) e->plan[i] = (int)bounded(e, STREAM_TARGET, 3);
+            for (int i = 0; i < n; i++) e->plan[i] = (int)bounded(e, STREAM_TARGET, ram_amax(e));
             e->plan_len = n;
         }
         e->plan_cur = 0;
@@ -663,6 +666,7 @@ orc_env *orc_create(int map_type, int target_mode, int level, int max_steps, int
 void orc_destroy(orc_env *e) { free(e); }
 void orc_seed_np(orc_env *e, uint32_t seed) { mt_seed(&e->mt, seed); }
 void orc_set_obs_full(orc_env *e, int full) { e->obs_full = full ? 1 : 0; }
+void orc_set_action_type(orc_env *e, int moore) { e->moore = moore ? 1 : 0; }
 int orc_obs_size(const orc_env *e) { return e->obs_full ? 2 * e->side * e->side : 2 * ORC_OBS_CELLS; }
 
 /* Track1v1Env.init_maze — track_1v1.py:218-240. */
@@ -720,10 +724,11 @@ void orc_reset(orc_env *e, uint8_t *obs)
     free(scratch);
 }
 
-/* Track1v1Env._next_state — track_1v1.py:271-285 (VonNeumann). */
+/* Track1v1Env._next_state — track_1v1.py:271-285: the VonNeumann transitions are the first four of the Moore table; only
+ * the destination cell is tested (a diagonal move may cut a corner). */
 static void move_agent(orc_env *e, int id, int action)
 {
-    static const int DR[4] = {-1, 1, 0, 0}, DC[4] = {0, 0, -1, 1};
+    static const int DR[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, DC[8] = {0, 0, -1, 1, 1, 1, -1, -1};
     int r = e->pos[id][0] + DR[action], c = e->pos[id][1] + DC[action];
     if (e->maze[r * e->side + c] != 1) { e->pos[id][0] = r; e->pos[id][1] = c; }
 }
@@ -739,7 +744,8 @@ int orc_step(orc_env *e, const int *actions, uint8_t *obs, double *rewards, int 
         act[1] = nav_step(e, e->pos[1], scratch); /* old_state[1] (:84) */
         free(scratch);
     }
-    if (act[0] < 0 || act[0] > 3 || act[1] < 0 || act[1] > 3) return -1;
+    const int amax = e->moore ? 7 : 3;
+    if (act[0] < 0 || act[0] > amax || act[1] < 0 || act[1] > amax) return -1;
     move_agent(e, 0, act[0]);
     move_agent(e, 1, act[1]);
     int dr = e->pos[1][0] - e->pos[0][0], dc = e->pos[1][1] - e->pos[0][1];

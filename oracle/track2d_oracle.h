@@ -50,6 +50,8 @@ void orc_destroy(orc_env *e);
 /* obs_type: 0 = 'Partial' (default; obs u8[2][13][13]), 1 = 'Full' (obs u8[2][side][side], both agents see the
  * whole map with the tracker painted 2 and the target 4 — track_1v1.py:288-290,295-307). orc_obs_size = bytes. */
 void orc_set_obs_full(orc_env *e, int full);
+/* action_type (track_1v1.py:17,243-249,271-285): 0 'VonNeumann' (default), 1 'Moore' (8 actions, diagonals 4..7) */
+void orc_set_action_type(orc_env *e, int moore);
 int orc_obs_size(const orc_env *e);
 
 /* Re-seed the numpy-legacy stream (np.random.seed(int)). */

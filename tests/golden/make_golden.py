@@ -63,9 +63,21 @@ def chase_action(env, rs):
     return int(cands[rs.randint(0, len(cands))])
 
 
+def chase_action_moore(env, rs):
+    """Chase with the Moore table (track_1v1.py:277-279): diagonals 4 (-1,+1), 5 (+1,+1), 6 (-1,-1), 7 (+1,-1)."""
+    (r0, c0), (r1, c1) = [list(map(int, s)) for s in env.state]
+    dr, dc = (r1 > r0) - (r1 < r0), (c1 > c0) - (c1 < c0)
+    if rs.rand() < 0.15 or (dr == 0 and dc == 0):
+        return int(rs.randint(0, 8))
+    table = {(-1, 0): 0, (1, 0): 1, (0, -1): 2, (0, 1): 3, (-1, 1): 4, (1, 1): 5, (-1, -1): 6, (1, -1): 7}
+    return table[(dr, dc)]
+
+
 def run_case(map_type, mode, level, seed, n_episodes, max_steps, policy="random", time_limit=500, obs_type="Partial",
-             stop_on_done=True):
-    env = Track1v1Env(map_type=map_type, target_mode=mode, level=level, obs_type=obs_type)
+             stop_on_done=True, action_type="VonNeumann"):
+    env = Track1v1Env(map_type=map_type, target_mode=mode, level=level, obs_type=obs_type, action_type=action_type)
+    n_act = 8 if action_type == "Moore" else 4
+    assert env.action_space[0].n == n_act
     emitted = []
     if env.Target:
         tgt = env.Target[0]
@@ -93,8 +105,11 @@ def run_case(map_type, mode, level, seed, n_episodes, max_steps, policy="random"
             rec["navgoal0"] = np.array(env.Target[0].goal_states, np.int32).copy()
         t = 0
         while True:
-            a0 = chase_action(env, rs) if policy == "chase" else int(rs.randint(0, 4))
-            a1 = int(rs.randint(0, 4))
+            if policy == "chase":
+                a0 = chase_action_moore(env, rs) if n_act == 8 else chase_action(env, rs)
+            else:
+                a0 = int(rs.randint(0, n_act))
+            a1 = int(rs.randint(0, n_act))
             n_em = len(emitted)
             obs, rew, done, info = env.step([a0, a1])
             t += 1
@@ -180,6 +195,27 @@ def rpf_episodes():
               ((13, 13), (e["maze"].shape[0] * 5 // 6, 13))] for e in eps])
     out["names"] = np.array(names)
     np.savez_compressed(os.path.join(HERE, "episodes_rpf.npz"), **out)
+
+
+def moore_episodes():
+    """action_type='Moore' (track_1v1.py:17,243-249,277-279): 8 actions, diagonals cut corners (only the destination cell
+    is tested). No registered id selects it; the constructor argument exists, so the table is pinned too. (With a Nav /
+    RPF target the reference itself fails under Moore: the Navigator's A* receives the 8-action list and indexes its
+    4-entry transition table — Astar_solver.py:138,163-169 -> KeyError — so those combinations do not exist.)"""
+    out = {}
+    names = []
+    for (mp, mode, lvl, seed, n_ep, mx, pol) in (("Block", "PZR", 0, 61, 2, 150, "random"), ("Maze", "Adv", 0, 62, 2, 150, "random"),
+                                                 ("Block", "Far", 1, 63, 2, 200, "chase"), ("Maze", "PZR", 1, 64, 2, 200, "chase"),
+                                                 ("Block", "Ram", 0, 65, 2, 200, "chase"), ("Empty", "PZR", 0, 66, 1, 120, "chase")):
+        name = "%s_%s_l%d_s%d" % (mp, mode, lvl, seed)
+        eps = run_case(mp, mode, lvl, seed, n_ep, mx, pol, action_type="Moore")
+        flatten(name + "/", eps, out)
+        out[name + "/meta"] = np.array([mp, mode, str(lvl), str(seed), pol])
+        names.append(name)
+        acts = np.concatenate([np.array(e["act_applied"]).reshape(-1) for e in eps])
+        print("moore", name, [len(e["obs"]) for e in eps], "diagonal share %.2f" % float((acts >= 4).mean()))
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "episodes_moore.npz"), **out)
 
 
 def full_obs_episodes():
@@ -423,6 +459,9 @@ if __name__ == "__main__":
     if "--rpf-only" in sys.argv:
         rpf_episodes()
         sys.exit(0)
+    if "--moore-only" in sys.argv:
+        moore_episodes()
+        sys.exit(0)
     if "--model-only" in sys.argv:
         model_fixture()
         loss_fixture()
@@ -430,6 +469,7 @@ if __name__ == "__main__":
     episodes()
     full_obs_episodes()
     rpf_episodes()
+    moore_episodes()
     edge_cases()
     astar_cases()
     registry()

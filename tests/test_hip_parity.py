@@ -31,7 +31,7 @@ def _pad82(m):
     return out
 
 
-def _run_injected(vec, items):
+def _run_injected(vec, items, action_type="VonNeumann"):
     """items: list of dict(maze, pos0, actions[T,2], obs[T,2,13,13], rew[T,2] f64, done[T], cfar[T], pos[T,2,2],
     mode, obs0). Each item becomes one env of a batch (81- and 82-sided maps in separate batches)."""
     for side in (81, 82):
@@ -41,7 +41,7 @@ def _run_injected(vec, items):
         n = len(sel)
         modes = np.array([MODE_CODE[it["mode"]] for it in sel], np.uint8)
         env = vec.VecTrack2D(num_envs=n, map_type="Block", target_mode="Adv", level=1, auto_reset=False,
-                             max_episode_steps=500, target_mode_per_env=modes)
+                             max_episode_steps=500, target_mode_per_env=modes, action_type=action_type)
         env.inject(np.stack([it["maze"] for it in sel]), np.stack([it["pos0"].reshape(4) for it in sel]))
         obs0 = env.observe().cpu().numpy()
         for i, it in enumerate(sel):
@@ -99,6 +99,50 @@ def test_golden_rpf_episodes_injected(vec):
                               cfar=g[p + "cfar"], pos=g[p + "pos"], obs0=g[p + "obs0"], mode="Adv"))
     assert len(items) >= 6
     _run_injected(vec, items)
+
+
+def test_golden_moore_episodes_injected(vec):
+    """action_type='Moore' (track_1v1.py:243-249,275-279): the reference's 8-action episodes (diagonals that cut corners,
+    bumps into walls and map borders) replayed on the device; and the refusals that go with the table."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "episodes_moore.npz"))
+    items = []
+    for name in [str(n) for n in g["names"]]:
+        mode = str(g[name + "/meta"][1])
+        for ep in range(int(g[name + "/n_eps"])):
+            p = "%s/ep%d_" % (name, ep)
+            items.append(dict(name=p, maze=unpack_maze(g[p + "maze"], g[p + "side"]), pos0=g[p + "init"],
+                              actions=g[p + "act_applied"], obs=g[p + "obs"], rew=g[p + "rew"], done=g[p + "done"],
+                              cfar=g[p + "cfar"], pos=g[p + "pos"], obs0=g[p + "obs0"],
+                              mode=mode if mode in ("PZR", "Far") else "Adv"))
+    assert len(items) >= 10 and max(int(it["actions"].max()) for it in items) == 7
+    _run_injected(vec, items, action_type="Moore")
+    with pytest.raises(vec.T2DError):                      # scripted targets plan in the four-move table
+        vec.VecTrack2D("Track2D-BlockPartialRam-v0", num_envs=4, action_type="Moore")
+    with pytest.raises(TypeError):
+        vec.VecTrack2D("Track2D-BlockPartialPZR-v0", num_envs=4, action_type="Hex")
+    # action 4 is a fault in the four-move table, a diagonal in the eight-move one
+    for at, want in (("VonNeumann", 1), ("Moore", 0)):
+        env = vec.VecTrack2D("Track2D-BlockPartialPZR-v0", num_envs=8, seed=2, action_type=at)
+        env.reset()
+        a = torch.full((8,), 4, dtype=torch.int64, device="cuda")
+        env.step(a, a)
+        assert env.faults() == want, at
+        env.close()
+    # random-action stepping draws from all eight moves and stays on free cells
+    env = vec.VecTrack2D("Track2D-MazePartialAdv-v0", num_envs=512, seed=3, action_type="Moore")
+    env.reset()
+    p0 = env.get_state()["pos"].copy()
+    env.rollout_random(40, 7, keep_obs=False)
+    st, maps = env.get_state(), env.get_maps()
+    moved = st["pos"].astype(np.int64) - p0
+    assert (np.abs(moved[:, 0]).min(axis=1) > 0).any()     # some tracker has moved on both axes
+    for i in range(512):
+        for ag in range(2):
+            assert maps[i][st["pos"][i, ag, 0], st["pos"][i, ag, 1]] == 0
+    assert env.faults() == 0
+    env.close()
 
 
 def test_golden_edges_injected(vec, golden_edges):

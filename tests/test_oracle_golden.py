@@ -1,10 +1,12 @@
 """Pins the CPU oracle (oracle/track2d_oracle.c, numpy-legacy RNG mode) to the golden vectors captured
 from the reference env (tests/golden/make_golden.py): maps, spawns, goals, scripted-target actions,
 per-step obs / rewards / done — all bit-exact, over several consecutive episodes of one RNG stream."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import unpack_maze
+from conftest import GOLDEN, unpack_maze
 from oracle import oracle as orc
 
 
@@ -13,11 +15,22 @@ def _names(npz):
 
 
 def test_episode_cases_bit_exact(golden_episodes):
-    g = golden_episodes
+    assert _replay_from_seed(golden_episodes) > 2500
+
+
+def test_moore_action_cases_bit_exact():
+    """action_type='Moore' (track_1v1.py:243-249,277-279): the reference's episodes with the 8-action table — diagonal
+    moves that cut corners, bumps, the Ram target drawing its plans from 8 actions — replayed from the seed alone."""
+    g = np.load(os.path.join(GOLDEN, "episodes_moore.npz"))
+    assert _replay_from_seed(g, action_type="Moore") > 1400
+    assert max(int(g[n + "/ep0_act_applied"].max()) for n in _names(g)) == 7
+
+
+def _replay_from_seed(g, action_type="VonNeumann"):
     checked_steps = 0
     for name in _names(g):
         mp, mode, lvl, seed, _pol = [str(x) for x in g[name + "/meta"]]
-        env = orc.OracleEnv(mp, mode, int(lvl), 500, orc.RNG_NP, int(seed))
+        env = orc.OracleEnv(mp, mode, int(lvl), 500, orc.RNG_NP, int(seed), action_type=action_type)
         env.seed_np(int(seed))
         for ep in range(int(g[name + "/n_eps"])):
             p = "%s/ep%d_" % (name, ep)
@@ -44,7 +57,7 @@ def test_episode_cases_bit_exact(golden_episodes):
                 assert s["c_far"] == g[p + "cfar"][t]
                 assert np.array_equal(s["pos"], g[p + "pos"][t])
                 checked_steps += 1
-    assert checked_steps > 2500
+    return checked_steps
 
 
 def test_edge_cases_bit_exact(golden_edges):
