@@ -71,15 +71,15 @@ __global__ __launch_bounds__(256) void k_rollout_end(RolloutEnd a)
         reinterpret_cast<float4 *>(a.hxs)[i] = h;
         reinterpret_cast<float4 *>(a.cxs)[i] = c;
     }
+    if (i < (long long)a.T * a.N) a.keep[i] = a.dones[i] == 0 ? 1.f : 0.f;
     if (i < a.N) {
         // train.py:73-76 per env: the counter restarts at a done and counts the steps since; over T stored steps that is
         // eps_len * [no done in the rollout] + the number of steps after the last done
         int run = 0;
         bool alive = true;
+#pragma unroll 4
         for (int t = a.T - 1; t >= 0; t--) {
-            const bool nd = a.dones[(long long)t * a.N + i] == 0;
-            a.keep[(long long)t * a.N + i] = nd ? 1.f : 0.f;
-            alive = alive && nd;
+            alive = alive && a.dones[(long long)t * a.N + i] == 0;
             run += alive ? 1 : 0;
         }
         a.eps_len[i] = (alive ? a.eps_len[i] : 0) + run;
@@ -139,7 +139,7 @@ extern "C" int atr_rollout_end(const float *hT, const float *cT, long long pstri
     if (((uintptr_t)hxs | (uintptr_t)cxs | (uintptr_t)hT | (uintptr_t)cT) & 15u) return 1;
     RolloutEnd a{hT, cT, pstride, dones, hxs, cxs, eps_len, keep, T, N, A, R};
     long long work = (long long)N * A * (R / 4);
-    if (work < N) work = N;
+    if (work < (long long)T * N) work = (long long)T * N;
     hipLaunchKernelGGL(k_rollout_end, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
