@@ -8,7 +8,8 @@
 //                       -> row 0 of the rollout's observation store
 //   atr_rollout_end     masked final LSTM state of slot T -> [N,A,R]; episode-length counters; the done flags of the whole
 //                       rollout as the float keep-mask the learner's kernels read
-//   atr_adam_step       SharedAdam.step (Adam + AMSGrad, float64 step / beta powers on the device) over the flat bucket
+//   atr_adam_step       SharedAdam.step (Adam + AMSGrad, float64 step / beta powers on the device) over the flat bucket,
+//                       or torch.optim.Adam's form of it; atr_rmsprop_step: SharedRMSprop / torch.optim.RMSprop
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -86,20 +87,29 @@ __global__ __launch_bounds__(256) void k_rollout_end(RolloutEnd a)
     }
 }
 
-// state: [0] step, [1] beta1^step, [2] beta2^step (float64, as SharedAdam keeps them); step_size: one float
-__global__ void k_adam_scalars(double *state, float *step_size, double lr, double beta1, double beta2)
+// state: [0] step, [1] beta1^step, [2] beta2^step (float64, as SharedAdam keeps them); scal: [0] step size, [1] the factor
+// on sqrt(second moment). torch_eps = 0: SharedAdam (shared_optim.py:127-129,168-173 of the reference): eps is added to
+// the raw sqrt(v) and both bias corrections sit in the step size; 1: torch.optim.Adam, which the reference's per-worker
+// optimizer is (train.py:45-49): sqrt(v) / sqrt(1 - beta2^t) + eps, step size lr / (1 - beta1^t).
+__global__ void k_adam_scalars(double *state, float *scal, double lr, double beta1, double beta2, int torch_eps)
 {
     const double t = state[0] + 1.0, b1 = state[1] * beta1, b2 = state[2] * beta2;
     state[0] = t; state[1] = b1; state[2] = b2;
-    *step_size = (float)(lr * sqrt(1.0 - b2) / (1.0 - b1));      // shared_optim.py:127-129
+    if (torch_eps) {
+        scal[0] = (float)(lr / (1.0 - b1));
+        scal[1] = (float)(1.0 / sqrt(1.0 - b2));
+    } else {
+        scal[0] = (float)(lr * sqrt(1.0 - b2) / (1.0 - b1));
+        scal[1] = 1.0f;                                          // x * 1 is exact: SharedAdam's denominator is untouched
+    }
 }
 
 __global__ __launch_bounds__(256) void k_adam_update(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                      float *__restrict__ v, float *__restrict__ vmax,
-                                                     const float *__restrict__ step_size, float beta1, float beta2,
+                                                     const float *__restrict__ scal, float beta1, float beta2,
                                                      float omb1, float omb2, float eps, float wd, long long n)
 {
-    const float ss = *step_size;
+    const float ss = scal[0], ds = scal[1];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float gi = g[i];
         const float pi = p[i];
@@ -109,7 +119,23 @@ __global__ __launch_bounds__(256) void k_adam_update(float *__restrict__ p, cons
         m[i] = mi; v[i] = vi;
         float d = vi;
         if (vmax != nullptr) { d = fmaxf(vmax[i], vi); vmax[i] = d; }   // AMSGrad: max of all second-moment estimates so far
-        p[i] = pi - mi / (sqrtf(d) + eps) * ss;
+        p[i] = pi - mi / (sqrtf(d) * ds + eps) * ss;
+    }
+}
+
+// SharedRMSprop.step (shared_optim.py:43-87 of the reference; momentum = 0, not centered — its defaults, the only form
+// main.py:89-90 constructs) and torch.optim.RMSprop with the same settings: v = alpha v + (1 - alpha) g^2,
+// p -= lr g / (sqrt(v) + eps).
+__global__ __launch_bounds__(256) void k_rmsprop_update(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ v,
+                                                        float alpha, float oma, float eps, float lr, float wd, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float vi = fmaf(oma * gi, gi, v[i] * alpha);
+        v[i] = vi;
+        p[i] = fmaf(-lr, gi / (sqrtf(vi) + eps), pi);
     }
 }
 
@@ -145,16 +171,27 @@ extern "C" int atr_rollout_end(const float *hT, const float *cT, long long pstri
 }
 
 extern "C" int atr_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
-                             double *state, float *step_size, double lr, double beta1, double beta2, double eps,
-                             double weight_decay, long long n, void *stream)
+                             double *state, float *scalars, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, int torch_eps, long long n, void *stream)
 {
-    if (!params || !grad || !exp_avg || !exp_avg_sq || !state || !step_size || n <= 0) return 1;
+    if (!params || !grad || !exp_avg || !exp_avg_sq || !state || !scalars || n <= 0) return 1;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_adam_scalars, dim3(1), dim3(1), 0, st, state, step_size, lr, beta1, beta2);
+    hipLaunchKernelGGL(k_adam_scalars, dim3(1), dim3(1), 0, st, state, scalars, lr, beta1, beta2, torch_eps);
     long long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_adam_update, dim3((unsigned)blocks), dim3(256), 0, st, params, grad, exp_avg, exp_avg_sq,
-                       max_exp_avg_sq, step_size, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
+                       max_exp_avg_sq, scalars, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
                        (float)eps, (float)weight_decay, n);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" int atr_rmsprop_step(float *params, const float *grad, float *square_avg, double lr, double alpha, double eps,
+                                double weight_decay, long long n, void *stream)
+{
+    if (!params || !grad || !square_avg || n <= 0) return 1;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_rmsprop_update, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grad, square_avg,
+                       (float)alpha, (float)(1.0 - alpha), (float)eps, (float)lr, (float)weight_decay, n);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

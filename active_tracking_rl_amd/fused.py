@@ -66,7 +66,9 @@ def lib():
         L.atr_rollout_end.restype = i32
         L.atr_rollout_end.argtypes = [vp, vp, ll, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.atr_adam_step.restype = i32
-        L.atr_adam_step.argtypes = [vp] * 7 + [C.c_double] * 5 + [ll, vp]
+        L.atr_adam_step.argtypes = [vp] * 7 + [C.c_double] * 5 + [i32, ll, vp]
+        L.atr_rmsprop_step.restype = i32
+        L.atr_rmsprop_step.argtypes = [vp] * 3 + [C.c_double] * 4 + [ll, vp]
         _lib = L
     return _lib
 
@@ -604,9 +606,21 @@ def rollout_end(h_all, c_all, dones, hxs, cxs, eps_len, keep):
 
 
 @torch.no_grad()
-def adam_step(p, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, scalars, step_size, lr, beta1, beta2, eps, weight_decay):
-    """SharedAdam.step over the flat bucket (csrc/driver_hip.hip): scalars = [step, beta1^step, beta2^step] float64."""
+def adam_step(p, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, scalars, step_size, lr, beta1, beta2, eps, weight_decay,
+              torch_eps=False):
+    """SharedAdam.step over the flat bucket (csrc/driver_hip.hip): scalars = [step, beta1^step, beta2^step] float64;
+    step_size: two floats of scratch. torch_eps: torch.optim.Adam's placement of eps and the bias corrections."""
     rc = lib().atr_adam_step(_p(p), _p(grad), _p(exp_avg), _p(exp_avg_sq), _pn(max_exp_avg_sq), _p(scalars), _p(step_size),
-                             float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), p.numel(), _stream(p))
+                             float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), 1 if torch_eps else 0,
+                             p.numel(), _stream(p))
     if rc != 0:
         raise RuntimeError("atr_adam_step failed (%d)" % rc)
+
+
+@torch.no_grad()
+def rmsprop_step(p, grad, square_avg, lr, alpha, eps, weight_decay):
+    """SharedRMSprop.step (momentum 0, not centered) over the flat bucket (csrc/driver_hip.hip)."""
+    rc = lib().atr_rmsprop_step(_p(p), _p(grad), _p(square_avg), float(lr), float(alpha), float(eps), float(weight_decay),
+                                p.numel(), _stream(p))
+    if rc != 0:
+        raise RuntimeError("atr_rmsprop_step failed (%d)" % rc)

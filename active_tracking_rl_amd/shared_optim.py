@@ -68,8 +68,9 @@ class FlatParams(object):
 class SharedAdam(torch.optim.Optimizer):
     """Adam+AMSGrad with the reference's SharedAdam numerics over a FlatParams bucket."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-3, weight_decay=0, amsgrad=True):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-3, weight_decay=0, amsgrad=True, torch_eps=False):
         params = list(params)
+        self.torch_eps = bool(torch_eps)   # torch.optim.Adam's placement of eps / bias corrections (see local_optimizer)
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
         super(SharedAdam, self).__init__(params, defaults)
         self.bucket = FlatParams(params)
@@ -79,7 +80,7 @@ class SharedAdam(torch.optim.Optimizer):
         # float64 scalars on the device: step, beta1^t, beta2^t (one 3-vector, so that the fused step sees them together)
         self._scalars = torch.tensor([0.0, 1.0, 1.0], dtype=torch.float64, device=dev)
         self.step_t, self.b1_pow, self.b2_pow = self._scalars[0], self._scalars[1], self._scalars[2]
-        self._step_size = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._step_size = torch.zeros(2, dtype=torch.float32, device=dev)
         self.fused = True       # on the GPU: the whole update as one elementwise launch (csrc/driver_hip.hip)
 
     def share_memory(self):
@@ -98,7 +99,8 @@ class SharedAdam(torch.optim.Optimizer):
         if self.fused and p.is_cuda:
             from . import fused
             fused.adam_step(p, grad, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq if g['amsgrad'] else None,
-                            self._scalars, self._step_size, g['lr'], beta1, beta2, g['eps'], g['weight_decay'])
+                            self._scalars, self._step_size, g['lr'], beta1, beta2, g['eps'], g['weight_decay'],
+                            torch_eps=self.torch_eps)
             return loss
         if g['weight_decay'] != 0:
             grad = grad.add(p, alpha=g['weight_decay'])
@@ -107,15 +109,71 @@ class SharedAdam(torch.optim.Optimizer):
         self.b2_pow *= beta2
         self.exp_avg.mul_(beta1).add_(grad, alpha=1 - beta1)
         self.exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        second = self.exp_avg_sq
         if g['amsgrad']:
             torch.max(self.max_exp_avg_sq, self.exp_avg_sq, out=self.max_exp_avg_sq)
-            denom = self.max_exp_avg_sq.sqrt().add_(g['eps'])
+            second = self.max_exp_avg_sq
+        if self.torch_eps:      # torch.optim.Adam: sqrt(v / (1 - b2^t)) + eps, step size lr / (1 - b1^t)
+            denom = (second.sqrt() * (1.0 / torch.sqrt(1 - self.b2_pow)).to(torch.float32)).add_(g['eps'])
+            step_size = (g['lr'] / (1 - self.b1_pow)).to(torch.float32)
         else:
-            denom = self.exp_avg_sq.sqrt().add_(g['eps'])
-        step_size = (g['lr'] * torch.sqrt(1 - self.b2_pow) / (1 - self.b1_pow)).to(torch.float32)
+            denom = second.sqrt().add_(g['eps'])
+            step_size = (g['lr'] * torch.sqrt(1 - self.b2_pow) / (1 - self.b1_pow)).to(torch.float32)
         p.sub_(self.exp_avg / denom * step_size)
         return loss
 
     def state_dict_flat(self):
         return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, max_exp_avg_sq=self.max_exp_avg_sq,
                     step=self.step_t, b1_pow=self.b1_pow, b2_pow=self.b2_pow)
+
+
+class SharedRMSprop(torch.optim.Optimizer):
+    """The reference's SharedRMSprop (shared_optim.py:8-87: alpha 0.99, eps 0.1, no momentum, not centered — what
+    main.py:89-90 constructs) over a FlatParams bucket; same role as SharedAdam in the data-parallel design."""
+
+    def __init__(self, params, lr=7e-4, alpha=0.99, eps=0.1, weight_decay=0, momentum=0, centered=False):
+        if momentum != 0 or centered:
+            raise NotImplementedError("SharedRMSprop: momentum / centered are never used by the reference's drivers")
+        params = list(params)
+        super(SharedRMSprop, self).__init__(params, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay))
+        self.bucket = FlatParams(params)
+        self.square_avg = torch.zeros_like(self.bucket.flat)
+        self.fused = True
+
+    def share_memory(self):
+        return self
+
+    def zero_grad(self, set_to_none=False):
+        self.bucket.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        grad, p = self.bucket.grad, self.bucket.flat
+        if self.fused and p.is_cuda:
+            from . import fused
+            fused.rmsprop_step(p, grad, self.square_avg, g['lr'], g['alpha'], g['eps'], g['weight_decay'])
+            return loss
+        if g['weight_decay'] != 0:
+            grad = grad.add(p, alpha=g['weight_decay'])
+        self.square_avg.mul_(g['alpha']).addcmul_(grad, grad, value=1 - g['alpha'])
+        p.addcdiv_(grad, self.square_avg.sqrt().add_(g['eps']), value=-g['lr'])
+        return loss
+
+
+def make_optimizer(params, args):
+    """The optimizer main.py:86-95 + train.py:45-49 of the reference arrive at for these flags. With --shared-optimizer:
+    SharedAdam(lr, amsgrad) / SharedRMSprop(lr). Without it every worker builds torch.optim.Adam(lr) / RMSprop(lr) for
+    itself; in the synchronous data-parallel design all replicas see the same averaged gradient, so those per-worker
+    states are one and the same — kept as one flat bucket with torch.optim's numerics (Adam: eps 1e-8 inside the
+    bias-corrected root, no AMSGrad; RMSprop: alpha 0.99, eps 1e-8)."""
+    name = getattr(args, "optimizer", "Adam")
+    shared = bool(getattr(args, "shared_optimizer", True))
+    if name == 'Adam':
+        if shared:
+            return SharedAdam(params, lr=args.lr, amsgrad=args.amsgrad)
+        return SharedAdam(params, lr=args.lr, eps=1e-8, amsgrad=False, torch_eps=True)
+    if name == 'RMSprop':
+        return SharedRMSprop(params, lr=args.lr) if shared else SharedRMSprop(params, lr=args.lr, eps=1e-8)
+    raise ValueError("--optimizer %s: the reference knows Adam and RMSprop (main.py:28)" % name)

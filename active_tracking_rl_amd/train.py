@@ -20,7 +20,7 @@ import torch
 from .environment import create_env
 from .model import build_model
 from .player_util import Agent
-from .shared_optim import SharedAdam
+from .shared_optim import SharedAdam, make_optimizer  # noqa: F401  (SharedAdam re-exported for callers)
 
 
 def default_args(**over):
@@ -59,7 +59,7 @@ def make_player(args, device, rank=0, world_size=1, env=None, model=None, optimi
         model = build_model(env.observation_space, env.action_space, args, device).to(device)
     model.train()
     if optimizer is None:
-        optimizer = SharedAdam(select_params(model, args.train_mode), lr=args.lr, amsgrad=args.amsgrad)
+        optimizer = make_optimizer(select_params(model, args.train_mode), args)
     torch.manual_seed(args.seed + rank)   # per-rank action sampling (train.py:20)
     if device.type == 'cuda':
         torch.cuda.manual_seed(args.seed + rank)

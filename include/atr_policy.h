@@ -138,16 +138,22 @@ int atr_gemm_tn(const float *x1, const float *x2, float *c, float *workspace, lo
  *   atr_rollout_end: the final state (slot T, same addressing) -> hxs/cxs [N,A,R], zeroed for envs whose last step
  *     finished an episode (the reset() of train.py:73-74); eps_len [N] int32 advanced as train.py:75-76 would have step by
  *     step (restart at a done, +1 per step); keep [T,N] float = (dones == 0), the episode mask the learner's kernels read.
- *   atr_adam_step: SharedAdam.step (shared_optim.py:80-134 of the reference: Adam with AMSGrad when max_exp_avg_sq != NULL,
- *     eps added to the square root, bias correction through step_size) over a flat fp32 bucket of n elements.
- *     state = {step, beta1^step, beta2^step} float64 on the device (advanced here); step_size: one float of scratch. */
+ *   atr_adam_step: SharedAdam.step (shared_optim.py:122-175 of the reference: Adam with AMSGrad when max_exp_avg_sq != NULL,
+ *     eps added to the raw square root, both bias corrections folded into the step size) over a flat fp32 bucket of n
+ *     elements; torch_eps != 0 gives torch.optim.Adam's form instead (the reference's per-worker optimizer when
+ *     --shared-optimizer is absent, train.py:45-49: sqrt(v / (1 - beta2^t)) + eps). state = {step, beta1^step, beta2^step}
+ *     float64 on the device (advanced here); scalars: two floats of scratch.
+ *   atr_rmsprop_step: SharedRMSprop.step (shared_optim.py:43-87; momentum 0, not centered, as main.py:89-90 builds it) =
+ *     torch.optim.RMSprop with the same settings. */
 int atr_rollout_begin(const float *hxs, const float *cxs, float *h0, float *c0, long long pstride, const void *obs_src,
                       void *obs_dst, long long obs_bytes, int N, int A, int R, void *stream);
 int atr_rollout_end(const float *hT, const float *cT, long long pstride, const uint8_t *dones, float *hxs, float *cxs,
                     int *eps_len, float *keep, int T, int N, int A, int R, void *stream);
 int atr_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq, double *state,
-                  float *step_size, double lr, double beta1, double beta2, double eps, double weight_decay, long long n,
-                  void *stream);
+                  float *scalars, double lr, double beta1, double beta2, double eps, double weight_decay, int torch_eps,
+                  long long n, void *stream);
+int atr_rmsprop_step(float *params, const float *grad, float *square_avg, double lr, double alpha, double eps,
+                     double weight_decay, long long n, void *stream);
 
 #ifdef __cplusplus
 }

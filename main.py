@@ -36,7 +36,7 @@ parser.add_argument('--test-eps', type=int, default=100, metavar='TE', help='eva
 parser.add_argument('--test-every', type=int, default=200, metavar='TI', help='training iterations between evaluations')
 parser.add_argument('--env', default='Track2D-BlockPartialPZR-v0', metavar='ENV', help='environment to train on')
 parser.add_argument('--env-base', default='Track2D-BlockPartialNav-v0', metavar='ENVB', help='environment to test on ')
-parser.add_argument('--optimizer', default='Adam', metavar='OPT', help='Adam (SharedAdam numerics)')
+parser.add_argument('--optimizer', default='Adam', metavar='OPT', help='shares optimizer choice of Adam or RMSprop')
 parser.add_argument('--amsgrad', default=True, metavar='AM', help='Adam optimizer amsgrad parameter')
 parser.add_argument('--load-model-dir', default=None, metavar='LMD', help='checkpoint to load')
 parser.add_argument('--log-dir', default='logs/', metavar='LG', help='folder to save logs')
@@ -50,7 +50,8 @@ parser.add_argument('--crop', dest='crop', action='store_true', help='crop image
 parser.add_argument('--inv', dest='inv', action='store_true', help='inverse image')
 parser.add_argument('--rescale', dest='rescale', action='store_true', help='rescale image to [-1, 1]')
 parser.add_argument('--render', dest='render', action='store_true', help='(not supported on the batched path)')
-parser.add_argument('--shared-optimizer', dest='shared_optimizer', action='store_true', help='accepted for compatibility')
+parser.add_argument('--shared-optimizer', dest='shared_optimizer', action='store_true',
+                    help='SharedAdam / SharedRMSprop numerics; without it torch.optim.Adam / RMSprop numerics (train.py:45-49)')
 parser.add_argument('--split', dest='split', action='store_true', help='split model to save')
 parser.add_argument('--train-mode', type=int, default=-1, metavar='TM', help='which agent to train(0:tracker 1:target)')
 parser.add_argument('--stack-frames', type=int, default=1, metavar='SF', help='Choose number of observations to stack')
@@ -85,9 +86,6 @@ if __name__ == '__main__':
     if args.load_model_dir is not None:
         saved_state = torch.load(args.load_model_dir, map_location=lambda storage, loc: storage)
         player.model.load_state_dict(saved_state)
-    if args.optimizer != 'Adam':
-        raise SystemExit("--optimizer %s: only Adam (SharedAdam numerics, shared_optim.py:90-175) is built; "
-                         "SharedRMSprop is out of the Track2D scope (DESIGN.md section 8)" % args.optimizer)
     # until the evaluator first speaks, the schedule of test.py:84-92 applies from iteration 0: tracker only while
     # n_iter < --init-step
     first_mode = 0 if args.init_step > 0 else args.train_mode

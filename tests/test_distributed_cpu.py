@@ -134,3 +134,40 @@ def test_flat_bucket_views_and_sharedadam_numerics():
         step_size = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
         p = p - step_size * m / (vmax.sqrt() + 1e-3)
         np.testing.assert_allclose(opt.bucket.flat.numpy(), p.float().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_rmsprop_and_per_worker_optimizer_numerics():
+    """The other three optimizers main.py / train.py of the reference can arrive at (shared_optim.make_optimizer):
+    SharedRMSprop (shared_optim.py:43-87) against its update rule in float64; the per-worker torch.optim.Adam / RMSprop
+    (train.py:45-49) against torch.optim itself on a twin module."""
+    import argparse
+    from active_tracking_rl_amd.shared_optim import SharedRMSprop, make_optimizer
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(7, 5)
+    opt = make_optimizer(lin.parameters(), argparse.Namespace(optimizer="RMSprop", shared_optimizer=True, lr=7e-4, amsgrad=True))
+    assert isinstance(opt, SharedRMSprop) and opt.param_groups[0]["eps"] == 0.1
+    p = opt.bucket.flat.double().clone()
+    v = torch.zeros_like(p)
+    for t in range(5):
+        opt.zero_grad()
+        (lin(torch.randn(4, 7)) ** 2).sum().backward()
+        g = opt.bucket.grad.double().clone()
+        opt.step()
+        v = v * 0.99 + 0.01 * g * g
+        p = p - 7e-4 * g / (v.sqrt() + 0.1)
+        np.testing.assert_allclose(opt.bucket.flat.numpy(), p.float().numpy(), rtol=1e-5, atol=1e-7)
+    for name, ref_cls in (("Adam", torch.optim.Adam), ("RMSprop", torch.optim.RMSprop)):
+        torch.manual_seed(2)
+        a, b = torch.nn.Linear(6, 3), torch.nn.Linear(6, 3)
+        b.load_state_dict(a.state_dict())
+        oa = make_optimizer(a.parameters(), argparse.Namespace(optimizer=name, shared_optimizer=False, lr=1e-3, amsgrad=True))
+        ob = ref_cls(b.parameters(), lr=1e-3)
+        for t in range(6):
+            x = torch.randn(5, 6)
+            oa.zero_grad(); ob.zero_grad()
+            (a(x) ** 2).sum().backward(); (b(x) ** 2).sum().backward()
+            oa.step(); ob.step()
+            for pa, pb in zip(a.parameters(), b.parameters()):
+                np.testing.assert_allclose(pa.detach().numpy(), pb.detach().numpy(), rtol=2e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        make_optimizer(lin.parameters(), argparse.Namespace(optimizer="SGD", shared_optimizer=True, lr=1e-3, amsgrad=True))

@@ -259,6 +259,30 @@ def test_fused_adam_step_matches_the_tensor_expression():
     assert float(oa.step_t) == 6.0
 
 
+def test_fused_rmsprop_and_torch_form_adam_match_the_tensor_expressions():
+    """atr_rmsprop_step and atr_adam_step(torch_eps) against the same optimizers with the fused path off, and against
+    torch.optim on the GPU."""
+    import argparse
+    from active_tracking_rl_amd.shared_optim import make_optimizer
+    for name, ref_cls in (("Adam", torch.optim.Adam), ("RMSprop", torch.optim.RMSprop)):
+        torch.manual_seed(0)
+        ws = [torch.randn(513, 37, device="cuda"), torch.randn(4097, device="cuda")]
+        pa = [torch.nn.Parameter(w.clone()) for w in ws]
+        pb = [torch.nn.Parameter(w.clone()) for w in ws]
+        pc = [torch.nn.Parameter(w.clone()) for w in ws]
+        ns = argparse.Namespace(optimizer=name, shared_optimizer=False, lr=1e-3, amsgrad=True)
+        oa, ob, oc = make_optimizer(pa, ns), make_optimizer(pb, ns), ref_cls(pc, lr=1e-3)
+        ob.fused = False
+        for step in range(5):
+            for a, b, c in zip(pa, pb, pc):
+                g = torch.randn_like(a)
+                a.grad.copy_(g); b.grad.copy_(g); c.grad = g.clone()
+            oa.step(); ob.step(); oc.step()
+            torch.testing.assert_close(oa.bucket.flat, ob.bucket.flat, rtol=1e-6, atol=1e-7)
+            for a, c in zip(pa, pc):
+                torch.testing.assert_close(a.detach(), c.detach(), rtol=2e-5, atol=1e-7)
+
+
 def _check_grads(ga, gb):
     n_checked = 0
     for a, b in zip(ga, gb):
