@@ -313,15 +313,16 @@ __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double
         if (b < 1681 && (y == 0 || y == 40 || x == 0 || x == 40)) zb |= 1u << k;
     }
     int nlog = 0;
-    // one growth step from node p in direction d: test the node bit, carve + log + move on a free node
-#define T2D_MAZE_MOVE(D)                                                                                               \
+    // one growth step from node p to node q = p + delta: test the node bit, carve + log + move on a free node. The log
+    // entry is the pair (p, q): the carved mid-point is the cell between them.
+#define T2D_MAZE_MOVE(DELTA)                                                                                           \
     do {                                                                                                               \
-        const uint32_t d_ = (D);                                                                                       \
-        const int q = p + (int)(int8_t)(kMazeDelta >> (8u * d_));                                                      \
+        const int q = p + (DELTA);                                                                                     \
         const uint32_t word = __builtin_amdgcn_readlane(zb, q >> 5);                                                   \
         if (((word >> (q & 31)) & 1u) == 0u) {                        /* Z[y_, x_] == 0: carve */                      \
             zb |= lane == (q >> 5) ? 1u << (q & 31) : 0u;                                                              \
-            log[nlog] = (uint32_t)p | (d_ << 11);                     /* by every lane: same word, no exec juggling */ \
+            log[nlog] = (uint32_t)p | ((uint32_t)q << 11);            /* by every lane: same word, no exec juggling   \
+               (a per-lane dump address instead was measured: no difference) */                                      \
             nlog++;                                                                                                    \
             p = q;                                                                                                     \
             interior = true;                                          /* a free node is never on the border */         \
@@ -341,20 +342,25 @@ __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double
             uint32_t d = 0u;
             for (uint32_t mm = m0; ; mm >>= 1, d++)
                 if (mm & 1u) { if (k == 0u) break; k--; }
-            T2D_MAZE_MOVE(d);
+            T2D_MAZE_MOVE((int)(int8_t)(kMazeDelta >> (8u * d)));
         }
         while (j < complexity) {                                       // interior: one word per move, block by block
             const uint32_t c = uni(ms.ctr);
             ms.ensure(c);
+            // the 64 moves this block of words stands for, decoded by all lanes at once: the walk then needs one
+            // v_readlane with a known index per move — off its dependent chain (position -> node word -> test)
+            const int dv = (int)(int8_t)(kMazeDelta >> (8u * (ms.wv & 3u)));
             const int c0 = (int)(c & 63u), n = min(64 - c0, complexity - j);
             int k = 0;
             for (; k + 4 <= n; k += 4) {                               // (unrolled by hand: one loop branch per four moves)
-                T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k) & 3u);
-                T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k + 1) & 3u);
-                T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k + 2) & 3u);
-                T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k + 3) & 3u);
+                const int d0 = (int)__builtin_amdgcn_readlane((uint32_t)dv, c0 + k), d1 = (int)__builtin_amdgcn_readlane((uint32_t)dv, c0 + k + 1);
+                const int d2 = (int)__builtin_amdgcn_readlane((uint32_t)dv, c0 + k + 2), d3 = (int)__builtin_amdgcn_readlane((uint32_t)dv, c0 + k + 3);
+                T2D_MAZE_MOVE(d0);
+                T2D_MAZE_MOVE(d1);
+                T2D_MAZE_MOVE(d2);
+                T2D_MAZE_MOVE(d3);
             }
-            for (; k < n; k++) T2D_MAZE_MOVE(__builtin_amdgcn_readlane(ms.wv, c0 + k) & 3u);
+            for (; k < n; k++) T2D_MAZE_MOVE((int)__builtin_amdgcn_readlane((uint32_t)dv, c0 + k));
             ms.ctr = c + (uint32_t)n;
             j += n;
         }
@@ -385,10 +391,10 @@ __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double
     }
     wave_lds_sync();
     for (int i = lane; i < nlog; i += 64) {
-        const uint32_t e = log[i];                                    // node p = y * 41 + x and the direction of the move
-        const uint32_t pp = e & 0x7ffu, d = e >> 11;
-        const uint32_t y = pp / 41u, x = pp - y * 41u;
-        const uint32_t row = 2u * y + (d == 2u ? -1 : (d == 3u ? 1 : 0)), col = 2u * x + (d == 0u ? -1 : (d == 1u ? 1 : 0));
+        const uint32_t e = log[i];                                    // nodes p and q (index y * 41 + x) of a carving move
+        const uint32_t pp = e & 0x7ffu, qq = e >> 11;
+        const uint32_t yp = pp / 41u, xp = pp - yp * 41u, yq = qq / 41u, xq = qq - yq * 41u;
+        const uint32_t row = yp + yq, col = xp + xq;                   // the cell between them, in full-resolution cells
         atomicOr(&tile[row * kRowWords + (col >> 5)], 1u << (col & 31u));
     }
     wave_lds_sync();
