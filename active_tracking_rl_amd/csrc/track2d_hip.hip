@@ -122,8 +122,11 @@ template <bool NAV>
 __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint32_t *tile, uint32_t *mlog, int lane, uint32_t cfg,
                                                  uint32_t episode, uint32_t *gdir, uint32_t &pos, uint32_t &goals,
                                                  uint32_t &plan, uint32_t &tctr, uint32_t &navgoal, uint32_t &d2,
-                                                 uint32_t &nav2)
+                                                 uint32_t &nav2, uint32_t *stamps = nullptr)
 {
+    // T2D_EXP == 9 (probe build only, tools/gen_timeline_probe.py): s_memtime stamps of the generator's phases
+#define T2D_GSTAMP(i) do { if (T2D_EXP == 9 && lane == 0) stamps[i] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+    T2D_GSTAMP(0);
     nav2 = 0u;
     const int map_type = cfg & 3, mode = (cfg >> 2) & 7, level = (cfg >> 5) & 15;
     const uint32_t genv = s.env_base + (uint32_t)e;
@@ -139,8 +142,10 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
     } else {
         gen_block(tile, lane, ms, 0.0);
     }
+    T2D_GSTAMP(1);
     const FreeIndex fi = build_free_index(tile, side, lane);
     const int n = fi.total;
+    T2D_GSTAMP(2);
     VStream ss;
     ss.init(s.k0, s.k1, episode, genv, STREAM_SPAWN, 0, lane);
     uint32_t g0, g1;
@@ -175,6 +180,7 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
     while (!rpf && (tr == g0 || tr == g1)) sample_goal2(); // goal_test loop, track_1v1.py:239-240
     pos = tr | (tg << 16);
     goals = g0 | (g1 << 16);
+    T2D_GSTAMP(3);
     VStream ts;
     ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, 0, lane);
     plan = 0;
@@ -190,6 +196,8 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
     tctr = ts.ctr;
     const int dr = (int)(tg & 0xffu) - r, dc = (int)(tg >> 8) - c;
     d2 = (uint32_t)(dr * dr + dc * dc);
+    T2D_GSTAMP(4);
+#undef T2D_GSTAMP
 }
 
 // The 13 map bits [c - 6, c + 6] of one row given as its three words (ones outside the map: np.pad(..., 1),
@@ -254,7 +262,15 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t lo, uint32_t h
     if (!need_gen) return;
     uint32_t pos, goals, plan, tctr, navgoal, d2, nav2;
     uint32_t *gdir = NAV ? s.n_dirf + (size_t)e * kDirWords : nullptr;
+#if T2D_EXP == 9
+    __shared__ uint32_t gst[kWavesPerBlock][8];
+    if (lane == 0) gst[wave][6] = (uint32_t)__builtin_readcyclecounter();            // kernel entry of this wave (incl. prefetch)
+    generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2, nav2, gst[wave]);
+    wave_lds_sync();
+    if (lane == 0) { gst[wave][5] = (uint32_t)__builtin_readcyclecounter(); for (int i = 0; i < 7; i++) tile[246 + i] = gst[wave][i]; }
+#else
     generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2, nav2);
+#endif
     wave_lds_sync();
     reinterpret_cast<uint4 *>(s.n_maps + (size_t)e * kTileWords)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
     if (lane < 2 * T2D_WIN) {
@@ -1509,12 +1525,13 @@ extern "C" int t2d_get_target(t2d_handle *h, int first, int count, int32_t *plan
     return T2D_OK;
 }
 
-#if T2D_EXP == 6
+#if T2D_EXP == 6 || T2D_EXP == 9
 extern "C" int t2d_debug_tile_words(t2d_handle *h, uint32_t *out_host /* [n][256] */)
 {
     DeviceGuard guard(h->device);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out_host, h->s.maps, (size_t)h->s.n * kTileWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_host, T2D_EXP == 9 ? h->s.n_maps : h->s.maps, (size_t)h->s.n * kTileWords * sizeof(uint32_t),
+                      hipMemcpyDeviceToHost));
     return T2D_OK;
 }
 #endif

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.." && mkdir -p scratch_exp
 SRC="track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip driver_hip.hip np_mode.cpp"
 FL="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared"
 cd active_tracking_rl_amd/csrc
-for x in 5 6 7 8; do /opt/rocm/bin/hipcc $FL -DT2D_EXP=$x -o ../../scratch_exp/libexp$x.so $SRC & done
+for x in 5 6 7 8 9; do /opt/rocm/bin/hipcc $FL -DT2D_EXP=$x -o ../../scratch_exp/libexp$x.so $SRC & done
 /opt/rocm/bin/hipcc $FL -DT2D_EXP_NOMAZE -o ../../scratch_exp/libnomaze.so $SRC &
 wait
 ls -la ../../scratch_exp/*.so
