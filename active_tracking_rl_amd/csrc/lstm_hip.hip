@@ -63,6 +63,11 @@ template <bool ACT> __global__ __launch_bounds__(256) void k_lstm_cell_fwd(CellF
         const float k = a.keep ? a.keep[n] : (a.done ? (a.done[n] == 0 ? 1.0f : 0.0f) : 1.0f);
         const float *ig = a.ig[p] + (long long)n * 4 * a.R + j;
         const float *hg = a.hg + ((long long)p * a.N + n) * 4 * a.R + j;
+        float4 aw[kMaxActions];                 // ACT: this lane's slice of the actor head, fetched with everything else
+        if (ACT) {
+#pragma unroll
+            for (int q = 0; q < kMaxActions; q++) aw[q] = q < a.A ? ld4(a.actor_w + q * a.R + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         float4 pi = fma4(k, ld4(hg), ld4(ig));
         float4 pf = fma4(k, ld4(hg + a.R), ld4(ig + a.R));
         float4 pg = fma4(k, ld4(hg + 2 * a.R), ld4(ig + 2 * a.R));
@@ -92,7 +97,7 @@ template <bool ACT> __global__ __launch_bounds__(256) void k_lstm_cell_fwd(CellF
             for (int q = 0; q < kMaxActions; q++) {
                 logit[q] = 0.f;
                 if (q < a.A) {
-                    const float4 w = ld4(a.actor_w + q * a.R + j);
+                    const float4 w = aw[q];
                     logit[q] = fmaf(h.x, w.x, fmaf(h.y, w.y, fmaf(h.z, w.z, h.w * w.w)));
                 }
             }
