@@ -33,6 +33,10 @@
 
 #include "../../include/atr_policy.h"
 
+#ifndef ATR_EXP
+#define ATR_EXP 0
+#endif
+
 namespace atr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -71,6 +75,9 @@ __global__ __launch_bounds__(256, 1) void k_actor_step(ActorStep a)
     const int u0 = sl * kUnits;
     const int row0 = rb * kRowsPerWg + wave * 32;
     if (row0 >= a.N) return;                               // no barrier anywhere: a wave may leave alone
+    // ATR_EXP == 1 (probe build only, tools/actor_step_timeline.py): s_memtime stamps of this wave
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    if (ATR_EXP == 1) ts0 = __builtin_readcyclecounter();
 
     // ---- per-row inputs of the cell, first half: the tracker-action indices (their dependent embedding loads follow
     // after the operand prefetch, so nothing here drains the load queue). This lane ends up with rows
@@ -180,6 +187,7 @@ __global__ __launch_bounds__(256, 1) void k_actor_step(ActorStep a)
 
     const float akeep = (has_done && adone != 0) ? 0.0f : 1.0f;
     const float *rd = mybuf + jj * kLs + 4 * kk;           // MFMA layout: lane (row / column jj, K slot kk)
+    if (ATR_EXP == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts1 = __builtin_readcyclecounter(); }
 #pragma unroll
     for (int blk = 0; blk < kBlocks; blk++) {
         if (blk + 1 < kBlocks) ATR_STORE_BLOCK(blk + 1);   // block blk + 1 (in registers since the previous iteration) -> LDS
@@ -211,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void k_actor_step(ActorStep a)
     for (int T = 0; T < 2; T++)
 #pragma unroll
         for (int r = 0; r < 16; r++) accs[T][r] = acc[T][0][r] + acc[T][1][r];
+    if (ATR_EXP == 1) { asm volatile("" :: "v"(accs[0][0]), "v"(accs[1][15])); ts2 = __builtin_readcyclecounter(); }
 
     // ---- gather the four gates of each (row, unit): lane jj < 16 holds (i, g), its partner jj + 16 holds (f, o).
     // Exchange k: the low lane sends its row-8+k values and receives the partner's row-k values, and vice versa.
@@ -239,6 +248,14 @@ __global__ __launch_bounds__(256, 1) void k_actor_step(ActorStep a)
                 float *ac = a.acts + (size_t)row * (4 * kR) + u;
                 ac[0] = si; ac[kR] = sf; ac[2 * kR] = tg; ac[3 * kR] = so;
             }
+        }
+    }
+    if (ATR_EXP == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts3 = __builtin_readcyclecounter();
+        if (l == 0 && sl == 0 && a.acts) {      // parked in the gate store of the wave's first row (the probe reads them back)
+            unsigned *dbg = reinterpret_cast<unsigned *>(a.acts + (size_t)row0 * (4 * kR));
+            dbg[0] = (unsigned)ts0; dbg[1] = (unsigned)ts1; dbg[2] = (unsigned)ts2; dbg[3] = (unsigned)ts3;
         }
     }
 }

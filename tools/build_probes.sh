@@ -8,5 +8,6 @@ FL="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared"
 cd active_tracking_rl_amd/csrc
 for x in 5 6 7 8 9; do /opt/rocm/bin/hipcc $FL -DT2D_EXP=$x -o ../../scratch_exp/libexp$x.so $SRC & done
 /opt/rocm/bin/hipcc $FL -DT2D_EXP_NOMAZE -o ../../scratch_exp/libnomaze.so $SRC &
+/opt/rocm/bin/hipcc $FL -DATR_EXP=1 -o ../../scratch_exp/libatrexp1.so $SRC &
 wait
 ls -la ../../scratch_exp/*.so
