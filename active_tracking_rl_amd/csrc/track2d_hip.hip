@@ -925,6 +925,7 @@ struct DeviceGuard {
 
 extern "C" const char *t2d_last_error(void) { return g_err; }
 extern "C" int t2d_abi_version(void) { return T2D_ABI_VERSION; }
+extern "C" int t2d_config_size(void) { return (int)sizeof(t2d_config); }
 
 extern "C" int t2d_num_envs(const t2d_handle *h) { return h ? h->s.n : T2D_ERR_INVALID; }
 

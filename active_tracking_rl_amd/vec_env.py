@@ -42,7 +42,7 @@ _lib = None
 
 # every symbol include/track2d.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
-    "t2d_last_error", "t2d_abi_version", "t2d_create", "t2d_destroy", "t2d_num_envs", "t2d_reset", "t2d_step",
+    "t2d_last_error", "t2d_abi_version", "t2d_config_size", "t2d_create", "t2d_destroy", "t2d_num_envs", "t2d_reset", "t2d_step",
     "t2d_observe", "t2d_inject", "t2d_inject_plan", "t2d_get_state", "t2d_get_maps", "t2d_get_target",
     "t2d_get_faults", "t2d_step_u8", "t2d_step_random", "t2d_rollout_random", "t2d_reward_table", "t2d_flush",
     "t2d_generator_async", "t2d_generator_join", "t2d_generator_cycle",
@@ -83,6 +83,9 @@ def load_library():
     L.t2d_generator_join.argtypes = [vp, vp]
     L.t2d_generator_cycle.restype = i32
     L.t2d_generator_cycle.argtypes = [vp]
+    L.t2d_config_size.restype = i32
+    if L.t2d_config_size() != C.sizeof(_Config):
+        raise T2DError("t2d_config is %d bytes in the library, %d in this binding" % (L.t2d_config_size(), C.sizeof(_Config)))
     L.t2d_inject.restype = i32
     L.t2d_inject.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.t2d_inject_plan.restype = i32

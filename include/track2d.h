@@ -86,6 +86,7 @@ typedef struct {
 
 const char *t2d_last_error(void);
 int t2d_abi_version(void);
+int t2d_config_size(void);   /* sizeof(t2d_config) as the library was built: a binding checks its struct against it */
 
 /* create_env(env_id, args) / Track1v1Env.__init__ — environment.py:11-32, G/envs/track_1v1.py:14-69 */
 int t2d_create(const t2d_config *cfg, t2d_handle **out);

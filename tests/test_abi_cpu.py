@@ -27,6 +27,8 @@ def test_library_exports_every_declared_symbol():
     assert sorted(vec_env.ABI_SYMBOLS) == syms
     lib.t2d_abi_version.restype = ctypes.c_int
     assert lib.t2d_abi_version() == vec_env.ABI_VERSION
+    lib.t2d_config_size.restype = ctypes.c_int
+    assert lib.t2d_config_size() == ctypes.sizeof(vec_env._Config) == 64      # action_type sits in former padding
     # the other two headers of the boundary: policy-side kernels and the reference-exact episode source
     from active_tracking_rl_amd import np_mode
     np_syms = _header_symbols("track2d_np.h", "t2d_np_")
