@@ -305,6 +305,23 @@ __global__ __launch_bounds__(256) void k_nav_prefetch(DevState s)
     nav_prefetch(s, e, tiles[wave], lane);
 }
 
+// Parity hook: park a plan to a GIVEN goal in the prefetch slot of one Nav env (what k_nav_prefetch does with a goal it
+// draws itself, minus the draw): the env's next step adopts it if the target stands on its current goal (t2d_inject leaves
+// it there) and the goal is reachable.
+__global__ __launch_bounds__(64) void k_nav_inject_goal(DevState s, int e, uint32_t goal)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kTileWords];
+    const int lane = (int)threadIdx.x;
+    reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(s.maps + (size_t)e * kTileWords)[lane];
+    wave_lds_sync();
+    const int side = (int)(s.cnt[e] >> 24);
+    NavField nf;
+    const uint32_t cur = s.navgoal[e];
+    bfs_dir_field(tile, side, lane, (int)(goal & 0xffu), (int)(goal >> 8), nf, false, (int)(cur & 0xffu), (int)(cur >> 8));
+    store_plan_field(s.p_field + (size_t)e * kPlanWords, nf, side, lane);
+    if (lane == 0) { s.p_goal[e] = goal; s.p_tctr[e] = s.tctr[e]; s.p_state[e] = 1u; }
+}
+
 // _get_obs / _get_partial_obs (track_1v1.py:287-326) for ONE env by ONE wave. Lanes 0..51 each expand one half
 // row (7 + 6 cells) of the 2 x 13 crop rows from the LDS tile into an LDS staging row (bits -> bytes by a
 // multiply spread, agent marks, v_cvt_f32_ubyteN); then all 64 lanes stream the 338 floats out as coalesced
@@ -1439,6 +1456,22 @@ extern "C" int t2d_inject_plan(t2d_handle *h, int env, const int32_t *plan_host,
     if ((rc = quiesce(h, (hipStream_t)stream))) return rc;
     HIP_TRY(hipMemcpyAsync(h->s.plan + env, &p, sizeof(p), hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return T2D_OK;
+}
+
+extern "C" int t2d_inject_nav_goal(t2d_handle *h, int env, int goal_r, int goal_c, void *stream)
+{
+    int rc = check_range(h, env, 1, "t2d_inject_nav_goal");
+    if (rc) return rc;
+    if (!h->has_navmode) return fail(T2D_ERR_INVALID, "t2d_inject_nav_goal: the handle has no Nav target");
+    if (goal_r < 0 || goal_c < 0 || goal_r >= T2D_MAX_SIDE || goal_c >= T2D_MAX_SIDE)
+        return fail(T2D_ERR_INVALID, "t2d_inject_nav_goal: goal (%d, %d)", goal_r, goal_c);
+    DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = quiesce(h, st))) return rc;
+    hipLaunchKernelGGL(k_nav_inject_goal, dim3(1), dim3(64), 0, st, h->s, env, (uint32_t)goal_r | ((uint32_t)goal_c << 8));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
     return T2D_OK;
 }
 

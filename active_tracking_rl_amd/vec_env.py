@@ -43,7 +43,7 @@ _lib = None
 # every symbol include/track2d.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "t2d_last_error", "t2d_abi_version", "t2d_config_size", "t2d_create", "t2d_destroy", "t2d_num_envs", "t2d_reset", "t2d_step",
-    "t2d_observe", "t2d_inject", "t2d_inject_plan", "t2d_get_state", "t2d_get_maps", "t2d_get_target",
+    "t2d_observe", "t2d_inject", "t2d_inject_plan", "t2d_inject_nav_goal", "t2d_get_state", "t2d_get_maps", "t2d_get_target",
     "t2d_get_faults", "t2d_step_u8", "t2d_step_random", "t2d_rollout_random", "t2d_reward_table", "t2d_flush",
     "t2d_generator_async", "t2d_generator_join", "t2d_generator_cycle",
 )
@@ -325,6 +325,12 @@ class VecTrack2D(object):
     def inject_plan(self, env, plan, cursor=0):
         plan = np.ascontiguousarray(plan, np.int32)
         _check(self.L.t2d_inject_plan(self.h, int(env), _np_ptr(plan), len(plan), int(cursor), self._stream()))
+
+    def inject_nav_goal(self, env, goal):
+        """Nav target of `env`: plan to `goal` (r, c) at the next step instead of to a self-drawn cell (after inject)."""
+        self.L.t2d_inject_nav_goal.restype = C.c_int
+        self.L.t2d_inject_nav_goal.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _check(self.L.t2d_inject_nav_goal(self.h, int(env), int(goal[0]), int(goal[1]), self._stream()))
 
     def get_state(self, first=0, count=None):
         count = self.num_envs - first if count is None else count

@@ -146,6 +146,10 @@ int t2d_inject(t2d_handle *h, int first, int count, int side, const uint8_t *maz
                const int32_t *pos_host, const int32_t *goals_host, void *stream);
 /* Ram target plan injection for one env: len in [1,10], actions 0..3. Synchronises. */
 int t2d_inject_plan(t2d_handle *h, int env, const int32_t *plan_host, int len, int cursor, void *stream);
+/* Nav target goal injection for one env (after t2d_inject): the target's next plan leads to (goal_r, goal_c) instead of a
+ * cell it would draw itself — Navigator.reset's plan to goal_states[1] (G/envs/navigator.py:43-63) with the reference's
+ * goal. Unreachable goals fall back to the target's own re-plan. Synchronises. */
+int t2d_inject_nav_goal(t2d_handle *h, int env, int goal_r, int goal_c, void *stream);
 
 /* State readback for tests/evaluators (synchronises). Any output pointer may be NULL.
  * pos/goals: [count][4]; maps: [count][82*82] u8 with row stride 82 (cells outside `side` are 0). */

@@ -623,3 +623,54 @@ def test_async_generator_is_bit_identical_to_the_in_order_one(env_id, max_steps)
         assert np.array_equal(sa[k], sb[k]), k
     assert np.array_equal(a.get_maps(), b.get_maps())
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_device_ram_and_nav_targets_follow_reference_plans(vec, golden_episodes):
+    """The device's OWN scripted-target code on reference data (not just the injected `act_applied` stream):
+    Ram — the reference's first plan (`plan0`, RamAgent.reset, navigator.py:90-93) injected with t2d_inject_plan: until its
+    last entry (which RamAgent.step may overwrite, :81-83) the device's target must move exactly as the reference's did;
+    Nav — the reference's first goal (`navgoal0`, Navigator.reset, navigator.py:43-63) injected with t2d_inject_nav_goal:
+    the device's target, following its BFS direction field on the reference's map, reaches it in exactly len(plan0)
+    steps — the length of the reference's A* plan — moving one cell every step."""
+    g = golden_episodes
+    checked_ram = checked_nav = 0
+    for name in [str(n) for n in g["names"]]:
+        mp, mode, lvl, seed, _ = [str(x) for x in g[name + "/meta"]]
+        if mode not in ("Ram", "Nav"):
+            continue
+        for ep in range(int(g[name + "/n_eps"])):
+            p = "%s/ep%d_" % (name, ep)
+            maze = unpack_maze(g[p + "maze"], g[p + "side"])
+            side = int(g[p + "side"])
+            plan0 = g[p + "plan0"]
+            env = vec.VecTrack2D(num_envs=1, map_type=mp, target_mode=mode, level=int(lvl), auto_reset=False,
+                                 max_episode_steps=500)
+            env.inject(maze[None], g[p + "init"].reshape(1, 4))
+            if mode == "Ram":
+                env.inject_plan(0, plan0)
+                n = min(len(plan0) - 1, len(g[p + "act_applied"]))
+                for t in range(n):
+                    a0 = torch.tensor([int(g[p + "act_applied"][t, 0])], device="cuda")
+                    obs, rew, done = env.step(a0, a0)        # the target's action argument is ignored: the plan decides
+                    assert int(g[p + "act_applied"][t, 1]) == int(plan0[t])
+                    assert np.array_equal(env.get_state()["pos"][0], g[p + "pos"][t]), (p, t)
+                    assert np.array_equal(obs.cpu().numpy()[0], g[p + "obs"][t].astype(np.float32)), (p, t)
+                    assert np.array_equal(rew.cpu().numpy()[0], g[p + "rew"][t].astype(np.float32)), (p, t)
+                    checked_ram += 1
+            else:
+                goal = g[p + "navgoal0"].reshape(-1)[:2]
+                env.inject_nav_goal(0, goal)
+                a0 = torch.zeros(1, dtype=torch.int64, device="cuda")
+                prev = env.get_state()["pos"][0, 1].copy()
+                for t in range(len(plan0)):
+                    env.step(a0, a0)
+                    cur = env.get_state()["pos"][0, 1]
+                    assert abs(int(cur[0]) - int(prev[0])) + abs(int(cur[1]) - int(prev[1])) == 1, (p, t)   # never bumps
+                    assert maze[cur[0], cur[1]] == 0
+                    assert (t == len(plan0) - 1) == bool(np.array_equal(cur, goal)), (p, t, cur, goal)
+                    prev = cur.copy()
+                    checked_nav += 1
+            assert env.faults() == 0
+            env.close()
+    assert checked_ram >= 40 and checked_nav >= 200
