@@ -422,6 +422,14 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
     uint32_t plan = 0, tctr = 0, navgoal = 0, d2 = 0, episode = 0;
     const int mode = (int)((cfg >> 2) & 7u);
     if (MULTI) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }   // carried in registers across steps
+    // Nav / RPF handles: the scripted target's state rides in the FIRST batch of loads (it was fetched inside the mode
+    // branch, one dependent round trip later), so that only the direction word — whose address needs the position —
+    // is left for a second one
+    uint32_t nv_plan = 0, nv_tctr = 0, nv_goal = 0, nv_nav2 = 0, nv_episode = 0, nv_pstate = 0;
+    if (NAV && OP == OP_STEP) {
+        nv_plan = s.plan[e]; nv_tctr = s.tctr[e]; nv_goal = s.navgoal[e]; nv_nav2 = s.nav2[e]; nv_episode = s.episode[e];
+        nv_pstate = s.p_state[e];
+    }
     wave_lds_sync();
 
   for (int k = 0; k < (MULTI ? nsteps : 1); k++) {
@@ -451,12 +459,12 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
         int r0 = (int)(pos & 0xffu), c0 = (int)((pos >> 8) & 0xffu);
         int r1 = (int)((pos >> 16) & 0xffu), c1 = (int)(pos >> 24);
         if (NAV && (mode == TGT_NAV || mode == TGT_RPF)) { // track_1v1.py:83-84 -> Navigator.step(old_state[1], ...) (navigator.py:11-41)
-            plan = s.plan[e]; tctr = s.tctr[e]; navgoal = s.navgoal[e];
+            plan = nv_plan; tctr = nv_tctr; navgoal = nv_goal;
             const bool rpf = mode == TGT_RPF;
-            uint32_t nav2 = rpf ? s.nav2[e] : 0u;
+            uint32_t nav2 = rpf ? nv_nav2 : 0u;
             uint32_t *gdir = s.dirf + (size_t)e * kDirWords;
             Stream ts;
-            ts.init(s.k0, s.k1, s.episode[e], genv, STREAM_TARGET, tctr);
+            ts.init(s.k0, s.k1, nv_episode, genv, STREAM_TARGET, tctr);
             bool planb = ((plan >> 28) & 1u) != 0u;
             // RPF: the plan is an open-loop action list made on the generator's map (the env may hold walls on the
             // patrol cells): follow the field from a virtual position for exactly the planned number of steps
@@ -464,15 +472,16 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
                                    : rpf ? (((nav2 >> 16) & 0x3fffu) == 0u)
                                          : (r1 == (int)(navgoal & 0xffu) && c1 == (int)(navgoal >> 8));
             int qr = rpf ? (int)(nav2 & 0xffu) : r1, qc = rpf ? (int)((nav2 >> 8) & 0xffu) : c1;
+            const uint32_t dir_here = load_dir(gdir, qr, qc);      // issued now, used if the current plan still stands
             uint32_t dir = 0;
             bool adopted = false, have_goal = false;
-            if (exhausted && !rpf && s.p_state[e] == 1u) {
+            if (exhausted && !rpf && nv_pstate == 1u) {
                 // a plan for the next goal was prepared by the generator pass (k_gen): adopt it if it is a valid plan
                 // from here (reachable, not already on the goal) — else fall through to the inline re-plan, which
                 // then starts from the same already-drawn goal
                 const uint32_t *pf = s.p_field + (size_t)e * kPlanWords;
                 const uint32_t g2 = s.p_goal[e];
-                ts.init(s.k0, s.k1, s.episode[e], genv, STREAM_TARGET, s.p_tctr[e]);
+                ts.init(s.k0, s.k1, nv_episode, genv, STREAM_TARGET, s.p_tctr[e]);
                 navgoal = g2;
                 have_goal = true;
                 if (load_vis(pf, r1, c1) != 0u && !(r1 == (int)(g2 & 0xffu) && c1 == (int)(g2 >> 8))) {
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
                 if (!planb) { store_dir_field(gdir, nf, side, lane); dir = nav_dir_from_regs(nf, qr, qc); }
                 navgoal_dirty = true;
             } else if (!planb && !adopted) {
-                dir = load_dir(gdir, qr, qc);
+                dir = dir_here;
             }
             if (rpf && !planb) {   // advance the virtual position along the field, one planned step consumed
                 qr += dir == 0u ? -1 : (dir == 1u ? 1 : 0); qc += dir == 2u ? -1 : (dir == 3u ? 1 : 0);
