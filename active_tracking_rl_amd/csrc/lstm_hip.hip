@@ -44,8 +44,9 @@ struct CellFwd {
     // categorical draw on the fresh hidden row (R/4 lanes of one wave hold a row)
     const float *emb;          // nullable: [n_in, 4R] rows added to the pre-activations, row = act_in[n]
     const long long *act_in;
-    const float *actor_w, *actor_b;   // [A, R], [A]
-    long long *actions_out;    // [N]
+    const float *actor_w[2], *actor_b[2];   // per player: [A, R], [A]
+    long long *actions_out;    // + p * N
+    const float *bias[2];      // nullable, per player [4R]: added to the pre-activations (ig then comes from a bias-free bmm)
     const unsigned long long *counter;
     unsigned long long seed;
     unsigned ordinal;
@@ -66,12 +67,17 @@ template <bool ACT> __global__ __launch_bounds__(256) void k_lstm_cell_fwd(CellF
         float4 aw[kMaxActions];                 // ACT: this lane's slice of the actor head, fetched with everything else
         if (ACT) {
 #pragma unroll
-            for (int q = 0; q < kMaxActions; q++) aw[q] = q < a.A ? ld4(a.actor_w + q * a.R + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < kMaxActions; q++) aw[q] = q < a.A ? ld4(a.actor_w[p] + q * a.R + j) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float4 pi = fma4(k, ld4(hg), ld4(ig));
         float4 pf = fma4(k, ld4(hg + a.R), ld4(ig + a.R));
         float4 pg = fma4(k, ld4(hg + 2 * a.R), ld4(ig + 2 * a.R));
         float4 po = fma4(k, ld4(hg + 3 * a.R), ld4(ig + 3 * a.R));
+        if (ACT && a.bias[p]) {
+            const float *bb = a.bias[p] + j;
+            pi = fma4(1.0f, ld4(bb), pi); pf = fma4(1.0f, ld4(bb + a.R), pf);
+            pg = fma4(1.0f, ld4(bb + 2 * a.R), pg); po = fma4(1.0f, ld4(bb + 3 * a.R), po);
+        }
         if (ACT && a.emb) {
             const float *e = a.emb + a.act_in[n] * 4 * a.R + j;
             pi = fma4(1.0f, ld4(e), pi); pf = fma4(1.0f, ld4(e + a.R), pf);
@@ -107,8 +113,9 @@ template <bool ACT> __global__ __launch_bounds__(256) void k_lstm_cell_fwd(CellF
                     if (q < a.A) logit[q] += __shfl_xor(logit[q], msk, 64);
             if (j == 0) {
 #pragma unroll
-                for (int q = 0; q < kMaxActions; q++) logit[q] = q < a.A ? logit[q] + a.actor_b[q] : -INFINITY;
-                a.actions_out[n] = (long long)draw_action(logit, a.A, n, *a.counter, a.seed, a.ordinal);
+                for (int q = 0; q < kMaxActions; q++) logit[q] = q < a.A ? logit[q] + a.actor_b[p][q] : -INFINITY;
+                // player p draws under ordinal + p: the same numbers as two one-player launches with consecutive ordinals
+                a.actions_out[(long long)p * a.N + n] = (long long)draw_action(logit, a.A, n, *a.counter, a.seed, a.ordinal + (unsigned)p);
             }
         }
     }
@@ -223,7 +230,8 @@ extern "C" int atr_lstm_cell_forward(const float *ig0, const float *ig1, const f
     a.ig[0] = ig0; a.ig[1] = ig1; a.hg = hg; a.c_prev = c_prev; a.c_prev_ps = c_prev_pstride; a.keep = keep; a.done = done;
     a.h_out = h_out; a.c_out = c_out; a.h_ps = h_pstride; a.c_ps = c_pstride; a.acts = acts; a.acts_ps = acts_pstride;
     a.P = P; a.N = N; a.R = R;
-    a.emb = nullptr; a.act_in = nullptr; a.actor_w = nullptr; a.actor_b = nullptr; a.actions_out = nullptr;
+    a.emb = nullptr; a.act_in = nullptr; a.actor_w[0] = a.actor_w[1] = nullptr; a.actor_b[0] = a.actor_b[1] = nullptr;
+    a.actions_out = nullptr; a.bias[0] = a.bias[1] = nullptr;
     a.counter = nullptr; a.seed = 0; a.ordinal = 0; a.A = 0;
     hipLaunchKernelGGL(k_lstm_cell_fwd<false>, dim3(grid_for((long long)P * N * (R / 4))), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -243,9 +251,34 @@ extern "C" int atr_lstm_cell_forward_act(const float *ig, const float *hg, const
     CellFwd a;
     a.ig[0] = ig; a.ig[1] = nullptr; a.hg = hg; a.c_prev = c_prev; a.c_prev_ps = 0; a.keep = nullptr; a.done = done;
     a.h_out = h_out; a.c_out = c_out; a.h_ps = 0; a.c_ps = 0; a.acts = acts; a.acts_ps = 0; a.P = 1; a.N = N; a.R = R;
-    a.emb = emb; a.act_in = act_in; a.actor_w = actor_w; a.actor_b = actor_b; a.actions_out = actions_out;
+    a.emb = emb; a.act_in = act_in; a.actor_w[0] = actor_w; a.actor_w[1] = nullptr; a.actor_b[0] = actor_b; a.actor_b[1] = nullptr;
+    a.actions_out = actions_out; a.bias[0] = a.bias[1] = nullptr;
     a.counter = counter; a.seed = seed; a.ordinal = ordinal; a.A = A;
     hipLaunchKernelGGL(k_lstm_cell_fwd<true>, dim3(grid_for((long long)N * rq)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int atr_lstm_cell_forward_act2(const float *ig, const float *hg, const float *bias0, const float *bias1,
+                                          const float *c_prev, long long c_prev_pstride, const unsigned char *done,
+                                          float *h_out, long long h_pstride, float *c_out, long long c_pstride, float *acts,
+                                          long long acts_pstride, const float *actor_w0, const float *actor_b0,
+                                          const float *actor_w1, const float *actor_b1, int A, long long *actions_out,
+                                          const unsigned long long *counter, unsigned long long seed, unsigned ordinal,
+                                          int N, int R, void *stream)
+{
+    const int rq = R / 4;
+    if (!ig || !hg || !c_prev || !h_out || !c_out || !actor_w0 || !actor_b0 || !actor_w1 || !actor_b1 || !actions_out ||
+        !counter || N < 0 || R <= 0 || (R & 3) || (rq != 16 && rq != 32 && rq != 64) || A < 1 || A > kMaxActions)
+        return -1;
+    if (N == 0) return 0;
+    CellFwd a;
+    a.ig[0] = ig; a.ig[1] = ig + (size_t)N * 4 * R; a.hg = hg; a.c_prev = c_prev; a.c_prev_ps = c_prev_pstride;
+    a.keep = nullptr; a.done = done; a.h_out = h_out; a.c_out = c_out; a.h_ps = h_pstride; a.c_ps = c_pstride;
+    a.acts = acts; a.acts_ps = acts_pstride; a.P = 2; a.N = N; a.R = R;
+    a.emb = nullptr; a.act_in = nullptr; a.actor_w[0] = actor_w0; a.actor_w[1] = actor_w1; a.actor_b[0] = actor_b0;
+    a.actor_b[1] = actor_b1; a.actions_out = actions_out; a.bias[0] = bias0; a.bias[1] = bias1;
+    a.counter = counter; a.seed = seed; a.ordinal = ordinal; a.A = A;
+    hipLaunchKernelGGL(k_lstm_cell_fwd<true>, dim3(grid_for((long long)2 * N * rq)), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

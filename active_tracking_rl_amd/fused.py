@@ -44,6 +44,9 @@ def lib():
         L.atr_lstm_cell_forward.argtypes = [vp, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp]
         L.atr_lstm_cell_forward_act.restype = i32
         L.atr_lstm_cell_forward_act.argtypes = [vp] * 11 + [i32, vp, vp, C.c_ulonglong, C.c_uint, i32, i32, vp]
+        L.atr_lstm_cell_forward_act2.restype = i32
+        L.atr_lstm_cell_forward_act2.argtypes = [vp] * 5 + [ll, vp, vp, ll, vp, ll, vp, ll] + [vp] * 4 + [i32, vp, vp,
+                                                 C.c_ulonglong, C.c_uint, i32, i32, vp]
         L.atr_actor_step.restype = i32
         L.atr_actor_step.argtypes = [vp] * 12 + [i32, i32, i32, vp]
         L.atr_lstm_cell_backward.restype = i32
@@ -421,6 +424,27 @@ def lstm_cell_into(ig, hg, c_prev, done, h_out, c_out, acts):
                                      _p(acts), 0, 1, N, R, _stream(ig))
     if rc != 0:
         raise RuntimeError("atr_lstm_cell_forward failed (%d)" % rc)
+
+
+@torch.no_grad()
+def lstm_cell_act2_into(ig, hg, biases, c_prev, done, h_out, c_out, acts, sampler, actors, actions_out):
+    """Both players' actor step after the GEMMs in ONE launch (players independent of each other's action): ig / hg
+    [2,N,4R] (ig without bias), biases = (b0, b1) [4R] each, c_prev / h_out / c_out [2,N,R] and acts [2,N,4R] views with
+    a player stride, actions_out [2,N] int64 contiguous. Only valid inside sampler.begin_block(); consumes two ordinals."""
+    P, N, R = c_prev.shape
+    assert P == 2 and sampler._ordinal is not None and ig.is_contiguous() and hg.is_contiguous() and actions_out.is_contiguous()
+    for t in (c_prev, h_out, c_out, acts):
+        assert t.stride(-1) == 1 and t.stride(-2) == t.shape[-1]
+    ordinal = sampler._ordinal + 1
+    sampler._ordinal += 2
+    rc = lib().atr_lstm_cell_forward_act2(
+        _p(ig), _p(hg), _p(biases[0]), _p(biases[1]), _p(c_prev), c_prev.stride(0), _pn(done), _p(h_out), h_out.stride(0),
+        _p(c_out), c_out.stride(0), _pn(acts), acts.stride(0) if acts is not None else 0, _p(actors[0].weight),
+        _p(actors[0].bias), _p(actors[1].weight), _p(actors[1].bias), actors[0].weight.shape[0], _p(actions_out),
+        _p(sampler.counter), sampler.seed, ordinal, N, R, _stream(ig))
+    if rc != 0:
+        raise RuntimeError("atr_lstm_cell_forward_act2 failed (%d)" % rc)
+    return actions_out
 
 
 @torch.no_grad()

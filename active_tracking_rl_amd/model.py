@@ -582,7 +582,12 @@ class A3C_Dueling(nn.Module):
         c = RolloutCache()
         c.T, c.N, c.frames = T, N, frames
         c.y = [torch.empty((T, N * f, 512), device=dev) for f in frames]
-        c.f = [torch.empty((T, N, p.encoder.outdim), device=dev) for p in (p0, p1)]
+        if p0.encoder.outdim == p1.encoder.outdim:      # one [2, T, N, F] store: a step's pair of rows is one strided batch
+            c.f_all = torch.empty((2, T, N, p0.encoder.outdim), device=dev)
+            c.f = [c.f_all[0], c.f_all[1]]
+        else:
+            c.f_all = None
+            c.f = [torch.empty((T, N, p.encoder.outdim), device=dev) for p in (p0, p1)]
         c.feat1 = torch.empty((T, N, p1.encoder.outdim), device=dev) if self.tat else None
         c.acts = torch.empty((2, T, N, 4 * R), device=dev)
         c.h_all = torch.empty((2, T + 1, N, R), device=dev)
@@ -590,6 +595,8 @@ class A3C_Dueling(nn.Module):
         c.actions = torch.empty((T, 2, N), dtype=torch.int64, device=dev) if self.fused_sampling else None
         c.bsum = [l.bias_ih + l.bias_hh for l in (p0.lstm, p1.lstm)]
         c.whh_t = torch.stack([l.weight_hh.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, R, 4R]
+        c.wih_t = (torch.stack([l.weight_ih.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, F, 4R]: the pair's input GEMM as one bmm
+                   if (not self.tat and c.f_all is not None and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape) else None)
         if self.tat:
             fa = p1.fc_action_tracker
             c.emb = fa.weight.t() + fa.bias                        # row a = fc_action_tracker(one_hot(a))
@@ -603,7 +610,8 @@ class A3C_Dueling(nn.Module):
         return self._act_step(states, cache, [cache.y[0][t], cache.y[1][t]], [cache.f[0][t], cache.f[1][t]],
                               cache.feat1[t] if cache.feat1 is not None else None,
                               cache.h_all[:, t], cache.c_all[:, t], cache.h_all[:, t + 1], cache.c_all[:, t + 1],
-                              cache.acts[:, t], cache.actions[t] if cache.actions is not None else None, done)
+                              cache.acts[:, t], cache.actions[t] if cache.actions is not None else None, done,
+                              f_pair=cache.f_all[:, t] if cache.f_all is not None else None)
 
     @torch.no_grad()
     def boot_values(self, states, cache, done, v_out):
@@ -617,19 +625,20 @@ class A3C_Dueling(nn.Module):
             b = cache.boot = RolloutCache()
             dev, N, R = states.device, cache.N, cache.h_all.shape[-1]
             b.y = [torch.empty_like(cache.y[i][0]) for i in range(2)]
-            b.f = [torch.empty_like(cache.f[i][0]) for i in range(2)]
+            b.f_all = torch.empty_like(cache.f_all[:, 0]) if cache.f_all is not None else None
+            b.f = [b.f_all[0], b.f_all[1]] if b.f_all is not None else [torch.empty_like(cache.f[i][0]) for i in range(2)]
             b.feat1 = torch.empty_like(cache.feat1[0]) if cache.feat1 is not None else None
             b.h, b.c = torch.empty((2, N, R), device=dev), torch.empty((2, N, R), device=dev)
             b.acts = torch.empty((2, N, 4 * R), device=dev)
             b.actions = torch.empty((2, N), dtype=torch.int64, device=dev) if cache.actions is not None else None
         T = cache.T
         self._act_step(states, cache, b.y, b.f, b.feat1, cache.h_all[:, T], cache.c_all[:, T], b.h, b.c, b.acts, b.actions,
-                       done)
+                       done, f_pair=b.f_all)
         for i, p in enumerate((self.player0, self.player1)):
             fused.heads_values(b.h[i], p.critic.critic_linear, v_out, i)
         return v_out
 
-    def _act_step(self, states, cache, y, f_out, feat1, h_prev, c_prev, h_out, c_out, acts, actions, done):
+    def _act_step(self, states, cache, y, f_out, feat1, h_prev, c_prev, h_out, c_out, acts, actions, done, f_pair=None):
         """One actor step of both players on explicit buffers: y / f_out per-player stem and fc outputs, h_prev / c_prev
         [2,N,R] (un-masked; `done` [N] uint8 of the previous step is applied inside), h_out / c_out [2,N,R], acts
         [2,N,4R] (activated gates), actions [2,N] int64 or None."""
@@ -655,6 +664,16 @@ class A3C_Dueling(nn.Module):
         hgs = None if mfma_step else torch.bmm(h_prev, cache.whh_t)
         one_launch = (actions is not None and self._sampler._ordinal is not None and R // 4 in (16, 32, 64)
                       and p0.actor.actor_linear.weight.shape[0] <= 8 and p1.actor.actor_linear.weight.shape[0] <= 8)
+        # players that do not see each other's action (maze-lstm pairs): both input projections as ONE batched GEMM on
+        # the pair's feature rows and both cells + heads + draws as ONE launch — 7 launches per env step instead of 9
+        if (one_launch and not mfma_step and not self.tat and f_pair is not None and getattr(cache, "wih_t", None) is not None
+                and p0.actor.actor_linear.weight.shape == p1.actor.actor_linear.weight.shape):
+            for i, p in enumerate((p0, p1)):
+                _addmm_relu(p.encoder.fc.bias, ys[i].view(n, -1), p.encoder.fc.weight.t(), f_out[i])
+            ig = torch.bmm(f_pair, cache.wih_t)
+            fused.lstm_cell_act2_into(ig, hgs, cache.bsum, c_prev, done, h_out, c_out, acts, self._sampler,
+                                      (p0.actor.actor_linear, p1.actor.actor_linear), actions)
+            return [actions[0], actions[1]]
         for i, p in enumerate((p0, p1)):
             enc = p.encoder
             f = _addmm_relu(enc.fc.bias, ys[i].view(n, -1), enc.fc.weight.t(), f_out[i])

@@ -78,6 +78,16 @@ int atr_lstm_cell_forward_act(const float *ig, const float *hg, const float *c_p
                               const float *actor_w, const float *actor_b, int A, long long *actions_out,
                               const unsigned long long *counter, unsigned long long seed, unsigned ordinal, int N,
                               int R, void *stream);
+/* The same for BOTH players of a model whose players do not depend on each other's action (maze-lstm pairs), one launch:
+ * ig [2,N,4R] = the two input projections WITHOUT bias (one batched GEMM), bias0 / bias1 [4R] (b_ih + b_hh, nullable)
+ * added here, hg [2,N,4R]; per-player strides for the state / gate stores as in atr_lstm_cell_forward; actions_out [2,N];
+ * player p draws under ordinal + p (the numbers two one-player calls with consecutive ordinals would draw). */
+int atr_lstm_cell_forward_act2(const float *ig, const float *hg, const float *bias0, const float *bias1, const float *c_prev,
+                               long long c_prev_pstride, const unsigned char *done, float *h_out, long long h_pstride,
+                               float *c_out, long long c_pstride, float *acts, long long acts_pstride,
+                               const float *actor_w0, const float *actor_b0, const float *actor_w1, const float *actor_b1,
+                               int A, long long *actions_out, const unsigned long long *counter, unsigned long long seed,
+                               unsigned ordinal, int N, int R, void *stream);
 /* The actor's whole LSTMCell step for ONE player as one f32-MFMA kernel (csrc/actor_step_hip.hip): both GEMMs of
  * nn.LSTMCell (model.py:110,172 of the reference) and the cell, without materialising the gate pre-activations:
  *   gates = f W_ih^T + (k h_prev) W_hh^T + bias [+ emb[act_in[n]]],  k[n] = (done[n] == 0) (1 if done is NULL)

@@ -321,3 +321,33 @@ def test_actor_step_mfma_kernel_matches_lstmcell(N):
         h_t, c_t = lstm(f, (h, c))
     torch.testing.assert_close(h_out, h_t, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(c_out, c_t, rtol=2e-5, atol=2e-5)
+
+
+def test_two_player_actor_cell_kernel_equals_two_one_player_launches():
+    """atr_lstm_cell_forward_act2 (both players' cell + head + draw in one launch, bias added inside, strided per-player
+    stores) against two atr_lstm_cell_forward_act launches with consecutive ordinals: same states and gates to fp32
+    round-off (the bias joins the sum at a different place) and the same actions."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(3)
+    N, R, T = 777, 128, 3
+    lins = [torch.nn.Linear(R, 4).cuda() for _ in range(2)]
+    ig = torch.randn(2, N, 4 * R, device="cuda")
+    hg = torch.randn(2, N, 4 * R, device="cuda")
+    bias = [torch.randn(4 * R, device="cuda") * 0.3 for _ in range(2)]
+    c_all = torch.randn(2, T, N, R, device="cuda")                 # strided per-player views, as in the rollout cache
+    done = (torch.rand(N, device="cuda") < 0.3).to(torch.uint8)
+    sa, sb = fused.ActionSampler("cuda", seed=9), fused.ActionSampler("cuda", seed=9)
+    sa.begin_block(); sb.begin_block()
+    h2, c2, acts2 = torch.empty(2, T, N, R, device="cuda"), torch.empty(2, T, N, R, device="cuda"), torch.empty(2, T, N, 4 * R, device="cuda")
+    act2 = torch.empty(2, N, dtype=torch.int64, device="cuda")
+    fused.lstm_cell_act2_into(ig, hg, bias, c_all[:, 1], done, h2[:, 2], c2[:, 2], acts2[:, 2], sa, lins, act2)
+    for p in range(2):
+        h1, c1, a1 = torch.empty(N, R, device="cuda"), torch.empty(N, R, device="cuda"), torch.empty(N, 4 * R, device="cuda")
+        act1 = torch.empty(N, dtype=torch.int64, device="cuda")
+        fused.lstm_cell_act_into((ig[p] + bias[p]).contiguous(), hg[p].contiguous(), c_all[p, 1].contiguous(), done, h1, c1, a1,
+                                 sb, lins[p], act1)
+        torch.testing.assert_close(h2[p, 2], h1, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(c2[p, 2], c1, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(acts2[p, 2], a1, rtol=1e-5, atol=1e-6)
+        assert float((act2[p] == act1).float().mean()) > 0.995
+    assert sa._ordinal == sb._ordinal == 2
