@@ -387,12 +387,13 @@ class _LstmSeqCached(torch.autograd.Function):
     Inputs: per-player features [T*N,F] and LSTMCell parameters; output: per-player h_seq [T,N,R]."""
 
     @staticmethod
-    def forward(ctx, keep, h_all, c_all, acts, *fw):
+    def forward(ctx, keep, h_all, c_all, acts, need, *fw):
         P = h_all.shape[0]
         feats, wih, whh_l = fw[:P], fw[P:2 * P], fw[2 * P:3 * P]
         whh = torch.stack([w.t() for w in whh_l], 0).contiguous()
         ctx.save_for_backward(keep.contiguous(), h_all, c_all, acts, whh, *feats, *wih)
         ctx.P = P
+        ctx.need = tuple(bool(x) for x in need) if need is not None else (True,) * P
         return tuple(h_all[p, 1:] for p in range(P))
 
     @staticmethod
@@ -400,20 +401,28 @@ class _LstmSeqCached(torch.autograd.Function):
         P = ctx.P
         keep, h_all, c_all, acts, whh = ctx.saved_tensors[:5]
         feats, wih = ctx.saved_tensors[5:5 + P], ctx.saved_tensors[5 + P:5 + 2 * P]
-        dG, _, _, dwhh = _lstm_bptt(whh, keep, h_all, c_all, acts, dhs)
-        dfeat = [dG[p] @ wih[p] for p in range(P)]
-        pairs = [gemm_tn(dG[p], feats[p], colsum=True) for p in range(P)]
-        dwih, db = [a for a, _ in pairs], [b for _, b in pairs]
-        dwhh_l = [dwhh[p].t() for p in range(P)]
-        return (None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + tuple(db)
+        dfeat, dwih, db, dwhh_l = [None] * P, [None] * P, [None] * P, [None] * P
+        if all(ctx.need):
+            groups = [list(range(P))]
+        else:       # a player the loss does not train (train-mode 0 / 1): none of its recurrence is back-propagated
+            groups = [[p] for p in range(P) if ctx.need[p]]
+        for grp in groups:
+            a, b = grp[0], grp[-1] + 1
+            dG, _, _, dwhh = _lstm_bptt(whh[a:b], keep, h_all[a:b], c_all[a:b], acts[a:b], dhs[a:b])
+            for i, p in enumerate(grp):
+                dfeat[p] = dG[i] @ wih[p]
+                dwih[p], db[p] = gemm_tn(dG[i], feats[p], colsum=True)
+                dwhh_l[p] = dwhh[i].t()
+        return (None, None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + tuple(db)
 
 
-def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts):
-    """feats: per-player [T*N, F] (with grad); lstms: the nn.LSTMCells; stored activations from the rollout."""
+def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts, need=None):
+    """feats: per-player [T*N, F] (with grad); lstms: the nn.LSTMCells; stored activations from the rollout.
+    need: per player, whether anything upstream of its hidden sequence is trained (None = all)."""
     P = len(lstms)
     args = list(feats) + [l.weight_ih for l in lstms] + [l.weight_hh for l in lstms] + \
         [l.bias_ih for l in lstms] + [l.bias_hh for l in lstms]
-    return _LstmSeqCached.apply(keep, h_all, c_all, acts, *args)
+    return _LstmSeqCached.apply(keep, h_all, c_all, acts, need, *args)
 
 
 @torch.no_grad()

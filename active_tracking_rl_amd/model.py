@@ -699,7 +699,7 @@ class A3C_Dueling(nn.Module):
                 acts_out.append(sample(h_out[i], p.actor.actor_linear))
         return acts_out
 
-    def cached_hidden(self, cache, states_seq, actions_seq, keep):
+    def cached_hidden(self, cache, states_seq, actions_seq, keep, need=None):
         """The differentiable graph (stem -> fc -> [+ tracker-action embedding] -> LSTM) rebuilt around a cached
         rollout's stored activations: per-player hidden sequences [T, N, R] with autograd history, nothing evaluated
         forward."""
@@ -718,7 +718,7 @@ class A3C_Dueling(nn.Module):
                 a2t = F.one_hot(actions_seq[:, :, 0].reshape(T * N), self.action_dim_tracker).to(f.dtype)
                 f = f + p.fc_action_tracker(a2t)
             feats.append(f)
-        return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, cache.acts)
+        return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, cache.acts, need)
 
     def forward_sequence_cached(self, cache, states_seq, actions_seq, keep):
         """forward_sequence over a cached rollout: only the heads are evaluated forward; the backward pass is the

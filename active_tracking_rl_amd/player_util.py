@@ -335,7 +335,9 @@ class Agent(object):
         T, N, A = self._cache.T, self.num_envs, self.num_agents
         dev = self.device
         players = (model.player0, model.player1)
-        h_seq = model.cached_hidden(self._cache, states, actions, nd)        # per player [T, N, R], with history
+        # (train-mode 0 / 1: the other player's loss terms carry coefficient 0 — its recurrence is not back-propagated)
+        need = (training_mode != 1, training_mode != 0) if A == 2 else None
+        h_seq = model.cached_hidden(self._cache, states, actions, nd, need)   # per player [T, N, R], with history
         R_dim = h_seq[0].shape[-1]
         v = torch.empty((T + 1, N, A, 1), dtype=torch.float32, device=dev)
         with torch.no_grad():

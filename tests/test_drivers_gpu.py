@@ -148,12 +148,16 @@ def test_full_observation_env_trains():
     player.env.close()
 
 
-def test_cached_rollout_learner_matches_the_recompute_learner():
+@pytest.mark.parametrize("train_mode", [-1, 0, 1])
+def test_cached_rollout_learner_matches_the_recompute_learner(train_mode):
     """Actor/learner with the rollout cache (forward evaluated once, in the rollout: model.act_cached +
     forward_sequence_cached) against the recompute learner (forward_sequence) on the SAME rollout: loss terms and
-    every parameter gradient agree to fp32 round-off (different GEMM shapes -> different summation orders)."""
+    every parameter gradient agree to fp32 round-off (different GEMM shapes -> different summation orders). Train-mode
+    0 / 1: the cached learner does not back-propagate the untrained player's recurrence — its parameters get no (or an
+    all-zero) gradient from either learner."""
     from active_tracking_rl_amd.train import default_args, make_player, rollout
-    args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=256, num_steps=6, network="tat-maze-lstm", seed=11)
+    args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=256, num_steps=6, network="tat-maze-lstm", seed=11,
+                        train_mode=train_mode)
     args.gpu_ids = [0]
     player, optimizer = make_player(args, torch.device("cuda:0"), 0, 1)
     assert player.cache_rollout
@@ -286,13 +290,14 @@ def test_fused_rmsprop_and_torch_form_adam_match_the_tensor_expressions():
 def _check_grads(ga, gb):
     n_checked = 0
     for a, b in zip(ga, gb):
-        assert (a is None) == (b is None)
-        if a is None:
+        if a is None or b is None:          # "no gradient" and "all-zero gradient" are the same statement
+            other = b if a is None else a
+            assert other is None or float(other.abs().max()) == 0.0
             continue
         scale = float(b.abs().max()) + 1e-7
         assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (a.shape, float((a - b).abs().max()), scale)
         n_checked += 1
-    assert n_checked >= 20
+    assert n_checked >= 10
 
 
 def test_rescale_wrapper_matches_the_reference_formula():
