@@ -8,7 +8,10 @@ from torch.profiler import ProfilerActivity, profile
 
 from active_tracking_rl_amd.train import default_args, make_player, rollout
 
-args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=4096, network="tat-maze-lstm", aux="reward", train_mode=-1)
+over = dict(env="Track2D-BlockPartialPZR-v0", num_envs=4096, network="tat-maze-lstm", aux="reward", train_mode=-1)
+if len(sys.argv) > 1:   # python tools/op_trace.py <env> <num_envs> <network> <aux> <train_mode>
+    over = dict(env=sys.argv[1], num_envs=int(sys.argv[2]), network=sys.argv[3], aux=sys.argv[4], train_mode=int(sys.argv[5]))
+args = default_args(**over)
 dev = torch.device("cuda:0")
 player, opt = make_player(args, dev, 0, 1)
 
