@@ -258,6 +258,28 @@ extern "C" int atr_lstm_cell_forward_act(const float *ig, const float *hg, const
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+extern "C" int atr_lstm_cell_forward_act1(const float *ig, const float *hg, const float *bias, const float *c_prev,
+                                         const unsigned char *done, float *h_out, float *c_out, float *acts,
+                                         const float *emb, const long long *act_in, const float *actor_w,
+                                         const float *actor_b, int A, long long *actions_out,
+                                         const unsigned long long *counter, unsigned long long seed, unsigned ordinal,
+                                         int N, int R, void *stream)
+{
+    const int rq = R / 4;
+    if (!ig || !hg || !c_prev || !h_out || !c_out || !actor_w || !actor_b || !actions_out || !counter || N < 0 || R <= 0 ||
+        (R & 3) || (rq != 16 && rq != 32 && rq != 64) || A < 1 || A > kMaxActions || ((emb != nullptr) != (act_in != nullptr)))
+        return -1;
+    if (N == 0) return 0;
+    CellFwd a;
+    a.ig[0] = ig; a.ig[1] = nullptr; a.hg = hg; a.c_prev = c_prev; a.c_prev_ps = 0; a.keep = nullptr; a.done = done;
+    a.h_out = h_out; a.c_out = c_out; a.h_ps = 0; a.c_ps = 0; a.acts = acts; a.acts_ps = 0; a.P = 1; a.N = N; a.R = R;
+    a.emb = emb; a.act_in = act_in; a.actor_w[0] = actor_w; a.actor_w[1] = nullptr; a.actor_b[0] = actor_b; a.actor_b[1] = nullptr;
+    a.actions_out = actions_out; a.bias[0] = bias; a.bias[1] = nullptr;
+    a.counter = counter; a.seed = seed; a.ordinal = ordinal; a.A = A;
+    hipLaunchKernelGGL(k_lstm_cell_fwd<true>, dim3(grid_for((long long)N * rq)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int atr_lstm_cell_forward_act2(const float *ig, const float *hg, const float *bias0, const float *bias1,
                                           const float *c_prev, long long c_prev_pstride, const unsigned char *done,
                                           float *h_out, long long h_pstride, float *c_out, long long c_pstride, float *acts,

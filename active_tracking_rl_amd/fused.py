@@ -44,6 +44,8 @@ def lib():
         L.atr_lstm_cell_forward.argtypes = [vp, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, i32, i32, i32, vp]
         L.atr_lstm_cell_forward_act.restype = i32
         L.atr_lstm_cell_forward_act.argtypes = [vp] * 11 + [i32, vp, vp, C.c_ulonglong, C.c_uint, i32, i32, vp]
+        L.atr_lstm_cell_forward_act1.restype = i32
+        L.atr_lstm_cell_forward_act1.argtypes = [vp] * 12 + [i32, vp, vp, C.c_ulonglong, C.c_uint, i32, i32, vp]
         L.atr_lstm_cell_forward_act2.restype = i32
         L.atr_lstm_cell_forward_act2.argtypes = [vp] * 5 + [ll, vp, vp, ll, vp, ll, vp, ll] + [vp] * 4 + [i32, vp, vp,
                                                  C.c_ulonglong, C.c_uint, i32, i32, vp]
@@ -457,17 +459,25 @@ def lstm_cell_act2_into(ig, hg, biases, c_prev, done, h_out, c_out, acts, sample
 
 
 @torch.no_grad()
-def lstm_cell_act_into(ig, hg, c_prev, done, h_out, c_out, acts, sampler, actor, actions_out, emb=None, act_in=None):
+def lstm_cell_act_into(ig, hg, c_prev, done, h_out, c_out, acts, sampler, actor, actions_out, emb=None, act_in=None,
+                       bias=None):
     """The actor's whole per-player step after the two GEMMs in ONE launch: masked LSTM cell (+ optional
     emb[act_in] added to the gates) written into the rollout-cache slots, then actor head + categorical draw on the
-    fresh hidden row into actions_out (int64 [N]). Only valid inside sampler.begin_block()."""
+    fresh hidden row into actions_out (int64 [N]). bias [4R]: added to the pre-activations here (ig from a bias-free
+    GEMM). Only valid inside sampler.begin_block()."""
     N, R = c_prev.shape
     assert sampler._ordinal is not None
     sampler._ordinal += 1
-    rc = lib().atr_lstm_cell_forward_act(_p(ig), _p(hg), _p(c_prev), _pn(done), _p(h_out), _p(c_out), _pn(acts),
-                                         _pn(emb), _pn(act_in), _p(actor.weight), _p(actor.bias), actor.weight.shape[0],
-                                         _p(actions_out), _p(sampler.counter), sampler.seed, sampler._ordinal, N, R,
-                                         _stream(ig))
+    if bias is not None:
+        rc = lib().atr_lstm_cell_forward_act1(_p(ig), _p(hg), _p(bias), _p(c_prev), _pn(done), _p(h_out), _p(c_out),
+                                              _pn(acts), _pn(emb), _pn(act_in), _p(actor.weight), _p(actor.bias),
+                                              actor.weight.shape[0], _p(actions_out), _p(sampler.counter), sampler.seed,
+                                              sampler._ordinal, N, R, _stream(ig))
+    else:
+        rc = lib().atr_lstm_cell_forward_act(_p(ig), _p(hg), _p(c_prev), _pn(done), _p(h_out), _p(c_out), _pn(acts),
+                                             _pn(emb), _pn(act_in), _p(actor.weight), _p(actor.bias), actor.weight.shape[0],
+                                             _p(actions_out), _p(sampler.counter), sampler.seed, sampler._ordinal, N, R,
+                                             _stream(ig))
     if rc != 0:
         raise RuntimeError("atr_lstm_cell_forward_act failed (%d)" % rc)
     return actions_out

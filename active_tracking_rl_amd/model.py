@@ -596,7 +596,7 @@ class A3C_Dueling(nn.Module):
         c.bsum = [l.bias_ih + l.bias_hh for l in (p0.lstm, p1.lstm)]
         c.whh_t = torch.stack([l.weight_hh.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, R, 4R]
         c.wih_t = (torch.stack([l.weight_ih.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, F, 4R]: the pair's input GEMM as one bmm
-                   if (not self.tat and c.f_all is not None and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape) else None)
+                   if (c.f_all is not None and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape) else None)
         if self.tat:
             fa = p1.fc_action_tracker
             c.emb = fa.weight.t() + fa.bias                        # row a = fc_action_tracker(one_hot(a))
@@ -674,10 +674,23 @@ class A3C_Dueling(nn.Module):
             fused.lstm_cell_act2_into(ig, hgs, cache.bsum, c_prev, done, h_out, c_out, acts, self._sampler,
                                       (p0.actor.actor_linear, p1.actor.actor_linear), actions)
             return [actions[0], actions[1]]
+        # tracker-aware pair below the MFMA-step threshold: the target's cell needs the tracker's action, its input
+        # projection does not — both projections still go out as one batched GEMM, ahead of the tracker's cell
+        ig_pair = None
+        if one_launch and not mfma_step and f_pair is not None and getattr(cache, "wih_t", None) is not None:
+            for i, p in enumerate((p0, p1)):
+                _addmm_relu(p.encoder.fc.bias, ys[i].view(n, -1), p.encoder.fc.weight.t(), f_out[i])
+            ig_pair = torch.bmm(f_pair, cache.wih_t)
         for i, p in enumerate((p0, p1)):
             enc = p.encoder
-            f = _addmm_relu(enc.fc.bias, ys[i].view(n, -1), enc.fc.weight.t(), f_out[i])
             tat = i == 1 and self.tat
+            if ig_pair is not None:
+                acts_out.append(fused.lstm_cell_act_into(
+                    ig_pair[i], hgs[i], c_prev[i], done, h_out[i], c_out[i], acts[i],
+                    self._sampler, p.actor.actor_linear, actions[i],
+                    emb=cache.emb_ih if tat else None, act_in=acts_out[0] if tat else None, bias=cache.bsum[i]))
+                continue
+            f = _addmm_relu(enc.fc.bias, ys[i].view(n, -1), enc.fc.weight.t(), f_out[i])
             if mfma_step:
                 fused.actor_step_into(f, h_prev[i], c_prev[i], done, p.lstm, cache.bsum[i], h_out[i], c_out[i], acts[i],
                                       emb=cache.emb_ih if tat else None, act_in=acts_out[0] if tat else None)

@@ -78,6 +78,13 @@ int atr_lstm_cell_forward_act(const float *ig, const float *hg, const float *c_p
                               const float *actor_w, const float *actor_b, int A, long long *actions_out,
                               const unsigned long long *counter, unsigned long long seed, unsigned ordinal, int N,
                               int R, void *stream);
+/* atr_lstm_cell_forward_act with the bias (b_ih + b_hh, [4R], nullable) added inside: ig then comes from a bias-free
+ * (batched) GEMM. */
+int atr_lstm_cell_forward_act1(const float *ig, const float *hg, const float *bias, const float *c_prev,
+                               const unsigned char *done, float *h_out, float *c_out, float *acts, const float *emb,
+                               const long long *act_in, const float *actor_w, const float *actor_b, int A,
+                               long long *actions_out, const unsigned long long *counter, unsigned long long seed,
+                               unsigned ordinal, int N, int R, void *stream);
 /* The same for BOTH players of a model whose players do not depend on each other's action (maze-lstm pairs), one launch:
  * ig [2,N,4R] = the two input projections WITHOUT bias (one batched GEMM), bias0 / bias1 [4R] (b_ih + b_hh, nullable)
  * added here, hg [2,N,4R]; per-player strides for the state / gate stores as in atr_lstm_cell_forward; actions_out [2,N];
