@@ -294,7 +294,9 @@ __device__ __forceinline__ uint32_t spread16(uint32_t v)   // bit i of the low 1
     v = (v | (v << 1)) & 0x55555555u;
     return v;
 }
-constexpr int kMazeLogMax = 47 * 24;     // density <= int(0.03 * 1600) = 47 seeds x complexity <= int(0.03 * 810) = 24 moves
+// one log entry per CARVING move, and a move only carves onto a free interior node, which it then fills: at most 39 * 39 entries
+// whatever the level (level 0 / 1 stay below 47 x 24; t2d_create admits level <= 15, i.e. up to 480 seeds x 243 moves)
+constexpr int kMazeLogMax = 39 * 39;
 constexpr uint32_t kMazeDelta = 0x29d701ffu;   // bytes -1, +1, -41, +41: node (y, x-2), (y, x+2), (y-2, x), (y+2, x)
 template <class S>
 __device__ __forceinline__ void gen_maze(uint32_t *tile, int lane, S &ms, double ratio, uint32_t *log)

@@ -66,7 +66,10 @@ class VecEnv(object):
         # obs_u8: observations stay bytes between the step kernel and the policy's conv stem (t2d_step_u8 ->
         # atr_stem_*_u8), i.e. frame_stack's np.float32 cast (environment.py:138,146) is fused into conv1. Only where
         # the kernels exist ('Partial' ids without Nav/RPF targets) and no host-side frame processing is asked for.
-        self.obs_u8 = bool(obs_u8) and self.stack_frames == 1 and not self.rescale and self.core.supports_u8
+        # (an odd env count leaves every other slot of the [T+1, N, 2, 13, 13] byte rollout store 2-byte aligned — the step
+        # kernel and the rollout prologue move dwords — so odd batches keep float observations)
+        self.obs_u8 = (bool(obs_u8) and self.stack_frames == 1 and not self.rescale and self.core.supports_u8
+                       and self.num_envs % 2 == 0)
         if self.rescale:
             for box in self.observation_space:
                 box.low, box.high = -1.0, 1.0

@@ -140,7 +140,8 @@ class Agent(object):
         obs0 = self.state.reshape(self._buf[0][0].shape) if self._buf is not None else None
         if self._cache is not None:                               # LSTM state lives in the cache: slot t -> t+1
             if (self.fused_bookkeeping and self.hxs.is_cuda and self.hxs.is_contiguous() and self.cxs.is_contiguous()
-                    and (obs0 is None or (obs0.dtype == self._buf[0].dtype and obs0.is_contiguous()))):
+                    and (obs0 is None or (obs0.dtype == self._buf[0].dtype and obs0.is_contiguous()
+                                          and (obs0.numel() * obs0.element_size()) % 4 == 0))):
                 from . import fused                               # both copies + the observation's in one launch
                 fused.rollout_begin(self.hxs, self.cxs, self._cache.h_all, self._cache.c_all, obs0,
                                     self._buf[0][0] if obs0 is not None else None)

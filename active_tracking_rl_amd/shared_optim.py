@@ -31,6 +31,11 @@ class FlatParams(object):
             p.grad = self.grad[off:off + n].view_as(p.data)
             off += n
         self.numel = total
+        # stand-in for gradients autograd reports as unused (set_grads): ordinary memory zeroed once, allocated HERE and
+        # not on first use — first use can fall inside a hipGraph capture, whose private pool and memset node would then
+        # belong to that one graph while the other per-mode graphs read the buffer too
+        self._zeros = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=ref.device)
+        self._views = None
 
     def zero_grad(self):
         self.grad.zero_()
@@ -54,10 +59,8 @@ class FlatParams(object):
         """Store freshly computed gradients (torch.autograd.grad output, None = unused) in the bucket with ONE batched
         concatenation kernel — instead of zeroing the bucket and letting autograd accumulate into ~40 views one add
         kernel at a time."""
-        if getattr(self, "_views", None) is None:
+        if self._views is None:
             self._views = self.grad_views()
-        if any(g is None for g in grads) and getattr(self, "_zeros", None) is None:
-            self._zeros = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=self.grad.device)
         flat = [g.reshape(-1) if g is not None else self._zeros[:p.numel()] for g, p in zip(grads, self.params)]
         torch.cat(flat, out=self.grad)
         for p, v in zip(self.params, self._views):

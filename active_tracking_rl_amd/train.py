@@ -104,9 +104,16 @@ class GraphedIteration(object):
     `train_modes[rank]` schedule (test.py:84-92: tracker-only until --init-step) selects the graph per iteration.
     All graphs read and write the same carry tensors, so switching modes does not disturb the env/LSTM state."""
 
-    def __init__(self, player, optimizer, args, warmup=2, fast=True):
+    def __init__(self, player, optimizer, args, warmup=2, fast=True, mode=None, keep_warmup_updates=False):
+        """mode: the training mode of the first iterations (main.py starts in mode 0 under --init-step); the eager
+        warm-up iterations and the first captured graph use it. The warm-up iterations are real rollouts + updates run to
+        settle allocations before the capture; unless keep_warmup_updates is set their effect on the parameters and the
+        optimizer state (step counter, moments) is rolled back, so that iteration 0 of the run is the first replay."""
         self.player, self.optimizer, self.args, self.fast = player, optimizer, args, fast
+        self.mode0 = args.train_mode if mode is None else int(mode)
         dev = player.device
+        snap = None if keep_warmup_updates else self._optimizer_tensors()
+        saved = [t.clone() for t in snap] if snap is not None else None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -114,13 +121,34 @@ class GraphedIteration(object):
                 self._eager()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if saved is not None:
+            with torch.no_grad():
+                for t, v in zip(snap, saved):
+                    t.copy_(v)
         self.carry = dict(state=player.state.clone(), hxs=player.hxs.detach().clone(),
                           cxs=player.cxs.detach().clone(), done=player.done.clone(), eps_len=player.eps_len.clone())
         self.g_rolls, self.stats_by_mode = {}, {}
-        self._capture(args.train_mode)
+        self._capture(self.mode0)
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             optimizer.step()
+        if saved is not None:          # (capturing a graph does not execute it; restore anyway in case a backend ran it)
+            with torch.no_grad():
+                for t, v in zip(snap, saved):
+                    t.copy_(v)
+
+    def _optimizer_tensors(self):
+        """Every tensor an update writes: the flat parameter bucket and the optimizer's own state tensors."""
+        opt = self.optimizer
+        bucket = getattr(opt, "bucket", None)
+        if bucket is None:
+            return None
+        seen, out = set(), []
+        for t in [bucket.flat] + [v for v in vars(opt).values() if isinstance(v, torch.Tensor)]:
+            if t.data_ptr() not in seen and t.numel() > 0:
+                seen.add(t.data_ptr())
+                out.append(t)
+        return out
 
     def _bind_carry(self):
         p = self.player
@@ -151,10 +179,10 @@ class GraphedIteration(object):
 
     def _eager(self):
         rollout(self.player, self.args.num_steps, fast=self.fast)
-        self.player.optimize(None, self.optimizer, self.player.model, self.args.train_mode, self.player.device)
+        self.player.optimize(None, self.optimizer, self.player.model, self.mode0, self.player.device)
 
     def run(self, mode=None):
-        mode = self.args.train_mode if mode is None else int(mode)
+        mode = self.mode0 if mode is None else int(mode)
         g = self.g_rolls.get(mode)
         if g is None:
             g = self._capture(mode)

@@ -90,7 +90,7 @@ if __name__ == '__main__':
     # n_iter < --init-step
     first_mode = 0 if args.init_step > 0 else args.train_mode
     train_modes, n_iters = [first_mode] * world, [0] * world
-    step = GraphedIteration(player, optimizer, args).run if not args.no_graph else None
+    step = GraphedIteration(player, optimizer, args, mode=first_mode).run if not args.no_graph else None
     it = 0
     eval_state = {}
     while True:

@@ -60,6 +60,8 @@ def lib():
         L.orc_get_plan.argtypes = [vp, pi, pi]
         L.orc_episode.restype = u32
         L.orc_episode.argtypes = [vp]
+        L.orc_step_batch.restype = i32
+        L.orc_step_batch.argtypes = [C.POINTER(vp), i32, pi, pu8, C.POINTER(f64), pu8, i32]
         L.orc_reward.argtypes = [C.c_int64, f64, C.POINTER(f64), C.POINTER(f64)]
         L.orc_mt_new.restype = vp
         L.orc_mt_new.argtypes = [u32]
@@ -167,6 +169,35 @@ class OracleEnv(object):
         cur = C.c_int(0)
         n = self.L.orc_get_plan(self.h, _p(buf, C.c_int), C.byref(cur))
         return buf[:min(n, 1024)].copy(), cur.value
+
+
+class OracleBatch(object):
+    """n scalar oracle envs stepped in lock step by one C call (orc_step_batch) — the checker of the full-size parity
+    tests: reset() -> obs u8 [n,2,13,13]; step(actions [n,2]) -> (obs, rewards f64 [n,2], done u8 [n]); with auto_reset a
+    finished env restarts inside the call and reports its next episode's first observation, as the product does."""
+
+    def __init__(self, envs, auto_reset=True):
+        self.envs, self.n, self.auto_reset = list(envs), len(envs), bool(auto_reset)
+        self.L = lib()
+        self._h = (C.c_void_p * self.n)(*[e.h for e in self.envs])
+        shape = self.envs[0]._obs.shape
+        assert all(e._obs.shape == shape for e in self.envs)
+        self._obs = np.zeros((self.n,) + shape, np.uint8)
+        self._rew = np.zeros((self.n, 2), np.float64)
+        self._done = np.zeros(self.n, np.uint8)
+
+    def reset(self):
+        for i, e in enumerate(self.envs):
+            self._obs[i] = e.reset()
+        return self._obs.copy()
+
+    def step(self, actions):
+        act = np.ascontiguousarray(actions, np.int32).reshape(self.n, 2)
+        rc = self.L.orc_step_batch(self._h, self.n, _p(act, C.c_int), _p(self._obs, C.c_uint8), _p(self._rew, C.c_double),
+                                   _p(self._done, C.c_uint8), 1 if self.auto_reset else 0)
+        if rc != 0:
+            raise ValueError("invalid action for env %d" % (-1 - rc))
+        return self._obs.copy(), self._rew.copy(), self._done.copy()
 
 
 def reward(d2, w_p):

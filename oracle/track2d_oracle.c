@@ -819,3 +819,19 @@ int orc_get_plan(const orc_env *e, int *plan, int *cursor)
     return e->plan_len;
 }
 uint32_t orc_episode(const orc_env *e) { return e->episode; }
+
+/* Lock-step helper for the full-size parity tests: n envs, one step each, and — as the vectorised product does inside its
+ * step launch — a finished env is reset at once and reports the FIRST observation of its next episode (the reference worker
+ * discards the terminal observation too: train.py:73-74). Plain loop over orc_step / orc_reset. */
+int orc_step_batch(orc_env **envs, int n, const int *actions, uint8_t *obs, double *rewards, uint8_t *done, int auto_reset)
+{
+    for (int i = 0; i < n; i++) {
+        orc_env *e = envs[i];
+        const int sz = orc_obs_size(e);
+        int d = 0;
+        if (orc_step(e, actions + 2 * i, obs + (size_t)i * sz, rewards + 2 * i, &d, NULL) != 0) return -1 - i;
+        done[i] = (uint8_t)d;
+        if (d && auto_reset) orc_reset(e, obs + (size_t)i * sz);
+    }
+    return 0;
+}

@@ -81,6 +81,11 @@ void orc_get_obs(const orc_env *e, uint8_t *obs);
 int orc_get_plan(const orc_env *e, int *plan /* up to 1024 */, int *cursor);
 uint32_t orc_episode(const orc_env *e);
 
+/* n envs in lock step (same obs size each): actions int[n][2] -> obs u8[n][obs_size], rewards f64[n][2], done u8[n];
+ * auto_reset != 0: a finished env is reset in the same call and obs holds the first observation of its next episode
+ * (what the batched product's in-launch auto-reset returns). Returns 0, or -1 - i for an invalid action of env i. */
+int orc_step_batch(orc_env **envs, int n, const int *actions, uint8_t *obs, double *rewards, uint8_t *done, int auto_reset);
+
 /* Pure helpers exposed for unit tests. */
 void orc_reward(int64_t d2, double w_p, double *r_track, double *r_target);
 /* numpy-legacy primitives on a standalone MT19937 (tests compare with numpy itself). */
