@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libtrack2d_hip.so")
 SOURCES = ["track2d_hip.hip", "stem_hip.hip", "policy_hip.hip", "lstm_hip.hip", "heads_hip.hip", "gemm_tn_hip.hip",
            "actor_step_hip.hip", "driver_hip.hip", "np_mode.cpp"]
 HEADERS = ["t2d_device.h", os.path.join("..", "..", "include", "track2d.h"),
-           os.path.join("..", "..", "include", "atr_policy.h"), "atr_sample.h",
+           os.path.join("..", "..", "include", "atr_policy.h"), "atr_sample.h", "atr_cell.h",
            os.path.join("..", "..", "include", "track2d_np.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]

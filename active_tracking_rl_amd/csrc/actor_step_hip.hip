@@ -51,8 +51,8 @@ constexpr int kOpFloats = 32 * kLs;                       // one staged operand 
 
 // sigmoid / tanh on the hardware exp and reciprocal (v_exp_f32, v_rcp_f32): ~1e-7 relative, far inside the 2e-5 the
 // summation order of a 384-term fp32 dot product already costs
-__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 struct ActorStep {
     const float *f, *h_prev, *c_prev;

@@ -16,17 +16,10 @@
 #include <stdint.h>
 
 #include "../../include/atr_policy.h"
+#include "atr_cell.h"
 #include "atr_sample.h"
 
 namespace atr {
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-__device__ __forceinline__ void st4(float *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
-__device__ __forceinline__ float4 fma4(float k, const float4 &a, const float4 &b)
-{
-    return make_float4(fmaf(k, a.x, b.x), fmaf(k, a.y, b.y), fmaf(k, a.z, b.z), fmaf(k, a.w, b.w));
-}
 
 struct CellFwd {
     const float *ig[2];        // per player: [N, 4R] pre-activations from the input projection (bias included)
@@ -84,13 +77,8 @@ template <bool ACT> __global__ __launch_bounds__(256) void k_lstm_cell_fwd(CellF
             pg = fma4(1.0f, ld4(e + 2 * a.R), pg); po = fma4(1.0f, ld4(e + 3 * a.R), po);
         }
         const float4 cp = ld4(a.c_prev + p * a.c_prev_ps + (long long)n * a.R + j);
-        const float4 gi = make_float4(sigmoidf_(pi.x), sigmoidf_(pi.y), sigmoidf_(pi.z), sigmoidf_(pi.w));
-        const float4 gf = make_float4(sigmoidf_(pf.x), sigmoidf_(pf.y), sigmoidf_(pf.z), sigmoidf_(pf.w));
-        const float4 gg = make_float4(tanhf(pg.x), tanhf(pg.y), tanhf(pg.z), tanhf(pg.w));
-        const float4 go = make_float4(sigmoidf_(po.x), sigmoidf_(po.y), sigmoidf_(po.z), sigmoidf_(po.w));
-        const float4 c = make_float4(gf.x * (k * cp.x) + gi.x * gg.x, gf.y * (k * cp.y) + gi.y * gg.y,
-                                     gf.z * (k * cp.z) + gi.z * gg.z, gf.w * (k * cp.w) + gi.w * gg.w);
-        const float4 h = make_float4(go.x * tanhf(c.x), go.y * tanhf(c.y), go.z * tanhf(c.z), go.w * tanhf(c.w));
+        const CellOut o = cell4(pi, pf, pg, po, cp, k);
+        const float4 gi = o.gi, gf = o.gf, gg = o.gg, go = o.go, c = o.c, h = o.h;
         st4(a.h_out + p * a.h_ps + (long long)n * a.R + j, h);
         st4(a.c_out + p * a.c_ps + (long long)n * a.R + j, c);
         if (a.acts) {
@@ -99,18 +87,7 @@ template <bool ACT> __global__ __launch_bounds__(256) void k_lstm_cell_fwd(CellF
         }
         if (ACT) {      // actor head on the fresh row: partial logits over this lane's 4 units, summed over the row's lanes
             float logit[kMaxActions];
-#pragma unroll
-            for (int q = 0; q < kMaxActions; q++) {
-                logit[q] = 0.f;
-                if (q < a.A) {
-                    const float4 w = aw[q];
-                    logit[q] = fmaf(h.x, w.x, fmaf(h.y, w.y, fmaf(h.z, w.z, h.w * w.w)));
-                }
-            }
-            for (int msk = 1; msk < rq; msk <<= 1)
-#pragma unroll
-                for (int q = 0; q < kMaxActions; q++)
-                    if (q < a.A) logit[q] += __shfl_xor(logit[q], msk, 64);
+            head_logits(h, aw, a.A, rq, logit);
             if (j == 0) {
 #pragma unroll
                 for (int q = 0; q < kMaxActions; q++) logit[q] = q < a.A ? logit[q] + a.actor_b[p][q] : -INFINITY;
@@ -168,7 +145,7 @@ __global__ __launch_bounds__(256) void k_lstm_cell_bwd(CellBwd a)
         const float cv[4] = {c.x, c.y, c.z, c.w}, cpv[4] = {cp.x, cp.y, cp.z, cp.w};
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const float tc = tanhf(cv[u]);
+            const float tc = tanhf_(cv[u]);     // the forward's tanh (atr_cell.h)
             const float dc = dcnv[u] + dhv[u] * ov[u] * (1.0f - tc * tc);
             dov[u] = dhv[u] * tc * ov[u] * (1.0f - ov[u]);
             di[u] = dc * gv[u] * iv[u] * (1.0f - iv[u]);

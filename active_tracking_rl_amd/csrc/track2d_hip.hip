@@ -17,7 +17,9 @@
 #include <new>
 #include <vector>
 
+#include "../../include/atr_policy.h"
 #include "../../include/track2d.h"
+#include "atr_cell.h"
 #include "t2d_device.h"
 
 #ifndef T2D_EXP
@@ -613,6 +615,283 @@ constexpr int kStage2Words = kStage2Rows + 192;     // + 169 dwords of mark byte
 #endif
 constexpr int kStep2Waves = T2D_STEP2_WAVES;        // waves (env pairs) per workgroup of k_step2
 
+// One env PAIR's step + observe by one wavefront, split into three phases so that a caller can put independent work
+// between them (k_act_step runs the policy's LSTM cells and draws between `rows` and `finish`, under the row loads):
+//   init    lane roles; issues the state loads (pos, cnt, cfg [, plan, tctr, episode])
+//   rows    needs the state: issues the 15 map-row loads of each agent and, for envs that can finish this step, the
+//           speculative next-episode loads
+//   finish  needs the two actions: scripted-target override, wall vote, reward, far counter / time limit, episode switch,
+//           state write-back, observation
+// k_step2 calls them back to back (per step of a MULTI launch: rows + finish).
+template <bool MULTI, int OBS, bool RAM>
+struct Step2 {
+    int lane, e0, e, sl, ag, k;
+    bool live, leader;
+    uint32_t *st, *mk;
+    uint32_t pos, cnt, cfg;
+    int mode;
+    bool ram;
+    uint32_t plan, tctr, episode, d2, genv;
+    const float2 *lut;
+    const uint32_t *gmap;
+    int cells;
+    // rows phase
+    int rowbase;
+    uint32_t w0, w1, w2;
+    bool maybe;
+    unsigned long long mb;
+    uint32_t sp_pos, sp_plan, sp_tctr, sp_d2, sp_goals, sp_navgoal, sp_episode, sp_win;
+    uint4 sp_tile0, sp_tile1;
+#if T2D_EXP == 6
+    uint32_t *tstamp;   // timeline probe: s_memtime stamps of this wave, parked in the spare words 246..253 of the env's tile
+#define T2D_STAMP(i) do { if (leader) tstamp[i] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+#define T2D_STAMP(i) do { } while (0)
+#endif
+
+    __device__ __forceinline__ void init(const DevState &s, int e0_, int lane_, uint32_t *stage)
+    {
+        lane = lane_; e0 = e0_;
+        sl = lane >> 5; ag = (lane >> 4) & 1; k = lane & 15;
+        live = e0 + sl < s.n;                   // false only for slot 1 of the last pair of an odd batch
+        e = live ? e0 + sl : e0;                // a dead slot shadows slot 0 (loads only; it never votes or stores)
+        leader = live && ag == 0 && k == 15;    // one lane per env: reward table, rew/done, state write-back
+        st = stage;
+        mk = st + kStage2Rows;
+#if T2D_EXP == 6
+        tstamp = s.maps + (size_t)e * kTileWords + 246;
+#endif
+        T2D_STAMP(0);
+        pos = s.pos[e]; cnt = s.cnt[e];
+        cfg = s.cfg[e];
+        plan = 0; tctr = 0; episode = 0; d2 = 0;
+    }
+    // second half of init, after the caller has issued ITS first loads (k_step2: the action loads): everything here
+    // only consumes cfg / kernel arguments
+    __device__ __forceinline__ void init2(const DevState &s, const void *obs, const float *rew, const uint8_t *done_out)
+    {
+        {   // every kernel argument the step needs, fetched NOW (one scalar round trip under the state loads' latency)
+            // instead of lazily at first use, where each would put its own s_load + wait on the critical path
+            const float2 *a0_ = s.rew_lut; const uint32_t *a1_ = s.maps, *a2_ = s.d2, *a3_ = s.faults;
+            const int a4_ = s.max_steps, a5_ = s.auto_reset; const uint32_t a6_ = s.env_base;
+            asm volatile("" ::"s"(a0_), "s"(a1_), "s"(a2_), "s"(a3_), "s"(a4_), "s"(a5_), "s"(a6_), "s"(obs), "s"(rew),
+                         "s"(done_out));
+        }
+        mode = (int)((cfg >> 2) & 7u);
+        // RAM = some env of the handle has the scripted Ram target; handles without one get a kernel without the plan /
+        // Philox code (the step kernel's duration at N = 4096 is partly instruction-fetch latency: code size matters)
+        ram = RAM && mode == TGT_RAM;
+        if (MULTI || ram) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }
+        genv = s.env_base + (uint32_t)e;
+        lut = s.rew_lut + (mode == TGT_PZR ? kLutN : (mode == TGT_FAR ? 2 * kLutN : 0));
+        gmap = s.maps + (size_t)e * kTileWords;
+        cells = (e0 + 1 < s.n) ? 2 * kObsPerEnv : kObsPerEnv;
+    }
+
+    __device__ __forceinline__ void rows(const DevState &s)
+    {
+        const int side = (int)(cnt >> 24);
+        const int c_far = (int)(cnt & 0xffu), t = (int)((cnt >> 8) & 0xffffu);
+        const int r0 = (int)(pos & 0xffu), r1 = (int)((pos >> 16) & 0xffu);
+        if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(1); }
+        // rows r_old - 7 .. r_old + 7 of this lane's agent: the move targets and every possible window row
+        rowbase = (ag ? r1 : r0) - 7;
+        w0 = 0xffffffffu; w1 = 0xffffffffu; w2 = 0xffffffffu;   // np.pad(..., 1): rows outside the map
+        if (k < 15 && (unsigned)(rowbase + k) < (unsigned)side) {
+            const uint32_t *rp = gmap + (rowbase + k) * kRowWords;
+            w0 = rp[0]; w1 = rp[1]; w2 = rp[2];
+        }
+        // A done is only possible this step if the far counter stands at 10 or the time limit is one step away (:106-111,
+        // TimeLimit): for those envs the next episode's scalars, the window rows of its first observation (n_win) and its map
+        // tile are fetched NOW, beside the rows, so that the episode switch below adds no dependent memory round trip.
+        maybe = live && s.auto_reset != 0 && (c_far >= 10 || (s.max_steps > 0 && t + 1 >= s.max_steps));
+        mb = __ballot(maybe);
+        sp_pos = 0; sp_plan = 0; sp_tctr = 0; sp_d2 = 0; sp_goals = 0; sp_navgoal = 0; sp_episode = 0; sp_win = 0x1fffu;
+        sp_tile0 = make_uint4(0u, 0u, 0u, 0u); sp_tile1 = sp_tile0;
+        if (__builtin_expect(mb != 0ull, 0)) {
+            if (maybe) {
+                sp_pos = s.n_pos[e]; sp_plan = s.n_plan[e]; sp_tctr = s.n_tctr[e]; sp_d2 = s.n_d2[e];
+                sp_goals = s.n_goals[e]; sp_navgoal = s.n_navgoal[e]; sp_episode = s.episode[e];
+                if (k >= 1 && k <= T2D_WIN) sp_win = s.n_win[(size_t)e * 32 + ag * T2D_WIN + (k - 1)];
+            }
+            if ((mb & 0xffffffffull) != 0ull)
+                sp_tile0 = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)e0 * kTileWords)[lane];
+            if ((mb >> 32) != 0ull)
+                sp_tile1 = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)(e0 + 1) * kTileWords)[lane];
+        }
+    }
+
+    // a_tr / a_tg: the two actions of this lane's env, already masked to the action table
+    __device__ __forceinline__ void finish(const DevState &s, int a_tr, int a_tg, int it, void *obs, float *rew,
+                                           uint8_t *done_out, uint32_t stamp)
+    {
+        const int side = (int)(cnt >> 24);
+        int c_far = (int)(cnt & 0xffu), t = (int)((cnt >> 8) & 0xffffu);
+        bool dirty = false;
+        if (ram) { // track_1v1.py:81-82
+            Stream ts;
+            ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, tctr);
+            a_tg = (int)ram_step(plan, ts);
+            tctr = ts.ctr;
+            dirty = true;
+        }
+        int r0 = (int)(pos & 0xffu), c0 = (int)((pos >> 8) & 0xffu);
+        int r1 = (int)((pos >> 16) & 0xffu), c1 = (int)(pos >> 24);
+        const int dy0 = move_dy(a_tr), dx0 = move_dx(a_tr);
+        const int dy1 = move_dy(a_tg), dx1 = move_dx(a_tg);
+        // the reward of each possible outcome (tracker moves / bumps) x (target moves / bumps): track_1v1.py:94-104
+        float2 rw_mm = make_float2(0.f, 0.f), rw_ms = rw_mm, rw_sm = rw_mm, rw_ss = rw_mm;
+        const int ddr = r1 - r0, ddc = c1 - c0;
+        if (leader) {
+            auto sq = [](int a, int b) { return a * a + b * b; };
+            rw_mm = lut[sq(ddr + dy1 - dy0, ddc + dx1 - dx0)];
+            rw_ms = lut[sq(ddr - dy0, ddc - dx0)];
+            rw_sm = lut[sq(ddr + dy1, ddc + dx1)];
+            rw_ss = lut[sq(ddr, ddc)];
+        }
+        // _next_state (track_1v1.py:271-285): the lane holding the destination row of its agent votes "wall"
+        const int mdy = ag ? dy1 : dy0, mcc = (ag ? c1 : c0) + (ag ? dx1 : dx0);
+        // (prvalues: `c ? w0 : w1` on members is an lvalue conditional, i.e. a load through a selected ADDRESS into the
+        // struct, which keeps the whole struct in scratch memory)
+        const uint32_t W0 = w0, W1 = w1, W2 = w2;
+        const uint32_t wsel = (mcc >> 5) == 0 ? +W0 : ((mcc >> 5) == 1 ? +W1 : +W2);
+        const bool vote = live && k == 7 + mdy && ((wsel >> (mcc & 31)) & 1u) != 0u;
+        const unsigned long long bal = __ballot(vote);
+        const uint32_t half = sl ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+        const bool wall_tr = (half & 0xffffu) != 0u, wall_tg = (half >> 16) != 0u;
+        if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(2); }
+        if (T2D_EXP == 8) {   // latency probe: level-1 loads -> rows + reward table -> one store
+            if (leader) reinterpret_cast<float2 *>(rew)[e] = wall_tr ? (wall_tg ? rw_ss : rw_sm) : (wall_tg ? rw_ms : rw_mm);
+            return;
+        }
+        if (!wall_tr) { r0 += dy0; c0 += dx0; }
+        if (!wall_tg) { r1 += dy1; c1 += dx1; }
+        pos = (uint32_t)r0 | ((uint32_t)c0 << 8) | ((uint32_t)r1 << 16) | ((uint32_t)c1 << 24);
+        {
+            const int dr = r1 - r0, dc = c1 - c0;
+            d2 = (uint32_t)(dr * dr + dc * dc);
+        }
+        c_far = d2 <= 36u ? 0 : min(c_far + 1, 255);  // distance <= 6 (track_1v1.py:106-109)
+        int dn = c_far > 10;
+        t = min(t + 1, 65535);
+        if (s.max_steps > 0 && t >= s.max_steps) dn = 1; // gym TimeLimit
+        cnt = (uint32_t)c_far | ((uint32_t)t << 8) | ((uint32_t)side << 24);
+        if (leader) {
+            const float2 rwd = wall_tr ? (wall_tg ? rw_ss : rw_sm) : (wall_tg ? rw_ms : rw_mm);
+            reinterpret_cast<float2 *>(rew)[(size_t)it * s.n + e] = rwd;
+            done_out[(size_t)it * s.n + e] = (uint8_t)dn;
+        }
+        const bool consume = live && dn != 0 && s.auto_reset != 0;
+
+        const unsigned long long cm = __ballot(consume);
+        bool switched = false;
+        if (__builtin_expect(cm != 0ull, 0)) {
+            // Track1v1Env.reset(): switch to the pre-generated next episode (k_gen). Everything it needs is already in
+            // registers (fetched speculatively in `rows`); the tile copy into `maps` is a fire-and-forget store.
+            if ((cm & 0xffffffffull) != 0ull)
+                reinterpret_cast<uint4 *>(s.maps + (size_t)e0 * kTileWords)[lane] = sp_tile0;
+            if ((cm >> 32) != 0ull)
+                reinterpret_cast<uint4 *>(s.maps + (size_t)(e0 + 1) * kTileWords)[lane] = sp_tile1;
+            if (consume) {
+                switched = true;
+                pos = sp_pos; plan = sp_plan; tctr = sp_tctr; d2 = sp_d2;
+                cnt = (uint32_t)side_of_cfg(cfg) << 24;
+                episode = sp_episode + 1u;
+                if (leader) {
+                    s.goals[e] = sp_goals; s.episode[e] = episode; s.navgoal[e] = sp_navgoal;
+                    s.gen_req[e] = stamp + (uint32_t)it;
+                }
+                r0 = (int)(pos & 0xffu); c0 = (int)((pos >> 8) & 0xffu);
+                r1 = (int)((pos >> 16) & 0xffu); c1 = (int)(pos >> 24);
+                rowbase = (ag ? r1 : r0) - 7;
+                // later steps of a multi-step launch read the NEW map from its n_maps slot, which nobody writes during this
+                // launch (the copy into `maps` above is for later launches): no store -> load hazard through the vector L1
+                gmap = s.n_maps + (size_t)e * kTileWords;
+            }
+        }
+        if (leader) {
+            s.pos[e] = pos; s.cnt[e] = cnt; s.d2[e] = d2;
+            if (consume || dirty) { s.plan[e] = plan; s.tctr[e] = tctr; }
+        }
+
+        T2D_STAMP(3);
+        if (obs != nullptr) {
+            // _get_obs / _get_partial_obs (track_1v1.py:287-326) in closed form: own cell = own colour, the other agent's
+            // colour where it falls in the window, else the map bit, outside the map 1
+            const int oside = (int)(cnt >> 24);
+            const int my_r = ag ? r1 : r0, my_c = ag ? c1 : c0, ot_r = ag ? r0 : r1, ot_c = ag ? c0 : c1;
+            const int rr = rowbase + k, y = rr - (my_r - T2D_POB);
+            if (k < 15 && (unsigned)y < (unsigned)T2D_WIN) {
+                // the lane that holds a row extracts its 13 window bits; after an episode switch they come ready-made from
+                // the next-episode slot (n_win, lane k <-> window row k - 1)
+                uint32_t bits = switched ? sp_win : window_row_bits(w0, w1, w2, oside, my_c);
+                if (y == T2D_POB) bits &= ~(1u << T2D_POB);                 // coloured cells carry no map bit
+                const int xo = ot_c - (my_c - T2D_POB);
+                if (rr == ot_r && (unsigned)xo < (unsigned)T2D_WIN) bits &= ~(1u << xo);
+                st[sl * 26 + ag * 13 + y] = bits;
+            }
+            mk[lane] = 0u; mk[lane + 64] = 0u;
+            if (lane < 169 - 128) mk[lane + 128] = 0u;
+            if (k == 0) {   // the four (slot, agent) windows: own colour at the centre (:313), the other agent if inside
+                uint8_t *mbp = reinterpret_cast<uint8_t *>(mk) + sl * kObsPerEnv + ag * (T2D_WIN * T2D_WIN)
+                               + T2D_POB * T2D_WIN + T2D_POB;
+                const int dr = ot_r - my_r, dc = ot_c - my_c;
+                if ((unsigned)(dr + T2D_POB) < (unsigned)T2D_WIN && (unsigned)(dc + T2D_POB) < (unsigned)T2D_WIN)
+                    mbp[dr * T2D_WIN + dc] = ag ? 2 : 4;
+                mbp[0] = ag ? 4 : 2;                                        // written last: own colour wins when co-located
+            }
+            wave_lds_sync();
+            T2D_STAMP(4);
+            const size_t ebase = ((size_t)it * s.n + e0) * kObsPerEnv;   // first cell of the pair in the output
+            // output groups of this lane: cells 4q .. 4q+3 of the pair's 676, q = lane + 64 i; cell p lives in window row
+            // p / 13 (52 rows: slot, agent, y), column p % 13 (locals, not members: an array member indexed in a loop keeps
+            // the whole struct out of registers)
+            int rj[3], rx[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int p = 4 * (lane + 64 * i);
+                rj[i] = (p * 1261) >> 14;               // p / 13, exact for p < 676
+                rx[i] = p - 13 * rj[i];
+            }
+            // all LDS reads of the three groups first (independent: their latencies overlap), then the math, then the stores
+            uint32_t glo[3], ghi[3], gmk[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                glo[i] = st[rj[i]]; ghi[i] = st[rj[i] + 1];
+                gmk[i] = mk[lane + 64 * i];                      // (the mark plane is padded to 192 dwords: always in bounds)
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int q = lane + 64 * i, p = 4 * q;
+                const uint32_t nib = ((glo[i] | (ghi[i] << 13)) >> rx[i]) & 0xfu;
+                const uint32_t bytes = (__umul24(nib, 0x204081u) & 0x01010101u) | gmk[i];   // bit c -> byte c, then colours
+                if (p >= cells) continue;
+                const int nvalid = min(4, cells - p);
+                if (OBS == OBS_U8) {
+                    uint8_t *o = reinterpret_cast<uint8_t *>(obs) + ebase + p;
+                    if (nvalid == 4) *reinterpret_cast<uint32_t *>(o) = bytes;
+                    else for (int c = 0; c < nvalid; c++) o[c] = (uint8_t)(bytes >> (8 * c));
+                } else {
+                    float *o = reinterpret_cast<float *>(obs) + ebase + p;
+                    const float f0 = (float)(bytes & 0xffu), f1 = (float)((bytes >> 8) & 0xffu);
+                    const float f2 = (float)((bytes >> 16) & 0xffu), f3 = (float)(bytes >> 24);
+                    if (OBS == OBS_F32_VEC4 && nvalid == 4) {
+                        *reinterpret_cast<float4 *>(o) = make_float4(f0, f1, f2, f3);
+                    } else {
+                        o[0] = f0;
+                        if (nvalid > 1) o[1] = f1;
+                        if (nvalid > 2) o[2] = f2;
+                        if (nvalid > 3) o[3] = f3;
+                    }
+                }
+            }
+            if (MULTI) wave_lds_sync();   // the next step overwrites the stage
+            T2D_STAMP(5);
+            if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(6); }
+        }
+    }
+};
+
 template <bool RANDOM, bool MULTI, int ADT, int OBS, bool RAM>
 __global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const void *act0, const void *act1, void *obs, float *rew,
                                                uint8_t *done_out, uint32_t aseed_lo, uint32_t aseed_hi,
@@ -623,251 +902,138 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const vo
     const int wave = uni((int)(threadIdx.x >> 6));
     const int e0 = ((int)blockIdx.x * kStep2Waves + wave) * 2;
     if (e0 >= s.n) return;
-    const int sl = lane >> 5, ag = (lane >> 4) & 1, k = lane & 15;
-    const bool live = e0 + sl < s.n;            // false only for slot 1 of the last pair of an odd batch
-    const int e = live ? e0 + sl : e0;          // a dead slot shadows slot 0 (loads only; it never votes or stores)
-    const bool leader = live && ag == 0 && k == 15;   // one lane per env: reward table, rew/done, state write-back
-    uint32_t *st = stage2[wave];
-    uint32_t *mk = st + kStage2Rows;
-
     // T2D_EXP (compile-time, 0 in the product build): latency probes behind the N = 4096 numbers in DESIGN.md section 3 —
     // 5 = empty kernel (launch floor), 7 = state loads -> one store, 8 = state -> rows + reward table -> one store,
     // 6 = s_memtime timeline (tools/timeline_probe.py); built and timed by tools/exp_variants.sh.
     if (T2D_EXP == 5) { if (lane == 0) done_out[e0] = 0; return; }
-#if T2D_EXP == 6
-    // timeline probe: s_memtime stamps of this wave, parked in the spare words 246..253 of the env's tile
-    uint32_t *tstamp = s.maps + (size_t)(live ? e0 + sl : e0) * kTileWords + 246;
-#define T2D_STAMP(i) do { if (leader) tstamp[i] = (uint32_t)__builtin_readcyclecounter(); } while (0)
-#else
-#define T2D_STAMP(i) do { } while (0)
-#endif
-    T2D_STAMP(0);
-    uint32_t pos = s.pos[e], cnt = s.cnt[e];
-    const uint32_t cfg = s.cfg[e];
+    Step2<MULTI, OBS, RAM> S;
+    S.init(s, e0, lane, stage2[wave]);
     long long act_raw0 = 0, act_raw1 = 0;
     if (!RANDOM) {
-        act_raw0 = load_action_raw<ADT>(act0, e);
-        act_raw1 = load_action_raw<ADT>(act1, e);
+        act_raw0 = load_action_raw<ADT>(act0, S.e);
+        act_raw1 = load_action_raw<ADT>(act1, S.e);
     }
     if (T2D_EXP == 7) {   // latency probe: level-1 loads -> one store
-        if (leader) done_out[e] = (uint8_t)((pos ^ cnt ^ cfg ^ (uint32_t)act_raw0 ^ (uint32_t)act_raw1) & 1u);
+        if (S.leader) done_out[S.e] = (uint8_t)((S.pos ^ S.cnt ^ S.cfg ^ (uint32_t)act_raw0 ^ (uint32_t)act_raw1) & 1u);
         return;
     }
-    {   // every kernel argument the step needs, fetched NOW (one scalar round trip under the state loads' latency)
-        // instead of lazily at first use, where each would put its own s_load + wait on the critical path
-        const float2 *a0_ = s.rew_lut; const uint32_t *a1_ = s.maps, *a2_ = s.d2, *a3_ = s.faults;
-        const int a4_ = s.max_steps, a5_ = s.auto_reset; const uint32_t a6_ = s.env_base;
-        asm volatile("" ::"s"(a0_), "s"(a1_), "s"(a2_), "s"(a3_), "s"(a4_), "s"(a5_), "s"(a6_), "s"(obs), "s"(rew),
-                     "s"(done_out));
+    S.init2(s, obs, rew, done_out);
+    for (int it = 0; it < (MULTI ? nsteps : 1); it++) {
+        int a_tr, a_tg;
+        if (RANDOM) {
+            u32x4 w = philox4x32_10(aseed_lo, aseed_hi, step_idx + (uint32_t)it, 0u, S.genv, STREAM_ACTION);
+            a_tr = (int)(w.x & (uint32_t)s.amask); a_tg = (int)(w.y & (uint32_t)s.amask);
+        } else {
+            if (S.leader && (act_raw0 < 0 || act_raw0 > s.amask || act_raw1 < 0 || act_raw1 > s.amask)) atomicOr(s.faults, 1u);
+            a_tr = (int)(act_raw0 & s.amask); a_tg = (int)(act_raw1 & s.amask);
+        }
+        S.rows(s);
+        S.finish(s, a_tr, a_tg, it, obs, rew, done_out, stamp);
+        if (T2D_EXP == 8) return;
     }
-    const int mode = (int)((cfg >> 2) & 7u);
-    // RAM = some env of the handle has the scripted Ram target; handles without one get a kernel without the plan /
-    // Philox code (the step kernel's duration at N = 4096 is partly instruction-fetch latency: code size matters)
-    const bool ram = RAM && mode == TGT_RAM;
-    uint32_t plan = 0, tctr = 0, episode = 0, d2 = 0;
-    if (MULTI || ram) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }
-    const uint32_t genv = s.env_base + (uint32_t)e;
-    const float2 *lut = s.rew_lut + (mode == TGT_PZR ? kLutN : (mode == TGT_FAR ? 2 * kLutN : 0));
-    const uint32_t *gmap = s.maps + (size_t)e * kTileWords;
+}
 
-    // output groups of this lane: cells 4q .. 4q+3 of the pair's 676, q = lane + 64 i; cell p lives in window row
-    // p / 13 (52 rows: slot, agent, y), column p % 13
-    int rj[3], rx[3];
+// =====================================================================================================
+// k_act_step — the END of a rollout step as one launch: both players' LSTM cells, actor heads and categorical draws
+// (train.py:81-88 -> player_util.py:44-67 -> model.py:238-265 of the reference: tracker first, the tracker-aware target
+// sees the tracker's fresh action) and, with those two actions still in registers, the env step + observation of
+// k_step2. One wavefront = one env PAIR: lanes 0..31 serve env e0, lanes 32..63 env e0 + 1 — for the cells a lane owns
+// four of the R = 128 hidden units of its env's row (the layout of atr::k_lstm_cell_fwd<true>: same expressions, same
+// butterfly, same Philox key -> bit-identical states and actions), for the env step it is k_step2's slot | agent | k.
+// What it replaces: two cell + head + draw launches, the action round trip through memory and the step launch — three
+// dependent launches of 5-10 us each at every batch size. The env's state loads go out first and its map-row loads as
+// soon as the state is there, so both fly under the cells' arithmetic.
+template <int OBS, bool RAM, bool ENV>
+__global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_act_step a, void *obs, float *rew,
+                                                               uint8_t *done_out, uint32_t stamp)
+{
+    using namespace atr;
+    __shared__ __attribute__((aligned(16))) uint32_t stage2[kStep2Waves][kStage2Words];
+    __shared__ __attribute__((aligned(16))) float emb_lds[kMaxActions * 4 * 128];   // the tracker-action embedding table
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int e0 = ((int)blockIdx.x * kStep2Waves + wave) * 2;
+    const int n = ENV ? s.n : a.N;
+    // the embedding rows (A x 4R floats, 8 KB) go to LDS now: the target's cell reads row a_tracker the moment the tracker's
+    // draw is known — an LDS read instead of a dependent trip to L2 in the middle of the kernel's serial chain
+    constexpr int kEmbTrips = kMaxActions * 128 / (64 * kStep2Waves);
+    float4 emb_st[kEmbTrips];
+    if (a.emb) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int p = 4 * (lane + 64 * i);
-        rj[i] = (p * 1261) >> 14;               // p / 13, exact for p < 676
-        rx[i] = p - 13 * rj[i];
-    }
-    const int cells = (e0 + 1 < s.n) ? 2 * kObsPerEnv : kObsPerEnv;
-
-  for (int it = 0; it < (MULTI ? nsteps : 1); it++) {
-    const int side = (int)(cnt >> 24);
-    int c_far = (int)(cnt & 0xffu), t = (int)((cnt >> 8) & 0xffffu);
-    int a_tr, a_tg;
-    if (RANDOM) {
-        u32x4 w = philox4x32_10(aseed_lo, aseed_hi, step_idx + (uint32_t)it, 0u, genv, STREAM_ACTION);
-        a_tr = (int)(w.x & (uint32_t)s.amask); a_tg = (int)(w.y & (uint32_t)s.amask);
-    } else {
-        if (leader && (act_raw0 < 0 || act_raw0 > s.amask || act_raw1 < 0 || act_raw1 > s.amask)) atomicOr(s.faults, 1u);
-        a_tr = (int)(act_raw0 & s.amask); a_tg = (int)(act_raw1 & s.amask);
-    }
-    bool dirty = false;
-    if (ram) { // track_1v1.py:81-82
-        Stream ts;
-        ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, tctr);
-        a_tg = (int)ram_step(plan, ts);
-        tctr = ts.ctr;
-        dirty = true;
-    }
-    int r0 = (int)(pos & 0xffu), c0 = (int)((pos >> 8) & 0xffu);
-    int r1 = (int)((pos >> 16) & 0xffu), c1 = (int)(pos >> 24);
-    if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(1); }
-    const int dy0 = move_dy(a_tr), dx0 = move_dx(a_tr);
-    const int dy1 = move_dy(a_tg), dx1 = move_dx(a_tg);
-    // rows r_old - 7 .. r_old + 7 of this lane's agent: the move targets and every possible window row
-    int rowbase = (ag ? r1 : r0) - 7;
-    uint32_t w0 = 0xffffffffu, w1 = 0xffffffffu, w2 = 0xffffffffu;   // np.pad(..., 1): rows outside the map
-    if (k < 15 && (unsigned)(rowbase + k) < (unsigned)side) {
-        const uint32_t *rp = gmap + (rowbase + k) * kRowWords;
-        w0 = rp[0]; w1 = rp[1]; w2 = rp[2];
-    }
-    // the reward of each possible outcome (tracker moves / bumps) x (target moves / bumps): track_1v1.py:94-104
-    float2 rw_mm = make_float2(0.f, 0.f), rw_ms = rw_mm, rw_sm = rw_mm, rw_ss = rw_mm;
-    const int ddr = r1 - r0, ddc = c1 - c0;
-    if (leader) {
-        auto sq = [](int a, int b) { return a * a + b * b; };
-        rw_mm = lut[sq(ddr + dy1 - dy0, ddc + dx1 - dx0)];
-        rw_ms = lut[sq(ddr - dy0, ddc - dx0)];
-        rw_sm = lut[sq(ddr + dy1, ddc + dx1)];
-        rw_ss = lut[sq(ddr, ddc)];
-    }
-    // A done is only possible this step if the far counter stands at 10 or the time limit is one step away (:106-111,
-    // TimeLimit): for those envs the next episode's scalars, the window rows of its first observation (n_win) and its map
-    // tile are fetched NOW, beside the rows, so that the episode switch below adds no dependent memory round trip.
-    const bool maybe = live && s.auto_reset != 0 && (c_far >= 10 || (s.max_steps > 0 && t + 1 >= s.max_steps));
-    const unsigned long long mb = __ballot(maybe);
-    uint32_t sp_pos = 0, sp_plan = 0, sp_tctr = 0, sp_d2 = 0, sp_goals = 0, sp_navgoal = 0, sp_episode = 0, sp_win = 0x1fffu;
-    uint4 sp_tile0 = make_uint4(0u, 0u, 0u, 0u), sp_tile1 = sp_tile0;
-    if (__builtin_expect(mb != 0ull, 0)) {
-        if (maybe) {
-            sp_pos = s.n_pos[e]; sp_plan = s.n_plan[e]; sp_tctr = s.n_tctr[e]; sp_d2 = s.n_d2[e];
-            sp_goals = s.n_goals[e]; sp_navgoal = s.n_navgoal[e]; sp_episode = s.episode[e];
-            if (k >= 1 && k <= T2D_WIN) sp_win = s.n_win[(size_t)e * 32 + ag * T2D_WIN + (k - 1)];
-        }
-        if ((mb & 0xffffffffull) != 0ull)
-            sp_tile0 = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)e0 * kTileWords)[lane];
-        if ((mb >> 32) != 0ull)
-            sp_tile1 = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)(e0 + 1) * kTileWords)[lane];
-    }
-    // _next_state (track_1v1.py:271-285): the lane holding the destination row of its agent votes "wall"
-    const int mdy = ag ? dy1 : dy0, mcc = (ag ? c1 : c0) + (ag ? dx1 : dx0);
-    const uint32_t wsel = (mcc >> 5) == 0 ? w0 : ((mcc >> 5) == 1 ? w1 : w2);
-    const bool vote = live && k == 7 + mdy && ((wsel >> (mcc & 31)) & 1u) != 0u;
-    const unsigned long long bal = __ballot(vote);
-    const uint32_t half = sl ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-    const bool wall_tr = (half & 0xffffu) != 0u, wall_tg = (half >> 16) != 0u;
-    if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(2); }
-    if (T2D_EXP == 8) {   // latency probe: level-1 loads -> rows + reward table -> one store
-        if (leader) reinterpret_cast<float2 *>(rew)[e] = wall_tr ? (wall_tg ? rw_ss : rw_sm) : (wall_tg ? rw_ms : rw_mm);
-        return;
-    }
-    if (!wall_tr) { r0 += dy0; c0 += dx0; }
-    if (!wall_tg) { r1 += dy1; c1 += dx1; }
-    pos = (uint32_t)r0 | ((uint32_t)c0 << 8) | ((uint32_t)r1 << 16) | ((uint32_t)c1 << 24);
-    {
-        const int dr = r1 - r0, dc = c1 - c0;
-        d2 = (uint32_t)(dr * dr + dc * dc);
-    }
-    c_far = d2 <= 36u ? 0 : min(c_far + 1, 255);  // distance <= 6 (track_1v1.py:106-109)
-    int dn = c_far > 10;
-    t = min(t + 1, 65535);
-    if (s.max_steps > 0 && t >= s.max_steps) dn = 1; // gym TimeLimit
-    cnt = (uint32_t)c_far | ((uint32_t)t << 8) | ((uint32_t)side << 24);
-    if (leader) {
-        const float2 rwd = wall_tr ? (wall_tg ? rw_ss : rw_sm) : (wall_tg ? rw_ms : rw_mm);
-        reinterpret_cast<float2 *>(rew)[(size_t)it * s.n + e] = rwd;
-        done_out[(size_t)it * s.n + e] = (uint8_t)dn;
-    }
-    const bool consume = live && dn != 0 && s.auto_reset != 0;
-
-    const unsigned long long cm = __ballot(consume);
-    bool switched = false;
-    if (__builtin_expect(cm != 0ull, 0)) {
-        // Track1v1Env.reset(): switch to the pre-generated next episode (k_gen). Everything it needs is already in
-        // registers (fetched speculatively above); the tile copy into `maps` is a fire-and-forget store.
-        if ((cm & 0xffffffffull) != 0ull)
-            reinterpret_cast<uint4 *>(s.maps + (size_t)e0 * kTileWords)[lane] = sp_tile0;
-        if ((cm >> 32) != 0ull)
-            reinterpret_cast<uint4 *>(s.maps + (size_t)(e0 + 1) * kTileWords)[lane] = sp_tile1;
-        if (consume) {
-            switched = true;
-            pos = sp_pos; plan = sp_plan; tctr = sp_tctr; d2 = sp_d2;
-            cnt = (uint32_t)side_of_cfg(cfg) << 24;
-            episode = sp_episode + 1u;
-            if (leader) {
-                s.goals[e] = sp_goals; s.episode[e] = episode; s.navgoal[e] = sp_navgoal;
-                s.gen_req[e] = stamp + (uint32_t)it;
-            }
-            r0 = (int)(pos & 0xffu); c0 = (int)((pos >> 8) & 0xffu);
-            r1 = (int)((pos >> 16) & 0xffu); c1 = (int)(pos >> 24);
-            rowbase = (ag ? r1 : r0) - 7;
-            // later steps of a multi-step launch read the NEW map from its n_maps slot, which nobody writes during this
-            // launch (the copy into `maps` above is for later launches): no store -> load hazard through the vector L1
-            gmap = s.n_maps + (size_t)e * kTileWords;
+        for (int i = 0; i < kEmbTrips; i++) {
+            const int idx = (int)threadIdx.x + i * 64 * kStep2Waves;
+            if (idx < a.A * 128) emb_st[i] = ld4(a.emb + 4 * idx);
         }
     }
-    if (leader) {
-        s.pos[e] = pos; s.cnt[e] = cnt; s.d2[e] = d2;
-        if (consume || dirty) { s.plan[e] = plan; s.tctr[e] = tctr; }
-    }
-
-    T2D_STAMP(3);
-    if (obs != nullptr) {
-        // _get_obs / _get_partial_obs (track_1v1.py:287-326) in closed form: own cell = own colour, the other agent's
-        // colour where it falls in the window, else the map bit, outside the map 1
-        const int oside = (int)(cnt >> 24);
-        const int my_r = ag ? r1 : r0, my_c = ag ? c1 : c0, ot_r = ag ? r0 : r1, ot_c = ag ? c0 : c1;
-        const int rr = rowbase + k, y = rr - (my_r - T2D_POB);
-        if (k < 15 && (unsigned)y < (unsigned)T2D_WIN) {
-            // the lane that holds a row extracts its 13 window bits; after an episode switch they come ready-made from
-            // the next-episode slot (n_win, lane k <-> window row k - 1)
-            uint32_t bits = switched ? sp_win : window_row_bits(w0, w1, w2, oside, my_c);
-            if (y == T2D_POB) bits &= ~(1u << T2D_POB);                 // coloured cells carry no map bit
-            const int xo = ot_c - (my_c - T2D_POB);
-            if (rr == ot_r && (unsigned)xo < (unsigned)T2D_WIN) bits &= ~(1u << xo);
-            st[sl * 26 + ag * 13 + y] = bits;
-        }
-        mk[lane] = 0u; mk[lane + 64] = 0u;
-        if (lane < 169 - 128) mk[lane + 128] = 0u;
-        if (k == 0) {   // the four (slot, agent) windows: own colour at the centre (:313), the other agent if inside
-            uint8_t *mb = reinterpret_cast<uint8_t *>(mk) + sl * kObsPerEnv + ag * (T2D_WIN * T2D_WIN)
-                          + T2D_POB * T2D_WIN + T2D_POB;
-            const int dr = ot_r - my_r, dc = ot_c - my_c;
-            if ((unsigned)(dr + T2D_POB) < (unsigned)T2D_WIN && (unsigned)(dc + T2D_POB) < (unsigned)T2D_WIN)
-                mb[dr * T2D_WIN + dc] = ag ? 2 : 4;
-            mb[0] = ag ? 4 : 2;                                         // written last: own colour wins when co-located
-        }
-        wave_lds_sync();
-        T2D_STAMP(4);
-        const size_t ebase = ((size_t)it * s.n + e0) * kObsPerEnv;   // first cell of the pair in the output
-        // all LDS reads of the three groups first (independent: their latencies overlap), then the math, then the stores
-        uint32_t glo[3], ghi[3], gmk[3];
+    const bool active = e0 < n;         // (no early return: every wave reaches the workgroup barrier below)
+    Step2<false, OBS, RAM> S;
+    if (ENV && active) S.init(s, e0, lane, stage2[wave]);          // env state loads first ...
+    const int sl = lane >> 5, q = lane & 31, j = q * 4;
+    const bool live = e0 + sl < n;
+    const int e = live ? e0 + sl : (active ? e0 : 0);
+    constexpr int R = 128;
+    // ... then everything both cells read, in one batch
+    const float k = a.done_prev ? (a.done_prev[e] == 0 ? 1.0f : 0.0f) : 1.0f;
+    float4 pre[2][4], cp[2], aw[2][kMaxActions];
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            glo[i] = st[rj[i]]; ghi[i] = st[rj[i] + 1];
-            gmk[i] = mk[lane + 64 * i];                      // (the mark plane is padded to 192 dwords: always in bounds)
-        }
+    for (int p = 0; p < 2; p++) {
+        const float *ig = a.ig[p] + (size_t)e * 4 * R + j;
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int q = lane + 64 * i, p = 4 * q;
-            const uint32_t nib = ((glo[i] | (ghi[i] << 13)) >> rx[i]) & 0xfu;
-            const uint32_t bytes = (__umul24(nib, 0x204081u) & 0x01010101u) | gmk[i];   // bit c -> byte c, then colours
-            if (p >= cells) continue;
-            const int nvalid = min(4, cells - p);
-            if (OBS == OBS_U8) {
-                uint8_t *o = reinterpret_cast<uint8_t *>(obs) + ebase + p;
-                if (nvalid == 4) *reinterpret_cast<uint32_t *>(o) = bytes;
-                else for (int c = 0; c < nvalid; c++) o[c] = (uint8_t)(bytes >> (8 * c));
-            } else {
-                float *o = reinterpret_cast<float *>(obs) + ebase + p;
-                const float f0 = (float)(bytes & 0xffu), f1 = (float)((bytes >> 8) & 0xffu);
-                const float f2 = (float)((bytes >> 16) & 0xffu), f3 = (float)(bytes >> 24);
-                if (OBS == OBS_F32_VEC4 && nvalid == 4) {
-                    *reinterpret_cast<float4 *>(o) = make_float4(f0, f1, f2, f3);
-                } else {
-                    o[0] = f0;
-                    if (nvalid > 1) o[1] = f1;
-                    if (nvalid > 2) o[2] = f2;
-                    if (nvalid > 3) o[3] = f3;
-                }
+        for (int g = 0; g < 4; g++) pre[p][g] = ld4(ig + g * R);
+        if (a.hg[p]) {
+            const float *hg = a.hg[p] + (size_t)e * 4 * R + j;
+#pragma unroll
+            for (int g = 0; g < 4; g++) pre[p][g] = fma4(k, ld4(hg + g * R), pre[p][g]);
+        }
+        if (a.bias[p]) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) pre[p][g] = fma4(1.0f, ld4(a.bias[p] + g * R + j), pre[p][g]);
+        }
+        cp[p] = ld4(a.c_prev[p] + (size_t)e * R + j);
+#pragma unroll
+        for (int x = 0; x < kMaxActions; x++) aw[p][x] = x < a.A ? ld4(a.actor_w[p] + x * R + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const unsigned long long ctr = *a.counter;
+    if (a.emb) {
+#pragma unroll
+        for (int i = 0; i < kEmbTrips; i++) {
+            const int idx = (int)threadIdx.x + i * 64 * kStep2Waves;
+            if (idx < a.A * 128) st4(emb_lds + 4 * idx, emb_st[i]);
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    if (ENV) { S.init2(s, obs, rew, done_out); S.rows(s); }   // (waits for the state only: vector loads return in order)
+    int act[2] = {0, 0};
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        if (p == 1 && a.emb) {     // tracker-aware target: fc_action_tracker(one_hot(a_tracker)) projected through W_ih (model.py:193-194)
+            const float *em = emb_lds + act[0] * 4 * R + j;
+#pragma unroll
+            for (int g = 0; g < 4; g++) pre[1][g] = fma4(1.0f, ld4(em + g * R), pre[1][g]);
+        }
+        const CellOut o = cell4(pre[p][0], pre[p][1], pre[p][2], pre[p][3], cp[p], k);
+        if (live) {
+            st4(a.h_out[p] + (size_t)e * R + j, o.h);
+            st4(a.c_out[p] + (size_t)e * R + j, o.c);
+            if (a.acts[p]) {
+                float *ac = a.acts[p] + (size_t)e * 4 * R + j;
+                st4(ac, o.gi); st4(ac + R, o.gf); st4(ac + 2 * R, o.gg); st4(ac + 3 * R, o.go);
             }
         }
-        if (MULTI) wave_lds_sync();   // the next step overwrites the stage
-        T2D_STAMP(5);
-        if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(6); }
+        float logit[kMaxActions];
+        head_logits(o.h, aw[p], a.A, 32, logit);
+        int mine = 0;
+        if (q == 0) {
+#pragma unroll
+            for (int x = 0; x < kMaxActions; x++) logit[x] = x < a.A ? logit[x] + a.actor_b[p][x] : -INFINITY;
+            // row index e and ordinal + p: the numbers atr_lstm_cell_forward_act* draw for this row
+            mine = draw_action(logit, a.A, e, ctr, a.seed, a.ordinal + (unsigned)p);
+            if (live) a.actions_out[(size_t)p * n + e] = (long long)mine;
+        }
+        act[p] = __shfl(mine, lane & 32, 64);
     }
-  }
+    if (ENV) S.finish(s, act[0] & s.amask, act[1] & s.amask, 0, obs, rew, done_out, stamp);
 }
 
 __global__ void k_build_reward_lut(float2 *lut)
@@ -1302,6 +1468,62 @@ extern "C" int t2d_step_u8(t2d_handle *h, const void *act_tracker_dev, const voi
     }
     launch_step2<false, false>(h, st, act_tracker_dev, act_target_dev, act_dtype, obs_u8_dev, true, rew_dev, done_dev, 0u,
                                0u, 0u, h->phase, 1);
+    HIP_TRY(hipGetLastError());
+    if (h->s.auto_reset) return window_end(h, st);
+    return T2D_OK;
+}
+
+// The rollout step's last launch (see k_act_step): policy cells + draws + env step. Same stamping / generator schedule
+// as t2d_step.
+extern "C" int atr_act_env_step(t2d_handle *h, const atr_act_step *args, void *obs_dev, int obs_is_u8, float *rew_dev,
+                                uint8_t *done_dev, void *stream)
+{
+    if (!args) return fail(T2D_ERR_INVALID, "atr_act_env_step: null argument");
+    const atr_act_step &a = *args;
+    for (int p = 0; p < 2; p++)
+        if (!a.ig[p] || !a.c_prev[p] || !a.h_out[p] || !a.c_out[p] || !a.actor_w[p] || !a.actor_b[p])
+            return fail(T2D_ERR_INVALID, "atr_act_env_step: null policy buffer (player %d)", p);
+    if (!a.actions_out || !a.counter || a.R != 128 || a.A < 1 || a.A > atr::kMaxActions)
+        return fail(T2D_ERR_INVALID, "atr_act_env_step: needs R = 128, 1 <= A <= %d, actions_out, counter", atr::kMaxActions);
+    hipStream_t st = (hipStream_t)stream;
+    if (!h) {   // policy half only (the learner's bootstrap step: one more actor step, no env step)
+        if (a.N <= 0) return fail(T2D_ERR_INVALID, "atr_act_env_step: N must be > 0 without an env handle");
+        DevState none;
+        std::memset(&none, 0, sizeof(none));
+        const unsigned grid = (unsigned)(((a.N + 1) / 2 + kStep2Waves - 1) / kStep2Waves);
+        hipLaunchKernelGGL((k_act_step<OBS_U8, false, false>), dim3(grid), dim3(64 * kStep2Waves), 0, st, none, a, nullptr,
+                           nullptr, nullptr, 0u);
+        HIP_TRY(hipGetLastError());
+        return T2D_OK;
+    }
+    if (!rew_dev || !done_dev || !obs_dev) return fail(T2D_ERR_INVALID, "atr_act_env_step: null env buffer");
+    if (!use_step2(h))
+        return fail(T2D_ERR_INVALID, "atr_act_env_step: exists for 'Partial' ids without Nav/RPF targets (the k_step2 family)");
+    if (a.N != h->s.n) return fail(T2D_ERR_INVALID, "atr_act_env_step: policy batch %d != %d envs", a.N, h->s.n);
+    if (a.A != h->s.amask + 1) return fail(T2D_ERR_INVALID, "atr_act_env_step: %d policy actions, env has %d", a.A, h->s.amask + 1);
+    if (obs_is_u8 && ((uintptr_t)obs_dev & 3u) != 0u) return fail(T2D_ERR_INVALID, "atr_act_env_step: obs buffer must be 4-byte aligned");
+    if (!h->reset_done) return fail(T2D_ERR_STATE, "atr_act_env_step: call t2d_reset (all envs) or t2d_inject first");
+    if (h->s.auto_reset && !h->primed) return fail(T2D_ERR_STATE, "atr_act_env_step: auto_reset needs one t2d_reset before stepping");
+    DeviceGuard guard(h->device);
+    if (h->s.auto_reset) {
+        int rc = window_begin(h, st);
+        if (rc) return rc;
+        h->phase++;
+    }
+    const int kind = obs_is_u8 ? OBS_U8 : ((((uintptr_t)obs_dev & 15u) == 0u) ? OBS_F32_VEC4 : OBS_F32_SCALAR);
+#define T2D_LAUNCH_ACT(KIND)                                                                                           \
+    do {                                                                                                               \
+        if (h->has_ram)                                                                                                \
+            hipLaunchKernelGGL((k_act_step<KIND, true, true>), pair_grid(h->s.n), dim3(64 * kStep2Waves), 0, st, h->s, a, \
+                               obs_dev, rew_dev, done_dev, h->phase);                                                  \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_act_step<KIND, false, true>), pair_grid(h->s.n), dim3(64 * kStep2Waves), 0, st, h->s, a, \
+                               obs_dev, rew_dev, done_dev, h->phase);                                                  \
+    } while (0)
+    if (kind == OBS_U8) T2D_LAUNCH_ACT(OBS_U8);
+    else if (kind == OBS_F32_VEC4) T2D_LAUNCH_ACT(OBS_F32_VEC4);
+    else T2D_LAUNCH_ACT(OBS_F32_SCALAR);
+#undef T2D_LAUNCH_ACT
     HIP_TRY(hipGetLastError());
     if (h->s.auto_reset) return window_end(h, st);
     return T2D_OK;

@@ -113,6 +113,21 @@ class VecEnv(object):
         obs, rew, done = (self.core.step_u8 if self.obs_u8 else self.core.step)(a0, a1, out=out)
         return self._stack(obs, done), rew, done, {}
 
+    def fused_step_out(self, out):
+        """(core, obs, rew, done) for fused.act_env_step — the env step inside the policy step's last launch — when this
+        env can take it ('Partial' observations, no Nav/RPF target, no host-side frame processing), else None."""
+        if not self.core.supports_u8 or self.stack_frames != 1 or self.rescale:
+            return None
+        obs, rew, done = out
+        if obs.dtype != (torch.uint8 if self.obs_u8 else torch.float32):
+            return None
+        return (self.core, obs, rew, done)
+
+    def after_fused_step(self, env_out):
+        """What step() returns, for a step that fused.act_env_step already ran into env_out's buffers."""
+        _, obs, rew, done = env_out
+        return self._stack(obs, done), rew, done, {}
+
     def rollout_buffers(self, num_steps):
         """Storage for one rollout the step kernel writes in place — obs [T+1,N,A,h,w] (slot 0 = the state the
         rollout starts from), rewards [T,N,A], done [T,N] — so the learner reads the rollout without a stacking

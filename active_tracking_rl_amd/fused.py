@@ -21,6 +21,15 @@ from . import vec_env
 _lib = None
 
 
+class ActStepArgs(C.Structure):
+    """atr_act_step of include/atr_policy.h."""
+    _fields_ = [("ig", C.c_void_p * 2), ("hg", C.c_void_p * 2), ("bias", C.c_void_p * 2), ("c_prev", C.c_void_p * 2),
+                ("h_out", C.c_void_p * 2), ("c_out", C.c_void_p * 2), ("acts", C.c_void_p * 2),
+                ("actor_w", C.c_void_p * 2), ("actor_b", C.c_void_p * 2), ("emb", C.c_void_p), ("done_prev", C.c_void_p),
+                ("actions_out", C.c_void_p), ("counter", C.c_void_p), ("seed", C.c_ulonglong), ("ordinal", C.c_uint),
+                ("A", C.c_int), ("N", C.c_int), ("R", C.c_int)]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -49,6 +58,8 @@ def lib():
         L.atr_lstm_cell_forward_act2.restype = i32
         L.atr_lstm_cell_forward_act2.argtypes = [vp] * 5 + [ll, vp, vp, ll, vp, ll, vp, ll] + [vp] * 4 + [i32, vp, vp,
                                                  C.c_ulonglong, C.c_uint, i32, i32, vp]
+        L.atr_act_env_step.restype = i32
+        L.atr_act_env_step.argtypes = [vp, C.POINTER(ActStepArgs), vp, i32, vp, vp, vp]
         L.atr_actor_step.restype = i32
         L.atr_actor_step.argtypes = [vp] * 12 + [i32, i32, i32, vp]
         L.atr_lstm_cell_backward.restype = i32
@@ -480,6 +491,47 @@ def lstm_cell_act_into(ig, hg, c_prev, done, h_out, c_out, acts, sampler, actor,
                                              _stream(ig))
     if rc != 0:
         raise RuntimeError("atr_lstm_cell_forward_act failed (%d)" % rc)
+    return actions_out
+
+
+@torch.no_grad()
+def act_env_step(env_core, ig, hg, biases, c_prev, done, h_out, c_out, acts, sampler, actors, actions_out, emb=None,
+                 env_out=None):
+    """The END of a rollout step as ONE launch (atr_act_env_step, csrc/track2d_hip.hip k_act_step): both players' cells +
+    actor heads + draws (tracker first; emb [A,4R] adds emb[a_tracker] to the target's pre-activations) and, with
+    env_core (a vec_env.VecTrack2D) and env_out = (obs [N,2,13,13] u8 | f32, rew [N,2], done [N] u8), the env step with
+    those actions. ig / hg: per-player [N,4R] contiguous (hg[p] None: ig[p] is the whole pre-activation); biases (b0, b1)
+    [4R] or None; c_prev / h_out / c_out per-player [N,R]; acts per-player [N,4R] or None; actions_out int64 [2,N].
+    Same results as lstm_cell_act_into x 2 + env.step. Only valid inside sampler.begin_block(); consumes two ordinals."""
+    N, R = c_prev[0].shape
+    assert sampler._ordinal is not None and actions_out.is_contiguous() and actions_out.shape == (2, N)
+    a = ActStepArgs()
+    for p in range(2):
+        for t in (ig[p], c_prev[p], h_out[p], c_out[p]):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        a.ig[p], a.hg[p] = ig[p].data_ptr(), (hg[p].data_ptr() if hg is not None and hg[p] is not None else None)
+        a.bias[p] = biases[p].data_ptr() if biases is not None and biases[p] is not None else None
+        a.c_prev[p], a.h_out[p], a.c_out[p] = c_prev[p].data_ptr(), h_out[p].data_ptr(), c_out[p].data_ptr()
+        a.acts[p] = acts[p].data_ptr() if acts is not None and acts[p] is not None else None
+        assert hg is None or hg[p] is None or hg[p].is_contiguous()
+        assert acts is None or acts[p] is None or acts[p].is_contiguous()
+        a.actor_w[p], a.actor_b[p] = actors[p].weight.data_ptr(), actors[p].bias.data_ptr()
+    a.emb = emb.data_ptr() if emb is not None else None
+    a.done_prev = done.data_ptr() if done is not None else None
+    a.actions_out, a.counter, a.seed = actions_out.data_ptr(), sampler.counter.data_ptr(), sampler.seed
+    a.ordinal = sampler._ordinal + 1
+    sampler._ordinal += 2
+    a.A, a.N, a.R = actors[0].weight.shape[0], N, R
+    L = lib()
+    if env_core is None:
+        rc = L.atr_act_env_step(None, C.byref(a), None, 0, None, None, _stream(ig[0]))
+    else:
+        obs, rew, done_out = env_out
+        assert obs.is_contiguous() and rew.is_contiguous() and done_out.is_contiguous() and obs.dtype in (torch.uint8, torch.float32)
+        rc = L.atr_act_env_step(env_core.h, C.byref(a), _p(obs), 1 if obs.dtype == torch.uint8 else 0, _p(rew), _p(done_out),
+                                _stream(ig[0]))
+    if rc != 0:
+        raise RuntimeError("atr_act_env_step failed (%d): %s" % (rc, L.t2d_last_error().decode()))
     return actions_out
 
 

@@ -513,6 +513,8 @@ class A3C_Dueling(nn.Module):
 
     fused_sampling = True   # GPU rollouts draw actions with the fused HIP head (csrc/policy_hip.hip)
     fused_actor_step = True  # ... and run the LSTMCell step as one MFMA kernel (csrc/actor_step_hip.hip)
+    fused_env_step = True    # ... and end the step with ONE launch: both cells + heads + draws + the env step (k_act_step)
+    mfma_step_min_rows = int(__import__('os').environ.get('ATR_MFMA_MIN_ROWS', '3072'))  # from this many rows up the LSTMCell GEMMs run inside atr_actor_step instead
 
     @torch.no_grad()
     def begin_act(self):
@@ -604,14 +606,16 @@ class A3C_Dueling(nn.Module):
         return c
 
     @torch.no_grad()
-    def act_cached(self, states, cache, t, done=None):
+    def act_cached(self, states, cache, t, done=None, env_out=None):
         """act() for step t of a cached rollout: same sampling and state update, every intermediate written into the
-        cache's slot t (LSTM state of step t lives in cache.h_all/c_all[:, t], the new one goes to slot t+1)."""
+        cache's slot t (LSTM state of step t lives in cache.h_all/c_all[:, t], the new one goes to slot t+1).
+        env_out = (vec_env.VecTrack2D, obs slot, reward slot, done slot): where the kernels allow it the env step runs
+        inside the step's last launch (fused.act_env_step); self.env_stepped tells the caller whether it did."""
         return self._act_step(states, cache, [cache.y[0][t], cache.y[1][t]], [cache.f[0][t], cache.f[1][t]],
                               cache.feat1[t] if cache.feat1 is not None else None,
                               cache.h_all[:, t], cache.c_all[:, t], cache.h_all[:, t + 1], cache.c_all[:, t + 1],
                               cache.acts[:, t], cache.actions[t] if cache.actions is not None else None, done,
-                              f_pair=cache.f_all[:, t] if cache.f_all is not None else None)
+                              f_pair=cache.f_all[:, t] if cache.f_all is not None else None, env_out=env_out)
 
     @torch.no_grad()
     def boot_values(self, states, cache, done, v_out):
@@ -638,7 +642,8 @@ class A3C_Dueling(nn.Module):
             fused.heads_values(b.h[i], p.critic.critic_linear, v_out, i)
         return v_out
 
-    def _act_step(self, states, cache, y, f_out, feat1, h_prev, c_prev, h_out, c_out, acts, actions, done, f_pair=None):
+    def _act_step(self, states, cache, y, f_out, feat1, h_prev, c_prev, h_out, c_out, acts, actions, done, f_pair=None,
+                  env_out=None):
         """One actor step of both players on explicit buffers: y / f_out per-player stem and fc outputs, h_prev / c_prev
         [2,N,R] (un-masked; `done` [N] uint8 of the previous step is applied inside), h_out / c_out [2,N,R], acts
         [2,N,4R] (activated gates), actions [2,N] int64 or None."""
@@ -659,11 +664,28 @@ class A3C_Dueling(nn.Module):
         # a second small launch; else hidden GEMMs as one bmm + per-player input GEMM + fused cell/head/draw kernel
         # (only from 3072 rows up: one wave tile per SIMD of the chip needs 4096 rows; at 1024 rows its 22 us per call lose to
         # the library GEMMs + cell kernel, measured with tools/config_sweep.py)
-        mfma_step = (self.fused_actor_step and n >= 3072 and actions is not None and self._sampler._ordinal is not None
+        self.env_stepped = False
+        mfma_step = (self.fused_actor_step and n >= self.mfma_step_min_rows and actions is not None and self._sampler._ordinal is not None
                      and fused.actor_step_supported(p0.encoder.outdim, R) and p1.encoder.outdim == p0.encoder.outdim)
         hgs = None if mfma_step else torch.bmm(h_prev, cache.whh_t)
         one_launch = (actions is not None and self._sampler._ordinal is not None and R // 4 in (16, 32, 64)
                       and p0.actor.actor_linear.weight.shape[0] <= 8 and p1.actor.actor_linear.weight.shape[0] <= 8)
+        # Below the MFMA-step threshold: both input projections as ONE batched GEMM on the pair's feature rows, then both
+        # cells + heads + draws (tracker first, the tracker-aware target adds emb[a_tracker]) and — given env_out — the env
+        # step itself as ONE launch (csrc/track2d_hip.hip k_act_step): stem, 2 x fc, 2 x bmm, act+env = 6 launches per step
+        if (one_launch and not mfma_step and self.fused_env_step and R == 128 and f_pair is not None
+                and getattr(cache, "wih_t", None) is not None
+                and p0.actor.actor_linear.weight.shape == p1.actor.actor_linear.weight.shape
+                and all(t.is_contiguous() for t in (c_prev[0], c_prev[1], h_out[0], h_out[1], c_out[0], c_out[1], acts[0], acts[1]))):
+            for i, p in enumerate((p0, p1)):
+                _addmm_relu(p.encoder.fc.bias, ys[i].view(n, -1), p.encoder.fc.weight.t(), f_out[i])
+            ig = torch.bmm(f_pair, cache.wih_t)
+            core = env_out[0] if env_out is not None else None
+            fused.act_env_step(core, ig, hgs, cache.bsum, c_prev, done, h_out, c_out, acts, self._sampler,
+                               (p0.actor.actor_linear, p1.actor.actor_linear), actions,
+                               emb=cache.emb_ih if self.tat else None, env_out=env_out[1:] if env_out is not None else None)
+            self.env_stepped = env_out is not None
+            return [actions[0], actions[1]]
         # players that do not see each other's action (maze-lstm pairs): both input projections as ONE batched GEMM on
         # the pair's feature rows and both cells + heads + draws as ONE launch — 7 launches per env step instead of 9
         if (one_launch and not mfma_step and not self.tat and f_pair is not None and getattr(cache, "wih_t", None) is not None

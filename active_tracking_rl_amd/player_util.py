@@ -81,8 +81,15 @@ class Agent(object):
         (model.act, no autograd graph); what the learner needs to re-evaluate the step (state, actions, done) is
         stored instead. LSTM states are kept per player as contiguous [N,R] tensors during the rollout."""
         self.n_steps += 1
+        stepped = False
         if self._cache is not None:
-            actions = self.model.act_cached(self.state, self._cache, len(self.states), self._pending_done)
+            # where the kernels allow it the env step runs inside the policy step's last launch (k_act_step)
+            env_out = None
+            if self._buf is not None and hasattr(self.env, "fused_step_out"):
+                t = len(self.states)
+                env_out = self.env.fused_step_out((self._buf[0][t + 1], self._buf[1][t], self._buf[2][t]))
+            actions = self.model.act_cached(self.state, self._cache, len(self.states), self._pending_done, env_out=env_out)
+            stepped = env_out is not None and getattr(self.model, "env_stepped", False)
         elif hasattr(self.model, "act") and self.num_agents == 2 and not getattr(self.model, "single", False):
             actions, self._hs, self._cs = self.model.act(self.state, self._hs, self._cs, self._pending_done)
         else:
@@ -93,7 +100,9 @@ class Agent(object):
         self.states.append(self.state)
         if self._actions_buf is None:                            # else the sampler wrote them in place
             self.actions.append(torch.stack(actions, 1))
-        if self._buf is not None:                       # the step kernel writes straight into the rollout storage
+        if stepped:                                     # the step's outputs are already in the rollout storage
+            state_multi, reward_multi, done, self.info = self.env.after_fused_step(env_out)
+        elif self._buf is not None:                     # the step kernel writes straight into the rollout storage
             t = len(self.states) - 1
             state_multi, reward_multi, done, self.info = self.env.step(
                 actions, out=(self._buf[0][t + 1], self._buf[1][t], self._buf[2][t]))

@@ -95,6 +95,42 @@ int atr_lstm_cell_forward_act2(const float *ig, const float *hg, const float *bi
                                const float *actor_w0, const float *actor_b0, const float *actor_w1, const float *actor_b1,
                                int A, long long *actions_out, const unsigned long long *counter, unsigned long long seed,
                                unsigned ordinal, int N, int R, void *stream);
+/* The END of a rollout step as ONE launch (csrc/track2d_hip.hip: k_act_step): both players' LSTM cells + actor heads +
+ * categorical draws — tracker first, then the target, whose pre-activations receive emb[a_tracker] when emb != NULL (the
+ * tracker-aware target, model.py:190-209,249-257 of the reference) — and, with the two fresh actions still in registers, the
+ * env step + observation of t2d_step / t2d_step_u8 (Track1v1Env.step, track_1v1.py:71-127; in-launch auto-reset). It is
+ * what train.py:81-88 -> player_util.py:44-67 does after the two GEMMs of each LSTMCell: replaces two
+ * atr_lstm_cell_forward_act1 launches, the action round trip and the step launch, with bit-identical results.
+ * Per player p: ig[p] [N,4R] input projection; hg[p] [N,4R] = h_prev W_hh^T (un-masked; NULL = ig[p] already holds the
+ * whole pre-activation); bias[p] [4R] (nullable, added here); c_prev[p] / h_out[p] / c_out[p] [N,R]; acts[p] [N,4R]
+ * (nullable: activated gates for atr_lstm_cell_backward); actor_w[p] [A,R], actor_b[p] [A]. done_prev [N] (nullable): the
+ * previous step's done flags (k = done == 0 masks hg and c_prev). actions_out int64 [2,N]. Draw key: (seed; row, *counter,
+ * ordinal + p) — the key of atr_lstm_cell_forward_act*. R must be 128. */
+typedef struct atr_act_step {
+    const float *ig[2];
+    const float *hg[2];
+    const float *bias[2];
+    const float *c_prev[2];
+    float *h_out[2];
+    float *c_out[2];
+    float *acts[2];
+    const float *actor_w[2];
+    const float *actor_b[2];
+    const float *emb;
+    const unsigned char *done_prev;
+    long long *actions_out;
+    const unsigned long long *counter;
+    unsigned long long seed;
+    unsigned ordinal;
+    int A, N, R;
+} atr_act_step;
+struct t2d_handle;
+/* env == NULL: the policy half alone (N rows; the learner's bootstrap step). Otherwise N must equal the handle's env count,
+ * obs is u8 [N,2,13,13] (obs_is_u8 != 0; 4-byte aligned) or float32 [N,2,13,13], rew float32 [N,2], done u8 [N]; only for
+ * handles t2d_step_u8 accepts ('Partial' observations, no Nav/RPF target). Returns 0 or a T2D_ERR_* code (t2d_last_error). */
+int atr_act_env_step(struct t2d_handle *env, const atr_act_step *args, void *obs, int obs_is_u8, float *rew,
+                     unsigned char *done, void *stream);
+
 /* The actor's whole LSTMCell step for ONE player as one f32-MFMA kernel (csrc/actor_step_hip.hip): both GEMMs of
  * nn.LSTMCell (model.py:110,172 of the reference) and the cell, without materialising the gate pre-activations:
  *   gates = f W_ih^T + (k h_prev) W_hh^T + bias [+ emb[act_in[n]]],  k[n] = (done[n] == 0) (1 if done is NULL)

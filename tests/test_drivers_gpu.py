@@ -408,3 +408,80 @@ def test_graphed_iteration_selects_the_training_mode_per_call():
     maps = player.env.core.get_maps()
     assert (maps[np.arange(128), st["pos"][:, 0, 0], st["pos"][:, 0, 1]] == 0).all()
     player.env.close()
+
+
+@pytest.mark.parametrize("env_id,n,u8,tat", [("Track2D-BlockPartialPZR-v0", 512, True, True),
+                                              ("Track2D-BlockPartialRam-v0", 257, False, False),
+                                              ("Track2D-MazePartialFar-v0", 96, True, True)])
+def test_act_env_step_equals_cells_draws_and_env_step(env_id, n, u8, tat):
+    """atr_act_env_step (k_act_step: both players' cells + heads + draws + the env step in ONE launch) against the launches
+    it replaces — atr_lstm_cell_forward_act1 for the tracker, again for the target (+ emb[a_tracker] when tracker-aware),
+    then t2d_step(_u8) with the two action tensors — from identical inputs on two env handles with the same seed: hidden /
+    cell states, activated gates, actions, observations, rewards, done flags and env state must be bit-identical, over
+    enough steps for episodes to end (in-launch auto-reset, generator passes) and with an odd batch (dead lane half)."""
+    from active_tracking_rl_amd import fused, vec_env
+    dev = torch.device("cuda:0")
+    R, A = 128, 4
+    torch.manual_seed(5)
+    envs = [vec_env.VecTrack2D(env_id, num_envs=n, seed=11) for _ in range(2)]
+    o0 = envs[0].reset()
+    assert torch.equal(o0, envs[1].reset())
+    actors = [torch.nn.Linear(R, A).to(dev) for _ in range(2)]
+    for l in actors:
+        l.weight.data.mul_(8.0)          # spread the action distribution a little
+    bias = [torch.randn(4 * R, device=dev) * 0.1 for _ in range(2)]
+    emb = torch.randn(A, 4 * R, device=dev) * 0.5 if tat else None
+    samplers = [fused.ActionSampler(dev, seed=77) for _ in range(2)]
+    mk = lambda *s: [torch.zeros(*s, device=dev) for _ in range(2)]
+    h, c = [mk(2, n, R) for _ in range(2)], [mk(2, n, R) for _ in range(2)]     # [impl][slot] -> [2, n, R]
+    for k in range(2):
+        c[k][0].copy_(torch.randn(2, n, R, device=dev))
+        c[1][0].copy_(c[0][0])
+    acts = [torch.zeros(2, n, 4 * R, device=dev) for _ in range(2)]
+    actions = [torch.zeros(2, n, dtype=torch.int64, device=dev) for _ in range(2)]
+    odt = torch.uint8 if u8 else torch.float32
+    outs = [(torch.zeros(n, 2, 13, 13, dtype=odt, device=dev), torch.zeros(n, 2, device=dev),
+             torch.zeros(n, dtype=torch.uint8, device=dev)) for _ in range(2)]
+    done_prev = [None, None]
+    n_done = 0
+    for t in range(70):
+        ig = torch.randn(2, n, 4 * R, device=dev)
+        hg = torch.randn(2, n, 4 * R, device=dev) * 0.5
+        cur, nxt = t % 2, (t + 1) % 2
+        for s_ in samplers:
+            s_.begin_block()
+        # (a) fused
+        fused.act_env_step(envs[0], [ig[0], ig[1]], [hg[0], hg[1]], bias, [c[0][cur][0], c[0][cur][1]], done_prev[0],
+                           [h[0][nxt][0], h[0][nxt][1]], [c[0][nxt][0], c[0][nxt][1]], [acts[0][0], acts[0][1]], samplers[0],
+                           actors, actions[0], emb=emb, env_out=outs[0])
+        # (b) the launches it replaces
+        for p in range(2):
+            fused.lstm_cell_act_into(ig[p], hg[p], c[1][cur][p], done_prev[1], h[1][nxt][p], c[1][nxt][p], acts[1][p],
+                                     samplers[1], actors[p], actions[1][p], emb=emb if (tat and p == 1) else None,
+                                     act_in=actions[1][0] if (tat and p == 1) else None, bias=bias[p])
+        (envs[1].step_u8 if u8 else envs[1].step)(actions[1][0], actions[1][1], out=outs[1])
+        for s_ in samplers:
+            s_.end_block()
+        assert torch.equal(actions[0], actions[1]), t
+        assert torch.equal(h[0][nxt], h[1][nxt]) and torch.equal(c[0][nxt], c[1][nxt]) and torch.equal(acts[0], acts[1]), t
+        for a_, b_ in zip(outs[0], outs[1]):
+            assert torch.equal(a_, b_), t
+        done_prev = [outs[0][2].clone(), outs[1][2].clone()]
+        n_done += int(outs[0][2].sum().item())
+    sa, sb = envs[0].get_state(), envs[1].get_state()
+    for k_ in ("pos", "c_far", "t", "episode", "d2"):
+        assert np.array_equal(sa[k_], sb[k_]), k_
+    assert n_done > n // 4 and envs[0].faults() == 0
+    # the policy half alone (the learner's bootstrap step): env handle None
+    for s_ in samplers:
+        s_.begin_block()
+    ig, hg = torch.randn(2, n, 4 * R, device=dev), torch.randn(2, n, 4 * R, device=dev)
+    fused.act_env_step(None, [ig[0], ig[1]], [hg[0], hg[1]], bias, [c[0][0][0], c[0][0][1]], done_prev[0],
+                       [h[0][1][0], h[0][1][1]], [c[0][1][0], c[0][1][1]], None, samplers[0], actors, actions[0], emb=emb)
+    for p in range(2):
+        fused.lstm_cell_act_into(ig[p], hg[p], c[1][0][p], done_prev[1], h[1][1][p], c[1][1][p], None, samplers[1], actors[p],
+                                 actions[1][p], emb=emb if (tat and p == 1) else None,
+                                 act_in=actions[1][0] if (tat and p == 1) else None, bias=bias[p])
+    assert torch.equal(actions[0], actions[1]) and torch.equal(h[0][1], h[1][1]) and torch.equal(c[0][1], c[1][1])
+    for e_ in envs:
+        e_.close()
