@@ -30,6 +30,14 @@ class ActStepArgs(C.Structure):
                 ("A", C.c_int), ("N", C.c_int), ("R", C.c_int)]
 
 
+class PairLinearArgs(C.Structure):
+    """atr_pair_linear_args of include/atr_policy.h."""
+    _fields_ = [("a1", C.c_void_p * 2), ("w1", C.c_void_p * 2), ("a2", C.c_void_p * 2), ("w2", C.c_void_p * 2),
+                ("bias", C.c_void_p * 2), ("c", C.c_void_p * 2), ("lda1", C.c_longlong * 2), ("lda2", C.c_longlong * 2),
+                ("ldc", C.c_longlong * 2), ("k1", C.c_int * 2), ("k2", C.c_int * 2), ("done", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("relu", C.c_int)]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -58,6 +66,8 @@ def lib():
         L.atr_lstm_cell_forward_act2.restype = i32
         L.atr_lstm_cell_forward_act2.argtypes = [vp] * 5 + [ll, vp, vp, ll, vp, ll, vp, ll] + [vp] * 4 + [i32, vp, vp,
                                                  C.c_ulonglong, C.c_uint, i32, i32, vp]
+        L.atr_pair_linear.restype = i32
+        L.atr_pair_linear.argtypes = [C.POINTER(PairLinearArgs), vp]
         L.atr_act_env_step.restype = i32
         L.atr_act_env_step.argtypes = [vp, C.POINTER(ActStepArgs), vp, i32, vp, vp, vp]
         L.atr_actor_step.restype = i32
@@ -492,6 +502,38 @@ def lstm_cell_act_into(ig, hg, c_prev, done, h_out, c_out, acts, sampler, actor,
     if rc != 0:
         raise RuntimeError("atr_lstm_cell_forward_act failed (%d)" % rc)
     return actions_out
+
+
+def _rows(t):
+    """(pointer, row stride) of a 2-D float32 tensor whose rows are contiguous."""
+    assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+    return t.data_ptr(), t.stride(0)
+
+
+@torch.no_grad()
+def pair_linear(a1, w1, out, bias=None, a2=None, w2=None, done=None, relu=False):
+    """out[p] = act(a1[p] @ w1[p].T [+ (k a2[p]) @ w2[p].T] + bias[p]) for the two players in ONE launch
+    (atr_pair_linear, csrc/pair_gemm_hip.hip) — made for small row counts. a1[p] [M, k1p], w1[p] [N, k1p] (nn.Linear
+    layout, contiguous), a2 / w2 optional second term, done [M] uint8: k = (done == 0) scales a2's rows; out[p] [M, N]."""
+    g = PairLinearArgs()
+    M, N = a1[0].shape[0], w1[0].shape[0]
+    for p in range(2):
+        assert a1[p].shape[0] == M and w1[p].shape[0] == N and w1[p].is_contiguous() and w1[p].shape[1] == a1[p].shape[1]
+        g.a1[p], g.lda1[p] = _rows(a1[p])
+        g.w1[p], g.k1[p] = w1[p].data_ptr(), a1[p].shape[1]
+        if a2 is not None:
+            assert w2[p].is_contiguous() and w2[p].shape == (N, a2[p].shape[1]) and a2[p].shape[0] == M
+            g.a2[p], g.lda2[p] = _rows(a2[p])
+            g.w2[p], g.k2[p] = w2[p].data_ptr(), a2[p].shape[1]
+        g.bias[p] = bias[p].data_ptr() if bias is not None and bias[p] is not None else None
+        assert out[p].shape == (M, N)
+        g.c[p], g.ldc[p] = _rows(out[p])
+    g.done = done.data_ptr() if done is not None else None
+    g.M, g.N, g.relu = M, N, 1 if relu else 0
+    rc = lib().atr_pair_linear(C.byref(g), _stream(a1[0]))
+    if rc != 0:
+        raise RuntimeError("atr_pair_linear failed (%d)" % rc)
+    return out
 
 
 @torch.no_grad()

@@ -514,6 +514,7 @@ class A3C_Dueling(nn.Module):
     fused_sampling = True   # GPU rollouts draw actions with the fused HIP head (csrc/policy_hip.hip)
     fused_actor_step = True  # ... and run the LSTMCell step as one MFMA kernel (csrc/actor_step_hip.hip)
     fused_env_step = True    # ... and end the step with ONE launch: both cells + heads + draws + the env step (k_act_step)
+    pair_gemm_max_rows = int(__import__('os').environ.get('ATR_PAIR_GEMM_MAX_ROWS', '1024'))  # up to here: GEMM pairs as one launch
     mfma_step_min_rows = int(__import__('os').environ.get('ATR_MFMA_MIN_ROWS', '3072'))  # from this many rows up the LSTMCell GEMMs run inside atr_actor_step instead
 
     @torch.no_grad()
@@ -595,6 +596,7 @@ class A3C_Dueling(nn.Module):
         c.h_all = torch.empty((2, T + 1, N, R), device=dev)
         c.c_all = torch.empty((2, T + 1, N, R), device=dev)
         c.actions = torch.empty((T, 2, N), dtype=torch.int64, device=dev) if self.fused_sampling else None
+        c.gates = torch.empty((2, N, 4 * R), device=dev) if N <= self.pair_gemm_max_rows else None   # scratch: pre-activations
         c.bsum = [l.bias_ih + l.bias_hh for l in (p0.lstm, p1.lstm)]
         c.whh_t = torch.stack([l.weight_hh.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, R, 4R]
         c.wih_t = (torch.stack([l.weight_ih.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, F, 4R]: the pair's input GEMM as one bmm
@@ -667,21 +669,35 @@ class A3C_Dueling(nn.Module):
         self.env_stepped = False
         mfma_step = (self.fused_actor_step and n >= self.mfma_step_min_rows and actions is not None and self._sampler._ordinal is not None
                      and fused.actor_step_supported(p0.encoder.outdim, R) and p1.encoder.outdim == p0.encoder.outdim)
-        hgs = None if mfma_step else torch.bmm(h_prev, cache.whh_t)
+        env_fused = (not mfma_step and self.fused_env_step and R == 128 and f_pair is not None and actions is not None
+                     and self._sampler._ordinal is not None and getattr(cache, "wih_t", None) is not None
+                     and p0.actor.actor_linear.weight.shape == p1.actor.actor_linear.weight.shape
+                     and p0.actor.actor_linear.weight.shape[0] <= 8
+                     and all(t.is_contiguous() for t in (c_prev[0], c_prev[1], h_out[0], h_out[1], c_out[0], c_out[1],
+                                                         acts[0], acts[1], h_prev[0], h_prev[1])))
+        pair_gemm = env_fused and n <= self.pair_gemm_max_rows and getattr(cache, "gates", None) is not None
+        hgs = None if (mfma_step or pair_gemm) else torch.bmm(h_prev, cache.whh_t)
         one_launch = (actions is not None and self._sampler._ordinal is not None and R // 4 in (16, 32, 64)
                       and p0.actor.actor_linear.weight.shape[0] <= 8 and p1.actor.actor_linear.weight.shape[0] <= 8)
         # Below the MFMA-step threshold: both input projections as ONE batched GEMM on the pair's feature rows, then both
         # cells + heads + draws (tracker first, the tracker-aware target adds emb[a_tracker]) and — given env_out — the env
         # step itself as ONE launch (csrc/track2d_hip.hip k_act_step): stem, 2 x fc, 2 x bmm, act+env = 6 launches per step
-        if (one_launch and not mfma_step and self.fused_env_step and R == 128 and f_pair is not None
-                and getattr(cache, "wih_t", None) is not None
-                and p0.actor.actor_linear.weight.shape == p1.actor.actor_linear.weight.shape
-                and all(t.is_contiguous() for t in (c_prev[0], c_prev[1], h_out[0], h_out[1], c_out[0], c_out[1], acts[0], acts[1]))):
-            for i, p in enumerate((p0, p1)):
-                _addmm_relu(p.encoder.fc.bias, ys[i].view(n, -1), p.encoder.fc.weight.t(), f_out[i])
-            ig = torch.bmm(f_pair, cache.wih_t)
+        if env_fused:
             core = env_out[0] if env_out is not None else None
-            fused.act_env_step(core, ig, hgs, cache.bsum, c_prev, done, h_out, c_out, acts, self._sampler,
+            if pair_gemm:
+                # small shards: each GEMM pair as ONE launch (csrc/pair_gemm_hip.hip) — fc + ReLU of both encoders, then both
+                # LSTMCell GEMMs of both players straight to the gate pre-activations (mask and bias inside): 4 launches per step
+                fused.pair_linear([ys[0].view(n, -1), ys[1].view(n, -1)], [p0.encoder.fc.weight, p1.encoder.fc.weight],
+                                  [f_out[0], f_out[1]], bias=[p0.encoder.fc.bias, p1.encoder.fc.bias], relu=True)
+                g = cache.gates
+                fused.pair_linear([f_out[0], f_out[1]], [p0.lstm.weight_ih, p1.lstm.weight_ih], [g[0], g[1]], bias=cache.bsum,
+                                  a2=[h_prev[0], h_prev[1]], w2=[p0.lstm.weight_hh, p1.lstm.weight_hh], done=done)
+                ig, hg_, bs = g, None, None
+            else:
+                for i, p in enumerate((p0, p1)):
+                    _addmm_relu(p.encoder.fc.bias, ys[i].view(n, -1), p.encoder.fc.weight.t(), f_out[i])
+                ig, hg_, bs = torch.bmm(f_pair, cache.wih_t), hgs, cache.bsum
+            fused.act_env_step(core, ig, hg_, bs, c_prev, done, h_out, c_out, acts, self._sampler,
                                (p0.actor.actor_linear, p1.actor.actor_linear), actions,
                                emb=cache.emb_ih if self.tat else None, env_out=env_out[1:] if env_out is not None else None)
             self.env_stepped = env_out is not None

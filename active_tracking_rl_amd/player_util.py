@@ -411,8 +411,12 @@ class Agent(object):
         world = dist.get_world_size()
         bucket = getattr(optimizer, "bucket", None)
         if bucket is not None:
-            dist.all_reduce(bucket.grad, op=dist.ReduceOp.SUM)
-            bucket.grad.div_(world)
+            if bucket.grad.is_cuda and dist.get_backend() == "nccl":
+                # RCCL averages inside the collective (ncclAvg): one call, no separate divide launch between the two graphs
+                dist.all_reduce(bucket.grad, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(bucket.grad, op=dist.ReduceOp.SUM)
+                bucket.grad.div_(world)
         else:
             for p in self.model.parameters():
                 if p.grad is not None:

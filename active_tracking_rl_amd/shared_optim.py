@@ -15,45 +15,45 @@ import torch
 
 
 class FlatParams(object):
-    """Re-homes a module's parameters (and their .grad) as views of two contiguous fp32 buffers."""
+    """Re-homes a module's parameters (and their .grad) as views of two contiguous fp32 buffers. Every parameter starts
+    on a 16-byte boundary (its slot is padded to a multiple of 4 floats: the two players' 1-element critic / aux biases
+    would otherwise leave everything behind them dword-aligned only, and the kernels fetch weight rows 16 bytes at a
+    time); the padding elements are zero in both buffers and stay zero under every update rule used here."""
+
+    ALIGN = 4   # floats
 
     def __init__(self, params):
         self.params = [p for p in params]
-        total = sum(p.numel() for p in self.params)
         ref = self.params[0]
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        total = off
         self.flat = torch.zeros(total, dtype=torch.float32, device=ref.device)
         self.grad = torch.zeros(total, dtype=torch.float32, device=ref.device)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view_as(p.data)
             p.grad = self.grad[off:off + n].view_as(p.data)
-            off += n
         self.numel = total
-        # stand-in for gradients autograd reports as unused (set_grads): ordinary memory zeroed once, allocated HERE and
-        # not on first use — first use can fall inside a hipGraph capture, whose private pool and memset node would then
-        # belong to that one graph while the other per-mode graphs read the buffer too
-        self._zeros = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=ref.device)
+        self.param_numel = sum(p.numel() for p in self.params)
+        # stand-in for gradients autograd reports as unused and for the padding (set_grads): ordinary memory zeroed once,
+        # allocated HERE and not on first use — first use can fall inside a hipGraph capture, whose private pool and memset
+        # node would then belong to that one graph while the other per-mode graphs read the buffer too
+        self._zeros = torch.zeros(max(p.numel() for p in self.params) + self.ALIGN, dtype=torch.float32, device=ref.device)
         self._views = None
 
     def zero_grad(self):
         self.grad.zero_()
-        off = 0
-        for p in self.params:  # re-attach in case autograd replaced .grad
+        for p, off in zip(self.params, self.offsets):  # re-attach in case autograd replaced .grad
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad[off:off + n].data_ptr():
                 p.grad = self.grad[off:off + n].view_as(p.data)
-            off += n
-
 
     def grad_views(self):
-        views, off = [], 0
-        for p in self.params:
-            n = p.numel()
-            views.append(self.grad[off:off + n].view_as(p.data))
-            off += n
-        return views
+        return [self.grad[off:off + p.numel()].view_as(p.data) for p, off in zip(self.params, self.offsets)]
 
     def set_grads(self, grads):
         """Store freshly computed gradients (torch.autograd.grad output, None = unused) in the bucket with ONE batched
@@ -61,7 +61,13 @@ class FlatParams(object):
         kernel at a time."""
         if self._views is None:
             self._views = self.grad_views()
-        flat = [g.reshape(-1) if g is not None else self._zeros[:p.numel()] for g, p in zip(grads, self.params)]
+        flat = []
+        for g, p in zip(grads, self.params):
+            n = p.numel()
+            flat.append(g.reshape(-1) if g is not None else self._zeros[:n])
+            pad = -n % self.ALIGN
+            if pad:
+                flat.append(self._zeros[:pad])
         torch.cat(flat, out=self.grad)
         for p, v in zip(self.params, self._views):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():

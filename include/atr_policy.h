@@ -131,6 +131,24 @@ struct t2d_handle;
 int atr_act_env_step(struct t2d_handle *env, const atr_act_step *args, void *obs, int obs_is_u8, float *rew,
                      unsigned char *done, void *stream);
 
+/* The rollout step's two small GEMM pairs as ONE launch each, for small row counts (csrc/pair_gemm_hip.hip; f32 MFMA):
+ *     C[p] = act( A1[p] W1[p]^T [+ (k A2[p]) W2[p]^T] + bias[p] ),  p = 0, 1 (the two players), k[m] = (done[m] == 0)
+ * A1[p] [M, k1[p]] (row stride lda1[p] floats), W1[p] [N, k1[p]] (nn.Linear layout), optional second term A2[p] [M, k2[p]],
+ * W2[p] [N, k2[p]] (both NULL to leave it out), bias[p] [N] (nullable), C[p] [M, N] (row stride ldc[p]); relu != 0 applies
+ * max(., 0). Uses: CNN_maze's fc + ReLU for both players (perception.py:81,90 of the reference; k1 = 512 / 1024), and both
+ * GEMMs of nn.LSTMCell for both players in one pass (model.py:110,137,172,203: A1 = features, W1 = weight_ih, A2 = previous
+ * hidden state masked by the previous step's done flags, W2 = weight_hh, bias = b_ih + b_hh). N and every k multiples of
+ * 32, (k1 + k2) >= 128, 16-byte aligned pointers, strides multiples of 4. Returns 0, -1 (bad argument), -2 (launch failure). */
+typedef struct atr_pair_linear_args {
+    const float *a1[2], *w1[2], *a2[2], *w2[2], *bias[2];
+    float *c[2];
+    long long lda1[2], lda2[2], ldc[2];
+    int k1[2], k2[2];
+    const unsigned char *done;
+    int M, N, relu;
+} atr_pair_linear_args;
+int atr_pair_linear(const atr_pair_linear_args *args, void *stream);
+
 /* The actor's whole LSTMCell step for ONE player as one f32-MFMA kernel (csrc/actor_step_hip.hip): both GEMMs of
  * nn.LSTMCell (model.py:110,172 of the reference) and the cell, without materialising the gate pre-activations:
  *   gates = f W_ih^T + (k h_prev) W_hh^T + bias [+ emb[act_in[n]]],  k[n] = (done[n] == 0) (1 if done is NULL)

@@ -351,3 +351,42 @@ def test_two_player_actor_cell_kernel_equals_two_one_player_launches():
         torch.testing.assert_close(acts2[p, 2], a1, rtol=1e-5, atol=1e-6)
         assert float((act2[p] == act1).float().mean()) > 0.995
     assert sa._ordinal == sb._ordinal == 2
+
+
+@pytest.mark.parametrize("M", [512, 1000, 37, 2048])
+def test_pair_linear_matches_float64(M):
+    """atr_pair_linear (csrc/pair_gemm_hip.hip: the rollout step's small GEMM pairs in one launch) against float64: the fc +
+    ReLU shape of both encoders (K = 512 / 1024 -> 256) and the LSTMCell shape (features x W_ih^T + masked hidden x W_hh^T +
+    bias -> 512 gate pre-activations), ragged row counts, strided outputs."""
+    from active_tracking_rl_amd import fused
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M)
+    y = [torch.randn(M, 512, device=dev), torch.randn(M, 1024, device=dev)]
+    w = [torch.randn(256, 512, device=dev) * 0.05, torch.randn(256, 1024, device=dev) * 0.05]
+    b = [torch.randn(256, device=dev), torch.randn(256, device=dev)]
+    store = torch.full((2, M, 256), float("nan"), device=dev)
+    fused.pair_linear(y, w, [store[0], store[1]], bias=b, relu=True)
+    for p in range(2):
+        ref = torch.relu(y[p].double() @ w[p].double().t() + b[p].double())
+        torch.testing.assert_close(store[p].double(), ref, rtol=2e-5, atol=2e-5)
+    f = [store[0], store[1]]
+    h = torch.randn(2, M, 128, device=dev)
+    wih = [torch.randn(512, 256, device=dev) * 0.1 for _ in range(2)]
+    whh = [torch.randn(512, 128, device=dev) * 0.1 for _ in range(2)]
+    done = (torch.rand(M, device=dev) < 0.3).to(torch.uint8)
+    g = torch.full((2, M, 512), float("nan"), device=dev)
+    fused.pair_linear(f, wih, [g[0], g[1]], bias=b_g(dev), a2=[h[0], h[1]], w2=whh, done=done)
+    k = (done == 0).double().unsqueeze(1)
+    for p in range(2):
+        ref = f[p].double() @ wih[p].double().t() + (k * h[p].double()) @ whh[p].double().t() + b_g(dev)[p].double()
+        torch.testing.assert_close(g[p].double(), ref, rtol=2e-5, atol=2e-5)
+    # no mask, no bias
+    fused.pair_linear(f, wih, [g[0], g[1]], a2=[h[0], h[1]], w2=whh)
+    for p in range(2):
+        ref = f[p].double() @ wih[p].double().t() + h[p].double() @ whh[p].double().t()
+        torch.testing.assert_close(g[p].double(), ref, rtol=2e-5, atol=2e-5)
+
+
+def b_g(dev):
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    return [torch.randn(512, generator=gen).to(dev), torch.randn(512, generator=gen).to(dev)]
