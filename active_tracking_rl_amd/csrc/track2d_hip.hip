@@ -943,27 +943,25 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const vo
 // What it replaces: two cell + head + draw launches, the action round trip through memory and the step launch — three
 // dependent launches of 5-10 us each at every batch size. The env's state loads go out first and its map-row loads as
 // soon as the state is there, so both fly under the cells' arithmetic.
-template <int OBS, bool RAM, bool ENV>
+// NA: compile-time number of actions (4 = every registered id; 8 = the 'Moore' table) — the head and draw code is sized to it
+template <int OBS, bool RAM, bool ENV, int NA>
 __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_act_step a, void *obs, float *rew,
                                                                uint8_t *done_out, uint32_t stamp)
 {
     using namespace atr;
     __shared__ __attribute__((aligned(16))) uint32_t stage2[kStep2Waves][kStage2Words];
-    __shared__ __attribute__((aligned(16))) float emb_lds[kMaxActions * 4 * 128];   // the tracker-action embedding table
+    __shared__ __attribute__((aligned(16))) float emb_lds[NA * 4 * 128];   // the tracker-action embedding table
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = uni((int)(threadIdx.x >> 6));
     const int e0 = ((int)blockIdx.x * kStep2Waves + wave) * 2;
     const int n = ENV ? s.n : a.N;
     // the embedding rows (A x 4R floats, 8 KB) go to LDS now: the target's cell reads row a_tracker the moment the tracker's
     // draw is known — an LDS read instead of a dependent trip to L2 in the middle of the kernel's serial chain
-    constexpr int kEmbTrips = kMaxActions * 128 / (64 * kStep2Waves);
+    constexpr int kEmbTrips = NA * 128 / (64 * kStep2Waves);
     float4 emb_st[kEmbTrips];
     if (a.emb) {
 #pragma unroll
-        for (int i = 0; i < kEmbTrips; i++) {
-            const int idx = (int)threadIdx.x + i * 64 * kStep2Waves;
-            if (idx < a.A * 128) emb_st[i] = ld4(a.emb + 4 * idx);
-        }
+        for (int i = 0; i < kEmbTrips; i++) emb_st[i] = ld4(a.emb + 4 * ((int)threadIdx.x + i * 64 * kStep2Waves));
     }
     const bool active = e0 < n;         // (no early return: every wave reaches the workgroup barrier below)
     Step2<false, OBS, RAM> S;
@@ -972,18 +970,24 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_a
     const bool live = e0 + sl < n;
     const int e = live ? e0 + sl : (active ? e0 : 0);
     constexpr int R = 128;
-    // ... then everything both cells read, in one batch
+    // ... then everything both cells read, in one batch. The gate pre-activations are touched exactly once (written by the
+    // GEMM just before, never read again): non-temporal loads keep them from displacing the weights in L2.
     const float k = a.done_prev ? (a.done_prev[e] == 0 ? 1.0f : 0.0f) : 1.0f;
-    float4 pre[2][4], cp[2], aw[2][kMaxActions];
+    float4 pre[2][4], cp[2], aw[2][NA];
+    auto ldnt = [](const float *p_) {
+        const float4 *q_ = reinterpret_cast<const float4 *>(p_);
+        return make_float4(__builtin_nontemporal_load(&q_->x), __builtin_nontemporal_load(&q_->y),
+                           __builtin_nontemporal_load(&q_->z), __builtin_nontemporal_load(&q_->w));
+    };
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         const float *ig = a.ig[p] + (size_t)e * 4 * R + j;
 #pragma unroll
-        for (int g = 0; g < 4; g++) pre[p][g] = ld4(ig + g * R);
+        for (int g = 0; g < 4; g++) pre[p][g] = ldnt(ig + g * R);
         if (a.hg[p]) {
             const float *hg = a.hg[p] + (size_t)e * 4 * R + j;
 #pragma unroll
-            for (int g = 0; g < 4; g++) pre[p][g] = fma4(k, ld4(hg + g * R), pre[p][g]);
+            for (int g = 0; g < 4; g++) pre[p][g] = fma4(k, ldnt(hg + g * R), pre[p][g]);
         }
         if (a.bias[p]) {
 #pragma unroll
@@ -991,15 +995,12 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_a
         }
         cp[p] = ld4(a.c_prev[p] + (size_t)e * R + j);
 #pragma unroll
-        for (int x = 0; x < kMaxActions; x++) aw[p][x] = x < a.A ? ld4(a.actor_w[p] + x * R + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int x = 0; x < NA; x++) aw[p][x] = ld4(a.actor_w[p] + x * R + j);
     }
     const unsigned long long ctr = *a.counter;
     if (a.emb) {
 #pragma unroll
-        for (int i = 0; i < kEmbTrips; i++) {
-            const int idx = (int)threadIdx.x + i * 64 * kStep2Waves;
-            if (idx < a.A * 128) st4(emb_lds + 4 * idx, emb_st[i]);
-        }
+        for (int i = 0; i < kEmbTrips; i++) st4(emb_lds + 4 * ((int)threadIdx.x + i * 64 * kStep2Waves), emb_st[i]);
     }
     __syncthreads();
     if (!active) return;
@@ -1016,19 +1017,35 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_a
         if (live) {
             st4(a.h_out[p] + (size_t)e * R + j, o.h);
             st4(a.c_out[p] + (size_t)e * R + j, o.c);
-            if (a.acts[p]) {
+            if (a.acts[p]) {   // read next by the learner, a whole rollout later: streamed past the caches
                 float *ac = a.acts[p] + (size_t)e * 4 * R + j;
-                st4(ac, o.gi); st4(ac + R, o.gf); st4(ac + 2 * R, o.gg); st4(ac + 3 * R, o.go);
+                auto stnt = [](float *d_, const float4 &v_) {
+                    __builtin_nontemporal_store(v_.x, d_); __builtin_nontemporal_store(v_.y, d_ + 1);
+                    __builtin_nontemporal_store(v_.z, d_ + 2); __builtin_nontemporal_store(v_.w, d_ + 3);
+                };
+                stnt(ac, o.gi); stnt(ac + R, o.gf); stnt(ac + 2 * R, o.gg); stnt(ac + 3 * R, o.go);
             }
         }
+        // actor head on the fresh row (the expressions and the butterfly of atr::head_logits, sized to NA)
         float logit[kMaxActions];
-        head_logits(o.h, aw[p], a.A, 32, logit);
+#pragma unroll
+        for (int x = 0; x < kMaxActions; x++) {
+            logit[x] = -INFINITY;
+            if (x < NA) {
+                const float4 w = aw[p][x];
+                logit[x] = fmaf(o.h.x, w.x, fmaf(o.h.y, w.y, fmaf(o.h.z, w.z, o.h.w * w.w)));
+            }
+        }
+#pragma unroll
+        for (int msk = 1; msk < 32; msk <<= 1)
+#pragma unroll
+            for (int x = 0; x < NA; x++) logit[x] += __shfl_xor(logit[x], msk, 64);
         int mine = 0;
         if (q == 0) {
 #pragma unroll
-            for (int x = 0; x < kMaxActions; x++) logit[x] = x < a.A ? logit[x] + a.actor_b[p][x] : -INFINITY;
+            for (int x = 0; x < NA; x++) logit[x] = logit[x] + a.actor_b[p][x];
             // row index e and ordinal + p: the numbers atr_lstm_cell_forward_act* draw for this row
-            mine = draw_action(logit, a.A, e, ctr, a.seed, a.ordinal + (unsigned)p);
+            mine = draw_action(logit, NA, e, ctr, a.seed, a.ordinal + (unsigned)p);
             if (live) a.actions_out[(size_t)p * n + e] = (long long)mine;
         }
         act[p] = __shfl(mine, lane & 32, 64);
@@ -1483,16 +1500,20 @@ extern "C" int atr_act_env_step(t2d_handle *h, const atr_act_step *args, void *o
     for (int p = 0; p < 2; p++)
         if (!a.ig[p] || !a.c_prev[p] || !a.h_out[p] || !a.c_out[p] || !a.actor_w[p] || !a.actor_b[p])
             return fail(T2D_ERR_INVALID, "atr_act_env_step: null policy buffer (player %d)", p);
-    if (!a.actions_out || !a.counter || a.R != 128 || a.A < 1 || a.A > atr::kMaxActions)
-        return fail(T2D_ERR_INVALID, "atr_act_env_step: needs R = 128, 1 <= A <= %d, actions_out, counter", atr::kMaxActions);
+    if (!a.actions_out || !a.counter || a.R != 128 || (a.A != 4 && a.A != 8))
+        return fail(T2D_ERR_INVALID, "atr_act_env_step: needs R = 128, A = 4 or 8, actions_out, counter");
     hipStream_t st = (hipStream_t)stream;
     if (!h) {   // policy half only (the learner's bootstrap step: one more actor step, no env step)
         if (a.N <= 0) return fail(T2D_ERR_INVALID, "atr_act_env_step: N must be > 0 without an env handle");
         DevState none;
         std::memset(&none, 0, sizeof(none));
         const unsigned grid = (unsigned)(((a.N + 1) / 2 + kStep2Waves - 1) / kStep2Waves);
-        hipLaunchKernelGGL((k_act_step<OBS_U8, false, false>), dim3(grid), dim3(64 * kStep2Waves), 0, st, none, a, nullptr,
-                           nullptr, nullptr, 0u);
+        if (a.A == 4)
+            hipLaunchKernelGGL((k_act_step<OBS_U8, false, false, 4>), dim3(grid), dim3(64 * kStep2Waves), 0, st, none, a, nullptr,
+                               nullptr, nullptr, 0u);
+        else
+            hipLaunchKernelGGL((k_act_step<OBS_U8, false, false, 8>), dim3(grid), dim3(64 * kStep2Waves), 0, st, none, a, nullptr,
+                               nullptr, nullptr, 0u);
         HIP_TRY(hipGetLastError());
         return T2D_OK;
     }
@@ -1511,18 +1532,18 @@ extern "C" int atr_act_env_step(t2d_handle *h, const atr_act_step *args, void *o
         h->phase++;
     }
     const int kind = obs_is_u8 ? OBS_U8 : ((((uintptr_t)obs_dev & 15u) == 0u) ? OBS_F32_VEC4 : OBS_F32_SCALAR);
+#define T2D_LAUNCH_ACT2(KIND, RAMV, NAV)                                                                                \
+    hipLaunchKernelGGL((k_act_step<KIND, RAMV, true, NAV>), pair_grid(h->s.n), dim3(64 * kStep2Waves), 0, st, h->s, a,    \
+                       obs_dev, rew_dev, done_dev, h->phase)
 #define T2D_LAUNCH_ACT(KIND)                                                                                           \
     do {                                                                                                               \
-        if (h->has_ram)                                                                                                \
-            hipLaunchKernelGGL((k_act_step<KIND, true, true>), pair_grid(h->s.n), dim3(64 * kStep2Waves), 0, st, h->s, a, \
-                               obs_dev, rew_dev, done_dev, h->phase);                                                  \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_act_step<KIND, false, true>), pair_grid(h->s.n), dim3(64 * kStep2Waves), 0, st, h->s, a, \
-                               obs_dev, rew_dev, done_dev, h->phase);                                                  \
+        if (a.A == 4) { if (h->has_ram) T2D_LAUNCH_ACT2(KIND, true, 4); else T2D_LAUNCH_ACT2(KIND, false, 4); }        \
+        else { if (h->has_ram) T2D_LAUNCH_ACT2(KIND, true, 8); else T2D_LAUNCH_ACT2(KIND, false, 8); }                 \
     } while (0)
     if (kind == OBS_U8) T2D_LAUNCH_ACT(OBS_U8);
     else if (kind == OBS_F32_VEC4) T2D_LAUNCH_ACT(OBS_F32_VEC4);
     else T2D_LAUNCH_ACT(OBS_F32_SCALAR);
+#undef T2D_LAUNCH_ACT2
 #undef T2D_LAUNCH_ACT
     HIP_TRY(hipGetLastError());
     if (h->s.auto_reset) return window_end(h, st);

@@ -513,9 +513,13 @@ class A3C_Dueling(nn.Module):
 
     fused_sampling = True   # GPU rollouts draw actions with the fused HIP head (csrc/policy_hip.hip)
     fused_actor_step = True  # ... and run the LSTMCell step as one MFMA kernel (csrc/actor_step_hip.hip)
+    env_step_fused_seen = False   # (diagnostic: some step of this model ran its env step inside k_act_step)
     fused_env_step = True    # ... and end the step with ONE launch: both cells + heads + draws + the env step (k_act_step)
     pair_gemm_max_rows = int(__import__('os').environ.get('ATR_PAIR_GEMM_MAX_ROWS', '1024'))  # up to here: GEMM pairs as one launch
-    mfma_step_min_rows = int(__import__('os').environ.get('ATR_MFMA_MIN_ROWS', '3072'))  # from this many rows up the LSTMCell GEMMs run inside atr_actor_step instead
+    # atr_actor_step (both LSTMCell GEMMs + cell as one MFMA kernel per player, then two draw launches and the step launch)
+    # is kept as an option: since k_act_step the GEMM pair + ONE fused cell/draw/env launch is faster at every batch size
+    # measured (4096 rows: 6.15 vs 6.21 ms per iteration); ATR_MFMA_MIN_ROWS=3072 restores round 2's choice
+    mfma_step_min_rows = int(__import__('os').environ.get('ATR_MFMA_MIN_ROWS', str(1 << 30)))
 
     @torch.no_grad()
     def begin_act(self):
@@ -701,6 +705,7 @@ class A3C_Dueling(nn.Module):
                                (p0.actor.actor_linear, p1.actor.actor_linear), actions,
                                emb=cache.emb_ih if self.tat else None, env_out=env_out[1:] if env_out is not None else None)
             self.env_stepped = env_out is not None
+            self.env_step_fused_seen = self.env_step_fused_seen or self.env_stepped
             return [actions[0], actions[1]]
         # players that do not see each other's action (maze-lstm pairs): both input projections as ONE batched GEMM on
         # the pair's feature rows and both cells + heads + draws as ONE launch — 7 launches per env step instead of 9

@@ -122,7 +122,9 @@ def main():
                          "fused cell kernel (default: the model's setting)")
     ap.add_argument("--f32-obs", action="store_true", help="float32 observations between env and policy (default: bytes, "
                                                           "decoded in the stem's conv1)")
-    ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K-step region (median reported)")
+    ap.add_argument("--repeats", type=int, default=5, help="minimum number of timed repeats of the K-step region (median "
+                                                          "reported; more are run until they hold >= 1 s of GPU work)")
+    ap.add_argument("--no-shards", action="store_true", help="skip the per-shard-size sweep of the N=1 line")
     ap.add_argument("--global-envs", type=int, default=4096, help="env count of the strong-scaling form")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, verify the communicator and print a stub line (runs without a GPU "
@@ -161,14 +163,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def measure(envs_per_gpu):
+    def measure(envs_per_gpu, min_gpu_seconds=1.0):
         """Build the player for `envs_per_gpu` envs on this rank, warm up, then time `repeats` repeats of `steps` env
         steps, each bracketed by barrier + synchronize; per repeat the MAX over ranks; returns the median repeat."""
         args = default_args(env=a.env, network=a.network, num_envs=envs_per_gpu, num_steps=T, gpu_ids=[local_rank],
                             aux="reward" if "tat" in a.network else "none", train_mode=-1, obs_u8=not a.f32_obs)
         player, optimizer = make_player(args, device, rank, world)
-        if a.actor_step is not None:
+        if a.actor_step is not None:       # "mfma": round 2's atr_actor_step path from 3072 rows up; "gemm": never
             player.model.fused_actor_step = a.actor_step == "mfma"
+            player.model.mfma_step_min_rows = 3072 if a.actor_step == "mfma" else (1 << 30)
 
         def eager_iteration():
             rollout(player, T, fast=not a.per_step_autograd)
@@ -184,14 +187,21 @@ def main():
                 torch.cuda.synchronize(device)
         for _ in range(warm // T):
             iteration()
-        times = []
-        for _ in range(repeats):
+
+        def timed_repeat():
             fence()
             t0 = time.perf_counter()
             for _ in range(steps // T):
                 iteration()
             fence()
-            times.append(time.perf_counter() - t0)
+            return time.perf_counter() - t0
+        # whatever --steps is, the timed repeats together hold >= min_gpu_seconds of GPU work (a 20-step region is 6 ms):
+        # a pilot repeat sizes the count, every rank uses the same count (max over ranks of the pilot time)
+        pilot = torch.tensor([timed_repeat()], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(pilot, op=dist.ReduceOp.MAX)
+        reps = max(repeats, int(min_gpu_seconds / max(float(pilot.item()), 1e-6)) + 1)
+        times = [timed_repeat() for _ in range(reps)]
         tt = torch.tensor(times, dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -212,7 +222,8 @@ def main():
             dist.all_reduce(tu, op=dist.ReduceOp.MAX)
             ar_us = float(tu.item())
         res = {"value": steps * envs_per_gpu * world / med, "ms_per_step": med * 1e3 / steps,
-               "envs_per_gpu": envs_per_gpu, "global_envs": envs_per_gpu * world, "repeats": repeats,
+               "ms_per_iteration": med * 1e3 / (steps // T), "timed_gpu_seconds": float(sum(ts)),
+               "envs_per_gpu": envs_per_gpu, "global_envs": envs_per_gpu * world, "repeats": reps,
                "spread": {"min_ms_per_step": ts[0] * 1e3 / steps, "max_ms_per_step": ts[-1] * 1e3 / steps},
                "hipgraph": graphed, "allreduce_us": ar_us,
                "allreduce_elems": int(optimizer.bucket.grad.numel()) if hasattr(optimizer, "bucket") else None}
@@ -227,7 +238,26 @@ def main():
         p_.env.close()
         del p_, o_
         torch.cuda.empty_cache()
+    # N=1: the per-GPU term of the strong form at every N — the same workload on 4096/8, /4, /2 envs on this one GPU
+    shards = None
+    if world == 1 and not a.no_shards:
+        shards = {"note": "headline workload at the per-GPU shard sizes of the strong form (4096 envs over 8/4/2/1 GPUs), "
+                          "measured on ONE GPU; the N-GPU strong value is bounded by N x shard value, minus the gradient "
+                          "all-reduce (allreduce_us of an N>1 line: %d fp32 elements)" % 0, "sizes": {}}
+        for per in (a.global_envs // 8, a.global_envs // 4, a.global_envs // 2):
+            r_, p_, o_, _ = measure(per, min_gpu_seconds=0.5)
+            shards["sizes"][str(per)] = {"value": r_["value"], "ms_per_iteration": r_["ms_per_iteration"],
+                                         "ms_per_step": r_["ms_per_step"], "repeats": r_["repeats"], "spread": r_["spread"]}
+            p_.env.close()
+            del p_, o_
+            torch.cuda.empty_cache()
     weak, player, optimizer, args = measure(a.envs_per_gpu)
+    if shards is not None:
+        shards["sizes"][str(a.envs_per_gpu)] = {"value": weak["value"], "ms_per_iteration": weak["ms_per_iteration"],
+                                                "ms_per_step": weak["ms_per_step"], "repeats": weak["repeats"],
+                                                "spread": weak["spread"]}
+        shards["note"] = shards["note"].replace("(allreduce_us of an N>1 line: 0 fp32 elements)",
+                                                "(allreduce_us of an N>1 line: %s fp32 elements)" % weak["allreduce_elems"])
     graphed = weak["hipgraph"]
     value, n_total = weak["value"], a.envs_per_gpu * world
     if strong is None:
@@ -304,6 +334,56 @@ def main():
             torch.cuda.synchronize(device)
             tot += e0.elapsed_time(e1)
         k8_us = tot * 1e3 / (40 * 9)
+    # the fused end-of-step kernel (k_act_step: both players' cells + heads + draws + env step), when the timed region uses it
+    # at this batch size: the same 9-launch graph, gate pre-activations of the shape the rollout feeds it
+    fused_in_region = bool(getattr(player.model, "env_step_fused_seen", False))
+    ka_us, ka_bytes = None, None
+    if getattr(core, "supports_u8", False) and n % 2 == 0:
+        from active_tracking_rl_amd import fused as fz
+        mdl = player.model
+        R = args.rnn_out
+        pairg = n <= getattr(mdl, "pair_gemm_max_rows", 0)
+        gts = torch.randn(2, n, 4 * R, device=device)
+        hgt = None if pairg else torch.randn(2, n, 4 * R, device=device)
+        cprev, hout, cout = (torch.zeros(2, n, R, device=device) for _ in range(3))
+        actst = torch.empty(2, n, 4 * R, device=device)
+        actn = torch.empty(2, n, dtype=torch.int64, device=device)
+        smp = fz.ActionSampler(device, seed=5)
+        heads = (mdl.player0.actor.actor_linear, mdl.player1.actor.actor_linear)
+        bsum = None if pairg else [torch.zeros(4 * R, device=device) for _ in range(2)]
+        embt = torch.randn(4, 4 * R, device=device) if getattr(mdl, "tat", False) else None
+        out8 = (torch.empty((n, 2, 13, 13), dtype=torch.uint8, device=device), out[1], out[2])
+
+        def act_launch():
+            fz.act_env_step(core, [gts[0], gts[1]], [hgt[0], hgt[1]] if hgt is not None else None, bsum,
+                            [cprev[0], cprev[1]], out[2], [hout[0], hout[1]], [cout[0], cout[1]], [actst[0], actst[1]], smp,
+                            heads, actn, emb=embt, env_out=out8)
+        core.flush()
+        smp.begin_block()
+        with torch.cuda.stream(side):
+            act_launch()
+            core.flush()
+        torch.cuda.synchronize(device)
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+            for i in range(9):
+                act_launch()
+        smp.end_block()
+        core.flush()
+        torch.cuda.synchronize(device)
+        tot = 0.0
+        for _ in range(40):
+            e0.record()
+            ga.replay()
+            e1.record()
+            torch.cuda.synchronize(device)
+            tot += e0.elapsed_time(e1)
+        ka_us = tot * 1e3 / (40 * 9)
+        # algorithmic bytes per env-step of the fused kernel: the env's 709 B (u8 observations) + per player: gate
+        # pre-activations read (4R floats, twice when ig / hg arrive separately), c_prev read, h / c written, activated gates
+        # written (the learner's cache), + actions 16 B + previous done 1 B
+        per_player = 4 * R * 4 * (1 if pairg else 2) + 3 * R * 4 + 4 * R * 4
+        ka_bytes = B_STEP_U8 + 2 * per_player + 17
     core.reset()
     achieved = B_STEP * n / (k_us * 1e-6) / 1e9
     # env-only loop with on-device random actions
@@ -365,18 +445,68 @@ def main():
     except Exception as ex:
         stem_roof = {"error": repr(ex)}
 
-    traffic, traffic_src = None, None
-    try:   # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (cannot be taken inside this run)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-        if pm.get("n_envs") == n:
-            traffic, traffic_src = pm["traffic_bytes_per_launch"], "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+    traffic, traffic_src, traffic_u8, traffic_u8_src = None, None, None, None
+    for fname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:   # HBM traffic of the same kernels from the committed rocprofv3 --pmc passes (cannot be taken inside this run)
+            pm = json.load(open(os.path.join(ROOT, "profiles", fname)))
+            if pm.get("n_envs") == n and traffic is None:
+                traffic = pm["traffic_bytes_per_launch"]
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % fname
+            if pm.get("n_envs") == n and traffic_u8 is None and pm.get("traffic_bytes_per_launch_u8") is not None:
+                traffic_u8 = pm["traffic_bytes_per_launch_u8"]
+                traffic_u8_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, k_step2<OBS_U8>)" % fname
+        except Exception:
+            pass
+    kernel_sum = None
+    try:   # sum of the kernel durations of one replayed iteration from the committed rocprofv3 table of this workload
+        for ln in open(os.path.join(ROOT, "profiles", "r03_iteration_kernel_stats.txt")):
+            if ln.startswith("# total kernel time"):
+                tot_ms = float(ln.split()[4])
+            if ln.startswith("# iterations"):
+                kernel_sum = {"ms": tot_ms / float(ln.split()[2]), "source": "profiles/r03_iteration_kernel_stats.txt "
+                              "(rocprofv3 --kernel-trace --stats of tools/iter_profile.py: total kernel time / iterations)"}
     except Exception:
         pass
+    note_k = ("avg_launch_us = the kernel alone: a hipGraph of 9 policy-shaped launches captured right after a generator pass "
+              "(no k_gen inside) replayed 40x, HIP events on the launch stream around each replay; it contains the in-graph "
+              "kernel boundaries, so it sits a few tenths of a us above rocprofv3's average for the kernel "
+              "(profiles/r03_*kernel_stats*.txt); the generator pass every 10th step is reported separately "
+              "(avg_step_us_incl_generator)")
+    f32_variant = {"kernel": "t2d::k_step2<..., OBS_F32_VEC4> (t2d_step: float32 observations, SURVEY 8(d) B_step = 1723 B)",
+                   "in_timed_region": not getattr(player.env, "obs_u8", False) and not fused_in_region,
+                   "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                   "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": B_STEP * n, "avg_launch_us": k_us,
+                   "avg_step_us_incl_generator": step_us, "achieved_incl_generator": B_STEP * n / (step_us * 1e-6) / 1e9}
+    u8_variant = None if k8_us is None else {
+        "kernel": "t2d::k_step2<..., OBS_U8> (t2d_step_u8: observations left as bytes, decoded by the policy stem's conv1 "
+                  "load; SURVEY 8(d) B_step = 709 B)",
+        "in_timed_region": bool(getattr(player.env, "obs_u8", False)) and not fused_in_region,
+        "achieved": B_STEP_U8 * n / (k8_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": B_STEP_U8 * n / (k8_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_u8, "traffic_source": traffic_u8_src,
+        "bytes_per_launch": B_STEP_U8 * n, "avg_launch_us": k8_us}
+    act_variant = None if ka_us is None else {
+        "kernel": "t2d::k_act_step<OBS_U8> (atr_act_env_step: both players' LSTM cells + heads + draws + env step + "
+                  "observation in one launch)",
+        "in_timed_region": fused_in_region,
+        "achieved": ka_bytes * n / (ka_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": ka_bytes * n / (ka_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": ka_bytes * n,
+        "bytes_per_env_step": ka_bytes, "avg_launch_us": ka_us,
+        "bytes_note": "env 709 B (u8 observations) + per player: gate pre-activations read, c_prev read, h / c written, "
+                      "activated gates written for the learner + actions + previous done"}
+    # `roofline` = the env kernel of the TIMED REGION at this batch size; the other variants ride along, each with its flag
+    variants = {"step_f32": f32_variant, "step_u8": u8_variant, "act_step_u8": act_variant}
+    pick = "act_step_u8" if (fused_in_region and act_variant) else ("step_u8" if (u8_variant and u8_variant["in_timed_region"])
+                                                                    else "step_f32")
+    roofline = dict(variants[pick])
+    roofline.update(bound="hbm", variant=pick, note=note_k,
+                    other_variants={k: v for k, v in variants.items() if k != pick and v is not None})
     line = {
         "metric": "env steps/sec, Track2D-BlockPartialPZR-v0 @4096 envs, 1/2/4/8 GPU",
         "value": value, "unit": "env steps/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
         "warmup_effective": warm, "steps_requested": a.steps, "repeats": repeats, "spread": weak["spread"],
-        "ms_per_step": weak["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": weak["ms_per_step"], "ms_per_iteration": weak["ms_per_iteration"],
+        "timed_gpu_seconds": weak["timed_gpu_seconds"], "repeats_run": weak["repeats"], "kernel_sum_per_iteration": kernel_sum,
+        "shards": shards, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "rccl_ranks": comm["rccl_ranks"], "devices": comm["devices"], "dist_backend": comm["backend"],
         "allreduce_us": weak["allreduce_us"], "allreduce_elems": weak["allreduce_elems"],
         "weak": {k: weak[k] for k in ("value", "ms_per_step", "envs_per_gpu", "global_envs", "allreduce_us")},
@@ -389,24 +519,7 @@ def main():
                    "global_envs": n_total, "rollout": T, "hipgraph": graphed,
                    "obs": "u8 (t2d_step_u8 -> atr_stem_*_u8)" if getattr(player.env, "obs_u8", False) else "f32",
                    "gemm_algos": "TunableOp picks from tunableop_gfx950.csv" if tuned else "library default", "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},
-        "roofline": {"bound": "hbm", "kernel": "t2d::k_step2 (step+observe, f32 observations, in-launch auto-reset)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": B_STEP * n,
-                     "avg_launch_us": k_us, "avg_step_us_incl_generator": step_us,
-                     "achieved_incl_generator": B_STEP * n / (step_us * 1e-6) / 1e9,
-                     "note": "avg_launch_us = the step kernel alone: hipGraph of 9 policy-shaped step launches (no "
-                             "generator pass inside) replayed 40x, HIP events on the launch stream around each replay; "
-                             "it still contains the in-graph kernel boundaries, so it sits a few tenths of a us above "
-                             "rocprofv3's k_step2 average (profiles/r02_*kernel_stats*.txt). avg_step_us_incl_generator = "
-                             "100-launch graph replayed 5x, generator pass (k_gen) every 10th step included"},
-        "roofline_u8": None if k8_us is None else {
-            "bound": "hbm", "kernel": "t2d::k_step2<..., OBS_U8> (t2d_step_u8: observations left as bytes, decoded by "
-                                      "the policy stem's conv1 load)",
-            "achieved": B_STEP_U8 * n / (k8_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": B_STEP_U8 * n / (k8_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": B_STEP_U8 * n,
-            "avg_launch_us": k8_us,
-            "note": "SURVEY 8(d) B_step = 709 B variant (obs 338 B instead of 1352 B), same measurement as `roofline`; "
-                    "this is the kernel the end-to-end `value` uses when config.obs is u8"},
+        "roofline": roofline,
         "env_only": {"value": n * world / (eo_us * 1e-6), "unit": "env steps/s", "us_per_launch": eo_us,
                      "note": "same kernel, on-device random actions, one launch per batched step, per-rank x ranks",
                      "fused_value": n * world / (eof_us * 1e-6), "fused_us_per_step": eof_us,
