@@ -215,12 +215,8 @@ def train(rank, args, shared_model, optimizer, train_modes, n_iters, env=None):
         train_modes.append(training_mode)
         n_iters.append(0)
     player, optimizer = make_player(args, device, rank, world, env=env, model=shared_model, optimizer=optimizer)
-    writer = None
-    try:
-        from tensorboardX import SummaryWriter  # optional, as in the reference (train.py:9,17)
-        writer = SummaryWriter(os.path.join(args.log_dir, 'Agent:{}'.format(rank)))
-    except Exception:
-        pass
+    from .utils import ScalarWriter, log_train_scalars
+    writer = ScalarWriter(os.path.join(args.log_dir, 'Agent:{}'.format(rank)))
     n_iter = 0
     try:
         while True:
@@ -231,16 +227,12 @@ def train(rank, args, shared_model, optimizer, train_modes, n_iters, env=None):
                 None, optimizer, shared_model, training_mode, device)
             n_iter += 1
             n_iters[rank] = n_iter
-            if writer is not None and n_iter % 10 == 0:
+            if n_iter % 10 == 0:
                 torch.cuda.synchronize(device)
                 fps = args.num_steps * player.num_envs / (time.time() - t0)
-                for i in range(min(player.num_agents, 3)):
-                    writer.add_scalar('train/policy_loss_' + str(i), policy_loss[i].mean().item(), player.n_steps)
-                    writer.add_scalar('train/value_loss_' + str(i), value_loss[i].item(), player.n_steps)
-                    writer.add_scalar('train/entropies' + str(i), entropies[i].mean().item(), player.n_steps)
-                writer.add_scalar('train/pred_R_loss', pred_loss.item(), player.n_steps)
-                writer.add_scalar('train/mode', training_mode, player.n_steps)
-                writer.add_scalar('train/fps', fps, player.n_steps)
+                log_train_scalars(writer, (policy_loss, value_loss, entropies, pred_loss), training_mode, fps, player.n_steps,
+                                  player.num_agents)
+                writer.flush()
             if train_modes[rank] == -100 or n_iter * world > args.max_step:   # test.py:129-134 stop rule
                 break
         player.env.close()

@@ -13,6 +13,7 @@ from __future__ import print_function, division
 import os
 os.environ["OMP_NUM_THREADS"] = "1"
 import argparse
+import time
 from datetime import datetime
 
 import torch
@@ -21,6 +22,7 @@ import torch.distributed as dist
 from active_tracking_rl_amd import build
 from active_tracking_rl_amd.test import test
 from active_tracking_rl_amd.train import GraphedIteration, make_player, sync_train_modes
+from active_tracking_rl_amd.utils import ScalarWriter, log_train_scalars
 
 parser = argparse.ArgumentParser(description='A3C (MI355X data-parallel)')
 parser.add_argument('--lr', type=float, default=0.001, metavar='LR', help='learning rate (2D: 0.001, 3D: 0.0001)')
@@ -63,6 +65,7 @@ parser.add_argument('--init-step', type=int, default=-1, metavar='IS', help='ste
 parser.add_argument('--max-grad-norm', type=float, default=None, help='clip (off by default, as the reference effectively is)')
 parser.add_argument('--f32-obs', dest='obs_u8', action='store_false', help='float32 observations between env and policy (default: bytes, decoded in conv1)')
 parser.add_argument('--no-graph', action='store_true', help='run iterations eagerly instead of as hipGraphs')
+parser.add_argument('--log-every', type=int, default=10, metavar='LE', help='training iterations between train/* scalar records')
 
 if __name__ == '__main__':
     args = parser.parse_args()
@@ -93,23 +96,37 @@ if __name__ == '__main__':
     step = GraphedIteration(player, optimizer, args, mode=first_mode).run if not args.no_graph else None
     it = 0
     eval_state = {}
+    # train/* scalars of train.py:97-104 from the graphed path: the loss statistics of an iteration are static outputs of the
+    # captured graph (device tensors the next replay overwrites), so reading them costs one synchronisation per --log-every
+    # iterations and nothing in between; train/fps = env steps of this rank since the last record / wall time
+    writer = ScalarWriter(os.path.join(args.log_dir, 'Agent:{}'.format(rank)))
+    t_log, it_log = time.time(), 0
     while True:
         if train_modes[rank] == -100:                       # the evaluator's stop sentinel (test.py:129-134)
             break
         if step is not None:
-            step(train_modes[rank])                         # one hipGraph per training mode (test.py:84-92 schedule)
+            stats = step(train_modes[rank])                 # one hipGraph per training mode (test.py:84-92 schedule)
         else:
             from active_tracking_rl_amd.train import rollout
             rollout(player, args.num_steps)
-            player.optimize(None, optimizer, player.model, train_modes[rank], device)
+            stats = player.optimize(None, optimizer, player.model, train_modes[rank], device)
         it += 1
         n_iters[:] = [it] * world
+        if args.log_every > 0 and it % args.log_every == 0:
+            torch.cuda.synchronize(device)
+            now = time.time()
+            fps = (it - it_log) * args.num_steps * player.num_envs / max(now - t_log, 1e-9)
+            log_train_scalars(writer, stats, train_modes[rank], fps, it * args.num_steps * player.num_envs, player.num_agents)
+            writer.flush()
+            t_log, it_log = time.time(), it
         if it % args.test_every == 0 or it > args.max_step:
             if rank == 0:
                 test(args, player.model, train_modes, n_iters, rounds=1, state=eval_state)
             sync_train_modes(train_modes, device)           # rank 0 owns the schedule; a broadcast is also a barrier
+            t_log, it_log = time.time(), it                 # (the evaluation's wall time is not training time)
         if it > args.max_step:
             break
+    writer.close()
     player.env.close()
     if world > 1:
         dist.destroy_process_group()

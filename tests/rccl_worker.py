@@ -1,0 +1,53 @@
+"""One rank of tests/test_rccl_gpu.py (started by torch.distributed.run, one rank per GPU): the N>1 product path on RCCL —
+env shard keyed by the global env id, GraphedIteration (two hipGraph replays with the eager gradient all-reduce between
+them), identical SharedAdam update on every replica."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player, rollout
+    args = default_args(num_envs=256, seed=7)
+    player, opt = make_player(args, dev, rank, world)
+    assert player.env.core is not None
+    # (a) eager: the all-reduced gradient is the mean of the ranks' gradients
+    rollout(player, args.num_steps)
+    player.compute_grads(opt, args.train_mode)
+    local_g = opt.bucket.grad.clone()
+    gathered = [torch.zeros_like(local_g) for _ in range(world)]
+    dist.all_gather(gathered, local_g)
+    player.allreduce_grads(opt)
+    mean = sum(gathered) / world
+    assert torch.allclose(opt.bucket.grad, mean, rtol=1e-5, atol=1e-7), "all-reduced gradient is not the mean over ranks"
+    assert world == 1 or not torch.equal(gathered[0], gathered[1]), "ranks saw the same envs"
+    opt.step()
+    # (b) graphed: 3 replayed iterations, replicas bit-identical afterwards
+    it = GraphedIteration(player, opt, args)
+    for _ in range(3):
+        it.run()
+    torch.cuda.synchronize(dev)
+    flats = [torch.zeros_like(opt.bucket.flat) for _ in range(world)]
+    dist.all_gather(flats, opt.bucket.flat)
+    for f in flats[1:]:
+        assert torch.equal(flats[0], f), "replicas diverged"
+    assert torch.isfinite(opt.bucket.flat).all()
+    st = player.env.core.get_state()
+    assert (st["episode"] >= 1).all()
+    if rank == 0:
+        print("RCCL_OK world=%d elems=%d" % (world, opt.bucket.grad.numel()), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
