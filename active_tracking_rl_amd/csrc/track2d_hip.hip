@@ -623,8 +623,13 @@ constexpr int kStep2Waves = T2D_STEP2_WAVES;        // waves (env pairs) per wor
 //   finish  needs the two actions: scripted-target override, wall vote, reward, far counter / time limit, episode switch,
 //           state write-back, observation
 // k_step2 calls them back to back (per step of a MULTI launch: rows + finish).
-template <bool MULTI, int OBS, bool RAM>
+// NAV: some env of the handle has the scripted Nav target (navigator.py:5-70): its action is one 2-bit read of the env's BFS
+// direction planes at the target's cell; when the target stands on its goal the plan prepared by the generator pass is
+// adopted (a 2 KiB copy whose source was fetched speculatively beside the map rows) or, rarely, re-made inline by the whole
+// wave on an LDS tile (`tile`: 1 KiB per wave, NAV handles only).
+template <bool MULTI, int OBS, bool RAM, bool NAV = false>
 struct Step2 {
+    static_assert(!(NAV && MULTI), "a re-plan rewrites the direction field other lanes re-read: one step per launch");
     int lane, e0, e, sl, ag, k;
     bool live, leader;
     uint32_t *st, *mk;
@@ -642,6 +647,13 @@ struct Step2 {
     unsigned long long mb;
     uint32_t sp_pos, sp_plan, sp_tctr, sp_d2, sp_goals, sp_navgoal, sp_episode, sp_win;
     uint4 sp_tile0, sp_tile1;
+    // Nav target
+    bool nav, nv_exh;
+    uint32_t navgoal, pstate, nv_dA, nv_dB;                   // direction words at the target's cell (current plan)
+    uint32_t sp_pgoal, sp_ptctr, sp_vis, sp_pdA, sp_pdB;      // prepared plan: goal, stream position, words at the target's cell
+    uint4 sp_fld0, sp_fld1, sp_fld2, sp_fld3;                 // ... its direction planes (this lane's 64 B of the 2 KiB)
+    uint4 sp_nd0, sp_nd1, sp_nd2, sp_nd3;                     // next episode's direction planes (episode switch)
+    uint32_t *tile;
 #if T2D_EXP == 6
     uint32_t *tstamp;   // timeline probe: s_memtime stamps of this wave, parked in the spare words 246..253 of the env's tile
 #define T2D_STAMP(i) do { if (leader) tstamp[i] = (uint32_t)__builtin_readcyclecounter(); } while (0)
@@ -658,6 +670,7 @@ struct Step2 {
         leader = live && ag == 0 && k == 15;    // one lane per env: reward table, rew/done, state write-back
         st = stage;
         mk = st + kStage2Rows;
+        tile = nullptr;
 #if T2D_EXP == 6
         tstamp = s.maps + (size_t)e * kTileWords + 246;
 #endif
@@ -681,7 +694,10 @@ struct Step2 {
         // RAM = some env of the handle has the scripted Ram target; handles without one get a kernel without the plan /
         // Philox code (the step kernel's duration at N = 4096 is partly instruction-fetch latency: code size matters)
         ram = RAM && mode == TGT_RAM;
-        if (MULTI || ram) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }
+        nav = NAV && mode == TGT_NAV;
+        navgoal = 0; pstate = 0;
+        if (MULTI || ram || nav) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }
+        if (nav) { navgoal = s.navgoal[e]; pstate = s.p_state[e]; }
         genv = s.env_base + (uint32_t)e;
         lut = s.rew_lut + (mode == TGT_PZR ? kLutN : (mode == TGT_FAR ? 2 * kLutN : 0));
         gmap = s.maps + (size_t)e * kTileWords;
@@ -704,6 +720,28 @@ struct Step2 {
         // A done is only possible this step if the far counter stands at 10 or the time limit is one step away (:106-111,
         // TimeLimit): for those envs the next episode's scalars, the window rows of its first observation (n_win) and its map
         // tile are fetched NOW, beside the rows, so that the episode switch below adds no dependent memory round trip.
+        nv_exh = false; nv_dA = 0; nv_dB = 0;
+        sp_pgoal = 0; sp_ptctr = 0; sp_vis = 0; sp_pdA = 0; sp_pdB = 0;
+        sp_fld0 = make_uint4(0u, 0u, 0u, 0u); sp_fld1 = sp_fld0; sp_fld2 = sp_fld0; sp_fld3 = sp_fld0;
+        sp_nd0 = sp_fld0; sp_nd1 = sp_fld0; sp_nd2 = sp_fld0; sp_nd3 = sp_fld0;
+        if (NAV && nav) {   // Navigator.step (navigator.py:11-41) on old_state[1] (track_1v1.py:84)
+            const int c1 = (int)(pos >> 24);
+            const bool planb = ((plan >> 28) & 1u) != 0u;
+            nv_exh = planb ? (plan_cur(plan) >= plan_len(plan))
+                           : (r1 == (int)(navgoal & 0xffu) && c1 == (int)(navgoal >> 8));
+            const uint32_t *gdir = s.dirf + (size_t)e * kDirWords;
+            const int w = r1 * kRowWords + (c1 >> 5);
+            nv_dA = gdir[w]; nv_dB = gdir[256 + w];         // used if the current plan still stands
+            if (nv_exh && pstate == 1u) {
+                // the plan the generator pass prepared for the NEXT goal, fetched now (speculatively: it is adopted below if
+                // it reaches the target's cell) so that adopting it adds no dependent round trip to the step
+                const uint32_t *pf = s.p_field + (size_t)e * kPlanWords;
+                sp_pgoal = s.p_goal[e]; sp_ptctr = s.p_tctr[e];
+                sp_vis = pf[512 + w]; sp_pdA = pf[w]; sp_pdB = pf[256 + w];
+                const uint4 *src = reinterpret_cast<const uint4 *>(pf) + (lane & 31);
+                sp_fld0 = src[0]; sp_fld1 = src[32]; sp_fld2 = src[64]; sp_fld3 = src[96];
+            }
+        }
         maybe = live && s.auto_reset != 0 && (c_far >= 10 || (s.max_steps > 0 && t + 1 >= s.max_steps));
         mb = __ballot(maybe);
         sp_pos = 0; sp_plan = 0; sp_tctr = 0; sp_d2 = 0; sp_goals = 0; sp_navgoal = 0; sp_episode = 0; sp_win = 0x1fffu;
@@ -713,6 +751,10 @@ struct Step2 {
                 sp_pos = s.n_pos[e]; sp_plan = s.n_plan[e]; sp_tctr = s.n_tctr[e]; sp_d2 = s.n_d2[e];
                 sp_goals = s.n_goals[e]; sp_navgoal = s.n_navgoal[e]; sp_episode = s.episode[e];
                 if (k >= 1 && k <= T2D_WIN) sp_win = s.n_win[(size_t)e * 32 + ag * T2D_WIN + (k - 1)];
+                if (NAV && nav) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(s.n_dirf + (size_t)e * kDirWords) + (lane & 31);
+                    sp_nd0 = src[0]; sp_nd1 = src[32]; sp_nd2 = src[64]; sp_nd3 = src[96];
+                }
             }
             if ((mb & 0xffffffffull) != 0ull)
                 sp_tile0 = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)e0 * kTileWords)[lane];
@@ -737,6 +779,71 @@ struct Step2 {
         }
         int r0 = (int)(pos & 0xffu), c0 = (int)((pos >> 8) & 0xffu);
         int r1 = (int)((pos >> 16) & 0xffu), c1 = (int)(pos >> 24);
+        bool navgoal_dirty = false;
+        if (NAV) {
+            bool planb = ((plan >> 28) & 1u) != 0u, adopted = false, have_goal = false;
+            uint32_t dir = ((nv_dA >> (c1 & 31)) & 1u) | (((nv_dB >> (c1 & 31)) & 1u) << 1);
+            uint32_t *gdir = s.dirf + (size_t)e * kDirWords;
+            if (nav && nv_exh && pstate == 1u) {
+                // adopt the prepared plan if it is a valid plan from here (reachable, not already on its goal) — else the
+                // inline re-plan below starts from the same already-drawn goal (k_env<NAV> does exactly this)
+                navgoal = sp_pgoal; tctr = sp_ptctr; have_goal = true;
+                if (((sp_vis >> (c1 & 31)) & 1u) != 0u && !(r1 == (int)(sp_pgoal & 0xffu) && c1 == (int)(sp_pgoal >> 8))) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(gdir) + (lane & 31);
+                    dst[0] = sp_fld0; dst[32] = sp_fld1; dst[64] = sp_fld2; dst[96] = sp_fld3;
+                    dir = ((sp_pdA >> (c1 & 31)) & 1u) | (((sp_pdB >> (c1 & 31)) & 1u) << 1);
+                    plan = 0u; planb = false; adopted = true;
+                    navgoal_dirty = true;
+                }
+                if (leader) s.p_state[e] = 0u;
+            }
+            // rare: plan exhausted and nothing adoptable — Navigator's re-plan (navigator.py:15-38) by the whole wave, one slot
+            // at a time, on the env's tile in LDS (wave-uniform copies of the slot's scalars in, results back to its lanes)
+            const unsigned long long rm = __ballot(live && nav && nv_exh && !adopted);
+            if (__builtin_expect(rm != 0ull, 0)) {
+#pragma unroll 1
+                for (int slot = 0; slot < 2; slot++) {
+                    if (((rm >> (32 * slot)) & 1ull) == 0ull) continue;
+                    const int src = 32 * slot;
+                    const int es = e0 + slot;
+                    const uint32_t u_pos = __builtin_amdgcn_readlane(pos, src), u_cnt = __builtin_amdgcn_readlane(cnt, src);
+                    uint32_t u_goal = __builtin_amdgcn_readlane(navgoal, src), u_plan = __builtin_amdgcn_readlane(plan, src);
+                    const uint32_t u_tctr = __builtin_amdgcn_readlane(tctr, src), u_ep = __builtin_amdgcn_readlane(episode, src);
+                    const bool u_have = __builtin_amdgcn_readlane((uint32_t)have_goal, src) != 0u;
+                    const int u_side = (int)(u_cnt >> 24), ur = (int)((u_pos >> 16) & 0xffu), uc = (int)(u_pos >> 24);
+                    reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(s.maps + (size_t)es * kTileWords)[lane];
+                    wave_lds_sync();
+                    Stream ts;
+                    ts.init(s.k0, s.k1, u_ep, s.env_base + (uint32_t)es, STREAM_TARGET, u_tctr);
+                    const FreeIndex fi = build_free_index(tile, u_side, lane);
+                    if (!u_have) u_goal = select_free(tile, u_side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+                    NavField nf;
+                    uint32_t nav2_unused = 0u;
+                    nav_plan(tile, u_side, lane, ur, uc, fi, u_goal, ts, u_plan, nf, false, nav2_unused);
+                    const bool u_planb = ((u_plan >> 28) & 1u) != 0u;
+                    uint32_t u_dir = 0u;
+                    if (!u_planb) {
+                        store_dir_field(s.dirf + (size_t)es * kDirWords, nf, u_side, lane);
+                        u_dir = nav_dir_from_regs(nf, ur, uc);
+                    }
+                    wave_lds_sync();
+                    if (sl == slot) {
+                        navgoal = u_goal; plan = u_plan; tctr = ts.ctr; dir = u_dir; planb = u_planb;
+                        navgoal_dirty = true;
+                    }
+                }
+            }
+            if (nav) {
+                if (planb) {
+                    const uint32_t cur = plan_cur(plan);
+                    a_tg = (int)plan_act(plan, cur);
+                    plan = (plan & 0xf0ffffffu) | ((cur + 1u) << 24);
+                } else {
+                    a_tg = (int)dir;
+                }
+                dirty = true;
+            }
+        }
         const int dy0 = move_dy(a_tr), dx0 = move_dx(a_tr);
         const int dy1 = move_dy(a_tg), dx1 = move_dx(a_tg);
         // the reward of each possible outcome (tracker moves / bumps) x (target moves / bumps): track_1v1.py:94-104
@@ -797,6 +904,12 @@ struct Step2 {
                 pos = sp_pos; plan = sp_plan; tctr = sp_tctr; d2 = sp_d2;
                 cnt = (uint32_t)side_of_cfg(cfg) << 24;
                 episode = sp_episode + 1u;
+                if (NAV && nav) {       // the new episode's plan (made by k_gen at its reset); the prepared next plan is void
+                    uint4 *dst = reinterpret_cast<uint4 *>(s.dirf + (size_t)e * kDirWords) + (lane & 31);
+                    dst[0] = sp_nd0; dst[32] = sp_nd1; dst[64] = sp_nd2; dst[96] = sp_nd3;
+                    navgoal = sp_navgoal; navgoal_dirty = false;
+                    if (leader) s.p_state[e] = 0u;
+                }
                 if (leader) {
                     s.goals[e] = sp_goals; s.episode[e] = episode; s.navgoal[e] = sp_navgoal;
                     s.gen_req[e] = stamp + (uint32_t)it;
@@ -812,6 +925,7 @@ struct Step2 {
         if (leader) {
             s.pos[e] = pos; s.cnt[e] = cnt; s.d2[e] = d2;
             if (consume || dirty) { s.plan[e] = plan; s.tctr[e] = tctr; }
+            if (NAV && navgoal_dirty && !consume) s.navgoal[e] = navgoal;
         }
 
         T2D_STAMP(3);
@@ -892,12 +1006,13 @@ struct Step2 {
     }
 };
 
-template <bool RANDOM, bool MULTI, int ADT, int OBS, bool RAM>
+template <bool RANDOM, bool MULTI, int ADT, int OBS, bool RAM, bool NAV = false>
 __global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const void *act0, const void *act1, void *obs, float *rew,
                                                uint8_t *done_out, uint32_t aseed_lo, uint32_t aseed_hi,
                                                uint32_t step_idx, uint32_t stamp, int nsteps)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stage2[kStep2Waves][kStage2Words];
+    __shared__ __attribute__((aligned(16))) uint32_t navtiles[NAV ? kStep2Waves : 1][NAV ? kTileWords : 4];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = uni((int)(threadIdx.x >> 6));
     const int e0 = ((int)blockIdx.x * kStep2Waves + wave) * 2;
@@ -906,8 +1021,9 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const vo
     // 5 = empty kernel (launch floor), 7 = state loads -> one store, 8 = state -> rows + reward table -> one store,
     // 6 = s_memtime timeline (tools/timeline_probe.py); built and timed by tools/exp_variants.sh.
     if (T2D_EXP == 5) { if (lane == 0) done_out[e0] = 0; return; }
-    Step2<MULTI, OBS, RAM> S;
+    Step2<MULTI, OBS, RAM, NAV> S;
     S.init(s, e0, lane, stage2[wave]);
+    if (NAV) S.tile = navtiles[wave];
     long long act_raw0 = 0, act_raw1 = 0;
     if (!RANDOM) {
         act_raw0 = load_action_raw<ADT>(act0, S.e);
@@ -944,13 +1060,14 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const vo
 // dependent launches of 5-10 us each at every batch size. The env's state loads go out first and its map-row loads as
 // soon as the state is there, so both fly under the cells' arithmetic.
 // NA: compile-time number of actions (4 = every registered id; 8 = the 'Moore' table) — the head and draw code is sized to it
-template <int OBS, bool RAM, bool ENV, int NA>
+template <int OBS, bool RAM, bool ENV, int NA, bool NAV = false>
 __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_act_step a, void *obs, float *rew,
                                                                uint8_t *done_out, uint32_t stamp)
 {
     using namespace atr;
     __shared__ __attribute__((aligned(16))) uint32_t stage2[kStep2Waves][kStage2Words];
     __shared__ __attribute__((aligned(16))) float emb_lds[NA * 4 * 128];   // the tracker-action embedding table
+    __shared__ __attribute__((aligned(16))) uint32_t navtiles[NAV ? kStep2Waves : 1][NAV ? kTileWords : 4];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = uni((int)(threadIdx.x >> 6));
     const int e0 = ((int)blockIdx.x * kStep2Waves + wave) * 2;
@@ -964,8 +1081,8 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_a
         for (int i = 0; i < kEmbTrips; i++) emb_st[i] = ld4(a.emb + 4 * ((int)threadIdx.x + i * 64 * kStep2Waves));
     }
     const bool active = e0 < n;         // (no early return: every wave reaches the workgroup barrier below)
-    Step2<false, OBS, RAM> S;
-    if (ENV && active) S.init(s, e0, lane, stage2[wave]);          // env state loads first ...
+    Step2<false, OBS, RAM, NAV> S;
+    if (ENV && active) { S.init(s, e0, lane, stage2[wave]); if (NAV) S.tile = navtiles[wave]; }    // env state loads first ...
     const int sl = lane >> 5, q = lane & 31, j = q * 4;
     const bool live = e0 + sl < n;
     const int e = live ? e0 + sl : (active ? e0 : 0);
@@ -1089,6 +1206,7 @@ struct t2d_handle {
     bool has_rpf;      // some env has the RPF patrol target (an agent may then stand on a wall of the env's own map)
     uint32_t random_step;
     bool has_navmode;  // some env has the Nav target (its next plan is prefetched once per stamp window)
+    bool has_rpfmode;  // some env has the RPF patrol target: those handles stay on the general step kernel (k_env)
     uint32_t gen_every; // shortest possible episode = longest admissible generator period, in steps
     // Step stamps run 1..cycle; the cycle is one window of gen_every steps (generator in order on the caller's
     // stream) or, with the asynchronous generator, two windows of gen_every / 2: the slots consumed in window w are
@@ -1153,7 +1271,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         return fail(T2D_ERR_INVALID, "t2d_create: device %d out of range (%d visible)", cfg->device, ndev);
     const int n = cfg->num_envs;
     std::vector<uint32_t> hcfg((size_t)n);
-    bool has_nav = false, has_rpf = false, has_ram = false, has_navmode = false;
+    bool has_nav = false, has_rpf = false, has_ram = false, has_navmode = false, has_rpfmode = false;
     int n_maze = 0;
     if (cfg->obs_type > T2D_OBS_FULL) return fail(T2D_ERR_INVALID, "t2d_create: obs_type %u", cfg->obs_type);
     if (cfg->action_type > T2D_ACTIONS_MOORE) return fail(T2D_ERR_INVALID, "t2d_create: action_type %u", cfg->action_type);
@@ -1167,6 +1285,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         has_rpf = has_rpf || tm == T2D_TGT_RPF || tm == T2D_TGT_EXT;   // agents may stand on walls
         has_ram = has_ram || tm == T2D_TGT_RAM;
         has_navmode = has_navmode || tm == T2D_TGT_NAV;
+        has_rpfmode = has_rpfmode || tm == T2D_TGT_RPF;
         n_maze += mt == T2D_MAP_MAZE;
         if (lv > 15) return fail(T2D_ERR_INVALID, "t2d_create: level %u (env %d)", lv, i);
         // the scripted targets plan in the four-move table: RamAgent would draw from 8 actions (navigator.py:74-75) and the
@@ -1183,7 +1302,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     std::memset(&h->s, 0, sizeof(h->s));
     h->device = cfg->device;
     h->reset_done = false; h->primed = false; h->has_nav = has_nav; h->has_rpf = has_rpf; h->has_ram = has_ram;
-    h->has_navmode = has_navmode;
+    h->has_navmode = has_navmode; h->has_rpfmode = has_rpfmode;
     h->random_step = 0; h->phase = 0;
     h->gen_async = false; h->pending[0] = h->pending[1] = false;
     h->gen_stream = nullptr; h->ev_fork = nullptr; h->ev_join[0] = h->ev_join[1] = nullptr;
@@ -1307,7 +1426,7 @@ static int window_end(t2d_handle *h, hipStream_t st)
 }
 
 static inline dim3 pair_grid(int n) { return dim3((unsigned)(((n + 1) / 2 + kStep2Waves - 1) / kStep2Waves)); }
-static inline bool use_step2(const t2d_handle *h) { return !h->has_nav && !h->s.obs_full; }
+static inline bool use_step2(const t2d_handle *h) { return !h->has_rpfmode && !h->s.obs_full; }
 
 // k_step2 launcher. obs_kind: OBS_F32_* picked from the pointer / stride alignment, or OBS_U8.
 template <bool RANDOM, bool MULTI>
@@ -1319,6 +1438,13 @@ static void launch_step2(t2d_handle *h, hipStream_t st, const void *a0, const vo
     const int kind = u8 ? OBS_U8 : (vec4 ? OBS_F32_VEC4 : OBS_F32_SCALAR);
 #define T2D_LAUNCH2(ADTV, KIND)                                                                                         \
     do {                                                                                                                \
+        if constexpr (!MULTI) {                                                                                         \
+            if (h->has_navmode) {   /* Nav handles: one variant with the Ram code too (per-env mixed target modes) */  \
+                hipLaunchKernelGGL((k_step2<RANDOM, false, ADTV, KIND, true, true>), pair_grid(h->s.n),                 \
+                                   dim3(64 * kStep2Waves), 0, st, h->s, a0, a1, obs, rew, done, slo, shi, sidx, stamp, nsteps); \
+                break;                                                                                                  \
+            }                                                                                                           \
+        }                                                                                                               \
         if (h->has_ram)                                                                                                 \
             hipLaunchKernelGGL((k_step2<RANDOM, MULTI, ADTV, KIND, true>), pair_grid(h->s.n), dim3(64 * kStep2Waves), 0, \
                                st, h->s,   \
@@ -1472,7 +1598,7 @@ extern "C" int t2d_step_u8(t2d_handle *h, const void *act_tracker_dev, const voi
     if (!act_tracker_dev || !rew_dev || !done_dev) return fail(T2D_ERR_INVALID, "t2d_step_u8: null buffer");
     if (act_dtype < T2D_ACT_U8 || act_dtype > T2D_ACT_I64) return fail(T2D_ERR_INVALID, "t2d_step_u8: act_dtype %d", act_dtype);
     if (!use_step2(h))
-        return fail(T2D_ERR_INVALID, "t2d_step_u8: u8 observations exist for 'Partial' ids without Nav/RPF targets");
+        return fail(T2D_ERR_INVALID, "t2d_step_u8: u8 observations exist for 'Partial' ids without the RPF target");
     if (((uintptr_t)obs_u8_dev & 3u) != 0u) return fail(T2D_ERR_INVALID, "t2d_step_u8: obs buffer must be 4-byte aligned");
     if (!h->reset_done) return fail(T2D_ERR_STATE, "t2d_step_u8: call t2d_reset (all envs) or t2d_inject first");
     if (h->s.auto_reset && !h->primed) return fail(T2D_ERR_STATE, "t2d_step_u8: auto_reset needs one t2d_reset before stepping");
@@ -1519,7 +1645,7 @@ extern "C" int atr_act_env_step(t2d_handle *h, const atr_act_step *args, void *o
     }
     if (!rew_dev || !done_dev || !obs_dev) return fail(T2D_ERR_INVALID, "atr_act_env_step: null env buffer");
     if (!use_step2(h))
-        return fail(T2D_ERR_INVALID, "atr_act_env_step: exists for 'Partial' ids without Nav/RPF targets (the k_step2 family)");
+        return fail(T2D_ERR_INVALID, "atr_act_env_step: exists for 'Partial' ids without the RPF target (the k_step2 family)");
     if (a.N != h->s.n) return fail(T2D_ERR_INVALID, "atr_act_env_step: policy batch %d != %d envs", a.N, h->s.n);
     if (a.A != h->s.amask + 1) return fail(T2D_ERR_INVALID, "atr_act_env_step: %d policy actions, env has %d", a.A, h->s.amask + 1);
     if (obs_is_u8 && ((uintptr_t)obs_dev & 3u) != 0u) return fail(T2D_ERR_INVALID, "atr_act_env_step: obs buffer must be 4-byte aligned");
@@ -1532,13 +1658,14 @@ extern "C" int atr_act_env_step(t2d_handle *h, const atr_act_step *args, void *o
         h->phase++;
     }
     const int kind = obs_is_u8 ? OBS_U8 : ((((uintptr_t)obs_dev & 15u) == 0u) ? OBS_F32_VEC4 : OBS_F32_SCALAR);
-#define T2D_LAUNCH_ACT2(KIND, RAMV, NAV)                                                                                \
-    hipLaunchKernelGGL((k_act_step<KIND, RAMV, true, NAV>), pair_grid(h->s.n), dim3(64 * kStep2Waves), 0, st, h->s, a,    \
+#define T2D_LAUNCH_ACT2(KIND, RAMV, NAV, NAVF)                                                                          \
+    hipLaunchKernelGGL((k_act_step<KIND, RAMV, true, NAV, NAVF>), pair_grid(h->s.n), dim3(64 * kStep2Waves), 0, st, h->s, a, \
                        obs_dev, rew_dev, done_dev, h->phase)
 #define T2D_LAUNCH_ACT(KIND)                                                                                           \
     do {                                                                                                               \
-        if (a.A == 4) { if (h->has_ram) T2D_LAUNCH_ACT2(KIND, true, 4); else T2D_LAUNCH_ACT2(KIND, false, 4); }        \
-        else { if (h->has_ram) T2D_LAUNCH_ACT2(KIND, true, 8); else T2D_LAUNCH_ACT2(KIND, false, 8); }                 \
+        if (h->has_navmode) { if (a.A == 4) T2D_LAUNCH_ACT2(KIND, true, 4, true); else T2D_LAUNCH_ACT2(KIND, true, 8, true); } \
+        else if (a.A == 4) { if (h->has_ram) T2D_LAUNCH_ACT2(KIND, true, 4, false); else T2D_LAUNCH_ACT2(KIND, false, 4, false); } \
+        else { if (h->has_ram) T2D_LAUNCH_ACT2(KIND, true, 8, false); else T2D_LAUNCH_ACT2(KIND, false, 8, false); }   \
     } while (0)
     if (kind == OBS_U8) T2D_LAUNCH_ACT(OBS_U8);
     else if (kind == OBS_F32_VEC4) T2D_LAUNCH_ACT(OBS_F32_VEC4);

@@ -179,8 +179,8 @@ class VecTrack2D(object):
                 setattr(cfg, name, a.ctypes.data)
         self.scripted_target = target_mode in ("Ram", "Nav", "RPF") and target_mode_per_env is None
         tm = [registry.TARGET_CODE[target_mode]] if target_mode_per_env is None else list(np.asarray(target_mode_per_env))
-        nav = any(int(m) in (registry.TARGET_CODE["Nav"], registry.TARGET_CODE["RPF"]) for m in tm)
-        self.supports_u8 = obs_type == "Partial" and not nav     # t2d_step_u8 (the k_step2 kernel family)
+        rpf = any(int(m) == registry.TARGET_CODE["RPF"] for m in tm)
+        self.supports_u8 = obs_type == "Partial" and not rpf     # t2d_step_u8 / atr_act_env_step (the k_step2 kernel family)
         h = C.c_void_p()
         _check(self.L.t2d_create(C.byref(cfg), C.byref(h)))
         self.h = h

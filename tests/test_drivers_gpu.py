@@ -412,7 +412,9 @@ def test_graphed_iteration_selects_the_training_mode_per_call():
 
 @pytest.mark.parametrize("env_id,n,u8,tat", [("Track2D-BlockPartialPZR-v0", 512, True, True),
                                               ("Track2D-BlockPartialRam-v0", 257, False, False),
-                                              ("Track2D-MazePartialFar-v0", 96, True, True)])
+                                              ("Track2D-MazePartialFar-v0", 96, True, True),
+                                              ("Track2D-MazePartialNav-v0", 384, True, False),
+                                              ("Track2D-BlockPartialNav-v1", 130, True, True)])
 def test_act_env_step_equals_cells_draws_and_env_step(env_id, n, u8, tat):
     """atr_act_env_step (k_act_step: both players' cells + heads + draws + the env step in ONE launch) against the launches
     it replaces — atr_lstm_cell_forward_act1 for the tracker, again for the target (+ emb[a_tracker] when tracker-aware),
