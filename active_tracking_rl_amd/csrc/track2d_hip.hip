@@ -42,10 +42,13 @@ struct DevState {
     uint32_t *nav2;     // [N] RPF patrol: virtual position r | c<<8 | remaining plan steps<<16 (14 bits) | vector<<30
     uint32_t *d2;       // [N] last squared distance
     uint32_t *dirf;     // [N][512] Nav direction planes (only if some env has a Nav target)
-    // ---- next episode, generated ahead of time by k_gen (episode[e] + 1) ----
+    // ---- the next TWO episodes of every env, generated ahead of time by k_gen. Every array is [2][N]...: slot p holds the
+    // lowest not yet started episode number of parity p (episode[e] + 1 sits in slot (episode[e] + 1) & 1, episode[e] + 2 in
+    // the other one). An episode lasts >= 11 steps, so an env uses at most two slots in any 20 steps: ONE generator pass per
+    // 20 steps (one A3C rollout) keeps both valid.
     uint32_t *n_maps, *n_pos, *n_goals, *n_plan, *n_tctr, *n_navgoal, *n_nav2, *n_d2, *n_dirf;
-    uint32_t *n_win;    // [N][32] the 2 x 13 window rows (13 map bits each) of the next episode's FIRST observation
-    uint32_t *gen_req;  // [N] 0 = next slot valid; s > 0 = consumed at step stamp s, to be regenerated
+    uint32_t *n_win;    // [2][N][32] the 2 x 13 window rows (13 map bits each) of that episode's FIRST observation
+    uint32_t *gen_req;  // [2][N] 0 = slot valid; s > 0 = consumed at step stamp s, to be regenerated
     // ---- Nav targets: the NEXT plan of the current episode, prepared ahead of time by the generator pass ----
     uint32_t *p_field;  // [N][768] direction planes + visited plane of the BFS rooted at p_goal
     uint32_t *p_goal;   // [N] r | c<<8
@@ -254,27 +257,32 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t lo, uint32_t h
     __shared__ uint32_t mlogs[kWavesPerBlock][kMazeLogMax];     // move log of the maze generator (t2d_device.h gen_maze)
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = uni((int)(threadIdx.x >> 6));
-    const int e = (int)blockIdx.x * kWavesPerBlock + wave;
-    if (e >= s.n) return;
-    const uint32_t req = s.gen_req[e];
+    const int idx = (int)blockIdx.x * kWavesPerBlock + wave;       // (slot, env): the first N waves serve slot 0
+    if (idx >= 2 * s.n) return;
+    const int slot = idx >= s.n ? 1 : 0, e = idx - slot * s.n;
+    const size_t so = (size_t)slot * s.n + e;
+    const uint32_t req = s.gen_req[so];
     const uint32_t cfg = s.cfg[e];
     uint32_t *tile = tiles[wave];
     const bool need_gen = force || (req >= lo && req <= hi && req != 0u);
-    if (PREFETCH && !force && (int)((cfg >> 2) & 7u) == TGT_NAV && s.p_state[e] == 0u) nav_prefetch(s, e, tile, lane);
+    if (PREFETCH && slot == 0 && !force && (int)((cfg >> 2) & 7u) == TGT_NAV && s.p_state[e] == 0u) nav_prefetch(s, e, tile, lane);
     if (!need_gen) return;
+    // the episode this slot is to hold: the lowest number above the env's current one with the slot's parity
+    const uint32_t cur = s.episode[e];
+    const uint32_t target = ((cur + 1u) & 1u) == (uint32_t)slot ? cur + 1u : cur + 2u;
     uint32_t pos, goals, plan, tctr, navgoal, d2, nav2;
-    uint32_t *gdir = NAV ? s.n_dirf + (size_t)e * kDirWords : nullptr;
+    uint32_t *gdir = NAV ? s.n_dirf + so * kDirWords : nullptr;
 #if T2D_EXP == 9
     __shared__ uint32_t gst[kWavesPerBlock][8];
     if (lane == 0) gst[wave][6] = (uint32_t)__builtin_readcyclecounter();            // kernel entry of this wave (incl. prefetch)
-    generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2, nav2, gst[wave]);
+    generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, target, gdir, pos, goals, plan, tctr, navgoal, d2, nav2, gst[wave]);
     wave_lds_sync();
     if (lane == 0) { gst[wave][5] = (uint32_t)__builtin_readcyclecounter(); for (int i = 0; i < 7; i++) tile[246 + i] = gst[wave][i]; }
 #else
-    generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, s.episode[e] + 1u, gdir, pos, goals, plan, tctr, navgoal, d2, nav2);
+    generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, target, gdir, pos, goals, plan, tctr, navgoal, d2, nav2);
 #endif
     wave_lds_sync();
-    reinterpret_cast<uint4 *>(s.n_maps + (size_t)e * kTileWords)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
+    reinterpret_cast<uint4 *>(s.n_maps + so * kTileWords)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
     if (lane < 2 * T2D_WIN) {
         // the window rows of the episode's first observation, so that the step kernel that switches to this episode
         // needs no dependent map fetch (k_step2 reads them speculatively when a done is possible)
@@ -287,12 +295,12 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t lo, uint32_t h
             const uint32_t *w = tile + rr * kRowWords;
             bits = window_row_bits(w[0], w[1], w[2], gside, ac);
         }
-        s.n_win[(size_t)e * 32 + lane] = bits;
+        s.n_win[so * 32 + lane] = bits;
     }
     if (lane == 0) {
-        s.n_pos[e] = pos; s.n_goals[e] = goals; s.n_plan[e] = plan; s.n_tctr[e] = tctr;
-        s.n_navgoal[e] = navgoal; s.n_d2[e] = d2; s.gen_req[e] = 0u;
-        if (NAV) s.n_nav2[e] = nav2;
+        s.n_pos[so] = pos; s.n_goals[so] = goals; s.n_plan[so] = plan; s.n_tctr[so] = tctr;
+        s.n_navgoal[so] = navgoal; s.n_d2[so] = d2; s.gen_req[so] = 0u;
+        if (NAV) s.n_nav2[so] = nav2;
     }
 }
 
@@ -552,22 +560,23 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
 
     if (OP != OP_OBSERVE && consume) {
         // Track1v1Env.reset(): switch to the pre-generated next episode (k_gen) — one 1 KiB tile copy + scalars
-        const uint4 nt = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)e * kTileWords)[lane];
+        if (!MULTI) episode = s.episode[e];
+        const size_t so = (size_t)((episode + 1u) & 1u) * s.n + e;      // the slot that holds episode + 1
+        const uint4 nt = reinterpret_cast<const uint4 *>(s.n_maps + so * kTileWords)[lane];
         reinterpret_cast<uint4 *>(tile)[lane] = nt;
         reinterpret_cast<uint4 *>(gtile)[lane] = nt;
         if (NAV && (mode == TGT_NAV || mode == TGT_RPF)) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(s.n_dirf + (size_t)e * kDirWords);
+            const uint4 *src = reinterpret_cast<const uint4 *>(s.n_dirf + so * kDirWords);
             uint4 *dst = reinterpret_cast<uint4 *>(s.dirf + (size_t)e * kDirWords);
             dst[lane] = src[lane]; dst[lane + 64] = src[lane + 64];
         }
-        pos = s.n_pos[e]; plan = s.n_plan[e]; tctr = s.n_tctr[e]; navgoal = s.n_navgoal[e]; d2 = s.n_d2[e];
-        if (NAV && lane == 0) { s.nav2[e] = s.n_nav2[e]; s.p_state[e] = 0u; }   // new map: the prefetched plan is void
+        pos = s.n_pos[so]; plan = s.n_plan[so]; tctr = s.n_tctr[so]; navgoal = s.n_navgoal[so]; d2 = s.n_d2[so];
+        if (NAV && lane == 0) { s.nav2[e] = s.n_nav2[so]; s.p_state[e] = 0u; }   // new map: the prefetched plan is void
         cnt = (uint32_t)side_of_cfg(cfg) << 24;
-        if (!MULTI) episode = s.episode[e];
         episode += 1u;
         if (lane == 0) {
-            s.goals[e] = s.n_goals[e]; s.episode[e] = episode; s.navgoal[e] = navgoal;
-            s.gen_req[e] = stamp + (uint32_t)k;
+            s.goals[e] = s.n_goals[so]; s.episode[e] = episode; s.navgoal[e] = navgoal;
+            s.gen_req[so] = stamp + (uint32_t)k;
         }
         wave_lds_sync();
     }
@@ -696,7 +705,8 @@ struct Step2 {
         ram = RAM && mode == TGT_RAM;
         nav = NAV && mode == TGT_NAV;
         navgoal = 0; pstate = 0;
-        if (MULTI || ram || nav) { plan = s.plan[e]; tctr = s.tctr[e]; episode = s.episode[e]; }
+        episode = s.episode[e];       // (also names the next-episode slot: parity of episode + 1)
+        if (MULTI || ram || nav) { plan = s.plan[e]; tctr = s.tctr[e]; }
         if (nav) { navgoal = s.navgoal[e]; pstate = s.p_state[e]; }
         genv = s.env_base + (uint32_t)e;
         lut = s.rew_lut + (mode == TGT_PZR ? kLutN : (mode == TGT_FAR ? 2 * kLutN : 0));
@@ -747,19 +757,23 @@ struct Step2 {
         sp_pos = 0; sp_plan = 0; sp_tctr = 0; sp_d2 = 0; sp_goals = 0; sp_navgoal = 0; sp_episode = 0; sp_win = 0x1fffu;
         sp_tile0 = make_uint4(0u, 0u, 0u, 0u); sp_tile1 = sp_tile0;
         if (__builtin_expect(mb != 0ull, 0)) {
+            const uint32_t slot = (episode + 1u) & 1u;               // where this env's next episode sits
+            const size_t so = (size_t)slot * s.n + e;
             if (maybe) {
-                sp_pos = s.n_pos[e]; sp_plan = s.n_plan[e]; sp_tctr = s.n_tctr[e]; sp_d2 = s.n_d2[e];
-                sp_goals = s.n_goals[e]; sp_navgoal = s.n_navgoal[e]; sp_episode = s.episode[e];
-                if (k >= 1 && k <= T2D_WIN) sp_win = s.n_win[(size_t)e * 32 + ag * T2D_WIN + (k - 1)];
+                sp_pos = s.n_pos[so]; sp_plan = s.n_plan[so]; sp_tctr = s.n_tctr[so]; sp_d2 = s.n_d2[so];
+                sp_goals = s.n_goals[so]; sp_navgoal = s.n_navgoal[so]; sp_episode = episode;
+                if (k >= 1 && k <= T2D_WIN) sp_win = s.n_win[so * 32 + ag * T2D_WIN + (k - 1)];
                 if (NAV && nav) {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(s.n_dirf + (size_t)e * kDirWords) + (lane & 31);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(s.n_dirf + so * kDirWords) + (lane & 31);
                     sp_nd0 = src[0]; sp_nd1 = src[32]; sp_nd2 = src[64]; sp_nd3 = src[96];
                 }
             }
+            const size_t so0 = (size_t)__builtin_amdgcn_readlane(slot, 0) * s.n + e0;
+            const size_t so1 = (size_t)__builtin_amdgcn_readlane(slot, 32) * s.n + e0 + 1;
             if ((mb & 0xffffffffull) != 0ull)
-                sp_tile0 = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)e0 * kTileWords)[lane];
+                sp_tile0 = reinterpret_cast<const uint4 *>(s.n_maps + so0 * kTileWords)[lane];
             if ((mb >> 32) != 0ull)
-                sp_tile1 = reinterpret_cast<const uint4 *>(s.n_maps + (size_t)(e0 + 1) * kTileWords)[lane];
+                sp_tile1 = reinterpret_cast<const uint4 *>(s.n_maps + so1 * kTileWords)[lane];
         }
     }
 
@@ -910,16 +924,17 @@ struct Step2 {
                     navgoal = sp_navgoal; navgoal_dirty = false;
                     if (leader) s.p_state[e] = 0u;
                 }
+                const size_t so = (size_t)(episode & 1u) * s.n + e;     // the slot just consumed (parity of the new episode)
                 if (leader) {
                     s.goals[e] = sp_goals; s.episode[e] = episode; s.navgoal[e] = sp_navgoal;
-                    s.gen_req[e] = stamp + (uint32_t)it;
+                    s.gen_req[so] = stamp + (uint32_t)it;
                 }
                 r0 = (int)(pos & 0xffu); c0 = (int)((pos >> 8) & 0xffu);
                 r1 = (int)((pos >> 16) & 0xffu); c1 = (int)(pos >> 24);
                 rowbase = (ag ? r1 : r0) - 7;
                 // later steps of a multi-step launch read the NEW map from its n_maps slot, which nobody writes during this
                 // launch (the copy into `maps` above is for later launches): no store -> load hazard through the vector L1
-                gmap = s.n_maps + (size_t)e * kTileWords;
+                gmap = s.n_maps + so * kTileWords;
             }
         }
         if (leader) {
@@ -1306,11 +1321,15 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     h->random_step = 0; h->phase = 0;
     h->gen_async = false; h->pending[0] = h->pending[1] = false;
     h->gen_stream = nullptr; h->ev_fork = nullptr; h->ev_join[0] = h->ev_join[1] = nullptr;
-    // A slot consumed at step q cannot be needed again before step q + min(11, max_episode_steps): done needs 11
-    // consecutive far steps (track_1v1.py:106-111) or the TimeLimit. Launching the generator every G <= that many
-    // steps, in order on the caller's stream, therefore always refills a slot before its next use.
-    h->gen_every = 10u;
-    if (cfg->max_episode_steps > 0 && (uint32_t)cfg->max_episode_steps < h->gen_every) h->gen_every = (uint32_t)cfg->max_episode_steps;
+    // An episode lasts L = min(11, max_episode_steps) steps or more (done needs 11 consecutive far steps, track_1v1.py:106-111,
+    // or the TimeLimit), and every env has TWO pre-generated episodes: a slot consumed at step q is needed again only after
+    // the other slot has been consumed too, i.e. not before step q + 2 L. Launching the generator every G <= 2 L - 2 steps, in
+    // order on the caller's stream, therefore always refills a slot before its next use: G = 20 = one A3C rollout.
+    {
+        uint32_t L = 11u;
+        if (cfg->max_episode_steps > 0 && (uint32_t)cfg->max_episode_steps < L) L = (uint32_t)cfg->max_episode_steps;
+        h->gen_every = L >= 2u ? 2u * L - 2u : 1u;
+    }
     h->win = h->cycle = h->gen_every;
     DevState &s = h->s;
     s.n = n; s.env_base = cfg->env_id_base;
@@ -1326,13 +1345,14 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         if (err == hipSuccess) err = hipMalloc((void **)p, bytes);
         if (err == hipSuccess) err = hipMemset(*p, 0, bytes);
     };
-    alloc(&s.maps, tb); alloc(&s.n_maps, tb);
-    alloc(&s.n_win, (size_t)n * 32 * sizeof(uint32_t));
-    uint32_t **arrs[] = {&s.pos, &s.goals, &s.cnt, &s.cfg, &s.episode, &s.plan, &s.tctr, &s.navgoal, &s.d2,
-                         &s.n_pos, &s.n_goals, &s.n_plan, &s.n_tctr, &s.n_navgoal, &s.n_d2, &s.gen_req, &s.nav2, &s.n_nav2};
+    alloc(&s.maps, tb); alloc(&s.n_maps, 2 * tb);
+    alloc(&s.n_win, (size_t)2 * n * 32 * sizeof(uint32_t));
+    uint32_t **arrs[] = {&s.pos, &s.goals, &s.cnt, &s.cfg, &s.episode, &s.plan, &s.tctr, &s.navgoal, &s.d2, &s.nav2};
     for (auto a : arrs) alloc(a, nb);
+    uint32_t **narrs[] = {&s.n_pos, &s.n_goals, &s.n_plan, &s.n_tctr, &s.n_navgoal, &s.n_d2, &s.gen_req, &s.n_nav2};
+    for (auto a : narrs) alloc(a, 2 * nb);          // [2][N]: the two next-episode slots
     if (has_nav) {
-        alloc(&s.dirf, db); alloc(&s.n_dirf, db);
+        alloc(&s.dirf, db); alloc(&s.n_dirf, 2 * db);
         alloc(&s.p_field, (size_t)n * kPlanWords * sizeof(uint32_t));
         alloc(&s.p_goal, nb); alloc(&s.p_tctr, nb); alloc(&s.p_state, nb);
     }
@@ -1377,9 +1397,10 @@ static inline dim3 env_grid(int n) { return dim3((unsigned)((n + kWavesPerBlock 
 
 static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t lo, uint32_t hi, int force, bool prefetch = false)
 {
-    if (h->has_nav && prefetch) hipLaunchKernelGGL((k_gen<true, true>), env_grid(h->s.n), dim3(256), 0, st, h->s, lo, hi, force);
-    else if (h->has_nav) hipLaunchKernelGGL((k_gen<true, false>), env_grid(h->s.n), dim3(256), 0, st, h->s, lo, hi, force);
-    else hipLaunchKernelGGL((k_gen<false, false>), env_grid(h->s.n), dim3(256), 0, st, h->s, lo, hi, force);
+    const dim3 grid = env_grid(2 * h->s.n);        // one wave per (slot, env)
+    if (h->has_nav && prefetch) hipLaunchKernelGGL((k_gen<true, true>), grid, dim3(256), 0, st, h->s, lo, hi, force);
+    else if (h->has_nav) hipLaunchKernelGGL((k_gen<true, false>), grid, dim3(256), 0, st, h->s, lo, hi, force);
+    else hipLaunchKernelGGL((k_gen<false, false>), grid, dim3(256), 0, st, h->s, lo, hi, force);
 }
 
 // Make `st` wait for every forked generator launch.
@@ -1718,6 +1739,7 @@ extern "C" int t2d_rollout_random(t2d_handle *h, int steps, uint64_t action_seed
         if (h->s.auto_reset) {
             const int left = (int)(h->win - h->phase % h->win);
             if (chunk > left) chunk = left;
+            if (chunk > 10) chunk = 10;      // (one episode switch per env and launch at most: an episode lasts >= 11 steps)
             int rc = window_begin(h, st);
             if (rc) return rc;
         }

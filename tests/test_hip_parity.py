@@ -586,17 +586,18 @@ def test_unaligned_observation_buffer_takes_the_scalar_store_path():
                                               ("Track2D-BlockPartialRam-v0", 11), ("Track2D-MazePartialFar-v0", 7),
                                               ("Track2D-BlockPartialRPF-v0", 500)])
 def test_async_generator_is_bit_identical_to_the_in_order_one(env_id, max_steps):
-    """t2d_generator_async: consumed next-episode slots refilled on the library's side stream, one 5-step stamp window
-    behind the steps, against the in-order generator from the same seed — every observation, reward and done flag of
-    single-step launches and of the fused multi-step launches, the final state and maps. Episode lengths down to 7
-    (odd windows of 3 steps) and the far rule's 11-step minimum are both exercised."""
+    """t2d_generator_async: consumed next-episode slots refilled on the library's side stream, one stamp window (10 steps
+    with the two next-episode slots per env) behind the steps, against the in-order generator from the same seed — every
+    observation, reward and done flag of single-step launches and of the fused multi-step launches, the final state and
+    maps. Episode lengths down to 7 (windows of 6 steps) and the far rule's 11-step minimum are both exercised."""
     import torch
     from active_tracking_rl_amd.vec_env import VecTrack2D
     n = 515
     a = VecTrack2D(env_id, num_envs=n, seed=11, max_episode_steps=max_steps, async_gen=True)
     b = VecTrack2D(env_id, num_envs=n, seed=11, max_episode_steps=max_steps)
     assert a.async_gen and not b.async_gen
-    assert a.generator_cycle == 2 * (min(10, max_steps) // 2) and b.generator_cycle == min(10, max_steps)
+    g_every = 2 * min(11, max_steps) - 2          # two pre-generated episodes per env: one pass per 2 L - 2 steps
+    assert a.generator_cycle == 2 * (g_every // 2) and b.generator_cycle == g_every
     assert torch.equal(a.reset(), b.reset())
     ndone = 0
     for t in range(83):
