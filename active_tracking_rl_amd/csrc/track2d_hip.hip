@@ -50,10 +50,12 @@ struct DevState {
     uint32_t *n_win;    // [2][N][32] the 2 x 13 window rows (13 map bits each) of that episode's FIRST observation
     uint32_t *gen_req;  // [2][N] 0 = slot valid; s > 0 = consumed at step stamp s, to be regenerated
     // ---- Nav targets: the NEXT plan of the current episode, prepared ahead of time by the generator pass ----
-    uint32_t *p_field;  // [N][768] direction planes + visited plane of the BFS rooted at p_goal
-    uint32_t *p_goal;   // [N] r | c<<8
-    uint32_t *p_tctr;   // [N] TARGET stream word counter after drawing p_goal
-    uint32_t *p_state;  // [N] 1 = the three above are valid for the current episode and map
+    // A queue of up to TWO prepared plans per env (slot-major [2][N]...): the next goal's plan and the one after it.
+    uint32_t *p_field;  // [2][N][768] direction planes + visited plane of the BFS rooted at p_goal
+    uint32_t *p_goal;   // [2][N] r | c<<8
+    uint32_t *p_tctr;   // [2][N] TARGET stream word counter after drawing p_goal
+    uint32_t *p_state;  // [N] bits 0-1: prepared plans (0..2), bit 2: queue head slot, bit 3: the last prepared plan does
+                        //     not reach its start cell (it will be re-made inline, with more draws: nothing can follow it)
     uint32_t *faults;   // [1]
     const float2 *rew_lut;    // [3][kLutN] (r_track, r_target) as float32(float64 formula), by w_p class and d^2
     int n;
@@ -217,29 +219,56 @@ __device__ __forceinline__ uint32_t window_row_bits(uint32_t w0, uint32_t w1, ui
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(sp & 31)) & 0x1fffu;
 }
 
-// Nav targets: prefetch the next plan on the CURRENT map, by the env's wave when no prefetched plan is pending. Draws
-// the goal the Navigator will draw when its plan is exhausted (navigator.py:17 — the TARGET stream has no other
-// consumer until then, so drawing it now keeps the stream order) and runs the BFS for it here, off the step kernel's
-// critical path. The step kernel adopts it if the target's position turns out reachable and different from the goal,
-// else re-plans inline. Reads the env's live state: only ever runs in order on the caller's stream, between two step
-// launches (inside the in-order generator launch, or as its own launch when the generator is forked).
+// Nav targets: prepare the next plans on the CURRENT map, off the step kernel's critical path. A plan is needed when the
+// target stands on its goal (navigator.py:15); the Navigator then draws a new goal (navigator.py:17 — the TARGET stream has no
+// other consumer in between, so drawing it NOW keeps the stream order) and plans from where it stands, i.e. from the goal of
+// the plan before. Up to two plans are queued: the second one starts at the first one's goal, from the stream position the
+// first one's draw left — valid as long as the first one turns out usable (reachable start, goal != start), which is known
+// here; otherwise the step kernel will re-plan inline with further draws and nothing can be prepared beyond it (bit 3).
+// The step kernel adopts the queue head if the target's position is reachable in it and differs from its goal, else re-plans
+// inline from the same already-drawn goal and drops the queue. Reads the env's live state: only ever runs in order on the
+// caller's stream, between two step launches (inside the in-order generator launch, or as its own launch when the generator
+// is forked). With a pass every 20 steps an inline re-plan needs two goals reached within those 20 steps.
+__device__ __forceinline__ uint32_t pq_count(uint32_t ps) { return ps & 3u; }
+__device__ __forceinline__ uint32_t pq_head(uint32_t ps) { return (ps >> 2) & 1u; }
+__device__ __forceinline__ uint32_t pq_pop(uint32_t ps)      // the head plan was adopted
+{
+    const uint32_t c = pq_count(ps) - 1u;
+    return c == 0u ? 0u : (c | ((pq_head(ps) ^ 1u) << 2) | (ps & 8u));
+}
 __device__ __forceinline__ void nav_prefetch(const DevState &s, int e, uint32_t *tile, int lane)
 {
+    uint32_t ps = s.p_state[e];
+    if (pq_count(ps) >= 2u || (ps & 8u) != 0u) return;
     reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(s.maps + (size_t)e * kTileWords)[lane];
     wave_lds_sync();
     const int side = (int)(s.cnt[e] >> 24);
     const FreeIndex fi = build_free_index(tile, side, lane);
-    Stream ts;
-    ts.init(s.k0, s.k1, s.episode[e], s.env_base + (uint32_t)e, STREAM_TARGET, s.tctr[e]);
-    const uint32_t g2 = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
-    NavField nf;
-    // the target will stand on its CURRENT goal when this plan is needed (navigator.py:15: a plan is exhausted exactly
-    // there), so the flood may stop once it has reached that cell; if the target is elsewhere (plan B), the adoption
-    // test in the step kernel (visited plane) sends it to the inline re-plan
-    const uint32_t cur = s.navgoal[e];
-    bfs_dir_field(tile, side, lane, (int)(g2 & 0xffu), (int)(g2 >> 8), nf, false, (int)(cur & 0xffu), (int)(cur >> 8));
-    store_plan_field(s.p_field + (size_t)e * kPlanWords, nf, side, lane);
-    if (lane == 0) { s.p_goal[e] = g2; s.p_tctr[e] = ts.ctr; s.p_state[e] = 1u; }
+    const uint32_t episode = s.episode[e], genv = s.env_base + (uint32_t)e;
+    // where the target will stand when the next plan is needed, and the stream position its goal is drawn from: the current
+    // goal / counter, or those of the one plan already queued (written by an earlier launch); carried in registers from
+    // there on
+    const size_t hs = (size_t)pq_head(ps) * s.n + e;
+    uint32_t start = pq_count(ps) == 0u ? s.navgoal[e] : s.p_goal[hs];
+    uint32_t ctr = pq_count(ps) == 0u ? s.tctr[e] : s.p_tctr[hs];
+    while (pq_count(ps) < 2u && (ps & 8u) == 0u) {
+        const uint32_t cnt = pq_count(ps), head = pq_head(ps);
+        const size_t slot = (size_t)((head + cnt) & 1u) * s.n + e;
+        Stream ts;
+        ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, ctr);
+        const uint32_t g2 = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+        NavField nf;
+        // the flood may stop once it has reached the start cell; if the target is elsewhere when the plan is needed (plan B),
+        // the adoption test in the step kernel (visited plane) sends it to the inline re-plan
+        const int sr = (int)(start & 0xffu), sc = (int)(start >> 8);
+        bfs_dir_field(tile, side, lane, (int)(g2 & 0xffu), (int)(g2 >> 8), nf, false, sr, sc);
+        store_plan_field(s.p_field + slot * kPlanWords, nf, side, lane);
+        const bool usable = rowbits_get(nf.visA, nf.visB, sr, sc) != 0u && g2 != start;
+        if (lane == 0) { s.p_goal[slot] = g2; s.p_tctr[slot] = ts.ctr; }
+        ps = (cnt + 1u) | (head << 2) | (usable ? 0u : 8u);
+        start = g2; ctr = ts.ctr;
+    }
+    if (lane == 0) s.p_state[e] = ps;
     wave_lds_sync();
 }
 
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t lo, uint32_t h
     const uint32_t cfg = s.cfg[e];
     uint32_t *tile = tiles[wave];
     const bool need_gen = force || (req >= lo && req <= hi && req != 0u);
-    if (PREFETCH && slot == 0 && !force && (int)((cfg >> 2) & 7u) == TGT_NAV && s.p_state[e] == 0u) nav_prefetch(s, e, tile, lane);
+    if (PREFETCH && slot == 0 && !force && (int)((cfg >> 2) & 7u) == TGT_NAV) nav_prefetch(s, e, tile, lane);
     if (!need_gen) return;
     // the episode this slot is to hold: the lowest number above the env's current one with the slot's parity
     const uint32_t cur = s.episode[e];
@@ -311,7 +340,7 @@ __global__ __launch_bounds__(256) void k_nav_prefetch(DevState s)
     const int wave = uni((int)(threadIdx.x >> 6));
     const int e = (int)blockIdx.x * kWavesPerBlock + wave;
     if (e >= s.n) return;
-    if ((int)((s.cfg[e] >> 2) & 7u) != TGT_NAV || s.p_state[e] != 0u) return;
+    if ((int)((s.cfg[e] >> 2) & 7u) != TGT_NAV) return;
     nav_prefetch(s, e, tiles[wave], lane);
 }
 
@@ -485,15 +514,17 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
             const uint32_t dir_here = load_dir(gdir, qr, qc);      // issued now, used if the current plan still stands
             uint32_t dir = 0;
             bool adopted = false, have_goal = false;
-            if (exhausted && !rpf && nv_pstate == 1u) {
+            if (exhausted && !rpf && pq_count(nv_pstate) != 0u) {
                 // a plan for the next goal was prepared by the generator pass (k_gen): adopt it if it is a valid plan
                 // from here (reachable, not already on the goal) — else fall through to the inline re-plan, which
-                // then starts from the same already-drawn goal
-                const uint32_t *pf = s.p_field + (size_t)e * kPlanWords;
-                const uint32_t g2 = s.p_goal[e];
-                ts.init(s.k0, s.k1, nv_episode, genv, STREAM_TARGET, s.p_tctr[e]);
+                // then starts from the same already-drawn goal (and voids whatever was prepared beyond it)
+                const size_t hs = (size_t)pq_head(nv_pstate) * s.n + e;
+                const uint32_t *pf = s.p_field + hs * kPlanWords;
+                const uint32_t g2 = s.p_goal[hs];
+                ts.init(s.k0, s.k1, nv_episode, genv, STREAM_TARGET, s.p_tctr[hs]);
                 navgoal = g2;
                 have_goal = true;
+                uint32_t new_ps = 0u;
                 if (load_vis(pf, r1, c1) != 0u && !(r1 == (int)(g2 & 0xffu) && c1 == (int)(g2 >> 8))) {
                     const uint4 *src = reinterpret_cast<const uint4 *>(pf);
                     uint4 *dst = reinterpret_cast<uint4 *>(gdir);
@@ -502,8 +533,9 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
                     plan = 0u; planb = false;
                     adopted = true;
                     navgoal_dirty = true;
+                    new_ps = pq_pop(nv_pstate);
                 }
-                if (lane == 0) s.p_state[e] = 0u;
+                if (lane == 0) s.p_state[e] = new_ps;
             }
             if (exhausted && !adopted) {
                 const FreeIndex fi = build_free_index(tile, side, lane);
@@ -742,11 +774,13 @@ struct Step2 {
             const uint32_t *gdir = s.dirf + (size_t)e * kDirWords;
             const int w = r1 * kRowWords + (c1 >> 5);
             nv_dA = gdir[w]; nv_dB = gdir[256 + w];         // used if the current plan still stands
-            if (nv_exh && pstate == 1u) {
-                // the plan the generator pass prepared for the NEXT goal, fetched now (speculatively: it is adopted below if
-                // it reaches the target's cell) so that adopting it adds no dependent round trip to the step
-                const uint32_t *pf = s.p_field + (size_t)e * kPlanWords;
-                sp_pgoal = s.p_goal[e]; sp_ptctr = s.p_tctr[e];
+            if (nv_exh && pq_count(pstate) != 0u) {
+                // the plan the generator pass prepared for the NEXT goal (the head of the env's plan queue), fetched now
+                // (speculatively: it is adopted below if it reaches the target's cell) so that adopting it adds no dependent
+                // round trip to the step
+                const size_t hs = (size_t)pq_head(pstate) * s.n + e;
+                const uint32_t *pf = s.p_field + hs * kPlanWords;
+                sp_pgoal = s.p_goal[hs]; sp_ptctr = s.p_tctr[hs];
                 sp_vis = pf[512 + w]; sp_pdA = pf[w]; sp_pdB = pf[256 + w];
                 const uint4 *src = reinterpret_cast<const uint4 *>(pf) + (lane & 31);
                 sp_fld0 = src[0]; sp_fld1 = src[32]; sp_fld2 = src[64]; sp_fld3 = src[96];
@@ -798,23 +832,29 @@ struct Step2 {
             bool planb = ((plan >> 28) & 1u) != 0u, adopted = false, have_goal = false;
             uint32_t dir = ((nv_dA >> (c1 & 31)) & 1u) | (((nv_dB >> (c1 & 31)) & 1u) << 1);
             uint32_t *gdir = s.dirf + (size_t)e * kDirWords;
-            if (nav && nv_exh && pstate == 1u) {
+            if (nav && nv_exh && pq_count(pstate) != 0u) {
                 // adopt the prepared plan if it is a valid plan from here (reachable, not already on its goal) — else the
-                // inline re-plan below starts from the same already-drawn goal (k_env<NAV> does exactly this)
+                // inline re-plan below starts from the same already-drawn goal (k_env<NAV> does exactly this) and whatever
+                // was prepared beyond it is void
                 navgoal = sp_pgoal; tctr = sp_ptctr; have_goal = true;
+                uint32_t new_ps = 0u;
                 if (((sp_vis >> (c1 & 31)) & 1u) != 0u && !(r1 == (int)(sp_pgoal & 0xffu) && c1 == (int)(sp_pgoal >> 8))) {
                     uint4 *dst = reinterpret_cast<uint4 *>(gdir) + (lane & 31);
                     dst[0] = sp_fld0; dst[32] = sp_fld1; dst[64] = sp_fld2; dst[96] = sp_fld3;
                     dir = ((sp_pdA >> (c1 & 31)) & 1u) | (((sp_pdB >> (c1 & 31)) & 1u) << 1);
                     plan = 0u; planb = false; adopted = true;
                     navgoal_dirty = true;
+                    new_ps = pq_pop(pstate);
                 }
-                if (leader) s.p_state[e] = 0u;
+                if (leader) s.p_state[e] = new_ps;
             }
             // rare: plan exhausted and nothing adoptable — Navigator's re-plan (navigator.py:15-38) by the whole wave, one slot
             // at a time, on the env's tile in LDS (wave-uniform copies of the slot's scalars in, results back to its lanes)
             const unsigned long long rm = __ballot(live && nav && nv_exh && !adopted);
             if (__builtin_expect(rm != 0ull, 0)) {
+#ifdef T2D_COUNT_REPLANS
+                if (lane == 0) atomicAdd(s.faults, (uint32_t)__popcll(rm & 0x100000001ull) << 8);   // probe build: inline re-plans
+#endif
 #pragma unroll 1
                 for (int slot = 0; slot < 2; slot++) {
                     if (((rm >> (32 * slot)) & 1ull) == 0ull) continue;
@@ -1353,8 +1393,8 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     for (auto a : narrs) alloc(a, 2 * nb);          // [2][N]: the two next-episode slots
     if (has_nav) {
         alloc(&s.dirf, db); alloc(&s.n_dirf, 2 * db);
-        alloc(&s.p_field, (size_t)n * kPlanWords * sizeof(uint32_t));
-        alloc(&s.p_goal, nb); alloc(&s.p_tctr, nb); alloc(&s.p_state, nb);
+        alloc(&s.p_field, (size_t)2 * n * kPlanWords * sizeof(uint32_t));      // two queued plans per env
+        alloc(&s.p_goal, 2 * nb); alloc(&s.p_tctr, 2 * nb); alloc(&s.p_state, nb);
     }
     alloc(&s.faults, sizeof(uint32_t));
     float2 *lut = nullptr;
