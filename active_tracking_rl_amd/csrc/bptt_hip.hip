@@ -1,0 +1,171 @@
+// bptt_hip.hip — back-propagation through time of the two players' LSTMCells over a whole rollout as ONE launch.
+//
+// The learner's recurrence backward was 2 launches per step and player pair (atr_lstm_cell_backward, then a batched GEMM
+// dG_t W_hh feeding step t - 1): 40 dependent launches of 5-12 us per iteration, with dG_t written by one kernel and re-read by
+// the next. But the recurrence is independent PER ROW (env): dh_{t-1}[n] = dG_t[n] W_hh. So one workgroup takes 16 rows of
+// one player through all T steps:
+//   * W_hh [4R, R] = [512, 128] stays in REGISTERS for the whole launch as MFMA B operands: wave w of the 8 owns output
+//     units [16 w, 16 w + 16) = 128 B-operand VGPRs of v_mfma_f32_16x16x4_f32 (exact f32), loaded once;
+//   * the accumulator layout of that MFMA (lane = unit column, 4 rows) IS the ownership of the element-wise cell backward:
+//     the gradient arriving through the hidden GEMM (dh_{t-1} contribution) and the cell-state carry never leave the
+//     registers of the thread that needs them at step t - 1;
+//   * per step: every thread evaluates the cell backward of its 4 (row, unit) pairs (the expressions of k_lstm_cell_bwd),
+//     stores the four gate gradients (the learner's weight-gradient GEMMs read dG afterwards) and parks them in a
+//     double-buffered LDS tile [16 rows x 512]; ONE barrier; then 128 MFMAs per wave contract the tile with the wave's
+//     weight slice (A operands by conflict-free ds_read_b128; the k <-> MFMA-slot assignment is the same permutation on both
+//     operands); the next step's activations are fetched from memory under those MFMAs.
+// Bounds: 2 x 16 x 512 x 128 flop per step and workgroup = 3.4 us on a CU's four SIMDs (the floor at small batches: 68 us per
+// 20-step rollout however few envs), and the stored activations + dG stream (~11 KB per row and step) at large batches.
+// Reference semantics: torch.nn.LSTMCell's backward under the truncated-BPTT rollout of player_util.py:104-161 (the episode
+// masks k_t cut the recurrence where an env finished: train.py:73-79).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/atr_policy.h"
+#include "atr_cell.h"
+
+namespace atr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBR = 128;                    // hidden units
+constexpr int kBK = 4 * kBR;                // contraction length: the four gates
+constexpr int kBRows = 16;                  // rows per workgroup (one MFMA M tile)
+constexpr int kBLd = kBK + 4;               // LDS row stride (floats): 16-B reads of 8 lanes hit 32 distinct banks
+
+struct Bptt {
+    const float *dh[2];        // per player: dL/dh_t from the heads [T, N, R] (nullable: zero)
+    const float *keep;         // [T, N] float episode masks
+    const float *acts;         // + p * acts_ps + (t * N + n) * 4R : activated gates (i, f, g, o)
+    long long acts_ps;
+    const float *c_all;        // + p * c_ps + (t * N + n) * R : cell states, slot t = before step t, slot t + 1 = after
+    long long c_ps;
+    const float *whh[2];       // per player: weight_hh [4R, R] (nn.LSTMCell layout)
+    float *dg;                 // + p * dg_ps + (t * N + n) * 4R : pre-activation gate gradients (out)
+    long long dg_ps;
+    float *dh0, *dc0;          // [P, N, R]: gradient into the rollout's initial hidden / cell state (out)
+    int P, T, N;
+};
+
+__global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
+{
+    extern __shared__ __attribute__((aligned(16))) float tileA[];      // [2][kBRows][kBLd]
+    const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int col = l & 15, q = l >> 4;
+    const int tiles = (a.N + kBRows - 1) / kBRows;
+    const int p = (int)blockIdx.x / tiles, rt = (int)blockIdx.x - p * tiles;
+    const int row0 = rt * kBRows;
+    const int u = 16 * w + col;                                         // this lane's hidden unit
+    // ---- this wave's slice of W_hh as MFMA B operands: step s = 4 g + t, slot q  <->  k = 16 g + 4 q + t
+    const float *W = a.whh[p];
+    float B[128];
+#pragma unroll
+    for (int g = 0; g < 32; g++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) B[4 * g + t] = W[(size_t)(16 * g + 4 * q + t) * kBR + u];
+    // ---- the 4 (row, unit) pairs of this thread: rows row0 + 4 q + i — the rows of its MFMA accumulator
+    int rows[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { rows[i] = row0 + 4 * q + i; ok[i] = rows[i] < a.N; rows[i] = min(rows[i], a.N - 1); }
+    const float *acts = a.acts + (size_t)p * a.acts_ps;
+    const float *call = a.c_all + (size_t)p * a.c_ps;
+    const float *dhp = a.dh[p];
+    float *dg = a.dg + (size_t)p * a.dg_ps;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};          // dG_{t+1} W_hh for this thread's pairs (gradient arriving through h_t)
+    float dcc[4] = {0.f, 0.f, 0.f, 0.f};       // dc_{t+1} f_{t+1}
+    // staged inputs of one step (fetched one step ahead, under the MFMAs)
+    float gi[4], gf[4], gg[4], go[4], cv[4], cpv[4], dhh[4], ko[4], ki[4];
+#define BPTT_FETCH(t_)                                                                                                 \
+    do {                                                                                                               \
+        const int tt_ = (t_);                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                \
+            const size_t r_ = (size_t)tt_ * a.N + rows[i];                                                             \
+            const float *ac_ = acts + r_ * kBK + u;                                                                    \
+            gi[i] = ac_[0]; gf[i] = ac_[kBR]; gg[i] = ac_[2 * kBR]; go[i] = ac_[3 * kBR];                              \
+            cv[i] = call[(r_ + a.N) * kBR + u];                  /* c after step t: slot t + 1 */                      \
+            cpv[i] = call[r_ * kBR + u];                         /* c before step t */                                 \
+            dhh[i] = dhp ? dhp[r_ * kBR + u] : 0.0f;                                                                   \
+            ko[i] = a.keep[r_];                                                                                        \
+            ki[i] = tt_ > 0 ? a.keep[r_ - a.N] : 1.0f;                                                                 \
+        }                                                                                                              \
+    } while (0)
+    BPTT_FETCH(a.T - 1);
+#pragma unroll 1
+    for (int t = a.T - 1; t >= 0; t--) {
+        float *At = tileA + (size_t)(t & 1) * kBRows * kBLd;
+        const bool has_next = t < a.T - 1;
+        // ---- cell backward of this thread's 4 pairs (k_lstm_cell_bwd's expressions)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float dh = dhh[i], dcn = 0.0f;
+            if (has_next) { dh = fmaf(ko[i], acc[i], dh); dcn = ko[i] * dcc[i]; }
+            const float tc = tanhf_(cv[i]);
+            const float dc = dcn + dh * go[i] * (1.0f - tc * tc);
+            const float d_o = dh * tc * go[i] * (1.0f - go[i]);
+            const float d_i = dc * gg[i] * gi[i] * (1.0f - gi[i]);
+            const float d_g = dc * gi[i] * (1.0f - gg[i] * gg[i]);
+            const float d_f = dc * (ki[i] * cpv[i]) * gf[i] * (1.0f - gf[i]);
+            dcc[i] = dc * gf[i];
+            float *ar = At + (4 * q + i) * kBLd + u;
+            ar[0] = d_i; ar[kBR] = d_f; ar[2 * kBR] = d_g; ar[3 * kBR] = d_o;
+            if (ok[i]) {
+                float *o = dg + ((size_t)t * a.N + rows[i]) * kBK + u;
+                o[0] = d_i; o[kBR] = d_f; o[2 * kBR] = d_g; o[3 * kBR] = d_o;
+            }
+        }
+        __syncthreads();                                   // the tile of step t is complete (the other buffer: step t + 1's
+                                                           // reads finished before this step's writes began two barriers ago)
+        if (t > 0) BPTT_FETCH(t - 1);                      // next step's inputs: in flight under the MFMAs
+        // ---- dh_{t-1} contribution: acc = dG_t[rows, :] W_hh[:, units of this wave]
+        acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+        const float *rd = At + col * kBLd + 4 * q;         // MFMA A layout: lane (row col, K slot q)
+#pragma unroll
+        for (int g = 0; g < 32; g++) {
+            const float4 av = *reinterpret_cast<const float4 *>(rd + 16 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, B[4 * g + 0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, B[4 * g + 1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, B[4 * g + 2], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, B[4 * g + 3], acc2, 0, 0, 0);
+        }
+        acc += acc2;
+    }
+#undef BPTT_FETCH
+    // ---- gradient into the rollout's initial state
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (ok[i]) {
+            const size_t o = ((size_t)p * a.N + rows[i]) * kBR + u;
+            a.dh0[o] = acc[i];
+            a.dc0[o] = dcc[i];
+        }
+}
+
+} // namespace atr
+
+using namespace atr;
+
+extern "C" int atr_lstm_bptt(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *acts,
+                             long long acts_pstride, const float *c_all, long long c_pstride, const float *whh0,
+                             const float *whh1, float *dg, long long dg_pstride, float *dh_init, float *dc_init, int P, int T,
+                             int N, int R, void *stream)
+{
+    if (!keep || !acts || !c_all || !whh0 || !dg || !dh_init || !dc_init || P < 1 || P > 2 || (P == 2 && !whh1) || T < 1 ||
+        N < 1 || R != kBR)
+        return -1;
+    Bptt a;
+    a.dh[0] = dh0_heads; a.dh[1] = dh1_heads; a.keep = keep; a.acts = acts; a.acts_ps = acts_pstride; a.c_all = c_all;
+    a.c_ps = c_pstride; a.whh[0] = whh0; a.whh[1] = whh1; a.dg = dg; a.dg_ps = dg_pstride; a.dh0 = dh_init; a.dc0 = dc_init;
+    a.P = P; a.T = T; a.N = N;
+    const size_t lds = (size_t)2 * kBRows * kBLd * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_lstm_bptt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)(P * ((N + kBRows - 1) / kBRows));
+    hipLaunchKernelGGL(k_lstm_bptt, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

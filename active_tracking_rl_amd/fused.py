@@ -66,6 +66,8 @@ def lib():
         L.atr_lstm_cell_forward_act2.restype = i32
         L.atr_lstm_cell_forward_act2.argtypes = [vp] * 5 + [ll, vp, vp, ll, vp, ll, vp, ll] + [vp] * 4 + [i32, vp, vp,
                                                  C.c_ulonglong, C.c_uint, i32, i32, vp]
+        L.atr_lstm_bptt.restype = i32
+        L.atr_lstm_bptt.argtypes = [vp, vp, vp, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, i32, i32, i32, i32, vp]
         L.atr_pair_linear.restype = i32
         L.atr_pair_linear.argtypes = [C.POINTER(PairLinearArgs), vp]
         L.atr_act_env_step.restype = i32
@@ -367,30 +369,45 @@ class _LstmSeq(torch.autograd.Function):
         return dG[0], (dG[1] if ctx.two else None), dwhh, dhn, dcc, None
 
 
-def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs):
+use_fused_bptt = True   # the whole recurrence backward as ONE launch (csrc/bptt_hip.hip) instead of 2 launches per step
+
+
+def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs, whh_nn=None):
     """Back-propagation through time over stored activations: dhs = per-player dL/dh_seq [T,N,R] (None = zero).
-    Returns dG [P, T*N, 4R] (= dL/d ig), dL/dh0, dL/dc0 [P,N,R] and dL/dW_hh^T [P,R,4R]."""
+    Returns dG [P, T*N, 4R] (= dL/d ig), dL/dh0, dL/dc0 [P,N,R] and dL/dW_hh^T [P,R,4R]. whh_nn: per-player weight_hh [4R,R]
+    (nn layout; made from whh [P,R,4R] when absent)."""
     L = lib()
     P, T1, N, R = h_all.shape
     T = T1 - 1
     dev = h_all.device
-    dhs = [torch.zeros((T, N, R), dtype=torch.float32, device=dev) if d is None else d.contiguous() for d in dhs]
-    pd = (dhs[1].data_ptr() - dhs[0].data_ptr()) // 4 if P > 1 else 0          # player stride between the two grads
     dG = torch.empty((P, T, N, 4 * R), dtype=torch.float32, device=dev)
     dhn = torch.empty((P, N, R), dtype=torch.float32, device=dev)
     dcc = torch.empty((P, N, R), dtype=torch.float32, device=dev)
-    whh_t = whh.transpose(1, 2)                                               # [P,4R,R]
     st = _stream(h_all)
     ps, pa, step, astep = (T + 1) * N * R, T * N * 4 * R, N * R * 4, N * 4 * R * 4
-    for t in range(T - 1, -1, -1):
-        rc = L.atr_lstm_cell_backward(
-            C.c_void_p(dhs[0].data_ptr() + t * step), pd, _p(dhn), _p(dcc), _p(keep[t]),
-            _p(keep[t - 1]) if t else None, C.c_void_p(acts.data_ptr() + t * astep), pa,
-            C.c_void_p(c_all.data_ptr() + (t + 1) * step), ps, C.c_void_p(c_all.data_ptr() + t * step), ps,
-            C.c_void_p(dG.data_ptr() + t * astep), pa, 1 if t < T - 1 else 0, P, N, R, st)
+    if use_fused_bptt and R == 128 and h_all.is_cuda and acts.is_contiguous() and c_all.is_contiguous() and keep.is_contiguous():
+        if whh_nn is None:
+            wt = whh.transpose(1, 2).contiguous()
+            whh_nn = [wt[p] for p in range(P)]
+        whh_nn = [w if w.is_contiguous() else w.contiguous() for w in whh_nn]
+        dh_c = [d.contiguous() if d is not None else None for d in dhs]
+        rc = L.atr_lstm_bptt(_pn(dh_c[0]), _pn(dh_c[1]) if P > 1 else None, _p(keep), _p(acts), pa, _p(c_all), ps,
+                             _p(whh_nn[0]), _p(whh_nn[1]) if P > 1 else None, _p(dG), pa, _p(dhn), _p(dcc), P, T, N, R, st)
         if rc != 0:
-            raise RuntimeError("atr_lstm_cell_backward failed (%d)" % rc)
-        torch.bmm(dG[:, t], whh_t, out=dhn)                                   # gradient into h_{t-1}
+            raise RuntimeError("atr_lstm_bptt failed (%d)" % rc)
+    else:
+        dhs = [torch.zeros((T, N, R), dtype=torch.float32, device=dev) if d is None else d.contiguous() for d in dhs]
+        pd = (dhs[1].data_ptr() - dhs[0].data_ptr()) // 4 if P > 1 else 0          # player stride between the two grads
+        whh_t = whh.transpose(1, 2)                                               # [P,4R,R]
+        for t in range(T - 1, -1, -1):
+            rc = L.atr_lstm_cell_backward(
+                C.c_void_p(dhs[0].data_ptr() + t * step), pd, _p(dhn), _p(dcc), _p(keep[t]),
+                _p(keep[t - 1]) if t else None, C.c_void_p(acts.data_ptr() + t * astep), pa,
+                C.c_void_p(c_all.data_ptr() + (t + 1) * step), ps, C.c_void_p(c_all.data_ptr() + t * step), ps,
+                C.c_void_p(dG.data_ptr() + t * astep), pa, 1 if t < T - 1 else 0, P, N, R, st)
+            if rc != 0:
+                raise RuntimeError("atr_lstm_cell_backward failed (%d)" % rc)
+            torch.bmm(dG[:, t], whh_t, out=dhn)                                   # gradient into h_{t-1}
     # W_hh: sum_t (k_{t-1} h_{t-1})^T dG_t as one GEMM per player over all T*N rows
     kprev = torch.cat([torch.ones_like(keep[:1]), keep[:-1]], 0)              # [T, N]: mask on h_{t-1}
     dG = dG.view(P, T * N, 4 * R)
@@ -414,7 +431,7 @@ class _LstmSeqCached(torch.autograd.Function):
         P = h_all.shape[0]
         feats, wih, whh_l = fw[:P], fw[P:2 * P], fw[2 * P:3 * P]
         whh = torch.stack([w.t() for w in whh_l], 0).contiguous()
-        ctx.save_for_backward(keep.contiguous(), h_all, c_all, acts, whh, *feats, *wih)
+        ctx.save_for_backward(keep.contiguous(), h_all, c_all, acts, whh, *feats, *wih, *whh_l)
         ctx.P = P
         ctx.need = tuple(bool(x) for x in need) if need is not None else (True,) * P
         return tuple(h_all[p, 1:] for p in range(P))
@@ -424,6 +441,7 @@ class _LstmSeqCached(torch.autograd.Function):
         P = ctx.P
         keep, h_all, c_all, acts, whh = ctx.saved_tensors[:5]
         feats, wih = ctx.saved_tensors[5:5 + P], ctx.saved_tensors[5 + P:5 + 2 * P]
+        whh_nn = ctx.saved_tensors[5 + 2 * P:5 + 3 * P]          # weight_hh [4R, R] as nn.LSTMCell holds it
         dfeat, dwih, db, dwhh_l = [None] * P, [None] * P, [None] * P, [None] * P
         if all(ctx.need):
             groups = [list(range(P))]
@@ -431,7 +449,7 @@ class _LstmSeqCached(torch.autograd.Function):
             groups = [[p] for p in range(P) if ctx.need[p]]
         for grp in groups:
             a, b = grp[0], grp[-1] + 1
-            dG, _, _, dwhh = _lstm_bptt(whh[a:b], keep, h_all[a:b], c_all[a:b], acts[a:b], dhs[a:b])
+            dG, _, _, dwhh = _lstm_bptt(whh[a:b], keep, h_all[a:b], c_all[a:b], acts[a:b], dhs[a:b], whh_nn=list(whh_nn[a:b]))
             for i, p in enumerate(grp):
                 dfeat[p] = dG[i] @ wih[p]
                 dwih[p], db[p] = gemm_tn(dG[i], feats[p], colsum=True)

@@ -168,6 +168,15 @@ int atr_lstm_cell_backward(const float *dh_out, long long dh_pstride, const floa
                            const float *keep_out, const float *keep_in, const float *acts, long long acts_pstride,
                            const float *c, long long c_pstride, const float *c_prev, long long c_prev_pstride, float *dg,
                            long long dg_pstride, int has_next, int P, int N, int R, void *stream);
+/* Back-propagation through time of P <= 2 LSTMCells over a whole T-step rollout as ONE launch (csrc/bptt_hip.hip) — T calls
+ * of atr_lstm_cell_backward interleaved with T batched GEMMs dG_t W_hh (the gradient arriving through the hidden state).
+ * dh{0,1}_heads [T,N,R] per player: dL/dh_t from the heads (NULL = zero); keep [T,N] float episode masks (keep[t] cuts what
+ * arrives from step t + 1, keep[t-1] masks step t's previous state); acts + p*acts_pstride [T,N,4R] activated gates; c_all +
+ * p*c_pstride [T+1,N,R] cell states (slot t before step t); whh{0,1} = weight_hh [4R,R]. Out: dg + p*dg_pstride [T,N,4R]
+ * = dL/d(pre-activations), dh_init / dc_init [P,N,R] = gradient into the rollout's initial state. R must be 128. */
+int atr_lstm_bptt(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *acts, long long acts_pstride,
+                  const float *c_all, long long c_pstride, const float *whh0, const float *whh1, float *dg,
+                  long long dg_pstride, float *dh_init, float *dc_init, int P, int T, int N, int R, void *stream);
 /* n-step returns and GAE terms of the A3C loss (player_util.py:118-141 of the reference) for all (env, agent) pairs:
  * rewards [T,N,A], values [T+1,N,A] (row T = bootstrap value), notdone [T,N] -> returns, gae [T,N,A]. */
 int atr_gae_returns(const float *rewards, const float *values, const float *notdone, float gamma, float tau,

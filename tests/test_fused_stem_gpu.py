@@ -390,3 +390,34 @@ def test_pair_linear_matches_float64(M):
 def b_g(dev):
     gen = torch.Generator(device="cpu").manual_seed(3)
     return [torch.randn(512, generator=gen).to(dev), torch.randn(512, generator=gen).to(dev)]
+
+
+@pytest.mark.parametrize("N,P,T", [(512, 2, 20), (1000, 2, 7), (37, 1, 5), (4096, 2, 20)])
+def test_fused_bptt_matches_the_per_step_path(N, P, T):
+    """atr_lstm_bptt (csrc/bptt_hip.hip: the whole recurrence backward of a rollout as ONE launch, W_hh in registers, the
+    hidden-state gradient never leaving the MFMA accumulators) against the per-step path it replaces (atr_lstm_cell_backward
+    + batched GEMM per step), on random stored activations with episode boundaries: dG, the gradient into the initial state
+    and dW_hh; ragged row counts, one or two players, a missing head gradient."""
+    from active_tracking_rl_amd import fused
+    dev = torch.device("cuda:0")
+    R = 128
+    torch.manual_seed(N + T)
+    whh = torch.randn(P, R, 4 * R, device=dev) * 0.08                    # W_hh^T per player
+    keep = (torch.rand(T, N, device=dev) > 0.15).float()
+    h_all = torch.randn(P, T + 1, N, R, device=dev) * 0.5
+    c_all = torch.randn(P, T + 1, N, R, device=dev)
+    acts = torch.rand(P, T, N, 4 * R, device=dev)
+    acts[:, :, :, 2 * R:3 * R] = acts[:, :, :, 2 * R:3 * R] * 2 - 1       # the g gate is a tanh
+    dhs = [torch.randn(T, N, R, device=dev) for _ in range(P)]
+    if P == 2 and T == 7:
+        dhs[1] = None                                                     # a player whose heads contribute nothing
+    res = []
+    for flag in (True, False):
+        fused.use_fused_bptt = flag
+        try:
+            res.append(fused._lstm_bptt(whh, keep, h_all, c_all, acts, list(dhs)))
+        finally:
+            fused.use_fused_bptt = True
+    for a_, b_, name in zip(res[0], res[1], ("dG", "dh0", "dc0", "dWhh")):
+        scale = float(b_.abs().max())
+        torch.testing.assert_close(a_, b_, rtol=2e-4, atol=2e-5 * max(scale, 1.0), msg=lambda m: name + ": " + m)
