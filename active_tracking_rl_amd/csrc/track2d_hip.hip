@@ -13,6 +13,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -63,6 +64,7 @@ struct DevState {
     int max_steps, auto_reset;
     int amask;                // highest action: 3 ('VonNeumann') or 7 ('Moore', track_1v1.py:243-249)
     int obs_full, obs_side;   // obs_type 'Full': every env writes [2][obs_side][obs_side] floats
+    int nt_obs;               // large batches: observations are streamed past the caches (non-temporal stores)
 };
 
 enum : int { OP_STEP = 0, OP_RESET = 1, OP_OBSERVE = 2 };
@@ -286,15 +288,19 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t lo, uint32_t h
     __shared__ uint32_t mlogs[kWavesPerBlock][kMazeLogMax];     // move log of the maze generator (t2d_device.h gen_maze)
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = uni((int)(threadIdx.x >> 6));
-    const int idx = (int)blockIdx.x * kWavesPerBlock + wave;       // (slot, env): the first N waves serve slot 0
-    if (idx >= 2 * s.n) return;
+    const int idx = (int)blockIdx.x * kWavesPerBlock + wave;       // (slot, env): the first N waves serve slot 0, the next N
+    if (idx >= (PREFETCH ? 3 : 2) * s.n) return;                    // slot 1; PREFETCH: N more waves prepare Nav plans
+    uint32_t *tile = tiles[wave];
+    if (PREFETCH && idx >= 2 * s.n) {       // (waves of their own: a prefetch and a generation are each one wave's serial chain)
+        const int ep = idx - 2 * s.n;
+        if (!force && (int)((s.cfg[ep] >> 2) & 7u) == TGT_NAV) nav_prefetch(s, ep, tile, lane);
+        return;
+    }
     const int slot = idx >= s.n ? 1 : 0, e = idx - slot * s.n;
     const size_t so = (size_t)slot * s.n + e;
     const uint32_t req = s.gen_req[so];
     const uint32_t cfg = s.cfg[e];
-    uint32_t *tile = tiles[wave];
     const bool need_gen = force || (req >= lo && req <= hi && req != 0u);
-    if (PREFETCH && slot == 0 && !force && (int)((cfg >> 2) & 7u) == TGT_NAV) nav_prefetch(s, e, tile, lane);
     if (!need_gen) return;
     // the episode this slot is to hold: the lowest number above the env's current one with the slot's parity
     const uint32_t cur = s.episode[e];
@@ -1038,14 +1044,21 @@ struct Step2 {
                 const int nvalid = min(4, cells - p);
                 if (OBS == OBS_U8) {
                     uint8_t *o = reinterpret_cast<uint8_t *>(obs) + ebase + p;
-                    if (nvalid == 4) *reinterpret_cast<uint32_t *>(o) = bytes;
-                    else for (int c = 0; c < nvalid; c++) o[c] = (uint8_t)(bytes >> (8 * c));
+                    if (nvalid == 4) {
+                        if (s.nt_obs) __builtin_nontemporal_store(bytes, reinterpret_cast<uint32_t *>(o));
+                        else *reinterpret_cast<uint32_t *>(o) = bytes;
+                    } else for (int c = 0; c < nvalid; c++) o[c] = (uint8_t)(bytes >> (8 * c));
                 } else {
                     float *o = reinterpret_cast<float *>(obs) + ebase + p;
                     const float f0 = (float)(bytes & 0xffu), f1 = (float)((bytes >> 8) & 0xffu);
                     const float f2 = (float)((bytes >> 16) & 0xffu), f3 = (float)(bytes >> 24);
                     if (OBS == OBS_F32_VEC4 && nvalid == 4) {
-                        *reinterpret_cast<float4 *>(o) = make_float4(f0, f1, f2, f3);
+                        // beyond the Infinity Cache (hundreds of MB of observations per step) the stores stream past the
+                        // caches: written once, read by another kernel much later
+                        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                        const f32x4_t v4 = {f0, f1, f2, f3};
+                        if (s.nt_obs) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4_t *>(o));
+                        else *reinterpret_cast<float4 *>(o) = make_float4(f0, f1, f2, f3);
                     } else {
                         o[0] = f0;
                         if (nvalid > 1) o[1] = f1;
@@ -1378,6 +1391,11 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     s.obs_full = cfg->obs_type == T2D_OBS_FULL ? 1 : 0;
     s.amask = cfg->action_type == T2D_ACTIONS_MOORE ? 7 : 3;
     s.obs_side = n_maze == n ? 81 : 82;
+    {
+        const char *nt = getenv("T2D_NT_OBS_MIN_ENVS");       // (experiment hook; default: from 8192 envs up — measured
+        // neutral at 4096, +7 % at 16384, +15-30 % from 65536 up; non-temporal LOADS of the map rows changed nothing)
+        s.nt_obs = n >= (nt ? atoi(nt) : 8192) ? 1 : 0;
+    }
     const size_t nb = (size_t)n * sizeof(uint32_t), tb = (size_t)n * kTileWords * sizeof(uint32_t),
                  db = (size_t)n * kDirWords * sizeof(uint32_t);
     hipError_t err = hipSuccess;
@@ -1438,7 +1456,7 @@ static inline dim3 env_grid(int n) { return dim3((unsigned)((n + kWavesPerBlock 
 static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t lo, uint32_t hi, int force, bool prefetch = false)
 {
     const dim3 grid = env_grid(2 * h->s.n);        // one wave per (slot, env)
-    if (h->has_nav && prefetch) hipLaunchKernelGGL((k_gen<true, true>), grid, dim3(256), 0, st, h->s, lo, hi, force);
+    if (h->has_nav && prefetch) hipLaunchKernelGGL((k_gen<true, true>), env_grid(3 * h->s.n), dim3(256), 0, st, h->s, lo, hi, force);
     else if (h->has_nav) hipLaunchKernelGGL((k_gen<true, false>), grid, dim3(256), 0, st, h->s, lo, hi, force);
     else hipLaunchKernelGGL((k_gen<false, false>), grid, dim3(256), 0, st, h->s, lo, hi, force);
 }
