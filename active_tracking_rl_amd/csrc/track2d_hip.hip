@@ -51,11 +51,13 @@ struct DevState {
     uint32_t *n_win;    // [2][N][32] the 2 x 13 window rows (13 map bits each) of that episode's FIRST observation
     uint32_t *gen_req;  // [2][N] 0 = slot valid; s > 0 = consumed at step stamp s, to be regenerated
     // ---- Nav targets: the NEXT plan of the current episode, prepared ahead of time by the generator pass ----
-    // A queue of up to TWO prepared plans per env (slot-major [2][N]...): the next goal's plan and the one after it.
-    uint32_t *p_field;  // [2][N][768] direction planes + visited plane of the BFS rooted at p_goal
-    uint32_t *p_goal;   // [2][N] r | c<<8
-    uint32_t *p_tctr;   // [2][N] TARGET stream word counter after drawing p_goal
-    uint32_t *p_state;  // [N] bits 0-1: prepared plans (0..2), bit 2: queue head slot, bit 3: the last prepared plan does
+    // A queue of up to TWO prepared plans per env and EPISODE (the next goal's plan and the one after it), in three rotating
+    // sets indexed by episode % 3: the current episode's queue and those the generator prepared for the two pre-generated next
+    // episodes never share storage. Queue slot q of episode ep of env e = index ((ep % 3) * 2 + q) * N + e.
+    uint32_t *p_field;  // [3][2][N][768] direction planes + visited plane of the BFS rooted at p_goal
+    uint32_t *p_goal;   // [3][2][N] r | c<<8
+    uint32_t *p_tctr;   // [3][2][N] TARGET stream word counter after drawing p_goal
+    uint32_t *p_state;  // [3][N] bits 0-1: prepared plans (0..2), bit 2: queue head slot, bit 3: the last prepared plan does
                         //     not reach its start cell (it will be re-made inline, with more draws: nothing can follow it)
     uint32_t *faults;   // [1]
     const float2 *rew_lut;    // [3][kLutN] (r_track, r_target) as float32(float64 formula), by w_p class and d^2
@@ -124,6 +126,76 @@ __device__ __forceinline__ uint32_t nav_dir_from_regs(const NavField &f, int r, 
 }
 
 __device__ __forceinline__ int side_of_cfg(uint32_t cfg) { return (cfg & 3u) == (uint32_t)MAP_MAZE ? 81 : 82; }
+
+// Nav targets: prepare the next plans on the CURRENT map, off the step kernel's critical path. A plan is needed when the
+// target stands on its goal (navigator.py:15); the Navigator then draws a new goal (navigator.py:17 — the TARGET stream has no
+// other consumer in between, so drawing it NOW keeps the stream order) and plans from where it stands, i.e. from the goal of
+// the plan before. Up to two plans are queued: the second one starts at the first one's goal, from the stream position the
+// first one's draw left — valid as long as the first one turns out usable (reachable start, goal != start), which is known
+// here; otherwise the step kernel will re-plan inline with further draws and nothing can be prepared beyond it (bit 3).
+// The step kernel adopts the queue head if the target's position is reachable in it and differs from its goal, else re-plans
+// inline from the same already-drawn goal and drops the queue. Reads the env's live state: only ever runs in order on the
+// caller's stream, between two step launches (inside the in-order generator launch, or as its own launch when the generator
+// is forked). With a pass every 20 steps an inline re-plan needs two goals reached within those 20 steps.
+__device__ __forceinline__ uint32_t pq_count(uint32_t ps) { return ps & 3u; }
+__device__ __forceinline__ uint32_t pq_head(uint32_t ps) { return (ps >> 2) & 1u; }
+__device__ __forceinline__ uint32_t pq_pop(uint32_t ps)      // the head plan was adopted
+{
+    const uint32_t c = pq_count(ps) - 1u;
+    return c == 0u ? 0u : (c | ((pq_head(ps) ^ 1u) << 2) | (ps & 8u));
+}
+__device__ __forceinline__ size_t pq_index(const DevState &s, uint32_t episode, uint32_t qslot, int e)
+{
+    return (size_t)((episode % 3u) * 2u + qslot) * s.n + e;
+}
+__device__ __forceinline__ size_t pq_state_index(const DevState &s, uint32_t episode, int e)
+{
+    return (size_t)(episode % 3u) * s.n + e;
+}
+// Top the plan queue of episode `episode` of env e up to two plans, on the map in `tile` (LDS; free index `fi`). ps: the
+// queue's state; (start, ctr): where the target will stand when the next plan is needed and the stream position its goal is
+// drawn from — the current goal / counter, or those of the one plan already queued; carried in registers from there on.
+// Returns the new state (the caller stores it).
+__device__ __forceinline__ uint32_t nav_fill_queue(const DevState &s, int e, uint32_t episode, const uint32_t *tile, int side,
+                                                    const FreeIndex &fi, int lane, uint32_t ps, uint32_t start, uint32_t ctr)
+{
+    const uint32_t genv = s.env_base + (uint32_t)e;
+    while (pq_count(ps) < 2u && (ps & 8u) == 0u) {
+        const uint32_t cnt = pq_count(ps), head = pq_head(ps);
+        const size_t slot = pq_index(s, episode, (head + cnt) & 1u, e);
+        Stream ts;
+        ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, ctr);
+        const uint32_t g2 = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
+        NavField nf;
+        // the flood may stop once it has reached the start cell; if the target is elsewhere when the plan is needed (plan B),
+        // the adoption test in the step kernel (visited plane) sends it to the inline re-plan
+        const int sr = (int)(start & 0xffu), sc = (int)(start >> 8);
+        bfs_dir_field(tile, side, lane, (int)(g2 & 0xffu), (int)(g2 >> 8), nf, false, sr, sc);
+        store_plan_field(s.p_field + slot * kPlanWords, nf, side, lane);
+        const bool usable = rowbits_get(nf.visA, nf.visB, sr, sc) != 0u && g2 != start;
+        if (lane == 0) { s.p_goal[slot] = g2; s.p_tctr[slot] = ts.ctr; }
+        ps = (cnt + 1u) | (head << 2) | (usable ? 0u : 8u);
+        start = g2; ctr = ts.ctr;
+    }
+    return ps;
+}
+__device__ __forceinline__ void nav_prefetch(const DevState &s, int e, uint32_t *tile, int lane)
+{
+    const uint32_t episode = s.episode[e];
+    const size_t si = pq_state_index(s, episode, e);
+    uint32_t ps = s.p_state[si];
+    if (pq_count(ps) >= 2u || (ps & 8u) != 0u) return;
+    reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(s.maps + (size_t)e * kTileWords)[lane];
+    wave_lds_sync();
+    const int side = (int)(s.cnt[e] >> 24);
+    const FreeIndex fi = build_free_index(tile, side, lane);
+    const size_t hs = pq_index(s, episode, pq_head(ps), e);
+    const uint32_t start = pq_count(ps) == 0u ? s.navgoal[e] : s.p_goal[hs];
+    const uint32_t ctr = pq_count(ps) == 0u ? s.tctr[e] : s.p_tctr[hs];
+    ps = nav_fill_queue(s, e, episode, tile, side, fi, lane, ps, start, ctr);
+    if (lane == 0) s.p_state[si] = ps;
+    wave_lds_sync();
+}
 
 // Track1v1Env.reset -> init_maze (track_1v1.py:134-168,218-240) for one env and one episode number, executed by
 // one wave on an LDS tile. All arguments are wave-uniform. `gdir` receives the Nav direction planes.
@@ -201,6 +273,13 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
         nav_plan(tile, side, lane, (int)(tg & 0xffu), (int)(tg >> 8), fi, navgoal, ts, plan, nf, rpf, nav2);
         if (!rpf) nav2 = 0u;
         if (((plan >> 28) & 1u) == 0u) store_dir_field(gdir, nf, side, lane);
+        if (!rpf) {
+            // ... and the two plans AFTER it, into the new episode's own queue (set episode % 3): a fresh episode's first path
+            // is often shorter than the 20 steps to the next generator pass, and then the step kernel would have to re-plan
+            // inline (measured: every inline re-plan of a random-policy batch came from an episode <= 20 steps old)
+            const uint32_t ps = nav_fill_queue(s, e, episode, tile, side, fi, lane, 0u, navgoal, ts.ctr);
+            if (lane == 0) s.p_state[pq_state_index(s, episode, e)] = ps;
+        }
     }
     tctr = ts.ctr;
     const int dr = (int)(tg & 0xffu) - r, dc = (int)(tg >> 8) - c;
@@ -219,59 +298,6 @@ __device__ __forceinline__ uint32_t window_row_bits(uint32_t w0, uint32_t w1, ui
     const uint32_t lo = j == 0 ? 0xffffffffu : (j == 1 ? w0 : (j == 2 ? w1 : W2));
     const uint32_t hi = j == 0 ? w0 : (j == 1 ? w1 : (j == 2 ? W2 : 0xffffffffu));
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(sp & 31)) & 0x1fffu;
-}
-
-// Nav targets: prepare the next plans on the CURRENT map, off the step kernel's critical path. A plan is needed when the
-// target stands on its goal (navigator.py:15); the Navigator then draws a new goal (navigator.py:17 — the TARGET stream has no
-// other consumer in between, so drawing it NOW keeps the stream order) and plans from where it stands, i.e. from the goal of
-// the plan before. Up to two plans are queued: the second one starts at the first one's goal, from the stream position the
-// first one's draw left — valid as long as the first one turns out usable (reachable start, goal != start), which is known
-// here; otherwise the step kernel will re-plan inline with further draws and nothing can be prepared beyond it (bit 3).
-// The step kernel adopts the queue head if the target's position is reachable in it and differs from its goal, else re-plans
-// inline from the same already-drawn goal and drops the queue. Reads the env's live state: only ever runs in order on the
-// caller's stream, between two step launches (inside the in-order generator launch, or as its own launch when the generator
-// is forked). With a pass every 20 steps an inline re-plan needs two goals reached within those 20 steps.
-__device__ __forceinline__ uint32_t pq_count(uint32_t ps) { return ps & 3u; }
-__device__ __forceinline__ uint32_t pq_head(uint32_t ps) { return (ps >> 2) & 1u; }
-__device__ __forceinline__ uint32_t pq_pop(uint32_t ps)      // the head plan was adopted
-{
-    const uint32_t c = pq_count(ps) - 1u;
-    return c == 0u ? 0u : (c | ((pq_head(ps) ^ 1u) << 2) | (ps & 8u));
-}
-__device__ __forceinline__ void nav_prefetch(const DevState &s, int e, uint32_t *tile, int lane)
-{
-    uint32_t ps = s.p_state[e];
-    if (pq_count(ps) >= 2u || (ps & 8u) != 0u) return;
-    reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(s.maps + (size_t)e * kTileWords)[lane];
-    wave_lds_sync();
-    const int side = (int)(s.cnt[e] >> 24);
-    const FreeIndex fi = build_free_index(tile, side, lane);
-    const uint32_t episode = s.episode[e], genv = s.env_base + (uint32_t)e;
-    // where the target will stand when the next plan is needed, and the stream position its goal is drawn from: the current
-    // goal / counter, or those of the one plan already queued (written by an earlier launch); carried in registers from
-    // there on
-    const size_t hs = (size_t)pq_head(ps) * s.n + e;
-    uint32_t start = pq_count(ps) == 0u ? s.navgoal[e] : s.p_goal[hs];
-    uint32_t ctr = pq_count(ps) == 0u ? s.tctr[e] : s.p_tctr[hs];
-    while (pq_count(ps) < 2u && (ps & 8u) == 0u) {
-        const uint32_t cnt = pq_count(ps), head = pq_head(ps);
-        const size_t slot = (size_t)((head + cnt) & 1u) * s.n + e;
-        Stream ts;
-        ts.init(s.k0, s.k1, episode, genv, STREAM_TARGET, ctr);
-        const uint32_t g2 = select_free(tile, side, fi, (int)ts.bounded((uint32_t)(fi.total - 1)), lane);
-        NavField nf;
-        // the flood may stop once it has reached the start cell; if the target is elsewhere when the plan is needed (plan B),
-        // the adoption test in the step kernel (visited plane) sends it to the inline re-plan
-        const int sr = (int)(start & 0xffu), sc = (int)(start >> 8);
-        bfs_dir_field(tile, side, lane, (int)(g2 & 0xffu), (int)(g2 >> 8), nf, false, sr, sc);
-        store_plan_field(s.p_field + slot * kPlanWords, nf, side, lane);
-        const bool usable = rowbits_get(nf.visA, nf.visB, sr, sc) != 0u && g2 != start;
-        if (lane == 0) { s.p_goal[slot] = g2; s.p_tctr[slot] = ts.ctr; }
-        ps = (cnt + 1u) | (head << 2) | (usable ? 0u : 8u);
-        start = g2; ctr = ts.ctr;
-    }
-    if (lane == 0) s.p_state[e] = ps;
-    wave_lds_sync();
 }
 
 // Generator kernel: fills the "next episode" slot (episode[e] + 1) of every env whose slot was consumed at a step
@@ -363,8 +389,10 @@ __global__ __launch_bounds__(64) void k_nav_inject_goal(DevState s, int e, uint3
     NavField nf;
     const uint32_t cur = s.navgoal[e];
     bfs_dir_field(tile, side, lane, (int)(goal & 0xffu), (int)(goal >> 8), nf, false, (int)(cur & 0xffu), (int)(cur >> 8));
-    store_plan_field(s.p_field + (size_t)e * kPlanWords, nf, side, lane);
-    if (lane == 0) { s.p_goal[e] = goal; s.p_tctr[e] = s.tctr[e]; s.p_state[e] = 1u; }
+    const uint32_t episode = s.episode[e];
+    const size_t q0 = pq_index(s, episode, 0u, e);
+    store_plan_field(s.p_field + q0 * kPlanWords, nf, side, lane);
+    if (lane == 0) { s.p_goal[q0] = goal; s.p_tctr[q0] = s.tctr[e]; s.p_state[pq_state_index(s, episode, e)] = 1u; }
 }
 
 // _get_obs / _get_partial_obs (track_1v1.py:287-326) for ONE env by ONE wave. Lanes 0..51 each expand one half
@@ -473,7 +501,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
     uint32_t nv_plan = 0, nv_tctr = 0, nv_goal = 0, nv_nav2 = 0, nv_episode = 0, nv_pstate = 0;
     if (NAV && OP == OP_STEP) {
         nv_plan = s.plan[e]; nv_tctr = s.tctr[e]; nv_goal = s.navgoal[e]; nv_nav2 = s.nav2[e]; nv_episode = s.episode[e];
-        nv_pstate = s.p_state[e];
+        nv_pstate = s.p_state[pq_state_index(s, nv_episode, e)];
     }
     wave_lds_sync();
 
@@ -524,7 +552,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
                 // a plan for the next goal was prepared by the generator pass (k_gen): adopt it if it is a valid plan
                 // from here (reachable, not already on the goal) — else fall through to the inline re-plan, which
                 // then starts from the same already-drawn goal (and voids whatever was prepared beyond it)
-                const size_t hs = (size_t)pq_head(nv_pstate) * s.n + e;
+                const size_t hs = pq_index(s, nv_episode, pq_head(nv_pstate), e);
                 const uint32_t *pf = s.p_field + hs * kPlanWords;
                 const uint32_t g2 = s.p_goal[hs];
                 ts.init(s.k0, s.k1, nv_episode, genv, STREAM_TARGET, s.p_tctr[hs]);
@@ -541,7 +569,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
                     navgoal_dirty = true;
                     new_ps = pq_pop(nv_pstate);
                 }
-                if (lane == 0) s.p_state[e] = new_ps;
+                if (lane == 0) s.p_state[pq_state_index(s, nv_episode, e)] = new_ps;
             }
             if (exhausted && !adopted) {
                 const FreeIndex fi = build_free_index(tile, side, lane);
@@ -609,7 +637,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
             dst[lane] = src[lane]; dst[lane + 64] = src[lane + 64];
         }
         pos = s.n_pos[so]; plan = s.n_plan[so]; tctr = s.n_tctr[so]; navgoal = s.n_navgoal[so]; d2 = s.n_d2[so];
-        if (NAV && lane == 0) { s.nav2[e] = s.n_nav2[so]; s.p_state[e] = 0u; }   // new map: the prefetched plan is void
+        if (NAV && lane == 0) { s.nav2[e] = s.n_nav2[so]; s.p_state[pq_state_index(s, episode, e)] = 0u; }   // the finished episode's queue is void
         cnt = (uint32_t)side_of_cfg(cfg) << 24;
         episode += 1u;
         if (lane == 0) {
@@ -745,7 +773,12 @@ struct Step2 {
         navgoal = 0; pstate = 0;
         episode = s.episode[e];       // (also names the next-episode slot: parity of episode + 1)
         if (MULTI || ram || nav) { plan = s.plan[e]; tctr = s.tctr[e]; }
-        if (nav) { navgoal = s.navgoal[e]; pstate = s.p_state[e]; }
+        if (nav) {      // (the queue state of all three sets: the right one is picked by episode % 3 without a dependent load)
+            navgoal = s.navgoal[e];
+            const uint32_t ps0 = s.p_state[e], ps1 = s.p_state[(size_t)s.n + e], ps2 = s.p_state[(size_t)2 * s.n + e];
+            const uint32_t m3 = episode % 3u;
+            pstate = m3 == 0u ? ps0 : (m3 == 1u ? ps1 : ps2);
+        }
         genv = s.env_base + (uint32_t)e;
         lut = s.rew_lut + (mode == TGT_PZR ? kLutN : (mode == TGT_FAR ? 2 * kLutN : 0));
         gmap = s.maps + (size_t)e * kTileWords;
@@ -784,7 +817,7 @@ struct Step2 {
                 // the plan the generator pass prepared for the NEXT goal (the head of the env's plan queue), fetched now
                 // (speculatively: it is adopted below if it reaches the target's cell) so that adopting it adds no dependent
                 // round trip to the step
-                const size_t hs = (size_t)pq_head(pstate) * s.n + e;
+                const size_t hs = pq_index(s, episode, pq_head(pstate), e);
                 const uint32_t *pf = s.p_field + hs * kPlanWords;
                 sp_pgoal = s.p_goal[hs]; sp_ptctr = s.p_tctr[hs];
                 sp_vis = pf[512 + w]; sp_pdA = pf[w]; sp_pdB = pf[256 + w];
@@ -852,14 +885,19 @@ struct Step2 {
                     navgoal_dirty = true;
                     new_ps = pq_pop(pstate);
                 }
-                if (leader) s.p_state[e] = new_ps;
+                if (leader) s.p_state[pq_state_index(s, episode, e)] = new_ps;
             }
             // rare: plan exhausted and nothing adoptable — Navigator's re-plan (navigator.py:15-38) by the whole wave, one slot
             // at a time, on the env's tile in LDS (wave-uniform copies of the slot's scalars in, results back to its lanes)
             const unsigned long long rm = __ballot(live && nav && nv_exh && !adopted);
             if (__builtin_expect(rm != 0ull, 0)) {
 #ifdef T2D_COUNT_REPLANS
-                if (lane == 0) atomicAdd(s.faults, (uint32_t)__popcll(rm & 0x100000001ull) << 8);   // probe build: inline re-plans
+                {   // probe build: inline re-plans, split by the episode's age (bits 8-19: <= 20 steps old, 20-31: older)
+                    const int age = (int)((cnt >> 8) & 0xffffu);
+                    const unsigned long long young = __ballot(live && nav && nv_exh && !adopted && age <= 20);
+                    if (lane == 0) atomicAdd(s.faults, ((uint32_t)__popcll(young & 0x100000001ull) << 8) +
+                                                           ((uint32_t)__popcll(rm & ~young & 0x100000001ull) << 20));
+                }
 #endif
 #pragma unroll 1
                 for (int slot = 0; slot < 2; slot++) {
@@ -968,7 +1006,7 @@ struct Step2 {
                     uint4 *dst = reinterpret_cast<uint4 *>(s.dirf + (size_t)e * kDirWords) + (lane & 31);
                     dst[0] = sp_nd0; dst[32] = sp_nd1; dst[64] = sp_nd2; dst[96] = sp_nd3;
                     navgoal = sp_navgoal; navgoal_dirty = false;
-                    if (leader) s.p_state[e] = 0u;
+                    if (leader) s.p_state[pq_state_index(s, episode - 1u, e)] = 0u;    // the finished episode's queue is void
                 }
                 const size_t so = (size_t)(episode & 1u) * s.n + e;     // the slot just consumed (parity of the new episode)
                 if (leader) {
@@ -1411,8 +1449,8 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     for (auto a : narrs) alloc(a, 2 * nb);          // [2][N]: the two next-episode slots
     if (has_nav) {
         alloc(&s.dirf, db); alloc(&s.n_dirf, 2 * db);
-        alloc(&s.p_field, (size_t)2 * n * kPlanWords * sizeof(uint32_t));      // two queued plans per env
-        alloc(&s.p_goal, 2 * nb); alloc(&s.p_tctr, 2 * nb); alloc(&s.p_state, nb);
+        alloc(&s.p_field, (size_t)6 * n * kPlanWords * sizeof(uint32_t));      // three episode sets x two queued plans per env
+        alloc(&s.p_goal, 6 * nb); alloc(&s.p_tctr, 6 * nb); alloc(&s.p_state, 3 * nb);
     }
     alloc(&s.faults, sizeof(uint32_t));
     float2 *lut = nullptr;
@@ -1894,7 +1932,9 @@ extern "C" int t2d_inject(t2d_handle *h, int first, int count, int side, const u
     HIP_TRY(hipMemcpyAsync(s.navgoal + first, navgoal.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s.plan + first, zero.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s.nav2 + first, zero.data(), nb, hipMemcpyHostToDevice, st));   // RPF: re-plan to patrol cell 1
-    if (s.p_state) HIP_TRY(hipMemcpyAsync(s.p_state + first, zero.data(), nb, hipMemcpyHostToDevice, st));
+    if (s.p_state)
+        for (int k3 = 0; k3 < 3; k3++)
+            HIP_TRY(hipMemcpyAsync(s.p_state + (size_t)k3 * s.n + first, zero.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (first == 0 && count == s.n) h->reset_done = true;
     return T2D_OK;

@@ -10,4 +10,4 @@ for it in range(10):
     tot+=20
     torch.cuda.synchronize()
     f=env.faults()
-    print("steps",tot,"inline replans so far",f>>8, "per step", (f>>8)/tot, flush=True)
+    print("steps", tot, "inline re-plans per step: episodes <= 20 steps old %.2f, older %.2f" % (((f >> 8) & 0xfff) / tot, (f >> 20) / tot), flush=True)
