@@ -139,6 +139,83 @@ __global__ __launch_bounds__(256) void k_rmsprop_update(float *__restrict__ p, c
     }
 }
 
+
+// fc_action_tracker(one_hot(a_tracker)) added to the target's features (TAT.forward, model.py:193-194 of the reference) over
+// all stored steps of a rollout: out[r][c] = f[r][c] + W[c][a[r]] + b[c] with W = fc_action_tracker.weight [C, A]. As tensor
+// ops that is one_hot (scatter) + a [rows, A] x [A, C] GEMM + an add forward, and a GEMM + a column-sum reduction backward —
+// 7 launches of up to 37 us on [81 920, 256] for what is a row gather: here one launch forward, two backward.
+__global__ __launch_bounds__(256) void k_embed_add(const float *__restrict__ f, const float *__restrict__ w,
+                                                   const float *__restrict__ b, const long long *__restrict__ act,
+                                                   long long act_stride, float *__restrict__ out, long long rows, int C, int A)
+{
+    const int c4 = C / 4;
+    const long long total = rows * c4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c4;
+        const int c = (int)(i - r * c4) * 4;
+        const int a = (int)act[r * act_stride];
+        float4 v = *reinterpret_cast<const float4 *>(f + r * C + c);
+        const float4 bb = *reinterpret_cast<const float4 *>(b + c);
+        v.x += w[(c + 0) * A + a] + bb.x; v.y += w[(c + 1) * A + a] + bb.y;
+        v.z += w[(c + 2) * A + a] + bb.z; v.w += w[(c + 3) * A + a] + bb.w;
+        *reinterpret_cast<float4 *>(out + r * C + c) = v;
+    }
+}
+
+// backward, pass 1: per workgroup the sums of dout's rows by action (thread = column, fixed row order, eight rows' loads in
+// flight), written as partial[a][c][wg] so that pass 2 reads them coalesced
+constexpr int kEmbMaxA = 8;
+__global__ __launch_bounds__(256) void k_embed_grad_partial(const float *__restrict__ dout, const long long *__restrict__ act,
+                                                            long long act_stride, float *__restrict__ partial, long long rows,
+                                                            int C, int A, int rows_per_wg, int nwg)
+{
+    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    const long long r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+    for (int c = (int)threadIdx.x; c < C; c += (int)blockDim.x) {
+        float acc[kEmbMaxA];
+#pragma unroll
+        for (int a = 0; a < kEmbMaxA; a++) acc[a] = 0.f;
+        long long r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            int av[8];
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { av[u] = (int)act[(r + u) * act_stride]; vv[u] = dout[(r + u) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int q = 0; q < kEmbMaxA; q++) acc[q] += q == av[u] ? vv[u] : 0.f;
+        }
+        for (; r < r1; r++) {
+            const int a = (int)act[r * act_stride];
+            const float v = dout[r * C + c];
+#pragma unroll
+            for (int q = 0; q < kEmbMaxA; q++) acc[q] += q == a ? v : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < kEmbMaxA; a++)
+            if (a < A) partial[((size_t)a * C + c) * nwg + blockIdx.x] = acc[a];
+    }
+}
+// pass 2: one wave per column: dW[c][a] = sum over the workgroups' partials (lanes stride the records, butterfly sum: a
+// fixed order), db[c] = sum_a dW[c][a]
+__global__ __launch_bounds__(256) void k_embed_grad_reduce(const float *__restrict__ partial, float *__restrict__ dw,
+                                                           float *__restrict__ db, int nwg, int C, int A)
+{
+    const int c = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63u);
+    if (c >= C) return;
+    float tot = 0.f;
+    for (int a = 0; a < A; a++) {
+        const float *p = partial + ((size_t)a * C + c) * nwg;
+        float acc = 0.f;
+        for (int g = lane; g < nwg; g += 64) acc += p[g];
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if (lane == 0) dw[c * A + a] = acc;
+        tot += acc;
+    }
+    if (lane == 0) db[c] = tot;
+}
+
 } // namespace atr
 
 using namespace atr;
@@ -167,6 +244,38 @@ extern "C" int atr_rollout_end(const float *hT, const float *cT, long long pstri
     long long work = (long long)N * A * (R / 4);
     if (work < (long long)T * N) work = (long long)T * N;
     hipLaunchKernelGGL(k_rollout_end, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" int atr_embed_add(const float *f, const float *w, const float *b, const long long *actions, long long act_stride,
+                             float *out, long long rows, int C, int A, void *stream)
+{
+    if (!f || !w || !b || !actions || !out || rows <= 0 || C <= 0 || (C & 3) || A < 1 || A > kEmbMaxA) return 1;
+    if (((uintptr_t)f | (uintptr_t)out | (uintptr_t)b) & 15u) return 1;
+    long long blocks = (rows * (C / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_embed_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f, w, b, actions, act_stride, out,
+                       rows, C, A);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" long long atr_embed_grad_workspace_floats(long long rows, int C, int A)
+{
+    if (rows <= 0 || C <= 0 || A < 1 || A > kEmbMaxA) return -1;
+    const long long nwg = rows < 1024 * 64 ? (rows + 63) / 64 : 1024;
+    return nwg * A * C;
+}
+
+extern "C" int atr_embed_grad(const float *dout, const long long *actions, long long act_stride, float *dw, float *db,
+                              float *workspace, long long rows, int C, int A, void *stream)
+{
+    if (!dout || !actions || !dw || !db || !workspace || rows <= 0 || C <= 0 || A < 1 || A > kEmbMaxA) return 1;
+    const long long nwg = rows < 1024 * 64 ? (rows + 63) / 64 : 1024;
+    const int rpw = (int)((rows + nwg - 1) / nwg);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_embed_grad_partial, dim3((unsigned)nwg), dim3(256), 0, st, dout, actions, act_stride, workspace, rows, C,
+                       A, rpw, (int)nwg);
+    hipLaunchKernelGGL(k_embed_grad_reduce, dim3((unsigned)((C * 64 + 255) / 256)), dim3(256), 0, st, workspace, dw, db, (int)nwg, C, A);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -66,6 +66,12 @@ def lib():
         L.atr_lstm_cell_forward_act2.restype = i32
         L.atr_lstm_cell_forward_act2.argtypes = [vp] * 5 + [ll, vp, vp, ll, vp, ll, vp, ll] + [vp] * 4 + [i32, vp, vp,
                                                  C.c_ulonglong, C.c_uint, i32, i32, vp]
+        L.atr_embed_add.restype = i32
+        L.atr_embed_add.argtypes = [vp, vp, vp, vp, ll, vp, ll, i32, i32, vp]
+        L.atr_embed_grad_workspace_floats.restype = ll
+        L.atr_embed_grad_workspace_floats.argtypes = [ll, i32, i32]
+        L.atr_embed_grad.restype = i32
+        L.atr_embed_grad.argtypes = [vp, vp, ll, vp, vp, vp, ll, i32, i32, vp]
         L.atr_lstm_bptt.restype = i32
         L.atr_lstm_bptt.argtypes = [vp, vp, vp, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, i32, i32, i32, i32, vp]
         L.atr_pair_linear.restype = i32
@@ -698,6 +704,46 @@ def heads_loss(h, actor, critic, aux, actions, ret, gae, val, off, r_aux, aux_of
     return _HeadsLoss.apply(h, actor.weight, actor.bias, critic.weight, critic.bias,
                             aux.weight if aux is not None else None, aux.bias if aux is not None else None,
                             actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent, unit_coeff)
+
+
+class _EmbedAdd(torch.autograd.Function):
+    """f + fc_action_tracker(one_hot(actions)) as a row gather (csrc/driver_hip.hip): forward one launch, backward the
+    per-action column sums of the incoming gradient (two launches); the gradient w.r.t. f is the incoming one."""
+
+    @staticmethod
+    def forward(ctx, f, w, b, actions):
+        f = f.contiguous()
+        rows, Cc = f.shape
+        A = w.shape[1]
+        wc, bc = w.contiguous(), b.contiguous()
+        out = torch.empty_like(f)
+        rc = lib().atr_embed_add(_p(f), _p(wc), _p(bc), _p(actions), actions.stride(0), _p(out), rows, Cc, A, _stream(f))
+        if rc != 0:
+            raise RuntimeError("atr_embed_add failed (%d)" % rc)
+        ctx.save_for_backward(actions)
+        ctx.dims = (Cc, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (actions,) = ctx.saved_tensors
+        Cc, A = ctx.dims
+        dout = dout.contiguous()
+        rows = dout.shape[0]
+        L = lib()
+        ws = torch.empty(L.atr_embed_grad_workspace_floats(rows, Cc, A), dtype=torch.float32, device=dout.device)
+        dw = torch.empty((Cc, A), dtype=torch.float32, device=dout.device)
+        db = torch.empty(Cc, dtype=torch.float32, device=dout.device)
+        rc = L.atr_embed_grad(_p(dout), _p(actions), actions.stride(0), _p(dw), _p(db), _p(ws), rows, Cc, A, _stream(dout))
+        if rc != 0:
+            raise RuntimeError("atr_embed_grad failed (%d)" % rc)
+        return dout, dw, db, None
+
+
+def embed_add(f, linear, actions):
+    """f [rows, C] + linear(one_hot(actions [rows] int64 (any stride), A)) for linear = nn.Linear(A, C)."""
+    assert actions.dim() == 1 and actions.dtype == torch.int64 and f.dim() == 2
+    return _EmbedAdd.apply(f, linear.weight, linear.bias, actions)
 
 
 use_gemm_tn = True

@@ -770,9 +770,12 @@ class A3C_Dueling(nn.Module):
             enc = p.encoder
             y = fused.stem_cached(x_in[i], cache.y[i].view(-1, 512), enc.conv1, enc.conv2)
             f = fused.linear_relu_cached(y.view(T * N, -1), enc.fc, cache.f[i].view(T * N, -1))
-            if i == 1 and self.tat:
-                a2t = F.one_hot(actions_seq[:, :, 0].reshape(T * N), self.action_dim_tracker).to(f.dtype)
-                f = f + p.fc_action_tracker(a2t)
+            if i == 1 and self.tat:      # + fc_action_tracker(one_hot(a_tracker)) (model.py:193-194): a row gather
+                a_tr = actions_seq[:, :, 0].reshape(T * N)
+                if p.fc_action_tracker.weight.shape[1] <= 8 and f.shape[1] % 4 == 0:
+                    f = fused.embed_add(f, p.fc_action_tracker, a_tr)
+                else:
+                    f = f + p.fc_action_tracker(F.one_hot(a_tr, self.action_dim_tracker).to(f.dtype))
             feats.append(f)
         return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, cache.acts, need)
 

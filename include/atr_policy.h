@@ -177,6 +177,16 @@ int atr_lstm_cell_backward(const float *dh_out, long long dh_pstride, const floa
 int atr_lstm_bptt(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *acts, long long acts_pstride,
                   const float *c_all, long long c_pstride, const float *whh0, const float *whh1, float *dg,
                   long long dg_pstride, float *dh_init, float *dc_init, int P, int T, int N, int R, void *stream);
+/* fc_action_tracker(one_hot(a_tracker)) added to the target's features over all stored steps (TAT.forward, model.py:193-194 of
+ * the reference): out[r][c] = f[r][c] + w[c][actions[r * act_stride]] + b[c], w = fc_action_tracker.weight [C, A] (A <= 8, C
+ * multiple of 4), actions int64. atr_embed_grad: the parameter gradients given dout = dL/dout (the gradient w.r.t. f is dout
+ * itself): dw[c][a] = sum of dout[r][c] over the rows with action a, db[c] = sum over all rows; workspace:
+ * atr_embed_grad_workspace_floats(rows, C, A) floats; fixed summation order (reproducible). */
+int atr_embed_add(const float *f, const float *w, const float *b, const long long *actions, long long act_stride, float *out,
+                  long long rows, int C, int A, void *stream);
+long long atr_embed_grad_workspace_floats(long long rows, int C, int A);
+int atr_embed_grad(const float *dout, const long long *actions, long long act_stride, float *dw, float *db, float *workspace,
+                   long long rows, int C, int A, void *stream);
 /* n-step returns and GAE terms of the A3C loss (player_util.py:118-141 of the reference) for all (env, agent) pairs:
  * rewards [T,N,A], values [T+1,N,A] (row T = bootstrap value), notdone [T,N] -> returns, gae [T,N,A]. */
 int atr_gae_returns(const float *rewards, const float *values, const float *notdone, float gamma, float tau,

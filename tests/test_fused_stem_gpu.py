@@ -421,3 +421,24 @@ def test_fused_bptt_matches_the_per_step_path(N, P, T):
     for a_, b_, name in zip(res[0], res[1], ("dG", "dh0", "dc0", "dWhh")):
         scale = float(b_.abs().max())
         torch.testing.assert_close(a_, b_, rtol=2e-4, atol=2e-5 * max(scale, 1.0), msg=lambda m: name + ": " + m)
+
+
+def test_embed_add_matches_one_hot_linear():
+    """fused.embed_add (f + fc_action_tracker(one_hot(a)) as a row gather, csrc/driver_hip.hip) against the tensor expression
+    it replaces (TAT.forward, model.py:193-194 of the reference): output, and gradients w.r.t. f, weight and bias."""
+    from active_tracking_rl_amd import fused
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    for rows in (10240, 777):
+        lin = torch.nn.Linear(4, 256).to(dev)
+        f = torch.randn(rows, 256, device=dev, requires_grad=True)
+        a = torch.randint(0, 4, (rows,), device=dev)
+        g = torch.randn(rows, 256, device=dev)
+        out = fused.embed_add(f, lin, a)
+        ref = f + lin(torch.nn.functional.one_hot(a, 4).float())
+        torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+        got = torch.autograd.grad(out, [f, lin.weight, lin.bias], g)
+        want = torch.autograd.grad(ref, [f, lin.weight, lin.bias], g)
+        torch.testing.assert_close(got[0], want[0], rtol=0, atol=0)
+        torch.testing.assert_close(got[1], want[1], rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(got[2], want[2], rtol=1e-4, atol=1e-3)
