@@ -17,7 +17,7 @@ from active_tracking_rl_amd.train import default_args, make_player, rollout  # n
 
 dev = torch.device("cuda:0")
 for net, aux in (("tat-maze-lstm", "reward"), ("maze-lstm", "none")):
-    for n in (4096, 1024):
+    for n in (4096, 2048, 1024, 512):       # the headline batch and the strong-scaling shard sizes
         args = default_args(network=net, aux=aux, num_envs=n)
         player, opt = make_player(args, dev)
         for _ in range(2):
