@@ -445,13 +445,16 @@ def main():
     except Exception as ex:
         stem_roof = {"error": repr(ex)}
 
-    traffic, traffic_src, traffic_u8, traffic_u8_src = None, None, None, None
+    traffic, traffic_src, traffic_u8, traffic_u8_src, traffic_act, traffic_act_src = None, None, None, None, None, None
     for fname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:   # HBM traffic of the same kernels from the committed rocprofv3 --pmc passes (cannot be taken inside this run)
             pm = json.load(open(os.path.join(ROOT, "profiles", fname)))
             if pm.get("n_envs") == n and traffic is None:
                 traffic = pm["traffic_bytes_per_launch"]
                 traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % fname
+            if pm.get("n_envs") == n and traffic_act is None and pm.get("act_step") is not None:
+                traffic_act = pm["act_step"]["traffic_bytes_per_launch"]
+                traffic_act_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, k_act_step with ig + hg)" % fname
             if pm.get("n_envs") == n and traffic_u8 is None and pm.get("traffic_bytes_per_launch_u8") is not None:
                 traffic_u8 = pm["traffic_bytes_per_launch_u8"]
                 traffic_u8_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, k_step2<OBS_U8>)" % fname
@@ -489,7 +492,9 @@ def main():
                   "observation in one launch)",
         "in_timed_region": fused_in_region,
         "achieved": ka_bytes * n / (ka_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": ka_bytes * n / (ka_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": ka_bytes * n,
+        "frac": ka_bytes * n / (ka_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        "traffic": traffic_act if not pairg else None, "traffic_source": traffic_act_src if not pairg else None,
+        "bytes_per_launch": ka_bytes * n,
         "bytes_per_env_step": ka_bytes, "avg_launch_us": ka_us,
         "bytes_note": "env 709 B (u8 observations) + per player: gate pre-activations read, c_prev read, h / c written, "
                       "activated gates written for the learner + actions + previous done"}

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round 3 evidence, regenerated under gpurun_out/r03/ on the GPU box (copy what is to be judged to profiles/):
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles_r03.sh'
+# PMC passes are separate runs with no trace domains besides the counter collection (pool rule).
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
+export PYTHONPATH=$R; cd /tmp; export TMPDIR=/tmp
+# --- the bench line, and the same command under the profiler
+timeout 1200 python $R/bench.py > $O/bench.json 2> $O/bench.err
+rm -rf /tmp/p_bench; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -- python $R/bench.py --no-cpu-baseline --no-shards > $O/bench_under_rocprof.json 2> /dev/null
+python $R/tools/summarize_prof.py stats /tmp/p_bench > $O/bench_kernel_stats.txt
+# --- one replayed iteration per kernel: the headline batch and every shard size, and the other BASELINE configurations
+for n in 4096 2048 1024 512; do bash $R/tools/prof_shard.sh $n final; done
+cp $O/iter_stats_final_4096.txt $O/iteration_kernel_stats.txt
+bash $R/tools/prof_cfg.sh final_config1 Track2D-BlockPartialRam-v0 1024 maze-lstm none 0
+bash $R/tools/prof_cfg.sh final_config3 Track2D-MazePartialNav-v0 1024 maze-lstm none 0
+timeout 600 python $R/tools/config_sweep.py > $O/config_sweep.txt 2>&1
+timeout 600 python $R/tools/shard_sweep.py > $O/shard_sweep.txt 2>&1
+# --- the round's kernels alone
+timeout 300 python $R/tools/act_step_bench.py > $O/act_step_bench.txt 2>&1
+timeout 300 python $R/tools/pair_gemm_bench.py > $O/pair_gemm_bench.txt 2>&1
+timeout 300 python $R/tools/bptt_bench.py > $O/bptt_bench.txt 2>&1
+# --- env-only: step kernel alone at every size (rocprofv3 stats), sweep, the other env ids, Nav split
+for n in 4096 65536 262144 1048576; do
+  rm -rf /tmp/p_env; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_env -- python $R/tools/env_only_bench.py --n $n --steps 600 --warmup 100 > $O/env_only_$n.txt 2> /dev/null
+  python $R/tools/summarize_prof.py stats /tmp/p_env > $O/env_only_kernel_stats_$n.txt
+done
+for e in Track2D-BlockPartialRam-v0 Track2D-MazePartialNav-v0 Track2D-BlockPartialAdv-v0; do timeout 300 python $R/tools/env_only_bench.py --n 8192 --env $e --steps 300 --warmup 30; done > $O/env_only_other_configs.txt 2>&1
+bash $R/tools/prof_nav.sh > $O/nav_profile.txt 2>&1
+# --- HBM traffic (PMC): FETCH_SIZE and WRITE_SIZE in separate passes, env-only step kernel at three sizes ...
+bash $R/tools/pmc_traffic.sh r03 4096 262144 1048576 > /dev/null 2>&1
+# ... and the fused end-of-step kernel of the timed region (k_act_step) + the byte-observation step kernel, from act_step_bench
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p_pmc; ACT_BENCH_MODE=sep timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_pmc -- python $R/tools/act_step_bench.py 4096 > /dev/null 2>&1
+  python $R/tools/summarize_prof.py pmc /tmp/p_pmc k_act_step > $O/act_step_pmc_${c}_4096.txt
+done
+ls -la $O
