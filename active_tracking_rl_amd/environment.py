@@ -10,8 +10,8 @@ Two adapters sit on the same C ABI (vec_env.VecTrack2D -> libtrack2d_hip.so):
                loops (gym_eval.py:97-121, random_agent_multi.py:17-53) run unchanged on top of the HIP path.
 
 frame_stack (environment.py:128-156) is folded in: obs are float32, `stack_frames` most recent frames per
-agent, the deque filled with the first frame on reset. Rescale / listspace / UnrealPreprocess belong to the
-image envs and are not built.
+agent, the deque filled with the first frame on reset. Rescale (--rescale, --inv) is folded in too; listspace
+(--single) and UnrealPreprocess belong to the single-agent / image envs.
 """
 import os
 
@@ -50,11 +50,15 @@ class VecEnv(object):
     step([a_tracker [N], a_target [N]]) -> (obs, rewards [N, A] f32, done [N] uint8, info)."""
 
     def __init__(self, env_id, num_envs, device="cuda:0", seed=1, stack_frames=1, env_id_base=0, auto_reset=True,
-                 rescale=False, obs_u8=False, async_gen=None, **overrides):
+                 rescale=False, obs_u8=False, async_gen=None, inv=False, **overrides):
         self.env_id = env_id
         self.num_envs = num_envs
         self.stack_frames = int(stack_frames)
-        self.rescale = bool(rescale)    # environment.Rescale (environment.py:35-79) without --inv: [0,255] -> [-1,1]
+        self.rescale = bool(rescale)    # environment.Rescale (environment.py:35-79): [0,255] -> [-1,1]
+        # --inv (environment.py:49,62-76): per EPISODE a coin flip (choose_rand_seed); an inverted episode's reset observation
+        # is -ob, its step observations are mx_d - ob = 255 - ob (of the RESCALED image — the reference's own arithmetic, kept)
+        self.inv = bool(inv) and self.rescale
+        self._inv_flags = None
         # t2d_generator_async (map generation forked onto the library's stream, under the following steps) is opt-in:
         # inside a captured hipGraph every fork/join of a side branch costs ~200 us on this ROCm (measured,
         # profiles/r02_async_generator_ab.txt), more than the generator launch it hides
@@ -86,6 +90,17 @@ class VecEnv(object):
         # obs [N, A, 13, 13] -> [N, A, stack, 1, 13, 13]
         if self.rescale:   # Rescale.rescale, same float32 operation order: ((clip(x) - 0) * 2) / 255 + (-1)
             obs = obs.clamp(0.0, 255.0).mul(2.0).div(255.0).add(-1.0)
+            if self.inv:
+                n = obs.shape[0]
+                if fill or self._inv_flags is None:      # reset(): every env draws its flag and returns -ob
+                    self._inv_flags = torch.rand(n, device=obs.device) < 0.5
+                    fresh = torch.ones(n, dtype=torch.bool, device=obs.device)
+                else:                                    # step(): auto-reset envs start a new episode (new flag, -ob)
+                    fresh = done.bool() if done is not None else torch.zeros(n, dtype=torch.bool, device=obs.device)
+                    self._inv_flags = torch.where(fresh, torch.rand(n, device=obs.device) < 0.5, self._inv_flags)
+                shp = (n,) + (1,) * (obs.dim() - 1)
+                f, r = self._inv_flags.view(shp), fresh.view(shp)
+                obs = torch.where(f & r, -obs, torch.where(f & ~r, 255.0 - obs, obs))
         cur = obs.unsqueeze(2).unsqueeze(3)
         if self.stack_frames == 1:
             return cur
@@ -173,7 +188,7 @@ class Track2DEnv(object):
     argument-less np.random.seed() calls inside generators.py:41,56 are NOT replayed (they make the reference itself
     irreproducible; the golden vectors were captured with them neutralised)."""
 
-    def __init__(self, env_id, device="cuda:0", seed=1, stack_frames=1, rescale=False, rng="philox"):
+    def __init__(self, env_id, device="cuda:0", seed=1, stack_frames=1, rescale=False, rng="philox", inv=False):
         if rng not in ("philox", "numpy"):
             raise ValueError("rng must be 'philox' or 'numpy'")
         self.rng = rng
@@ -186,7 +201,7 @@ class Track2DEnv(object):
             if self._np.scripted:      # the host drives the target; rewards use w_p = 0 either way (track_1v1.py:147-152)
                 over = dict(target_mode_per_env=np.array([registry.TARGET_CODE["Ext"]], np.uint8))
         self.vec = VecEnv(env_id, 1, device=device, seed=seed, stack_frames=stack_frames, auto_reset=False,
-                          rescale=rescale, **over)
+                          rescale=rescale, inv=inv, **over)
         self.observation_space, self.action_space = self.vec.observation_space, self.vec.action_space
 
     def seed(self, seed=None):
@@ -234,10 +249,13 @@ def create_env(env_id, args, num_envs=None, device=None, env_id_base=0, obs_u8=N
         raise NotImplementedError("only the Track2D-* ids are in scope (Unreal envs need UE4 binaries)")
     registry.spec(env_id)
     if getattr(args, "single", False):
-        raise NotImplementedError("--single (listspace) wraps single-agent image envs; Track2D envs have two agents")
+        # listspace (environment.py:159-175) exists for single-agent image envs. On a Track2D id the reference itself fails
+        # with --single: listspace.reset wraps the two-agent observation [2,1,13,13] in a one-element list, frame_stack then
+        # sees ONE agent whose frame is [2,1,13,13], and CNN_maze's conv receives a 5-D tensor.
+        raise NotImplementedError("--single (listspace) wraps single-agent image envs; Track2D envs have two agents "
+                                  "(the reference fails on this combination too)")
     rescale = bool(getattr(args, "rescale", False))
-    if rescale and getattr(args, "inv", False):
-        raise NotImplementedError("--inv (random image inversion, environment.py:62-76) is an image-env augmentation")
+    inv = bool(getattr(args, "inv", False)) and rescale
     n = num_envs if num_envs is not None else getattr(args, "num_envs", 1)
     if device is None:
         gpu_ids = getattr(args, "gpu_ids", [0])
@@ -249,6 +267,6 @@ def create_env(env_id, args, num_envs=None, device=None, env_id_base=0, obs_u8=N
         obs_u8 = bool(getattr(args, "obs_u8", False))
     if n > 1:
         return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base, rescale=rescale,
-                      obs_u8=obs_u8)
+                      obs_u8=obs_u8, inv=inv)
     rng = rng if rng is not None else getattr(args, "rng", "philox")
-    return Track2DEnv(env_id, device=device, seed=seed, stack_frames=stack, rescale=rescale, rng=rng)
+    return Track2DEnv(env_id, device=device, seed=seed, stack_frames=stack, rescale=rescale, rng=rng, inv=inv)

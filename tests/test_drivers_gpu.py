@@ -318,6 +318,38 @@ def test_rescale_wrapper_matches_the_reference_formula():
     a.close(); b.close()
 
 
+def test_inv_flag_follows_the_reference_rescale_wrapper():
+    """--rescale --inv (environment.Rescale, environment.py:49,58-76): a coin flip per EPISODE; an inverted episode's reset
+    observation is -rescale(ob), its step observations 255 - rescale(ob) (the reference's own arithmetic, on the already
+    rescaled image); envs that auto-reset inside a step draw a fresh flag and report -rescale(first observation)."""
+    import argparse
+    from active_tracking_rl_amd.environment import create_env
+    n = 256
+    args = argparse.Namespace(stack_frames=1, seed=3, gpu_ids=[0], rescale=True, single=False, inv=True, num_envs=n)
+    plain = argparse.Namespace(**dict(vars(args), inv=False))
+    torch.manual_seed(0)
+    a, b = create_env("Track2D-BlockPartialPZR-v0", args), create_env("Track2D-BlockPartialPZR-v0", plain)
+    oa, ob = a.reset(), b.reset()
+    flags = a._inv_flags.clone()
+    assert 0.25 * n < int(flags.sum()) < 0.75 * n
+    f = flags.view(n, 1, 1, 1, 1, 1)
+    assert torch.equal(oa, torch.where(f, -ob, ob))
+    seen_reset = 0
+    for t in range(40):
+        act = [torch.randint(0, 4, (n,), device="cuda"), torch.randint(0, 4, (n,), device="cuda")]
+        (oa, _, da, _), (ob, _, db, _) = a.step(act), b.step(act)
+        assert torch.equal(da, db)
+        fresh = da.bool()
+        new = a._inv_flags
+        assert torch.equal(new[~fresh], flags[~fresh])                      # flags only change at episode boundaries
+        f, r = new.view(n, 1, 1, 1, 1, 1), fresh.view(n, 1, 1, 1, 1, 1)
+        assert torch.equal(oa, torch.where(f & r, -ob, torch.where(f & ~r, 255.0 - ob, ob)))
+        flags = new.clone()
+        seen_reset += int(fresh.sum())
+    assert seen_reset > 20
+    a.close(); b.close()
+
+
 def test_byte_observations_train_exactly_like_float_observations():
     """obs_u8 (t2d_step_u8 -> atr_stem_*_u8: the observation crosses HBM as bytes and is decoded in conv1) against
     the float32 path from the same seeds: same trajectories, same loss, same gradients, bit for bit, through the
