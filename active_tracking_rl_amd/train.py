@@ -194,6 +194,201 @@ class GraphedIteration(object):
         return self.stats
 
 
+class _BucketOnly(object):
+    """What Agent.compute_grads needs of an optimizer: the flat bucket the gradients land in."""
+
+    def __init__(self, bucket):
+        self.bucket = bucket
+
+
+class PipelinedIteration(object):
+    """A3C iterations with the rollout of iteration i + 1 running WHILE the learner of iteration i runs: two HIP streams, each
+    replaying hipGraphs, events between them — no host synchronisation, no fork / join inside a graph.
+
+    The reference's workers are asynchronous by construction (Hogwild: a worker pulls the shared weights, spends a rollout +
+    backward on them while 15 others update the shared model, then pushes its gradient: main.py:86-116, train.py:71-95,
+    utils.py:36-44). The synchronous schedule of GraphedIteration (every gradient applied to exactly the weights it was
+    computed on) is one member of that family; this is another — ONE update of delay, fixed:
+
+        weights of rollout i = theta_{i-1};   g_i = gradient at theta_{i-1};   theta_{i+1} = update(theta_i, g_i)
+
+    Why: at the strong-scaling shard sizes an iteration is two chains of small dependent launches (rollout: 4 per env step;
+    learner: ~100), each launch ~4.5 us before it does anything; the two chains of DIFFERENT iterations have no dependence on
+    each other except through the weights, so they overlap (measured: two graph replays on two streams take 0.70 x their
+    serial time at 512 envs, 0.81 x at 1024, 0.91 x at 4096 — tools/overlap_probe.py), and with N > 1 the gradient all-reduce
+    runs under the next rollout as well.
+
+    Mechanics. Two replicas of the policy (M0, M1: own flat weight buffers F0, F1, own rollout / activation stores) over
+    ONE env shard; the optimizer owns the master weights theta. Iteration i uses replica k = i & 1:
+        stream R:  [wait O(i-2)]  R_k: rollout with F_k -> stores of k; carry (obs, LSTM state, done) handed to the next rollout
+        stream L:  [wait R(i)]    L_k: loss + backward through k's stores with F_k -> gradient bucket
+                                  all-reduce (eager, RCCL) ; O_k: optimizer step on theta, then theta -> F_k
+    F_k is next read by rollout i + 2, which waits for O(i); rollout i + 1 reads F_{1-k}, written by O(i-1): every kernel sees
+    exactly the weights of the schedule above, whatever the timing (serial=True replays the same graphs in program order on
+    one stream: bit-identical weights, tests/test_drivers_gpu.py)."""
+
+    def __init__(self, player, optimizer, args, warmup=2, mode=None, serial=False):
+        from .player_util import Agent
+        from .shared_optim import FlatParams
+        self.args, self.optimizer, self.master = args, optimizer, player
+        self.mode0 = args.train_mode if mode is None else int(mode)
+        self.serial = bool(serial)
+        dev = self.dev = player.device
+        env = player.env
+        # eager warm-up on the master (allocator, GEMM workspaces), its updates rolled back
+        tensors = [optimizer.bucket.flat] + [v for v in vars(optimizer).values() if isinstance(v, torch.Tensor)]
+        saved = [t.clone() for t in tensors]
+        for _ in range(warmup):
+            rollout(player, args.num_steps)
+            player.optimize(None, optimizer, player.model, self.mode0, dev)
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            for t, v in zip(tensors, saved):
+                t.copy_(v)
+        # the two replicas: same architecture, weights re-homed in flat buffers laid out like the optimizer's bucket
+        self.players, self.buckets = [], []
+        for k in range(2):
+            m = build_model(env.observation_space, env.action_space, args, dev).to(dev)
+            m.load_state_dict(player.model.state_dict())
+            m.train()
+            bucket = FlatParams(select_params(m, args.train_mode))
+            assert bucket.flat.numel() == optimizer.bucket.flat.numel()
+            # a draw stream of its own: the learner's bootstrap step reads the replica's counter, which only the replica's
+            # own rollouts advance (they wait for this learner), so its draws do not depend on the timing of the other stream
+            from . import fused
+            m._sampler = fused.ActionSampler(dev, seed=(int(torch.initial_seed()) + 7919 * (k + 1)) & 0xFFFFFFFFFFFFFFFF)
+            a = Agent(m, env, args, None, dev)
+            a.w_entropy_target = player.w_entropy_target
+            self.players.append(a)
+            self.buckets.append(bucket)
+        self.carry = dict(state=player.state.clone(), hxs=player.hxs.detach().clone(), cxs=player.cxs.detach().clone(),
+                          done=player.done.clone(), eps_len=player.eps_len.clone())
+        # the rollout is the latency chain (a launch every few us, each waiting for the one before): its stream gets the higher
+        # priority, so its workgroups are dispatched ahead of the learner's chip-filling GEMM workgroups when CUs free up
+        prio = int(os.environ.get("ATR_PIPE_PRIO", "0"))
+        self.sR = torch.cuda.Stream(device=dev, priority=-1 if prio == 1 else 0)
+        self.sL = torch.cuda.Stream(device=dev, priority=-1 if prio == 2 else 0)
+        self.ev_r = [torch.cuda.Event() for _ in range(2)]
+        self.ev_o = [torch.cuda.Event() for _ in range(2)]
+        self.graphs = {}          # (mode, k) -> (rollout graph, learner graph, stats)
+        self.g_opt = []
+        for k in range(2):        # O_k: the update on theta, then theta -> F_k
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                optimizer.step()
+                self.buckets[k].flat.copy_(optimizer.bucket.flat)
+            self.g_opt.append(g)
+        with torch.no_grad():
+            for t, v in zip(tensors, saved):
+                t.copy_(v)
+            for b in self.buckets:
+                b.flat.copy_(optimizer.bucket.flat)
+        self.i = 0
+        for k in range(2):
+            self._capture(self.mode0, k)
+        torch.cuda.synchronize(dev)
+
+    def _bind_carry(self, p):
+        p.state, p.hxs, p.cxs = self.carry["state"], self.carry["hxs"], self.carry["cxs"]
+        p.done, p.eps_len = self.carry["done"], self.carry["eps_len"]
+
+    def _capture(self, mode, k):
+        p, args = self.players[k], self.args
+        torch.cuda.synchronize(self.dev)
+        if hasattr(p.env, "flush"):
+            p.env.flush()
+        torch.cuda.synchronize(self.dev)
+        g_r = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_r, capture_error_mode="thread_local"):
+            self._bind_carry(p)
+            rollout(p, args.num_steps)
+            for key, src in (("state", p.state), ("hxs", p.hxs.detach()), ("cxs", p.cxs.detach()), ("done", p.done),
+                             ("eps_len", p.eps_len)):
+                if self.carry[key].data_ptr() != src.data_ptr():
+                    self.carry[key].copy_(src)
+        # the learner of THIS rollout reads the replica's own end-of-rollout tensors (last observation slot, LSTM state, done):
+        # the carry belongs to the next rollout by then
+        g_l = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_l, capture_error_mode="thread_local"):
+            stats = p.compute_grads(_BucketOnly(self.buckets[k]), mode)
+            self.optimizer.bucket.grad.copy_(self.buckets[k].grad)
+        self.graphs[(mode, k)] = (g_r, g_l, stats)
+        return self.graphs[(mode, k)]
+
+    def run(self, mode=None):
+        mode = self.mode0 if mode is None else int(mode)
+        k = self.i & 1
+        entry = self.graphs.get((mode, k))
+        if entry is None:            # a training mode seen for the first time (the evaluator's schedule): capture its pair
+            self.finish()
+            entry = self._capture(mode, k)
+        g_r, g_l, stats = entry
+        cur = torch.cuda.current_stream(self.dev)
+        if self.serial:
+            # the same graphs in program order on the caller's stream: R(i), L(i), O(i). The one-update delay lives in the
+            # double-buffered weights (rollout i + 1 reads F_{1-k}, which O(i) does not touch), not in the timing, so this
+            # is the same dataflow as the two-stream schedule below
+            g_r.replay()
+            g_l.replay()
+            self.master.allreduce_grads(self.optimizer)
+            self.g_opt[k].replay()
+        else:
+            if self.i == 0:
+                self.sR.wait_stream(cur)
+                self.sL.wait_stream(cur)
+            with torch.cuda.stream(self.sR):
+                if self.i >= 2:
+                    self.sR.wait_event(self.ev_o[k])      # F_k holds theta_{i-1}; the stores of replica k are free again
+                g_r.replay()
+                self.ev_r[k].record(self.sR)
+            with torch.cuda.stream(self.sL):
+                self.sL.wait_event(self.ev_r[k])
+                g_l.replay()
+                self.master.allreduce_grads(self.optimizer)   # (RCCL on this stream: under the next rollout)
+                self.g_opt[k].replay()
+                self.ev_o[k].record(self.sL)
+        self.master.n_steps += self.args.num_steps
+        self.i += 1
+        self.stats = stats
+        return stats
+
+    def finish(self):
+        """Make the caller's stream wait for everything issued so far (both streams)."""
+        if not self.serial and self.i > 0:
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_stream(self.sR)
+            cur.wait_stream(self.sL)
+
+    def tune_streams(self, candidates=4, iters=8):
+        """Pick the learner stream that actually overlaps with the rollout stream. HIP multiplexes its streams onto a few
+        hardware queues (4 by default) in an order the application does not control: two streams that land on one queue
+        run the two chains back to back (measured at 512 envs: 1.73 ms per iteration against 1.33 ms on distinct queues,
+        1.62 ms synchronous), and the mapping depends on how many streams the process created before. So: `iters` real
+        iterations (they are ordinary iterations of the schedule — the weights do not depend on the stream, see `serial`)
+        per candidate, timed on the host clock, the fastest kept. Returns [(ms per iteration, chosen)] per candidate."""
+        if self.serial:
+            return []
+        import time as _time
+        trials = []
+        for sL in [self.sL] + [torch.cuda.Stream(device=self.dev) for _ in range(candidates)]:
+            self.finish()
+            torch.cuda.synchronize(self.dev)
+            self.sL = sL
+            for _ in range(2):
+                self.run()
+            self.finish()
+            torch.cuda.synchronize(self.dev)
+            t0 = _time.perf_counter()
+            for _ in range(iters):
+                self.run()
+            self.finish()
+            torch.cuda.synchronize(self.dev)
+            trials.append(((_time.perf_counter() - t0) / iters * 1e3, sL))
+        best = min(trials, key=lambda t: t[0])
+        self.sL = best[1]
+        return [(ms, s is best[1]) for ms, s in trials]
+
+
 def sync_train_modes(train_modes, device, src=0):
     """Every rank must differentiate the same loss before the all-reduce: rank `src` (the only one running the
     evaluator, which owns the schedule — test.py:84-92,129-134) broadcasts its train_modes list."""

@@ -10,7 +10,10 @@ tat-maze-lstm tracker + target, train-mode -1, 20-step rollouts. A "step" is ONE
 A3C path: policy forward for both players (PyTorch-ROCm) -> HIP step/observe kernel for all envs (in-launch
 auto-reset) -> every 20th step the n-step/GAE loss, backward, ONE all-reduce of the flat gradient bucket (RCCL)
 and the SharedAdam update. value = (K x envs over all ranks) / max-over-ranks wall time of the MEDIAN of >= 5
-repeats of the K-step region. Weak scaling (`value`): 4096 envs per GPU, independent shards keyed by global env id;
+repeats of the K-step region. Two schedules of the same iteration are measured (--schedule both, the default): the
+PIPELINED one (`value`; main.py's default: the rollout of iteration i + 1 runs on a second HIP stream while the learner,
+all-reduce and update of iteration i run, every gradient exactly one update late — the bounded form of the reference's
+worker asynchrony) and the SYNCHRONOUS one (no overlap, no delay), whose numbers ride along in the `synchronous` object. Weak scaling (`value`): 4096 envs per GPU, independent shards keyed by global env id;
 the strong form of the same metric (4096 envs GLOBAL, 4096/N per GPU — SURVEY §8d's headline) is measured in the same
 run and reported in the `strong` object of the same line.
 
@@ -124,6 +127,13 @@ def main():
                                                           "decoded in the stem's conv1)")
     ap.add_argument("--repeats", type=int, default=5, help="minimum number of timed repeats of the K-step region (median "
                                                           "reported; more are run until they hold >= 1 s of GPU work)")
+    ap.add_argument("--schedule", choices=("both", "pipelined", "synchronous"), default="both",
+                    help="iteration schedule behind `value`: pipelined (rollout i+1 under learner i, one update of gradient "
+                         "delay; train.PipelinedIteration) or synchronous (train.GraphedIteration); both = value from the "
+                         "pipelined one, the synchronous numbers in the `synchronous` object")
+    ap.add_argument("--pipelined-timeout", type=float, default=600.0,
+                    help="seconds the pipelined measurements may take before the line is printed with the synchronous "
+                         "numbers only (a watchdog: an N>1 run must not hang the driver)")
     ap.add_argument("--no-shards", action="store_true", help="skip the per-shard-size sweep of the N=1 line")
     ap.add_argument("--global-envs", type=int, default=4096, help="env count of the strong-scaling form")
     ap.add_argument("--launch-check", action="store_true",
@@ -151,7 +161,7 @@ def main():
         dist.barrier()
     from active_tracking_rl_amd import gemm_tuning
     tuned = gemm_tuning.enable() and os.environ.get("ATR_DISABLE_GEMM_TUNING") != "1"
-    from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player, rollout
+    from active_tracking_rl_amd.train import GraphedIteration, PipelinedIteration, default_args, make_player, rollout
 
     T = 20
     steps = max(T, (a.steps + T - 1) // T * T)          # an A3C iteration is T env steps + one update
@@ -163,7 +173,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def measure(envs_per_gpu, min_gpu_seconds=1.0):
+    def measure(envs_per_gpu, min_gpu_seconds=1.0, schedule="synchronous"):
         """Build the player for `envs_per_gpu` envs on this rank, warm up, then time `repeats` repeats of `steps` env
         steps, each bracketed by barrier + synchronize; per repeat the MAX over ranks; returns the median repeat."""
         args = default_args(env=a.env, network=a.network, num_envs=envs_per_gpu, num_steps=T, gpu_ids=[local_rank],
@@ -177,8 +187,12 @@ def main():
             rollout(player, T, fast=not a.per_step_autograd)
             player.optimize(None, optimizer, player.model, args.train_mode, device)
 
-        iteration, graphed = eager_iteration, False
-        if not a.no_graph:
+        iteration, graphed, drain, trials = eager_iteration, False, (lambda: None), None
+        if schedule == "pipelined":
+            sched = PipelinedIteration(player, optimizer, args)
+            trials = [round(ms, 4) for ms, _ in sched.tune_streams()]
+            iteration, graphed, drain = sched.run, True, sched.finish
+        elif not a.no_graph:
             try:
                 iteration = GraphedIteration(player, optimizer, args, fast=not a.per_step_autograd).run
                 graphed = True
@@ -187,12 +201,14 @@ def main():
                 torch.cuda.synchronize(device)
         for _ in range(warm // T):
             iteration()
+        drain()
 
         def timed_repeat():
             fence()
             t0 = time.perf_counter()
             for _ in range(steps // T):
                 iteration()
+            drain()                      # pipelined: the caller's stream joins both streams; then barrier + synchronize
             fence()
             return time.perf_counter() - t0
         # whatever --steps is, the timed repeats together hold >= min_gpu_seconds of GPU work (a 20-step region is 6 ms):
@@ -225,43 +241,55 @@ def main():
                "ms_per_iteration": med * 1e3 / (steps // T), "timed_gpu_seconds": float(sum(ts)),
                "envs_per_gpu": envs_per_gpu, "global_envs": envs_per_gpu * world, "repeats": reps,
                "spread": {"min_ms_per_step": ts[0] * 1e3 / steps, "max_ms_per_step": ts[-1] * 1e3 / steps},
-               "hipgraph": graphed, "allreduce_us": ar_us,
+               "hipgraph": graphed, "schedule": schedule, "stream_trials_ms_per_iteration": trials, "allreduce_us": ar_us,
                "allreduce_elems": int(optimizer.bucket.grad.numel()) if hasattr(optimizer, "bucket") else None}
         return res, player, optimizer, args
 
-    # strong form first (4096 envs GLOBAL, sharded), then the weak form whose player also serves the kernel sections
-    strong = None
-    if world > 1:
-        per = a.global_envs // world
-        strong, p_, o_, _ = measure(per)
-        strong["scaling"] = "strong"
-        p_.env.close()
-        del p_, o_
-        torch.cuda.empty_cache()
-    # N=1: the per-GPU term of the strong form at every N — the same workload on 4096/8, /4, /2 envs on this one GPU
-    shards = None
-    if world == 1 and not a.no_shards:
-        shards = {"note": "headline workload at the per-GPU shard sizes of the strong form (4096 envs over 8/4/2/1 GPUs), "
-                          "measured on ONE GPU; the N-GPU strong value is bounded by N x shard value, minus the gradient "
-                          "all-reduce (allreduce_us of an N>1 line: %d fp32 elements)" % 0, "sizes": {}}
-        for per in (a.global_envs // 8, a.global_envs // 4, a.global_envs // 2):
-            r_, p_, o_, _ = measure(per, min_gpu_seconds=0.5)
-            shards["sizes"][str(per)] = {"value": r_["value"], "ms_per_iteration": r_["ms_per_iteration"],
-                                         "ms_per_step": r_["ms_per_step"], "repeats": r_["repeats"], "spread": r_["spread"]}
+    def measure_set(schedule, keep_player):
+        """All the timed regions of one schedule: the strong form (N > 1: 4096 envs GLOBAL, sharded), at N = 1 the per-GPU
+        shard sizes of the strong form at every N (4096/8, /4, /2 envs on this one GPU), and the weak form (headline)."""
+        strong = None
+        if world > 1:
+            per = a.global_envs // world
+            strong, p_, o_, _ = measure(per, schedule=schedule)
+            strong["scaling"] = "strong"
             p_.env.close()
             del p_, o_
             torch.cuda.empty_cache()
-    weak, player, optimizer, args = measure(a.envs_per_gpu)
-    if shards is not None:
-        shards["sizes"][str(a.envs_per_gpu)] = {"value": weak["value"], "ms_per_iteration": weak["ms_per_iteration"],
-                                                "ms_per_step": weak["ms_per_step"], "repeats": weak["repeats"],
-                                                "spread": weak["spread"]}
-        shards["note"] = shards["note"].replace("(allreduce_us of an N>1 line: 0 fp32 elements)",
-                                                "(allreduce_us of an N>1 line: %s fp32 elements)" % weak["allreduce_elems"])
+        shards = None
+        if world == 1 and not a.no_shards:
+            shards = {"note": "headline workload at the per-GPU shard sizes of the strong form (4096 envs over 8/4/2/1 "
+                              "GPUs), measured on ONE GPU; the N-GPU strong value is bounded by N x shard value, minus the "
+                              "gradient all-reduce (allreduce_us of an N>1 line: %d fp32 elements)" % 0, "sizes": {}}
+            for per in (a.global_envs // 8, a.global_envs // 4, a.global_envs // 2):
+                r_, p_, o_, _ = measure(per, min_gpu_seconds=0.5, schedule=schedule)
+                shards["sizes"][str(per)] = {k: r_[k] for k in ("value", "ms_per_iteration", "ms_per_step", "repeats",
+                                                                "spread", "stream_trials_ms_per_iteration")}
+                p_.env.close()
+                del p_, o_
+                torch.cuda.empty_cache()
+        weak, player, optimizer, args = measure(a.envs_per_gpu, schedule=schedule)
+        if shards is not None:
+            shards["sizes"][str(a.envs_per_gpu)] = {k: weak[k] for k in ("value", "ms_per_iteration", "ms_per_step", "repeats",
+                                                                         "spread", "stream_trials_ms_per_iteration")}
+            shards["note"] = shards["note"].replace("(allreduce_us of an N>1 line: 0 fp32 elements)",
+                                                    "(allreduce_us of an N>1 line: %s fp32 elements)" % weak["allreduce_elems"])
+        if strong is None:
+            strong = dict(weak, scaling="strong", note="N=1: the strong and weak forms coincide")
+        if not keep_player:
+            player.env.close()
+            player = optimizer = None
+            torch.cuda.empty_cache()
+        return {"strong": strong, "shards": shards, "weak": weak}, player, optimizer, args
+
+    # the synchronous schedule first (its player also serves the kernel sections below); the pipelined one is measured after
+    # the line is assembled, under a watchdog
+    first = "pipelined" if (a.schedule == "pipelined" and not a.no_graph) else "synchronous"
+    want_pipelined = a.schedule == "both" and not a.no_graph and not a.per_step_autograd
+    res0, player, optimizer, args = measure_set(first, keep_player=True)
+    strong, shards, weak = res0["strong"], res0["shards"], res0["weak"]
     graphed = weak["hipgraph"]
     value, n_total = weak["value"], a.envs_per_gpu * world
-    if strong is None:
-        strong = dict(weak, scaling="strong", note="N=1: the strong and weak forms coincide")
 
     # ---- roofline of the step/observe kernel: HIP events on the launch stream --------------------------
     # M policy-shaped launches (int64 action tensors, fresh per launch) are captured once into a hipGraph and
@@ -534,6 +562,50 @@ def main():
                                    "per-step launches" % T},
         "policy_stem": stem_roof,
     }
+    sched_note = {"synchronous": "rollout, learner, all-reduce, update in sequence (train.GraphedIteration): every gradient "
+                                 "applied to the weights it was computed on",
+                  "pipelined": "rollout i+1 on a second HIP stream while learner + all-reduce + update i run "
+                               "(train.PipelinedIteration; main.py's default): the same kernels and the same work per "
+                               "iteration, every gradient applied exactly one update late — the bounded form of the "
+                               "reference's Hogwild worker asynchrony (main.py:86-116, train.py:71-95)"}
+    line["schedule"] = first
+    line["schedule_note"] = sched_note[first]
+    line["config"]["schedule"] = first
+    if want_pipelined:
+        # a watchdog around the second schedule: if it does not come back (an N>1 run must never hang the driver), rank 0
+        # prints the line as assembled so far — the synchronous numbers — and every rank leaves
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["pipelined"] = {"error": "the pipelined measurements did not complete within %.0f s; value is the "
+                                              "synchronous schedule's" % a.pipelined_timeout}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(a.pipelined_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            res1, _, _, _ = measure_set("pipelined", keep_player=False)
+            dog.cancel()
+            w1 = res1["weak"]
+            line["synchronous"] = {"value": weak["value"], "ms_per_step": weak["ms_per_step"],
+                                   "ms_per_iteration": weak["ms_per_iteration"], "spread": weak["spread"],
+                                   "timed_gpu_seconds": weak["timed_gpu_seconds"], "repeats_run": weak["repeats"],
+                                   "allreduce_us": weak["allreduce_us"], "shards": shards, "weak": line["weak"],
+                                   "strong": line["strong"], "note": sched_note["synchronous"]}
+            line.update(value=w1["value"], spread=w1["spread"], ms_per_step=w1["ms_per_step"],
+                        ms_per_iteration=w1["ms_per_iteration"], timed_gpu_seconds=w1["timed_gpu_seconds"],
+                        repeats_run=w1["repeats"], shards=res1["shards"], allreduce_us=w1["allreduce_us"],
+                        stream_trials_ms_per_iteration=w1["stream_trials_ms_per_iteration"],
+                        weak={k: w1[k] for k in ("value", "ms_per_step", "envs_per_gpu", "global_envs", "allreduce_us")},
+                        strong={k: res1["strong"][k] for k in ("value", "ms_per_step", "envs_per_gpu", "global_envs",
+                                                               "allreduce_us", "spread") if k in res1["strong"]},
+                        schedule="pipelined", schedule_note=sched_note["pipelined"])
+            line["config"]["schedule"] = "pipelined"
+        except Exception as ex:
+            dog.cancel()
+            line["pipelined"] = {"error": repr(ex)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             # separate process: the baseline forks Hogwild workers, which must not inherit autograd/HIP state.

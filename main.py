@@ -5,8 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 main.py ... (one rank per GPU)
 
 What changes: `--workers` CPU processes become `--num-envs` envs per GPU stepped by the HIP kernels; the Hogwild shared
-model becomes synchronous data parallel (one all-reduce of the flat gradient bucket per update); the evaluator
-(`test`) runs on rank 0 between training iterations instead of in a forked process. `--gpu-ids` picks the device of a
+model becomes data parallel with one all-reduce of the flat gradient bucket per update — `--schedule pipelined` (default:
+the next rollout runs while the learner of the last one does, every gradient exactly one update late — the bounded form
+of the reference's worker asynchrony) or `--schedule synchronous` (no delay); the evaluator (`test`) runs on rank 0
+between training iterations instead of in a forked process. `--gpu-ids` picks the device of a
 single-process run; under torch.distributed.run each rank uses LOCAL_RANK.
 """
 from __future__ import print_function, division
@@ -21,7 +23,7 @@ import torch.distributed as dist
 
 from active_tracking_rl_amd import build
 from active_tracking_rl_amd.test import test
-from active_tracking_rl_amd.train import GraphedIteration, make_player, sync_train_modes
+from active_tracking_rl_amd.train import GraphedIteration, PipelinedIteration, make_player, sync_train_modes
 from active_tracking_rl_amd.utils import ScalarWriter, log_train_scalars
 
 parser = argparse.ArgumentParser(description='A3C (MI355X data-parallel)')
@@ -65,6 +67,9 @@ parser.add_argument('--init-step', type=int, default=-1, metavar='IS', help='ste
 parser.add_argument('--max-grad-norm', type=float, default=None, help='clip (off by default, as the reference effectively is)')
 parser.add_argument('--f32-obs', dest='obs_u8', action='store_false', help='float32 observations between env and policy (default: bytes, decoded in conv1)')
 parser.add_argument('--no-graph', action='store_true', help='run iterations eagerly instead of as hipGraphs')
+parser.add_argument('--schedule', choices=('pipelined', 'synchronous'), default='pipelined',
+                    help='pipelined: rollout i+1 overlaps learner i on a second HIP stream (gradients one update late); '
+                         'synchronous: rollout, learner, update in sequence')
 parser.add_argument('--log-every', type=int, default=10, metavar='LE', help='training iterations between train/* scalar records')
 
 if __name__ == '__main__':
@@ -93,7 +98,15 @@ if __name__ == '__main__':
     # n_iter < --init-step
     first_mode = 0 if args.init_step > 0 else args.train_mode
     train_modes, n_iters = [first_mode] * world, [0] * world
-    step = GraphedIteration(player, optimizer, args, mode=first_mode).run if not args.no_graph else None
+    sched = None
+    if not args.no_graph:
+        if args.schedule == 'pipelined':
+            sched = PipelinedIteration(player, optimizer, args, mode=first_mode)
+            sched.tune_streams()
+        else:
+            sched = GraphedIteration(player, optimizer, args, mode=first_mode)
+    step = sched.run if sched is not None else None
+    drain = getattr(sched, "finish", lambda: None)          # pipelined: both streams joined before the host reads anything
     it = 0
     eval_state = {}
     # train/* scalars of train.py:97-104 from the graphed path: the loss statistics of an iteration are static outputs of the
@@ -113,6 +126,7 @@ if __name__ == '__main__':
         it += 1
         n_iters[:] = [it] * world
         if args.log_every > 0 and it % args.log_every == 0:
+            drain()
             torch.cuda.synchronize(device)
             now = time.time()
             fps = (it - it_log) * args.num_steps * player.num_envs / max(now - t_log, 1e-9)
@@ -120,12 +134,16 @@ if __name__ == '__main__':
             writer.flush()
             t_log, it_log = time.time(), it
         if it % args.test_every == 0 or it > args.max_step:
+            drain()
+            torch.cuda.synchronize(device)
             if rank == 0:
                 test(args, player.model, train_modes, n_iters, rounds=1, state=eval_state)
             sync_train_modes(train_modes, device)           # rank 0 owns the schedule; a broadcast is also a barrier
             t_log, it_log = time.time(), it                 # (the evaluation's wall time is not training time)
         if it > args.max_step:
             break
+    drain()
+    torch.cuda.synchronize(device)
     writer.close()
     player.env.close()
     if world > 1:

@@ -519,3 +519,51 @@ def test_act_env_step_equals_cells_draws_and_env_step(env_id, n, u8, tat):
     assert torch.equal(actions[0], actions[1]) and torch.equal(h[0][1], h[1][1]) and torch.equal(c[0][1], c[1][1])
     for e_ in envs:
         e_.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,network,mode", [("Track2D-BlockPartialPZR-v0", "tat-maze-lstm", -1),
+                                                 ("Track2D-BlockPartialNav-v0", "maze-lstm", 0)])
+def test_pipelined_schedule_is_the_same_dataflow_on_one_stream_and_on_two(env_id, network, mode):
+    """PipelinedIteration (rollout i + 1 on one HIP stream under learner + update i on another; gradients one update late):
+    the delay lives in the double-buffered replica weights, not in the timing — replaying the same graphs in program order
+    on one stream (serial=True) must leave bit-identical master weights, replica weights, env state and carried LSTM state.
+    And the schedule itself: after i updates the replica that just finished holds theta_i, the other one theta_{i-1}."""
+    from active_tracking_rl_amd.train import PipelinedIteration, default_args, make_player
+    dev = torch.device("cuda:0")
+    res = []
+    for serial in (True, False):
+        args = default_args(env=env_id, network=network, aux="reward" if "tat" in network else "none", train_mode=mode,
+                            num_envs=256, seed=11)
+        player, opt = make_player(args, dev)
+        it = PipelinedIteration(player, opt, args, serial=serial)
+        thetas = [opt.bucket.flat.clone()]
+        for _ in range(7):
+            it.run()
+            it.finish()
+            torch.cuda.synchronize()
+            thetas.append(opt.bucket.flat.clone())
+        if not serial:                      # stream trials are ordinary iterations: run them here, mirror them below
+            trials = it.tune_streams(candidates=2, iters=3)
+            assert len(trials) == 3 and sum(c for _, c in trials) == 1
+        else:
+            for _ in range(3 * (2 + 3)):
+                it.run()
+        it.finish()
+        torch.cuda.synchronize()
+        assert it.i == 22
+        k = (it.i - 1) & 1
+        assert torch.equal(it.buckets[k].flat, opt.bucket.flat)                    # O(i): theta -> F_k
+        assert not torch.equal(it.buckets[1 - k].flat, opt.bucket.flat)            # the other replica is one update behind
+        assert all(not torch.equal(a, b) for a, b in zip(thetas[:-1], thetas[1:]))  # every iteration updates theta
+        assert torch.isfinite(opt.bucket.flat).all()
+        st = player.env.core.get_state()
+        res.append((thetas + [opt.bucket.flat.clone()], [b.flat.clone() for b in it.buckets],
+                    {k_: v.clone() for k_, v in it.carry.items()}, st["pos"].copy(), [s.clone() for s in it.stats]))
+        player.env.close()
+    (ta, fa, ca, pa, sa), (tb, fb, cb, pb, sb) = res
+    assert all(torch.equal(a, b) for a, b in zip(ta, tb))
+    assert all(torch.equal(a, b) for a, b in zip(fa, fb))
+    assert all(torch.equal(ca[k_], cb[k_]) for k_ in ca)
+    assert np.array_equal(pa, pb)
+    assert all(torch.equal(a, b) for a, b in zip(sa, sb))
