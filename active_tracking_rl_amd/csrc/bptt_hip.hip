@@ -111,7 +111,8 @@ __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
             ar[0] = d_i; ar[kBR] = d_f; ar[2 * kBR] = d_g; ar[3 * kBR] = d_o;
             if (ok[i]) {
                 float *o = dg + ((size_t)t * a.N + rows[i]) * kBK + u;
-                o[0] = d_i; o[kBR] = d_f; o[2 * kBR] = d_g; o[3 * kBR] = d_o;
+                __builtin_nontemporal_store(d_i, o); __builtin_nontemporal_store(d_f, o + kBR);      // streamed out: the
+                __builtin_nontemporal_store(d_g, o + 2 * kBR); __builtin_nontemporal_store(d_o, o + 3 * kBR);  // GEMMs read dG later
             }
         }
         __syncthreads();                                   // the tile of step t is complete (the other buffer: step t + 1's

@@ -53,6 +53,10 @@ struct RolloutEnd {
     int *eps_len;                    // [N], in place
     float *keep;                     // [T, N] = (dones == 0)
     int T, N, A, R;
+    const uint32_t *obs_src;         // optional: the observation after the last step (obs_words dwords) -> obs_dst, and
+    uint32_t *obs_dst;               // dones[T-1] -> done_dst [N]: what the next rollout starts from, published here instead
+    long long obs_words;             // of by three separate copy launches
+    uint8_t *done_dst;
 };
 
 __global__ __launch_bounds__(256) void k_rollout_end(RolloutEnd a)
@@ -73,6 +77,9 @@ __global__ __launch_bounds__(256) void k_rollout_end(RolloutEnd a)
         reinterpret_cast<float4 *>(a.cxs)[i] = c;
     }
     if (i < (long long)a.T * a.N) a.keep[i] = a.dones[i] == 0 ? 1.f : 0.f;
+    if (a.obs_src)
+        for (long long j = i; j < a.obs_words; j += (long long)gridDim.x * blockDim.x) a.obs_dst[j] = a.obs_src[j];
+    if (a.done_dst && i < a.N) a.done_dst[i] = a.dones[(long long)(a.T - 1) * a.N + i];
     if (i < a.N) {
         // train.py:73-76 per env: the counter restarts at a done and counts the steps since; over T stored steps that is
         // eps_len * [no done in the rollout] + the number of steps after the last done
@@ -144,16 +151,27 @@ __global__ __launch_bounds__(256) void k_rmsprop_update(float *__restrict__ p, c
 // all stored steps of a rollout: out[r][c] = f[r][c] + W[c][a[r]] + b[c] with W = fc_action_tracker.weight [C, A]. As tensor
 // ops that is one_hot (scatter) + a [rows, A] x [A, C] GEMM + an add forward, and a GEMM + a column-sum reduction backward —
 // 7 launches of up to 37 us on [81 920, 256] for what is a row gather: here one launch forward, two backward.
+// Row r of a [T*N]-row operand takes its action from act[(r / act_n) * act_tstride + (r % act_n) * act_stride]: the rollout
+// stores actions as [T, players, N], so one player's actions are N contiguous entries per step, steps players * N apart
+// (act_n = N, act_tstride = players * N, act_stride = 1) — read in place instead of through a gathered copy. A flat vector
+// is act_n >= rows.
+__device__ __forceinline__ long long act_index(long long r, long long act_n, long long act_tstride, long long act_stride)
+{
+    const long long t = r / act_n;
+    return t * act_tstride + (r - t * act_n) * act_stride;
+}
+
 __global__ __launch_bounds__(256) void k_embed_add(const float *__restrict__ f, const float *__restrict__ w,
                                                    const float *__restrict__ b, const long long *__restrict__ act,
-                                                   long long act_stride, float *__restrict__ out, long long rows, int C, int A)
+                                                   long long act_stride, long long act_n, long long act_tstride,
+                                                   float *__restrict__ out, long long rows, int C, int A)
 {
     const int c4 = C / 4;
     const long long total = rows * c4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / c4;
         const int c = (int)(i - r * c4) * 4;
-        const int a = (int)act[r * act_stride];
+        const int a = (int)act[act_index(r, act_n, act_tstride, act_stride)];
         float4 v = *reinterpret_cast<const float4 *>(f + r * C + c);
         const float4 bb = *reinterpret_cast<const float4 *>(b + c);
         v.x += w[(c + 0) * A + a] + bb.x; v.y += w[(c + 1) * A + a] + bb.y;
@@ -166,7 +184,8 @@ __global__ __launch_bounds__(256) void k_embed_add(const float *__restrict__ f, 
 // flight), written as partial[a][c][wg] so that pass 2 reads them coalesced
 constexpr int kEmbMaxA = 8;
 __global__ __launch_bounds__(256) void k_embed_grad_partial(const float *__restrict__ dout, const long long *__restrict__ act,
-                                                            long long act_stride, float *__restrict__ partial, long long rows,
+                                                            long long act_stride, long long act_n, long long act_tstride,
+                                                            float *__restrict__ partial, long long rows,
                                                             int C, int A, int rows_per_wg, int nwg)
 {
     const long long r0 = (long long)blockIdx.x * rows_per_wg;
@@ -180,14 +199,14 @@ __global__ __launch_bounds__(256) void k_embed_grad_partial(const float *__restr
             int av[8];
             float vv[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { av[u] = (int)act[(r + u) * act_stride]; vv[u] = dout[(r + u) * C + c]; }
+            for (int u = 0; u < 8; u++) { av[u] = (int)act[act_index(r + u, act_n, act_tstride, act_stride)]; vv[u] = dout[(r + u) * C + c]; }
 #pragma unroll
             for (int u = 0; u < 8; u++)
 #pragma unroll
                 for (int q = 0; q < kEmbMaxA; q++) acc[q] += q == av[u] ? vv[u] : 0.f;
         }
         for (; r < r1; r++) {
-            const int a = (int)act[r * act_stride];
+            const int a = (int)act[act_index(r, act_n, act_tstride, act_stride)];
             const float v = dout[r * C + c];
 #pragma unroll
             for (int q = 0; q < kEmbMaxA; q++) acc[q] += q == a ? v : 0.f;
@@ -237,10 +256,21 @@ extern "C" int atr_rollout_begin(const float *hxs, const float *cxs, float *h0, 
 extern "C" int atr_rollout_end(const float *hT, const float *cT, long long pstride, const uint8_t *dones, float *hxs,
                                float *cxs, int *eps_len, float *keep, int T, int N, int A, int R, void *stream)
 {
+    return atr_rollout_end2(hT, cT, pstride, dones, hxs, cxs, eps_len, keep, T, N, A, R, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int atr_rollout_end2(const float *hT, const float *cT, long long pstride, const uint8_t *dones, float *hxs,
+                                float *cxs, int *eps_len, float *keep, int T, int N, int A, int R, const void *obs_src,
+                                void *obs_dst, long long obs_bytes, uint8_t *done_dst, void *stream)
+{
     if (!hT || !cT || !dones || !hxs || !cxs || !eps_len || !keep || T <= 0 || N <= 0 || A <= 0 || R <= 0 || (R & 3) || (pstride & 3))
         return 1;
     if (((uintptr_t)hxs | (uintptr_t)cxs | (uintptr_t)hT | (uintptr_t)cT) & 15u) return 1;
-    RolloutEnd a{hT, cT, pstride, dones, hxs, cxs, eps_len, keep, T, N, A, R};
+    if ((obs_src != nullptr) != (obs_dst != nullptr) || obs_bytes < 0 || (obs_bytes & 3) ||
+        (((uintptr_t)obs_src | (uintptr_t)obs_dst) & 3u))
+        return 1;
+    RolloutEnd a{hT, cT, pstride, dones, hxs, cxs, eps_len, keep, T, N, A, R, (const uint32_t *)obs_src, (uint32_t *)obs_dst,
+                 obs_src ? obs_bytes / 4 : 0, done_dst};
     long long work = (long long)N * A * (R / 4);
     if (work < (long long)T * N) work = (long long)T * N;
     hipLaunchKernelGGL(k_rollout_end, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
@@ -248,14 +278,14 @@ extern "C" int atr_rollout_end(const float *hT, const float *cT, long long pstri
 }
 
 extern "C" int atr_embed_add(const float *f, const float *w, const float *b, const long long *actions, long long act_stride,
-                             float *out, long long rows, int C, int A, void *stream)
+                             long long act_n, long long act_tstride, float *out, long long rows, int C, int A, void *stream)
 {
-    if (!f || !w || !b || !actions || !out || rows <= 0 || C <= 0 || (C & 3) || A < 1 || A > kEmbMaxA) return 1;
+    if (!f || !w || !b || !actions || !out || rows <= 0 || C <= 0 || (C & 3) || A < 1 || A > kEmbMaxA || act_n < 1) return 1;
     if (((uintptr_t)f | (uintptr_t)out | (uintptr_t)b) & 15u) return 1;
     long long blocks = (rows * (C / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_embed_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f, w, b, actions, act_stride, out,
-                       rows, C, A);
+    hipLaunchKernelGGL(k_embed_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f, w, b, actions, act_stride, act_n,
+                       act_tstride, out, rows, C, A);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
@@ -266,15 +296,16 @@ extern "C" long long atr_embed_grad_workspace_floats(long long rows, int C, int 
     return nwg * A * C;
 }
 
-extern "C" int atr_embed_grad(const float *dout, const long long *actions, long long act_stride, float *dw, float *db,
-                              float *workspace, long long rows, int C, int A, void *stream)
+extern "C" int atr_embed_grad(const float *dout, const long long *actions, long long act_stride, long long act_n,
+                              long long act_tstride, float *dw, float *db, float *workspace, long long rows, int C, int A,
+                              void *stream)
 {
-    if (!dout || !actions || !dw || !db || !workspace || rows <= 0 || C <= 0 || A < 1 || A > kEmbMaxA) return 1;
+    if (!dout || !actions || !dw || !db || !workspace || rows <= 0 || C <= 0 || A < 1 || A > kEmbMaxA || act_n < 1) return 1;
     const long long nwg = rows < 1024 * 64 ? (rows + 63) / 64 : 1024;
     const int rpw = (int)((rows + nwg - 1) / nwg);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_embed_grad_partial, dim3((unsigned)nwg), dim3(256), 0, st, dout, actions, act_stride, workspace, rows, C,
-                       A, rpw, (int)nwg);
+    hipLaunchKernelGGL(k_embed_grad_partial, dim3((unsigned)nwg), dim3(256), 0, st, dout, actions, act_stride, act_n, act_tstride,
+                       workspace, rows, C, A, rpw, (int)nwg);
     hipLaunchKernelGGL(k_embed_grad_reduce, dim3((unsigned)((C * 64 + 255) / 256)), dim3(256), 0, st, workspace, dw, db, (int)nwg, C, A);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
@@ -291,6 +322,50 @@ extern "C" int atr_adam_step(float *params, const float *grad, float *exp_avg, f
     hipLaunchKernelGGL(k_adam_update, dim3((unsigned)blocks), dim3(256), 0, st, params, grad, exp_avg, exp_avg_sq,
                        max_exp_avg_sq, scalars, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
                        (float)eps, (float)weight_decay, n);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// Up to 64 (source, offset, length) segments copied into one flat buffer by ONE launch: the gradients autograd hands back as
+// ~40 separate small tensors go into the flat bucket this way (source null = the segment is zero-filled: a parameter the
+// loss did not reach). Sources may start at any float (slices of a kernel's packed output), so the copy is per element.
+struct ScatterSegs {
+    const float *src[atr_scatter_max_segments];
+    long long dst_off[atr_scatter_max_segments];
+    int n[atr_scatter_max_segments];
+    int blk_begin[atr_scatter_max_segments];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void k_scatter_segments(const ScatterSegs a, float *__restrict__ dst)
+{
+    const int b = (int)blockIdx.x;
+    int q = 0;
+    for (int j = 1; j < a.count; j++)
+        if (b >= a.blk_begin[j]) q = j;
+    const float *__restrict__ src = a.src[q];
+    float *__restrict__ d = dst + a.dst_off[q];
+    const int n = a.n[q], i0 = (b - a.blk_begin[q]) * 1024 + (int)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = i0 + k * 256;
+        if (i < n) d[i] = src ? src[i] : 0.0f;
+    }
+}
+
+extern "C" int atr_scatter_segments(const float *const *src, const long long *dst_off, const int *n, int count, float *dst,
+                                    void *stream)
+{
+    if (!src || !dst_off || !n || !dst || count < 1 || count > atr_scatter_max_segments) return 1;
+    ScatterSegs a;
+    int blocks = 0;
+    for (int q = 0; q < count; q++) {
+        if (n[q] < 0 || dst_off[q] < 0) return 1;
+        a.src[q] = src[q]; a.dst_off[q] = dst_off[q]; a.n[q] = n[q]; a.blk_begin[q] = blocks;
+        blocks += (n[q] + 1023) / 1024;
+    }
+    a.count = count;
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(k_scatter_segments, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, dst);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

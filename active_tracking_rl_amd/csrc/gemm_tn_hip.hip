@@ -12,9 +12,16 @@
 //   * XCD-aware workgroup order: the output tiles of one K-slice run on the same XCD back to back, so each operand
 //     slice is fetched from HBM once and re-read from that XCD's L2 by the other tiles;
 //   * split-K partials are reduced in a fixed order by a second kernel (reproducible sums, no atomics).
+//   * GROUPED form (atr_gemm_tn_grouped): all weight gradients of one backward pass share K (the T*N rows), so up to 8 of
+//     them go out as ONE launch + ONE reduction launch. Alone, the small ones (dW_hh: 4 output tiles) need 128 K-slices to
+//     fill the chip — 3 chunks of work per workgroup and 33 MB of partials each; together the problems hold 40-48 tiles, 16
+//     slices fill it (768 workgroups = 3 per CU, 20 chunks each), the partials shrink 8x and 14 launches become 2. The
+//     reduction writes straight into the destinations the caller names (slices of the flat gradient bucket), the bias
+//     gradient into up to two of them (bias_ih and bias_hh receive the same sums).
 // fp32 MFMA is an exact fmaf chain, so this is the reference's arithmetic type.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/atr_policy.h"
 
@@ -27,20 +34,49 @@ constexpr int kGemmThreads = 256;
 
 struct GemmLds { float a[2][kKC][kLd]; float b[2][kKC][kLd]; };   // 64 KB: two workgroups per CU
 
-__global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const float *__restrict__ x1, const float *__restrict__ x2,
-                                                             float *__restrict__ partial, long long K, int M, int N,
-                                                             int slices, int chunks_per_slice,
-                                                             const float *__restrict__ row_scale,
-                                                             float *__restrict__ colsum_partial)
+constexpr int kMaxProblems = 8;
+
+struct TnProblem {
+    const float *x1, *x2;          // [K, M], [K, N] row-major
+    float *partial;                // [slices, M, N]
+    float *cs_partial;             // [slices, M] or null
+    const float *row_scale;        // nullable: row k of X1 is multiplied by row_scale[k - rs_shift] (1 for k < rs_shift)
+    float *c;                      // [M, N] destination of the reduction
+    float *cs_out0, *cs_out1;      // [M] destinations of the column sums (nullable)
+    long long rs_shift;
+    int M, N;
+    int tile_begin;                // first tile of this problem in the group's tile order
+    int red_begin;                 // first block of this problem in the reduction launch
+};
+
+struct TnGroup {
+    TnProblem p[kMaxProblems];
+    long long K;
+    int count, slices, chunks_per_slice, tiles_total;
+    int red_blocks;                // matrix blocks of the reduction launch; column-sum blocks follow
+};
+
+__global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const TnGroup g)
 {
     __shared__ __attribute__((aligned(16))) GemmLds s;
     const int tid = (int)threadIdx.x, l = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = N / kTile, tiles = (M / kTile) * tiles_n;
-    // XCD-aware order: workgroup i runs on XCD i % 8; give each XCD whole K-slices (all their tiles back to back)
+    // XCD-aware order: workgroup i runs on XCD i % 8; give each XCD whole K-slices (all their tiles, of every problem, back
+    // to back): an operand slice is fetched from HBM once and re-read from that XCD's L2 by the other tiles — and by the other
+    // problems that share it (dW_ih and dW_hh of a player both contract dG)
     const int i = (int)blockIdx.x, xcd = i & 7, in_xcd = i >> 3;
-    const int slice = xcd + 8 * (in_xcd / tiles), tile = in_xcd % tiles;
-    if (slice >= slices) return;
+    const int slice = xcd + 8 * (in_xcd / g.tiles_total), tg = in_xcd % g.tiles_total;
+    if (slice >= g.slices) return;
+    int q = 0;
+#pragma unroll
+    for (int j = 1; j < kMaxProblems; j++)
+        if (j < g.count && tg >= g.p[j].tile_begin) q = j;
+    const float *__restrict__ x1 = g.p[q].x1, *__restrict__ x2 = g.p[q].x2;
+    float *__restrict__ partial = g.p[q].partial, *__restrict__ colsum_partial = g.p[q].cs_partial;
+    const float *__restrict__ row_scale = g.p[q].row_scale;
+    const long long rs_shift = g.p[q].rs_shift, K = g.K;
+    const int M = g.p[q].M, N = g.p[q].N, tile = tg - g.p[q].tile_begin, chunks_per_slice = g.chunks_per_slice;
+    const int tiles_n = N / kTile;
     const int m0 = (tile / tiles_n) * kTile, n0 = (tile % tiles_n) * kTile;
     const long long k_begin = (long long)slice * chunks_per_slice * kKC;
     long long k_end = k_begin + (long long)chunks_per_slice * kKC;
@@ -68,8 +104,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const float *__rest
         if (kc_ < k_end) { ra2 = g1[kc_ * ldm]; rb2 = g2[kc_ * ldn]; }         \
         if (kd_ < k_end) { ra3 = g1[kd_ * ldm]; rb3 = g2[kd_ * ldn]; }         \
         if (row_scale) {                                                       \
-            const float s0_ = ka_ < k_end ? row_scale[ka_] : 0.f, s1_ = kb_ < k_end ? row_scale[kb_] : 0.f;   \
-            const float s2_ = kc_ < k_end ? row_scale[kc_] : 0.f, s3_ = kd_ < k_end ? row_scale[kd_] : 0.f;   \
+            float s0_ = 1.f, s1_ = 1.f, s2_ = 1.f, s3_ = 1.f;   /* (rows past k_end hold zeros already) */              \
+            if (ka_ >= rs_shift && ka_ < k_end) s0_ = row_scale[ka_ - rs_shift];                                       \
+            if (kb_ >= rs_shift && kb_ < k_end) s1_ = row_scale[kb_ - rs_shift];                                       \
+            if (kc_ >= rs_shift && kc_ < k_end) s2_ = row_scale[kc_ - rs_shift];                                       \
+            if (kd_ >= rs_shift && kd_ < k_end) s3_ = row_scale[kd_ - rs_shift];                                       \
             ra0.x *= s0_; ra0.y *= s0_; ra0.z *= s0_; ra0.w *= s0_; ra1.x *= s1_; ra1.y *= s1_; ra1.z *= s1_; ra1.w *= s1_; \
             ra2.x *= s2_; ra2.y *= s2_; ra2.z *= s2_; ra2.w *= s2_; ra3.x *= s3_; ra3.y *= s3_; ra3.z *= s3_; ra3.w *= s3_; \
         }                                                                      \
@@ -135,76 +174,152 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const float *__rest
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int row = (q & 3) + 8 * (q >> 2) + 4 * kr;
-            out[(size_t)(m0 + wm * 64 + mt * 32 + row) * N + n0 + wn * 64 + nt * 32 + col] = acc[q];
+            // (nontemporal: the partials are read once, by the reduction launch; kept out of L2 they are also not a pile of
+            // dirty lines that every kernel boundary of a concurrent stream has to write back — the pipelined schedule)
+            __builtin_nontemporal_store(acc[q], &out[(size_t)(m0 + wm * 64 + mt * 32 + row) * N + n0 + wn * 64 + nt * 32 + col]);
         }
     };
     store(acc00, 0, 0); store(acc01, 0, 1); store(acc10, 1, 0); store(acc11, 1, 1);
 }
 
-// C = sum over slices, fixed order
-__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float *__restrict__ partial, float *__restrict__ c, int slices,
-                                                        long long mn)
+// C = sum over slices, fixed order — all problems of a group in one launch: blocks [red_begin, ...) of a problem cover its
+// M*N outputs (1024 per block), the blocks after red_blocks its column sums (one wavefront per column: lanes stride over the
+// slices, then a fixed-order butterfly; 4 columns per block)
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const TnGroup g)
 {
-    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= mn) return;
-    float4 acc = *reinterpret_cast<const float4 *>(partial + i);
+    const int b = (int)blockIdx.x;
+    if (b < g.red_blocks) {
+        int q = 0;
+#pragma unroll
+        for (int j = 1; j < kMaxProblems; j++)
+            if (j < g.count && b >= g.p[j].red_begin) q = j;
+        const long long mn = (long long)g.p[q].M * g.p[q].N;
+        const long long i = ((long long)(b - g.p[q].red_begin) * 256 + threadIdx.x) * 4;
+        if (i >= mn) return;
+        const float *__restrict__ partial = g.p[q].partial;
+        float4 acc = *reinterpret_cast<const float4 *>(partial + i);
 #pragma unroll 8
-    for (int z = 1; z < slices; z++) {
-        const float4 t = *reinterpret_cast<const float4 *>(partial + (size_t)z * mn + i);
-        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        for (int z = 1; z < g.slices; z++) {
+            const float4 t = *reinterpret_cast<const float4 *>(partial + (size_t)z * mn + i);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        *reinterpret_cast<float4 *>(g.p[q].c + i) = acc;
+        return;
     }
-    *reinterpret_cast<float4 *>(c + i) = acc;
+    int cb = b - g.red_blocks;                       // column-sum blocks: problem by problem, M / 4 blocks each
+    for (int q = 0; q < g.count; q++) {
+        if (!g.p[q].cs_partial) continue;
+        const int nb = g.p[q].M / 4;
+        if (cb >= nb) { cb -= nb; continue; }
+        const int col = cb * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u), M = g.p[q].M;
+        const float *__restrict__ partial = g.p[q].cs_partial;
+        float acc = 0.f;
+        for (int z = lane; z < g.slices; z += 64) acc += partial[(size_t)z * M + col];
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if (lane == 0) {
+            if (g.p[q].cs_out0) g.p[q].cs_out0[col] = acc;
+            if (g.p[q].cs_out1) g.p[q].cs_out1[col] = acc;
+        }
+        return;
+    }
 }
 
-// one wavefront per column: lanes stride over the slices, then a fixed-order butterfly
-__global__ __launch_bounds__(256) void k_gemm_tn_colsum(const float *__restrict__ partial, float *__restrict__ out, int slices, int M)
+// slices (a multiple of the 8 XCDs) for `tiles` output tiles in all: the estimate is rounds of 256-CU occupancy x rows per
+// workgroup, plus a fixed cost per round (prologue / epilogue of a workgroup ~ 64 rows of work)
+static void gemm_tn_plan(long long K, int tiles, int *slices, int *chunks_per_slice)
 {
-    const int col = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63u);
-    if (col >= M) return;
-    float acc = 0.f;
-    for (int z = lane; z < slices; z += 64) acc += partial[(size_t)z * M + col];
-    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    if (lane == 0) out[col] = acc;
-}
-
-static void gemm_tn_plan(long long K, int M, int N, int *slices, int *chunks_per_slice)
-{
-    const int tiles = (M / kTile) * (N / kTile);
+    // Two workgroups fit a CU (64 KB LDS each) and run best in pairs (one's MFMAs cover the other's load latency): count
+    // rounds of 512 co-resident workgroups at pair efficiency, a tail of <= 256 as a round of lone workgroups at solo
+    // efficiency; every workgroup pays a fixed prologue / epilogue worth ~64 rows
     const long long chunks = (K + kKC - 1) / kKC;
-    int s = (512 + tiles - 1) / tiles;                 // aim at ~512 workgroups (2 resident per CU, one round)
-    s = ((s + 7) / 8) * 8;                             // whole multiples of the 8 XCDs
-    if (s > chunks) s = (int)(((chunks + 7) / 8) * 8);
-    if (s < 8) s = 8;
-    *chunks_per_slice = (int)((chunks + s - 1) / s);
-    *slices = s;
+    const double eff_pair = 0.85, eff_solo = 0.6;
+    int best = 8;
+    double best_cost = 1e30;
+    static const int forced = getenv("ATR_GEMM_TN_SLICES") ? atoi(getenv("ATR_GEMM_TN_SLICES")) : 0;   // (tuning experiments)
+    for (int s = 8; s <= 512; s += 8) {
+        if (s > chunks && s > 8) break;
+        const long long cps = (chunks + s - 1) / s, wgs = (long long)tiles * s;
+        const double rows = (double)cps * kKC + 64.0;
+        const long long full = wgs / 512, rem = wgs - full * 512;
+        double cost = (double)full * 2.0 * rows / eff_pair;
+        if (rem > 256) cost += 2.0 * rows / eff_pair;
+        else if (rem > 0) cost += rows / eff_solo;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    if (forced >= 8 && forced % 8 == 0 && forced <= chunks) best = forced;
+    *slices = best;
+    *chunks_per_slice = (int)((chunks + best - 1) / best);
+}
+
+static int group_tiles(const atr_gemm_tn_problem *pr, int count)
+{
+    int tiles = 0;
+    for (int q = 0; q < count; q++) {
+        if (!pr[q].x1 || !pr[q].x2 || !pr[q].c || pr[q].M <= 0 || pr[q].N <= 0 || pr[q].M % kTile || pr[q].N % kTile) return -1;
+        tiles += (pr[q].M / kTile) * (pr[q].N / kTile);
+    }
+    return tiles;
 }
 
 } // namespace atr
 
 using namespace atr;
 
+extern "C" long long atr_gemm_tn_grouped_workspace_floats(const atr_gemm_tn_problem *problems, int count, long long K)
+{
+    if (!problems || count < 1 || count > kMaxProblems || K <= 0) return -1;
+    const int tiles = group_tiles(problems, count);
+    if (tiles < 0) return -1;
+    int s, c;
+    gemm_tn_plan(K, tiles, &s, &c);
+    long long total = 0;
+    for (int q = 0; q < count; q++) total += (long long)s * problems[q].M * problems[q].N + (long long)s * problems[q].M;
+    return total;
+}
+
+extern "C" int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int count, long long K, float *workspace, void *stream)
+{
+    if (!problems || !workspace || count < 1 || count > kMaxProblems || K <= 0) return -1;
+    const int tiles = group_tiles(problems, count);
+    if (tiles < 0) return -1;
+    TnGroup g;
+    gemm_tn_plan(K, tiles, &g.slices, &g.chunks_per_slice);
+    g.K = K; g.count = count; g.tiles_total = tiles;
+    float *ws = workspace;
+    int tile_begin = 0, red_begin = 0, cs_blocks = 0;
+    for (int q = 0; q < kMaxProblems; q++) {
+        TnProblem &d = g.p[q];
+        if (q >= count) { d = g.p[0]; d.tile_begin = 1 << 30; d.red_begin = 1 << 30; continue; }
+        const atr_gemm_tn_problem &p = problems[q];
+        const long long mn = (long long)p.M * p.N;
+        d.x1 = p.x1; d.x2 = p.x2; d.c = p.c; d.row_scale = p.row_scale; d.rs_shift = p.row_scale_shift; d.M = p.M; d.N = p.N;
+        d.cs_out0 = p.colsum0; d.cs_out1 = p.colsum1;
+        d.partial = ws; ws += (size_t)g.slices * mn;
+        const bool cs = p.colsum0 || p.colsum1;
+        d.cs_partial = cs ? ws : nullptr;
+        if (cs) { ws += (size_t)g.slices * p.M; cs_blocks += p.M / 4; }
+        d.tile_begin = tile_begin; tile_begin += (p.M / kTile) * (p.N / kTile);
+        d.red_begin = red_begin; red_begin += (int)((mn / 4 + 255) / 256);
+    }
+    g.red_blocks = red_begin;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)(g.slices * tiles)), dim3(kGemmThreads), 0, st, g);
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)(red_begin + cs_blocks)), dim3(256), 0, st, g);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" long long atr_gemm_tn_workspace_floats(long long K, int M, int N)
 {
-    if (K <= 0 || M <= 0 || N <= 0 || M % kTile || N % kTile) return -1;
-    int s, c;
-    gemm_tn_plan(K, M, N, &s, &c);
-    return (long long)s * M * N + (long long)s * M;
+    atr_gemm_tn_problem p = {};
+    float dummy = 0.f;
+    p.x1 = p.x2 = &dummy; p.c = &dummy; p.M = M; p.N = N; p.colsum0 = &dummy;
+    return atr_gemm_tn_grouped_workspace_floats(&p, 1, K);
 }
 
 extern "C" int atr_gemm_tn(const float *x1, const float *x2, float *c, float *workspace, long long K, int M, int N,
                            const float *row_scale, float *colsum, void *stream)
 {
-    if (!x1 || !x2 || !c || !workspace || K <= 0 || M <= 0 || N <= 0 || M % kTile || N % kTile) return -1;
-    int slices, cps;
-    gemm_tn_plan(K, M, N, &slices, &cps);
-    const int tiles = (M / kTile) * (N / kTile);
-    hipStream_t st = (hipStream_t)stream;
-    const long long mn = (long long)M * N;
-    float *cs_partial = colsum ? workspace + (size_t)slices * mn : nullptr;
-    hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)(slices * tiles)), dim3(kGemmThreads), 0, st, x1, x2, workspace, K, M, N,
-                       slices, cps, row_scale, cs_partial);
-    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, st, workspace, c, slices, mn);
-    if (colsum)
-        hipLaunchKernelGGL(k_gemm_tn_colsum, dim3((unsigned)((M * 64 + 255) / 256)), dim3(256), 0, st, cs_partial, colsum, slices, M);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    atr_gemm_tn_problem p = {};
+    p.x1 = x1; p.x2 = x2; p.c = c; p.M = M; p.N = N; p.row_scale = row_scale; p.row_scale_shift = 0; p.colsum0 = colsum;
+    return atr_gemm_tn_grouped(&p, 1, K, workspace, stream);
 }

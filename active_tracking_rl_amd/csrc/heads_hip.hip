@@ -39,11 +39,18 @@ __device__ __forceinline__ float row_sum(float v, int L)
 // values[row * vstride + voff] = h[row] . w_c + b_c
 __global__ __launch_bounds__(kHeadsBlock) void k_heads_values(const float *__restrict__ h, const float *__restrict__ wc,
                                                               const float *__restrict__ bc, float *__restrict__ values,
-                                                              long long rows, int R, int vstride, int voff)
+                                                              long long rows, int R, int vstride, int voff,
+                                                              const float *__restrict__ h1, const float *__restrict__ wc1,
+                                                              const float *__restrict__ bc1, int voff1)
 {
+    // (h1 != null: a second player's rows in the same launch — the upper half of the grid)
+    const int half = h1 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const bool second = h1 && (int)blockIdx.x >= half;
+    if (second) { h = h1; wc = wc1; bc = bc1; voff = voff1; }
+    const int bid = second ? (int)blockIdx.x - half : (int)blockIdx.x;
     const int L = R >> 2;
     const long long total = rows * L;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = (long long)bid * blockDim.x + threadIdx.x; idx < total; idx += (long long)half * blockDim.x) {
         const int j = (int)(idx % L) * 4;
         const long long row = idx / L;
         const float v = row_sum(dot4(h_ld4(h + row * R + j), h_ld4(wc + j)), L);
@@ -53,7 +60,8 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_values(const float *__res
 
 struct HeadsLoss {
     const float *h;            // [rows, R]
-    const long long *actions;  // [rows]
+    const long long *actions;  // row r reads actions[(r / act_n) * act_tstride + r % act_n] (a flat vector: act_n >= rows)
+    long long act_n, act_tstride;
     const float *ret, *gae, *val;   // [rows * stride + off]: n-step return, GAE term, value (as written by k_heads_values)
     int stride, off;
     const float *r_aux;        // nullable: reward the aux head predicts, [rows * aux_stride + aux_off]
@@ -66,10 +74,18 @@ struct HeadsLoss {
     float *partial;            // [grid, rec] records: dWa [A*R] | dWc [R] | dWaux [R] | dba [A] | dbc | dbaux | sums[4]
     long long rows;
     int R, A;
+    int grid;                  // workgroups of this player
 };
 
-__global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(HeadsLoss a)
+// up to two players (different weights, hidden sequences, loss coefficients) in one launch: workgroups [0, p[0].grid) are
+// player 0's, the rest player 1's
+struct HeadsLossMulti { HeadsLoss p[2]; };
+
+__global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(const HeadsLossMulti g)
 {
+    const int pi = (int)blockIdx.x >= g.p[0].grid ? 1 : 0;
+    const HeadsLoss &a = g.p[pi];
+    const int bid = (int)blockIdx.x - (pi ? g.p[0].grid : 0), nblk = a.grid;
     __shared__ float red[kHeadsBlock / 16][(kHeadsMaxA + 2) * 4 + 1];   // per row-slot partials during the block reduction
     const int L = a.R >> 2, A = a.A;
     const int slot = (int)threadIdx.x / L, slots = kHeadsBlock / L;
@@ -83,7 +99,7 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(HeadsLoss a)
     for (int i = 0; i < kHeadsMaxA; i++) wa[i] = i < A ? h_ld4(a.wa + i * a.R + j) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 wc = h_ld4(a.wc + j);
     const float4 wx = a.waux ? h_ld4(a.waux + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long row = (long long)blockIdx.x * slots + slot; row < a.rows; row += (long long)gridDim.x * slots) {
+    for (long long row = (long long)bid * slots + slot; row < a.rows; row += (long long)nblk * slots) {
         const float4 hv = h_ld4(a.h + row * a.R + j);
         float z[kHeadsMaxA];
 #pragma unroll
@@ -91,7 +107,8 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(HeadsLoss a)
         const float pred = a.waux ? row_sum(dot4(hv, wx), L) + a.baux[0] : 0.f;
         const long long s = row * a.stride + a.off;
         const float v = a.val[s], ret = a.ret[s], gae = a.gae[s];
-        const int act = (int)a.actions[row];
+        const long long at = row / a.act_n;
+        const int act = (int)a.actions[at * a.act_tstride + (row - at * a.act_n)];
         // softmax statistics (the train branch of sample_action)
         float mx = z[0];
 #pragma unroll
@@ -133,7 +150,11 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(HeadsLoss a)
                 gwa[i].z = fmaf(dz[i], hv.z, gwa[i].z); gwa[i].w = fmaf(dz[i], hv.w, gwa[i].w);
                 gba[i] += dz[i];
             }
-        *reinterpret_cast<float4 *>(a.dh + row * a.R + j) = dh;
+        {
+            float *dp = a.dh + row * a.R + j;             // streamed out (read by the BPTT launch)
+            __builtin_nontemporal_store(dh.x, dp); __builtin_nontemporal_store(dh.y, dp + 1);
+            __builtin_nontemporal_store(dh.z, dp + 2); __builtin_nontemporal_store(dh.w, dp + 3);
+        }
         gwc.x = fmaf(dv, hv.x, gwc.x); gwc.y = fmaf(dv, hv.y, gwc.y); gwc.z = fmaf(dv, hv.z, gwc.z); gwc.w = fmaf(dv, hv.w, gwc.w);
         gwx.x = fmaf(dpred, hv.x, gwx.x); gwx.y = fmaf(dpred, hv.y, gwx.y); gwx.z = fmaf(dpred, hv.z, gwx.z); gwx.w = fmaf(dpred, hv.w, gwx.w);
         gbc += dv; gbx += dpred;
@@ -145,7 +166,7 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(HeadsLoss a)
     // block reduction over the row slots (fixed order), one record per workgroup
     __shared__ float4 wred[kHeadsBlock];
     const int rec = (A + 2) * a.R + (A + 2) + 4;
-    float *out = a.partial + (size_t)blockIdx.x * rec;
+    float *out = a.partial + (size_t)bid * rec;
 #pragma unroll
     for (int q = 0; q < kHeadsMaxA + 2; q++) {
         if (q < A + 2) {                      // uniform: weight vector q = actor row q | critic | aux
@@ -183,27 +204,55 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(HeadsLoss a)
     }
 }
 
-// out[0..rec) = column sums of the records in a fixed order: 16 columns x 64 record slices per block
-__global__ __launch_bounds__(1024) void k_heads_reduce(const float *__restrict__ partial, int nrec, int rec, float *__restrict__ out)
+// out[0..rec) = column sums of the records in a fixed order: 16 columns x 64 record slices per block; blocks [0, nb) are
+// player 0's, [nb, 2 nb) player 1's. The block that holds the four loss sums (columns rec-4 .. rec-1, one block when they do
+// not straddle a multiple of 16) also finishes: out[rec] = this player's contribution to the objective, and the statistics
+// (policy, value, entropy, |aux error| sums x stats_scale) go to stats_out — no separate launches for either.
+struct HeadsReduce {
+    const float *partial[2];
+    float *out[2];
+    float *stats_out[2];       // nullable: 4 floats
+    float scale[2], scale_aux[2];
+    int nrec[2];
+    float stats_scale;
+    int rec, nb, fold;
+};
+
+__global__ __launch_bounds__(1024) void k_heads_reduce(const HeadsReduce f)
 {
     __shared__ float red[64][17];
+    __shared__ float tail[16];
+    const int pi = (int)blockIdx.x >= f.nb ? 1 : 0, b = (int)blockIdx.x - pi * f.nb;
+    const float *__restrict__ partial = f.partial[pi];
+    float *__restrict__ out = f.out[pi];
+    const int nrec = f.nrec[pi], rec = f.rec;
     const int jl = (int)(threadIdx.x & 15u), slice = (int)(threadIdx.x >> 4);
-    const int j = (int)blockIdx.x * 16 + jl;
+    const int j = b * 16 + jl;
     float acc = 0.f;
     if (j < rec)
         for (int r = slice; r < nrec; r += 64) acc += partial[(size_t)r * rec + j];
     red[slice][jl] = acc;
     __syncthreads();
-    if (slice == 0 && j < rec) {
+    if (slice == 0) {
         acc = 0.f;
         for (int q = 0; q < 64; q++) acc += red[q][jl];
-        out[j] = acc;
+        if (j < rec) out[j] = acc;
+        tail[jl] = acc;
+    }
+    __syncthreads();
+    if (f.fold && threadIdx.x == 0 && b == (rec - 4) / 16) {
+        const int o = (rec - 4) & 15;
+        out[rec] = f.scale[pi] * (tail[o] + 0.5f * tail[o + 1]) + f.scale_aux[pi] * tail[o + 3];
+        if (f.stats_out[pi])
+            for (int q = 0; q < 4; q++) f.stats_out[pi][q] = tail[o + q] * f.stats_scale;
     }
 }
-// out[rec] = this player's contribution to the objective
-__global__ void k_heads_finish(float *out, int rec, float scale, float scale_aux)
+// (the straddling case) out[rec] = this player's contribution to the objective
+__global__ void k_heads_finish(float *out, int rec, float scale, float scale_aux, float *stats_out, float stats_scale)
 {
     out[rec] = scale * (out[rec - 4] + 0.5f * out[rec - 3]) + scale_aux * out[rec - 1];
+    if (stats_out)
+        for (int q = 0; q < 4; q++) stats_out[q] = out[rec - 4 + q] * stats_scale;
 }
 
 static int heads_grid(long long rows, int R)
@@ -218,19 +267,26 @@ static int heads_grid(long long rows, int R)
 
 using namespace atr;
 
-extern "C" int atr_heads_values(const float *h, const float *wc, const float *bc, float *values, long long rows, int R,
-                                int vstride, int voff, void *stream)
+extern "C" int atr_heads_values2(const float *h, const float *wc, const float *bc, int voff, const float *h1, const float *wc1,
+                                 const float *bc1, int voff1, float *values, long long rows, int R, int vstride, void *stream)
 {
     const int L = R / 4;
     if (!h || !wc || !bc || !values || rows < 0 || R <= 0 || (R & 3) || (L != 16 && L != 32 && L != 64) || vstride < 1 ||
         voff < 0 || voff >= vstride)
         return -1;
+    if (h1 && (!wc1 || !bc1 || voff1 < 0 || voff1 >= vstride)) return -1;
     if (rows == 0) return 0;
     long long blocks = (rows * L + kHeadsBlock - 1) / kHeadsBlock;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_heads_values, dim3((unsigned)blocks), dim3(kHeadsBlock), 0, (hipStream_t)stream, h, wc, bc, values,
-                       rows, R, vstride, voff);
+    hipLaunchKernelGGL(k_heads_values, dim3((unsigned)(h1 ? 2 * blocks : blocks)), dim3(kHeadsBlock), 0, (hipStream_t)stream, h, wc,
+                       bc, values, rows, R, vstride, voff, h1, wc1, bc1, voff1);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int atr_heads_values(const float *h, const float *wc, const float *bc, float *values, long long rows, int R,
+                                int vstride, int voff, void *stream)
+{
+    return atr_heads_values2(h, wc, bc, voff, nullptr, nullptr, nullptr, 0, values, rows, R, vstride, stream);
 }
 
 extern "C" long long atr_heads_workspace_floats(long long rows, int R, int A)
@@ -239,26 +295,57 @@ extern "C" long long atr_heads_workspace_floats(long long rows, int R, int A)
     return (long long)heads_grid(rows, R) * ((A + 2) * R + (A + 2) + 4);
 }
 
+static int heads_fill(HeadsLoss &a, const atr_heads_loss_args &p)
+{
+    const int L = p.R / 4;
+    if (!p.h || !p.actions || !p.ret || !p.gae || !p.val || !p.wa || !p.ba || !p.wc || !p.dh || !p.grads_and_sums ||
+        !p.workspace || p.rows <= 0 || p.R <= 0 || (p.R & 3) || (L != 16 && L != 32 && L != 64) || p.A < 1 || p.A > kHeadsMaxA ||
+        p.stride < 1 || p.off < 0 || p.off >= p.stride || ((p.waux != nullptr) != (p.baux != nullptr)) || (p.r_aux && !p.waux) ||
+        p.act_n < 1)
+        return -1;
+    a.h = p.h; a.actions = p.actions; a.act_n = p.act_n; a.act_tstride = p.act_tstride; a.ret = p.ret; a.gae = p.gae;
+    a.val = p.val; a.stride = p.stride; a.off = p.off; a.r_aux = p.r_aux; a.aux_stride = p.aux_stride; a.aux_off = p.aux_off;
+    a.wa = p.wa; a.ba = p.ba; a.wc = p.wc; a.waux = p.waux; a.baux = p.baux; a.scale = p.scale; a.scale_aux = p.scale_aux;
+    a.w_ent = p.w_ent; a.dh = p.dh; a.partial = p.workspace; a.rows = p.rows; a.R = p.R; a.A = p.A;
+    a.grid = heads_grid(p.rows, p.R);
+    return 0;
+}
+
+extern "C" int atr_heads_loss_multi(const atr_heads_loss_args *players, int count, float stats_scale, void *stream)
+{
+    if (!players || count < 1 || count > 2) return -1;
+    HeadsLossMulti g;
+    HeadsReduce f;
+    for (int i = 0; i < 2; i++) {
+        const atr_heads_loss_args &p = players[i < count ? i : 0];
+        if (heads_fill(g.p[i], p) != 0) return -1;
+        if (i >= count) g.p[i].grid = 0;
+        f.partial[i] = p.workspace; f.out[i] = p.grads_and_sums; f.stats_out[i] = p.stats_out; f.scale[i] = p.scale;
+        f.scale_aux[i] = p.scale_aux; f.nrec[i] = g.p[i].grid;
+    }
+    if (count == 2 && (players[0].R != players[1].R || players[0].A != players[1].A)) return -1;
+    const int rec = (players[0].A + 2) * players[0].R + (players[0].A + 2) + 4;
+    f.stats_scale = stats_scale; f.rec = rec; f.nb = (rec + 15) / 16; f.fold = (rec - 4) / 16 == (rec - 1) / 16 ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_heads_loss, dim3((unsigned)(g.p[0].grid + g.p[1].grid)), dim3(kHeadsBlock), 0, st, g);
+    hipLaunchKernelGGL(k_heads_reduce, dim3((unsigned)(f.nb * count)), dim3(1024), 0, st, f);
+    if (!f.fold)
+        for (int i = 0; i < count; i++)
+            hipLaunchKernelGGL(k_heads_finish, dim3(1), dim3(1), 0, st, players[i].grads_and_sums, rec, players[i].scale,
+                               players[i].scale_aux, players[i].stats_out, stats_scale);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int atr_heads_loss(const float *h, const long long *actions, const float *ret, const float *gae,
                               const float *val, int stride, int off, const float *r_aux, int aux_stride, int aux_off,
                               const float *wa, const float *ba, const float *wc, const float *waux, const float *baux,
                               float scale, float scale_aux, float w_ent, float *dh, float *grads_and_sums,
                               float *workspace, long long rows, int R, int A, void *stream)
 {
-    const int L = R / 4;
-    if (!h || !actions || !ret || !gae || !val || !wa || !ba || !wc || !dh || !grads_and_sums || !workspace || rows <= 0 ||
-        R <= 0 || (R & 3) || (L != 16 && L != 32 && L != 64) || A < 1 || A > kHeadsMaxA || stride < 1 || off < 0 ||
-        off >= stride || ((waux != nullptr) != (baux != nullptr)) || (r_aux && !waux))
-        return -1;
-    HeadsLoss a;
-    a.h = h; a.actions = actions; a.ret = ret; a.gae = gae; a.val = val; a.stride = stride; a.off = off;
-    a.r_aux = r_aux; a.aux_stride = aux_stride; a.aux_off = aux_off; a.wa = wa; a.ba = ba; a.wc = wc; a.waux = waux;
-    a.baux = baux; a.scale = scale; a.scale_aux = scale_aux; a.w_ent = w_ent; a.dh = dh; a.partial = workspace;
-    a.rows = rows; a.R = R; a.A = A;
-    const int grid = heads_grid(rows, R), rec = (A + 2) * R + (A + 2) + 4;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_heads_loss, dim3((unsigned)grid), dim3(kHeadsBlock), 0, st, a);
-    hipLaunchKernelGGL(k_heads_reduce, dim3((unsigned)((rec + 15) / 16)), dim3(1024), 0, st, workspace, grid, rec, grads_and_sums);
-    hipLaunchKernelGGL(k_heads_finish, dim3(1), dim3(1), 0, st, grads_and_sums, rec, scale, scale_aux);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    atr_heads_loss_args p = {};
+    p.h = h; p.actions = actions; p.act_n = rows > 0 ? rows : 1; p.act_tstride = 0; p.ret = ret; p.gae = gae; p.val = val;
+    p.stride = stride; p.off = off; p.r_aux = r_aux; p.aux_stride = aux_stride; p.aux_off = aux_off; p.wa = wa; p.ba = ba;
+    p.wc = wc; p.waux = waux; p.baux = baux; p.scale = scale; p.scale_aux = scale_aux; p.w_ent = w_ent; p.dh = dh;
+    p.grads_and_sums = grads_and_sums; p.workspace = workspace; p.stats_out = nullptr; p.rows = rows; p.R = R; p.A = A;
+    return atr_heads_loss_multi(&p, 1, 1.0f, stream);
 }

@@ -38,6 +38,23 @@ class PairLinearArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("relu", C.c_int)]
 
 
+class HeadsLossArgs(C.Structure):
+    """atr_heads_loss_args of include/atr_policy.h."""
+    _fields_ = [("h", C.c_void_p), ("actions", C.c_void_p), ("act_n", C.c_longlong), ("act_tstride", C.c_longlong),
+                ("ret", C.c_void_p), ("gae", C.c_void_p), ("val", C.c_void_p), ("stride", C.c_int), ("off", C.c_int),
+                ("r_aux", C.c_void_p), ("aux_stride", C.c_int), ("aux_off", C.c_int), ("wa", C.c_void_p), ("ba", C.c_void_p),
+                ("wc", C.c_void_p), ("waux", C.c_void_p), ("baux", C.c_void_p), ("scale", C.c_float),
+                ("scale_aux", C.c_float), ("w_ent", C.c_float), ("dh", C.c_void_p), ("grads_and_sums", C.c_void_p),
+                ("workspace", C.c_void_p), ("stats_out", C.c_void_p), ("rows", C.c_longlong), ("R", C.c_int), ("A", C.c_int)]
+
+
+class GemmTnProblem(C.Structure):
+    """atr_gemm_tn_problem of include/atr_policy.h."""
+    _fields_ = [("x1", C.c_void_p), ("x2", C.c_void_p), ("c", C.c_void_p), ("row_scale", C.c_void_p),
+                ("row_scale_shift", C.c_longlong), ("colsum0", C.c_void_p), ("colsum1", C.c_void_p), ("M", C.c_int),
+                ("N", C.c_int)]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -67,11 +84,11 @@ def lib():
         L.atr_lstm_cell_forward_act2.argtypes = [vp] * 5 + [ll, vp, vp, ll, vp, ll, vp, ll] + [vp] * 4 + [i32, vp, vp,
                                                  C.c_ulonglong, C.c_uint, i32, i32, vp]
         L.atr_embed_add.restype = i32
-        L.atr_embed_add.argtypes = [vp, vp, vp, vp, ll, vp, ll, i32, i32, vp]
+        L.atr_embed_add.argtypes = [vp, vp, vp, vp, ll, ll, ll, vp, ll, i32, i32, vp]
         L.atr_embed_grad_workspace_floats.restype = ll
         L.atr_embed_grad_workspace_floats.argtypes = [ll, i32, i32]
         L.atr_embed_grad.restype = i32
-        L.atr_embed_grad.argtypes = [vp, vp, ll, vp, vp, vp, ll, i32, i32, vp]
+        L.atr_embed_grad.argtypes = [vp, vp, ll, ll, ll, vp, vp, vp, ll, i32, i32, vp]
         L.atr_lstm_bptt.restype = i32
         L.atr_lstm_bptt.argtypes = [vp, vp, vp, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, i32, i32, i32, i32, vp]
         L.atr_pair_linear.restype = i32
@@ -84,6 +101,10 @@ def lib():
         L.atr_lstm_cell_backward.argtypes = [vp, ll, vp, vp, vp, vp, vp, ll, vp, ll, vp, ll, vp, ll, i32, i32, i32, i32, vp]
         L.atr_heads_values.restype = i32
         L.atr_heads_values.argtypes = [vp, vp, vp, vp, ll, i32, i32, i32, vp]
+        L.atr_heads_values2.restype = i32
+        L.atr_heads_values2.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, ll, i32, i32, vp]
+        L.atr_heads_loss_multi.restype = i32
+        L.atr_heads_loss_multi.argtypes = [C.POINTER(HeadsLossArgs), i32, C.c_float, vp]
         L.atr_heads_workspace_floats.restype = ll
         L.atr_heads_workspace_floats.argtypes = [ll, i32, i32]
         L.atr_heads_loss.restype = i32
@@ -93,12 +114,20 @@ def lib():
         L.atr_gemm_tn_workspace_floats.argtypes = [ll, i32, i32]
         L.atr_gemm_tn.restype = i32
         L.atr_gemm_tn.argtypes = [vp, vp, vp, vp, ll, i32, i32, vp, vp, vp]
+        L.atr_gemm_tn_grouped_workspace_floats.restype = ll
+        L.atr_gemm_tn_grouped_workspace_floats.argtypes = [C.POINTER(GemmTnProblem), i32, ll]
+        L.atr_gemm_tn_grouped.restype = i32
+        L.atr_gemm_tn_grouped.argtypes = [C.POINTER(GemmTnProblem), i32, ll, vp, vp]
+        L.atr_scatter_segments.restype = i32
+        L.atr_scatter_segments.argtypes = [C.POINTER(C.c_void_p), C.POINTER(ll), C.POINTER(i32), i32, vp, vp]
         L.atr_gae_returns.restype = i32
         L.atr_gae_returns.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, i32, vp]
         L.atr_rollout_begin.restype = i32
         L.atr_rollout_begin.argtypes = [vp, vp, vp, vp, ll, vp, vp, ll, i32, i32, i32, vp]
         L.atr_rollout_end.restype = i32
         L.atr_rollout_end.argtypes = [vp, vp, ll, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+        L.atr_rollout_end2.restype = i32
+        L.atr_rollout_end2.argtypes = [vp, vp, ll, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, ll, vp, vp]
         L.atr_adam_step.restype = i32
         L.atr_adam_step.argtypes = [vp] * 7 + [C.c_double] * 5 + [i32, ll, vp]
         L.atr_rmsprop_step.restype = i32
@@ -225,14 +254,18 @@ class _LinearReluCached(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, f):
-        ctx.save_for_backward(x, w, f)
+        ctx.save_for_backward(x, w, f, b)
         return f.view_as(f)
 
     @staticmethod
     def backward(ctx, df):
-        x, w, f = ctx.saved_tensors
+        x, w, f, b = ctx.saved_tensors
         dpre = torch.ops.aten.threshold_backward(df.contiguous(), f, 0.0)
-        dw, db = gemm_tn(dpre, x, colsum=True)
+        r = _deferred.add(dpre, x, w, biases=(b,)) if _deferred is not None else None
+        if r is not None:                  # joins the backward pass's grouped weight-gradient launch
+            dw, (db,) = r
+        else:
+            dw, db = gemm_tn(dpre, x, colsum=True)
         return dpre @ w, dw, db, None
 
 
@@ -378,7 +411,7 @@ class _LstmSeq(torch.autograd.Function):
 use_fused_bptt = True   # the whole recurrence backward as ONE launch (csrc/bptt_hip.hip) instead of 2 launches per step
 
 
-def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs, whh_nn=None):
+def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs, whh_nn=None, want_dwhh=True):
     """Back-propagation through time over stored activations: dhs = per-player dL/dh_seq [T,N,R] (None = zero).
     Returns dG [P, T*N, 4R] (= dL/d ig), dL/dh0, dL/dc0 [P,N,R] and dL/dW_hh^T [P,R,4R]. whh_nn: per-player weight_hh [4R,R]
     (nn layout; made from whh [P,R,4R] when absent)."""
@@ -414,6 +447,8 @@ def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs, whh_nn=None):
             if rc != 0:
                 raise RuntimeError("atr_lstm_cell_backward failed (%d)" % rc)
             torch.bmm(dG[:, t], whh_t, out=dhn)                                   # gradient into h_{t-1}
+    if not want_dwhh:          # (the caller registers dW_hh with the grouped weight-gradient launch)
+        return dG.view(P, T * N, 4 * R), dhn, dcc, None
     # W_hh: sum_t (k_{t-1} h_{t-1})^T dG_t as one GEMM per player over all T*N rows
     kprev = torch.cat([torch.ones_like(keep[:1]), keep[:-1]], 0)              # [T, N]: mask on h_{t-1}
     dG = dG.view(P, T * N, 4 * R)
@@ -436,8 +471,10 @@ class _LstmSeqCached(torch.autograd.Function):
     def forward(ctx, keep, h_all, c_all, acts, need, *fw):
         P = h_all.shape[0]
         feats, wih, whh_l = fw[:P], fw[P:2 * P], fw[2 * P:3 * P]
-        whh = torch.stack([w.t() for w in whh_l], 0).contiguous()
-        ctx.save_for_backward(keep.contiguous(), h_all, c_all, acts, whh, *feats, *wih, *whh_l)
+        # ([P, R, 4R] transposed copy: only the per-step fallback recurrence reads it — the fused BPTT kernel takes weight_hh as is)
+        fused_path = use_fused_bptt and h_all.shape[-1] == 128 and h_all.is_cuda
+        whh = h_all.new_empty(0) if fused_path else torch.stack([w.t() for w in whh_l], 0).contiguous()
+        ctx.save_for_backward(keep.contiguous(), h_all, c_all, acts, whh, *feats, *wih, *whh_l, *fw[3 * P:5 * P])
         ctx.P = P
         ctx.need = tuple(bool(x) for x in need) if need is not None else (True,) * P
         return tuple(h_all[p, 1:] for p in range(P))
@@ -448,19 +485,47 @@ class _LstmSeqCached(torch.autograd.Function):
         keep, h_all, c_all, acts, whh = ctx.saved_tensors[:5]
         feats, wih = ctx.saved_tensors[5:5 + P], ctx.saved_tensors[5 + P:5 + 2 * P]
         whh_nn = ctx.saved_tensors[5 + 2 * P:5 + 3 * P]          # weight_hh [4R, R] as nn.LSTMCell holds it
+        bih, bhh = ctx.saved_tensors[5 + 3 * P:5 + 4 * P], ctx.saved_tensors[5 + 4 * P:5 + 5 * P]
         dfeat, dwih, db, dwhh_l = [None] * P, [None] * P, [None] * P, [None] * P
+        db2 = None
+        q = _deferred
+        T, N, R = h_all.shape[1] - 1, h_all.shape[2], h_all.shape[3]
+        if whh.numel() == 0 and not (use_fused_bptt and R == 128 and acts.is_contiguous() and c_all.is_contiguous()):
+            whh = torch.stack([w.t() for w in whh_nn], 0).contiguous()
         if all(ctx.need):
             groups = [list(range(P))]
         else:       # a player the loss does not train (train-mode 0 / 1): none of its recurrence is back-propagated
             groups = [[p] for p in range(P) if ctx.need[p]]
         for grp in groups:
             a, b = grp[0], grp[-1] + 1
-            dG, _, _, dwhh = _lstm_bptt(whh[a:b], keep, h_all[a:b], c_all[a:b], acts[a:b], dhs[a:b], whh_nn=list(whh_nn[a:b]))
+            defer = q is not None and use_fused_bptt and R == 128 and T * N >= 4096
+            dG, _, _, dwhh = _lstm_bptt(whh[a:b], keep, h_all[a:b], c_all[a:b], acts[a:b], dhs[a:b], whh_nn=list(whh_nn[a:b]),
+                                        want_dwhh=not defer)
             for i, p in enumerate(grp):
                 dfeat[p] = dG[i] @ wih[p]
+                if defer:
+                    # both products of this player contract dG: registered with the grouped launch. dW_hh^T = dG^T (k h):
+                    # the mask on h_{t-1} is keep[t-1] = the keep array shifted by one step of N rows, applied to dG's rows
+                    r1 = q.add(dG[i], feats[p], wih[p], biases=(bih[p], bhh[p]))
+                    r2 = q.add(dG[i], h_all[p, :T].reshape(T * N, R), whh_nn[p], row_scale=keep, shift=N) \
+                        if r1 is not None else None
+                    if r1 is not None and r2 is not None:
+                        dwih[p], (dbi, dbh) = r1
+                        dwhh_l[p] = r2[0]
+                        db[p] = dbi
+                        db2 = db2 if db2 is not None else [None] * P
+                        db2[p] = dbh
+                        continue
+                    if r1 is not None:         # (cannot happen for R = 128; keep the queue consistent if it ever does)
+                        raise RuntimeError("grouped weight gradients: dW_hh could not join the group after dW_ih did")
+                    kprev = torch.cat([torch.ones_like(keep[:1]), keep[:-1]], 0).reshape(T * N)
+                    dwhh_l[p] = gemm_tn(h_all[p, :T].reshape(T * N, R), dG[i], row_scale=kprev).t()
+                    dwih[p], db[p] = gemm_tn(dG[i], feats[p], colsum=True)
+                    continue
                 dwih[p], db[p] = gemm_tn(dG[i], feats[p], colsum=True)
                 dwhh_l[p] = dwhh[i].t()
-        return (None, None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + tuple(db)
+        db_hh = tuple(db2[p] if (db2 is not None and db2[p] is not None) else db[p] for p in range(P))
+        return (None, None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + db_hh
 
 
 def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts, need=None):
@@ -649,6 +714,107 @@ def heads_values(h, critic, values, off):
         raise RuntimeError("atr_heads_values failed (%d)" % rc)
 
 
+@torch.no_grad()
+def heads_values2(hs, critics, values):
+    """heads_values for both players in one launch: values[..., p] = critics[p](hs[p]) for p = 0, 1."""
+    h0, h1 = hs[0].contiguous(), hs[1].contiguous()
+    rows, R = h0.shape
+    assert h1.shape == h0.shape
+    A = values.shape[-2] if values.shape[-1] == 1 else values.shape[-1]
+    rc = lib().atr_heads_values2(_p(h0), _p(critics[0].weight), _p(critics[0].bias), 0, _p(h1), _p(critics[1].weight),
+                                 _p(critics[1].bias), 1, _p(values), rows, R, A, _stream(h0))
+    if rc != 0:
+        raise RuntimeError("atr_heads_values2 failed (%d)" % rc)
+
+
+def _act_layout(actions, rows):
+    """(tensor whose data_ptr is the first action, act_n, act_tstride) for actions given as a flat [rows] vector or as a
+    [T, N] view whose rows are contiguous (one player's column of the rollout's [T, players, N] store): read in place."""
+    if actions.dim() == 2 and actions.stride(1) == 1 and actions.shape[0] * actions.shape[1] == rows:
+        return actions, actions.shape[1], actions.stride(0)
+    a = actions.reshape(rows).contiguous()
+    return a, rows, 0
+
+
+class _HeadsLossPair(torch.autograd.Function):
+    """Both players' heads + A3C loss terms over all stored steps as ONE autograd node and one launch + one reduction launch
+    (atr_heads_loss_multi): forward already produces dL/dh and the head-parameter gradients for coefficient 1; backward hands
+    them out (the two outputs must enter the objective with coefficient 1 each — Agent._loss_fused_heads differentiates
+    their sum). Inputs per player: h, actor w/b, critic w/b, aux w/b (None). Outputs: (term0, term1, stats [2, 4])."""
+
+    @staticmethod
+    def forward(ctx, cfg, *t):
+        L = lib()
+        arr = (HeadsLossArgs * 2)()
+        hs, keep = [], []
+        for p in range(2):
+            h, wa, ba, wc, bc, waux, baux = t[7 * p:7 * p + 7]
+            c = cfg[p]
+            h = h.contiguous()
+            rows, R = h.shape
+            A = wa.shape[0]
+            rec = (A + 2) * R + (A + 2) + 4
+            dh = torch.empty_like(h)
+            gs = torch.empty(rec + 1, dtype=torch.float32, device=h.device)
+            ws = torch.empty(L.atr_heads_workspace_floats(rows, R, A), dtype=torch.float32, device=h.device)
+            acts, act_n, act_ts = _act_layout(c["actions"], rows)
+            ret = c["ret"]
+            a = arr[p]
+            a.h, a.actions, a.act_n, a.act_tstride = h.data_ptr(), acts.data_ptr(), act_n, act_ts
+            a.ret, a.gae, a.val = ret.data_ptr(), c["gae"].data_ptr(), c["val"].data_ptr()
+            a.stride = ret.shape[-2] if ret.shape[-1] == 1 else ret.shape[-1]
+            a.off = c["off"]
+            r_aux = c.get("r_aux")
+            a.r_aux = r_aux.data_ptr() if r_aux is not None else None
+            a.aux_stride = (r_aux.shape[-2] if r_aux.shape[-1] == 1 else r_aux.shape[-1]) if r_aux is not None else 0
+            a.aux_off = c.get("aux_off", 0)
+            a.wa, a.ba, a.wc = wa.data_ptr(), ba.data_ptr(), wc.data_ptr()
+            a.waux = waux.data_ptr() if waux is not None else None
+            a.baux = baux.data_ptr() if baux is not None else None
+            a.scale, a.scale_aux, a.w_ent = float(c["scale"]), float(c["scale_aux"]), float(c["w_ent"])
+            a.dh, a.grads_and_sums, a.workspace = dh.data_ptr(), gs.data_ptr(), ws.data_ptr()
+            a.rows, a.R, a.A = rows, R, A
+            hs.append((dh, gs, A, R, waux is not None, rec))
+            keep += [h, acts, ws]
+        stats = torch.empty((2, 4), dtype=torch.float32, device=hs[0][0].device)
+        arr[0].stats_out, arr[1].stats_out = stats.data_ptr(), stats.data_ptr() + 16
+        rc = L.atr_heads_loss_multi(arr, 2, float(cfg[0]["stats_scale"]), _stream(hs[0][0]))
+        if rc != 0:
+            raise RuntimeError("atr_heads_loss_multi failed (%d)" % rc)
+        ctx.save_for_backward(hs[0][0], hs[0][1], hs[1][0], hs[1][1])
+        ctx.dims = [(x[2], x[3], x[4]) for x in hs]
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(stats)
+        return hs[0][1][hs[0][5]], hs[1][1][hs[1][5]], stats
+
+    @staticmethod
+    def backward(ctx, g0, g1, gstats):
+        sv = ctx.saved_tensors
+        out = [None]
+        for p in range(2):
+            dh, gs = sv[2 * p], sv[2 * p + 1]
+            A, R, has_aux = ctx.dims[p]
+            if (g0, g1)[p] is None:                 # this player's term is not part of the differentiated objective
+                out += [None] * 7
+                continue
+            o = (A + 2) * R
+            dwa, dwc, dwx = gs[:A * R].view(A, R), gs[A * R:(A + 1) * R].view(1, R), gs[(A + 1) * R:o].view(1, R)
+            dba, dbc, dbx = gs[o:o + A], gs[o + A:o + A + 1], gs[o + A + 1:o + A + 2]
+            out += [dh, dwa, dba, dwc, dbc, dwx if has_aux else None, dbx if has_aux else None]
+        return tuple(out)
+
+
+def heads_loss_pair(hs, actors, critics, auxes, cfg):
+    """-> (term0, term1, stats [2, 4]); cfg: per player dict(actions, ret, gae, val, off, r_aux, aux_off, scale, scale_aux, w_ent,
+    stats_scale). The terms must be summed into the objective with coefficient 1 (their gradients are handed out as they are)."""
+    t = []
+    for p in range(2):
+        aux = auxes[p]
+        t += [hs[p], actors[p].weight, actors[p].bias, critics[p].weight, critics[p].bias,
+              aux.weight if aux is not None else None, aux.bias if aux is not None else None]
+    return _HeadsLossPair.apply(cfg, *t)
+
+
 class _HeadsLoss(torch.autograd.Function):
     """One player's heads + A3C loss terms over all stored steps as ONE autograd node (csrc/heads_hip.hip): forward
     launches the fused kernel, which already produces dL/dh and the head-parameter gradients; backward hands them
@@ -717,36 +883,129 @@ class _EmbedAdd(torch.autograd.Function):
         A = w.shape[1]
         wc, bc = w.contiguous(), b.contiguous()
         out = torch.empty_like(f)
-        rc = lib().atr_embed_add(_p(f), _p(wc), _p(bc), _p(actions), actions.stride(0), _p(out), rows, Cc, A, _stream(f))
+        acts, act_n, act_ts = _act_layout(actions, rows)
+        rc = lib().atr_embed_add(_p(f), _p(wc), _p(bc), _p(acts), 1, act_n, act_ts, _p(out), rows, Cc, A, _stream(f))
         if rc != 0:
             raise RuntimeError("atr_embed_add failed (%d)" % rc)
-        ctx.save_for_backward(actions)
-        ctx.dims = (Cc, A)
+        ctx.save_for_backward(acts)
+        ctx.dims = (Cc, A, act_n, act_ts)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (actions,) = ctx.saved_tensors
-        Cc, A = ctx.dims
+        (acts,) = ctx.saved_tensors
+        Cc, A, act_n, act_ts = ctx.dims
         dout = dout.contiguous()
         rows = dout.shape[0]
         L = lib()
         ws = torch.empty(L.atr_embed_grad_workspace_floats(rows, Cc, A), dtype=torch.float32, device=dout.device)
         dw = torch.empty((Cc, A), dtype=torch.float32, device=dout.device)
         db = torch.empty(Cc, dtype=torch.float32, device=dout.device)
-        rc = L.atr_embed_grad(_p(dout), _p(actions), actions.stride(0), _p(dw), _p(db), _p(ws), rows, Cc, A, _stream(dout))
+        rc = L.atr_embed_grad(_p(dout), _p(acts), 1, act_n, act_ts, _p(dw), _p(db), _p(ws), rows, Cc, A, _stream(dout))
         if rc != 0:
             raise RuntimeError("atr_embed_grad failed (%d)" % rc)
         return dout, dw, db, None
 
 
 def embed_add(f, linear, actions):
-    """f [rows, C] + linear(one_hot(actions [rows] int64 (any stride), A)) for linear = nn.Linear(A, C)."""
-    assert actions.dim() == 1 and actions.dtype == torch.int64 and f.dim() == 2
+    """f [rows, C] + linear(one_hot(actions, A)) for linear = nn.Linear(A, C); actions int64: a flat [rows] vector, or a [T, N]
+    view with contiguous rows (one player's column of the rollout's [T, players, N] store, read in place)."""
+    assert actions.dtype == torch.int64 and f.dim() == 2 and actions.numel() == f.shape[0]
     return _EmbedAdd.apply(f, linear.weight, linear.bias, actions)
 
 
 use_gemm_tn = True
+use_grouped_dw = True       # the learner's weight-gradient GEMMs of one backward pass as ONE grouped launch (DeferredWeightGrads)
+_deferred = None            # the open DeferredWeightGrads of the backward pass in flight, if any
+
+
+class DeferredWeightGrads(object):
+    """The weight-gradient GEMMs of one backward pass, collected and launched together (atr_gemm_tn_grouped).
+
+    Each cached-forward autograd node used to launch its own split-K GEMM, reduction and bias column-sum as it ran: 16
+    launches for six products that share K = T*N rows, the small ones split into 128 K-slices to fill the chip on their own.
+    Opened around torch.autograd.grad by Agent.compute_grads, this object lets those nodes only REGISTER their product
+    (operands, the parameter it belongs to) and hands them the parameter's slice of the flat gradient bucket as the gradient
+    they return — filled when flush() launches all products as one grouped GEMM + one reduction that writes straight into
+    those slices (so FlatParams.set_grads has nothing to copy for them). Operands are kept alive until the flush."""
+
+    MAX = 8
+
+    def __init__(self, bucket):
+        self.views = {}
+        for prm, v in zip(bucket.params, bucket.grad_views()):
+            self.views[prm.data_ptr()] = v
+        self.problems, self.K, self.registered = [], None, set()
+
+    def view(self, prm):
+        return self.views.get(prm.data_ptr()) if prm is not None else None
+
+    def add(self, x1, x2, weight, biases=(), row_scale=None, shift=0):
+        """Register dW = x1^T x2 -> `weight`'s gradient slice, colsum(x1) -> the slices of `biases` (<= 2). Returns
+        (dW view, [bias views]) or None when this product cannot join the group (shape class, parameter not in the bucket, a
+        different K, group full): the caller then computes it on the spot."""
+        K, M = x1.shape
+        N = x2.shape[1]
+        dst = self.view(weight)
+        bv = [self.view(b) for b in biases]
+        if (dst is None or any(v is None for v in bv) or len(bv) > 2 or len(self.problems) >= self.MAX
+                or (self.K is not None and K != self.K) or K < 4096 or M % 128 or N % 128
+                or not (x1.is_cuda and x1.dtype == torch.float32 and x2.dtype == torch.float32
+                        and x1.is_contiguous() and x2.is_contiguous())
+                or tuple(dst.shape) != (M, N) or (row_scale is not None and not row_scale.is_contiguous())):
+            return None
+        self.K = K
+        self.problems.append((x1, x2, dst, row_scale, int(shift), bv, M, N))
+        self.registered.update(v.data_ptr() for v in [dst] + bv)
+        return dst, bv
+
+    def check(self, grads):
+        """The gradients autograd handed back for the registered parameters must BE the bucket slices the nodes returned (a
+        parameter feeding two nodes would make autograd sum into a fresh tensor before the slice is filled)."""
+        got = set(g.data_ptr() for g in grads if g is not None)
+        if not self.registered <= got:
+            raise RuntimeError("grouped weight gradients: autograd did not return the registered bucket slices as they are "
+                               "(a parameter with more than one gradient contribution?); set fused.use_grouped_dw = False")
+
+    @torch.no_grad()
+    def flush(self):
+        if not self.problems:
+            return
+        n = len(self.problems)
+        arr = (GemmTnProblem * n)()
+        for q, (x1, x2, dst, rs, shift, bv, M, N) in enumerate(self.problems):
+            arr[q].x1, arr[q].x2, arr[q].c = x1.data_ptr(), x2.data_ptr(), dst.data_ptr()
+            arr[q].row_scale = rs.data_ptr() if rs is not None else None
+            arr[q].row_scale_shift = shift
+            arr[q].colsum0 = bv[0].data_ptr() if len(bv) > 0 else None
+            arr[q].colsum1 = bv[1].data_ptr() if len(bv) > 1 else None
+            arr[q].M, arr[q].N = M, N
+        L = lib()
+        x0 = self.problems[0][0]
+        ws = torch.empty(L.atr_gemm_tn_grouped_workspace_floats(arr, n, self.K), dtype=torch.float32, device=x0.device)
+        rc = L.atr_gemm_tn_grouped(arr, n, self.K, _p(ws), _stream(x0))
+        if rc != 0:
+            raise RuntimeError("atr_gemm_tn_grouped failed (%d)" % rc)
+        self.problems, self.K = [], None
+
+
+class deferred_weight_grads(object):
+    """with deferred_weight_grads(bucket) as q: grads = torch.autograd.grad(...); q.flush()"""
+
+    def __init__(self, bucket):
+        self.bucket = bucket
+
+    def __enter__(self):
+        global _deferred
+        self.q = DeferredWeightGrads(self.bucket) if (use_grouped_dw and use_gemm_tn and self.bucket.grad.is_cuda) else None
+        _deferred = self.q
+        return self.q
+
+    def __exit__(self, *exc):
+        global _deferred
+        _deferred = None
+        return False
+
 
 
 @torch.no_grad()
@@ -792,16 +1051,24 @@ def rollout_begin(hxs, cxs, h_all, c_all, obs_src=None, obs_dst=None):
 
 
 @torch.no_grad()
-def rollout_end(h_all, c_all, dones, hxs, cxs, eps_len, keep):
+def rollout_end(h_all, c_all, dones, hxs, cxs, eps_len, keep, obs_src=None, obs_dst=None, done_dst=None):
     """Slot T of h_all/c_all [A,T+1,N,R], masked by dones[T-1], -> hxs/cxs [N,A,R] (in place); eps_len [N] int32 advanced
-    over the rollout's dones [T,N] uint8 (in place); keep [T,N] float32 = (dones == 0)."""
+    over the rollout's dones [T,N] uint8 (in place); keep [T,N] float32 = (dones == 0). Optionally, in the same launch:
+    obs_src -> obs_dst (same bytes: the observation the next rollout starts from) and dones[T-1] -> done_dst [N] uint8."""
     A, T1, N, R = h_all.shape
     T = T1 - 1
     assert dones.shape == (T, N) and dones.dtype == torch.uint8 and dones.is_contiguous()
     assert hxs.shape == (N, A, R) and hxs.is_contiguous() and cxs.is_contiguous() and keep.is_contiguous()
     assert eps_len.dtype == torch.int32 and eps_len.is_contiguous() and keep.shape == (T, N)
-    rc = lib().atr_rollout_end(_p(h_all[0, T]), _p(c_all[0, T]), h_all.stride(0), _p(dones), _p(hxs), _p(cxs), _p(eps_len),
-                               _p(keep), T, N, A, R, _stream(hxs))
+    nbytes = 0
+    if obs_src is not None:
+        assert obs_src.is_contiguous() and obs_dst.is_contiguous() and obs_src.dtype == obs_dst.dtype
+        nbytes = obs_src.numel() * obs_src.element_size()
+        assert nbytes == obs_dst.numel() * obs_dst.element_size() and nbytes % 4 == 0
+    if done_dst is not None:
+        assert done_dst.dtype == torch.uint8 and done_dst.is_contiguous() and done_dst.numel() == N
+    rc = lib().atr_rollout_end2(_p(h_all[0, T]), _p(c_all[0, T]), h_all.stride(0), _p(dones), _p(hxs), _p(cxs), _p(eps_len),
+                                _p(keep), T, N, A, R, _pn(obs_src), _pn(obs_dst), nbytes, _pn(done_dst), _stream(hxs))
     if rc != 0:
         raise RuntimeError("atr_rollout_end failed (%d)" % rc)
 

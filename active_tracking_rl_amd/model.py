@@ -644,8 +644,7 @@ class A3C_Dueling(nn.Module):
         T = cache.T
         self._act_step(states, cache, b.y, b.f, b.feat1, cache.h_all[:, T], cache.c_all[:, T], b.h, b.c, b.acts, b.actions,
                        done, f_pair=b.f_all)
-        for i, p in enumerate((self.player0, self.player1)):
-            fused.heads_values(b.h[i], p.critic.critic_linear, v_out, i)
+        fused.heads_values2([b.h[0], b.h[1]], (self.player0.critic.critic_linear, self.player1.critic.critic_linear), v_out)
         return v_out
 
     def _act_step(self, states, cache, y, f_out, feat1, h_prev, c_prev, h_out, c_out, acts, actions, done, f_pair=None,
@@ -771,10 +770,11 @@ class A3C_Dueling(nn.Module):
             y = fused.stem_cached(x_in[i], cache.y[i].view(-1, 512), enc.conv1, enc.conv2)
             f = fused.linear_relu_cached(y.view(T * N, -1), enc.fc, cache.f[i].view(T * N, -1))
             if i == 1 and self.tat:      # + fc_action_tracker(one_hot(a_tracker)) (model.py:193-194): a row gather
-                a_tr = actions_seq[:, :, 0].reshape(T * N)
                 if p.fc_action_tracker.weight.shape[1] <= 8 and f.shape[1] % 4 == 0:
-                    f = fused.embed_add(f, p.fc_action_tracker, a_tr)
+                    # ([T, N] view of the tracker's column of the [T, players, N] action store: read in place)
+                    f = fused.embed_add(f, p.fc_action_tracker, actions_seq[:, :, 0])
                 else:
+                    a_tr = actions_seq[:, :, 0].reshape(T * N)
                     f = f + p.fc_action_tracker(F.one_hot(a_tr, self.action_dim_tracker).to(f.dtype))
             feats.append(f)
         return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, cache.acts, need)

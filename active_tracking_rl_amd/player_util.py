@@ -39,6 +39,8 @@ class Agent(object):
         self.fused_heads = True     # ... and evaluates heads + loss terms as one fused HIP node per player
         self.fused_bookkeeping = True   # rollout prologue / epilogue as one launch each (csrc/driver_hip.hip)
         self._keep = None
+        self.carry_out, self.carry_written, self._want_loss_terms = None, (), False
+        self._one = torch.ones((), dtype=torch.float32, device=device)   # seed of the backward pass (made outside any capture)
         self.done = torch.ones(self.num_envs, dtype=torch.uint8, device=device)
         self.info = None
         self.reward = 0
@@ -178,12 +180,27 @@ class Agent(object):
             if hasattr(self.model, "_bsum"):
                 self.model._bsum = None
             N, R = self.num_envs, self._cache.h_all.shape[-1]
-            self.hxs = torch.empty((N, 2, R), device=self.device)
-            self.cxs = torch.empty((N, 2, R), device=self.device)
             self.eps_len = self.eps_len.contiguous()
             self._keep = torch.empty((T, N), device=self.device)
-            fused.rollout_end(self._cache.h_all, self._cache.c_all, self._buf[2], self.hxs, self.cxs, self.eps_len,
-                              self._keep)
+            # carry_out (set by the graphed drivers): the tensors the NEXT rollout starts from. The final LSTM state goes
+            # straight there (this rollout's begin already copied the old one into the store), and the same launch publishes
+            # the last observation and done flags — instead of four copy launches after the learner
+            co = getattr(self, "carry_out", None)
+            self.carry_written = ()
+            if (co is not None and co["hxs"].shape == (N, 2, R) and co["hxs"].is_contiguous() and co["cxs"].is_contiguous()
+                    and co["state"].dtype == self.state.dtype and co["state"].numel() == self.state.numel()
+                    and self.state.is_contiguous() and co["state"].is_contiguous()
+                    and (self.state.numel() * self.state.element_size()) % 4 == 0
+                    and co["done"].dtype == torch.uint8 and co["done"].is_contiguous()):
+                self.hxs, self.cxs = co["hxs"], co["cxs"]
+                fused.rollout_end(self._cache.h_all, self._cache.c_all, self._buf[2], self.hxs, self.cxs, self.eps_len,
+                                  self._keep, obs_src=self.state, obs_dst=co["state"], done_dst=co["done"])
+                self.carry_written = ("state", "hxs", "cxs", "done")
+            else:
+                self.hxs = torch.empty((N, 2, R), device=self.device)
+                self.cxs = torch.empty((N, 2, R), device=self.device)
+                fused.rollout_end(self._cache.h_all, self._cache.c_all, self._buf[2], self.hxs, self.cxs, self.eps_len,
+                                  self._keep)
             self._pending_done = None
             return
         self._apply_pending_done()
@@ -351,8 +368,12 @@ class Agent(object):
         R_dim = h_seq[0].shape[-1]
         v = torch.empty((T + 1, N, A, 1), dtype=torch.float32, device=dev)
         with torch.no_grad():
-            for p in range(A):
-                fused.heads_values(h_seq[p].detach().reshape(T * N, R_dim), players[p].critic.critic_linear, v, p)
+            if A == 2:
+                fused.heads_values2([h_seq[p].detach().reshape(T * N, R_dim) for p in range(2)],
+                                    [players[p].critic.critic_linear for p in range(2)], v)
+            else:
+                for p in range(A):
+                    fused.heads_values(h_seq[p].detach().reshape(T * N, R_dim), players[p].critic.critic_linear, v, p)
             sampler = getattr(model, "_sampler", None)
             if hasattr(model, "boot_values") and sampler is not None and getattr(sampler, "_last", None) is not None:
                 sampler.reopen_block()       # V(s_T) with the rollout's kernels: one more actor step + the critic heads
@@ -369,16 +390,32 @@ class Agent(object):
             scale = [1.0 / N, 1.0 / N]
         scale_aux = 1.0 / N if (use_aux and training_mode != 0) else 0.0
         rew_c = rewards.contiguous()
-        loss, stats = 0, []
-        for p in range(A):
-            aux = players[p].reward_aux if (p == 1 and use_aux) else None
-            lp, st = fused.heads_loss(h_seq[p].reshape(T * N, R_dim), players[p].actor.actor_linear,
-                                      players[p].critic.critic_linear, aux, actions[:, :, p].reshape(T * N), R, gae, v, p,
-                                      rew_c if aux is not None else None, 0, scale[p], scale_aux if aux is not None else 0.0,
-                                      w_ent[p], unit_coeff=True)   # summed and differentiated as is
-            loss = loss + lp
-            stats.append(st)
-        st = torch.stack(stats, 0) / N                                       # [A, 4]: policy, value, entropy, |aux|
+        if A == 2 and players[0].actor.actor_linear.weight.shape == players[1].actor.actor_linear.weight.shape:
+            # both players' heads + loss terms: one launch + one reduction launch, actions read in place from the rollout's
+            # [T, players, N] store, statistics already averaged over envs
+            cfg = []
+            for p in range(2):
+                aux = players[p].reward_aux if (p == 1 and use_aux) else None
+                cfg.append(dict(actions=actions[:, :, p], ret=R, gae=gae, val=v, off=p, r_aux=rew_c if aux is not None else None,
+                                aux_off=0, scale=scale[p], scale_aux=scale_aux if aux is not None else 0.0, w_ent=w_ent[p],
+                                stats_scale=1.0 / N))
+            auxes = [None, players[1].reward_aux if use_aux else None]
+            l0, l1, st = fused.heads_loss_pair([h_seq[p].reshape(T * N, R_dim) for p in range(2)],
+                                               [players[p].actor.actor_linear for p in range(2)],
+                                               [players[p].critic.critic_linear for p in range(2)], auxes, cfg)
+            # the objective is l0 + l1; compute_grads differentiates the two terms directly (no add launches, no seed fills)
+            loss = (l0, l1) if getattr(self, "_want_loss_terms", False) else l0 + l1
+        else:
+            loss, stats = 0, []
+            for p in range(A):
+                aux = players[p].reward_aux if (p == 1 and use_aux) else None
+                lp, st_ = fused.heads_loss(h_seq[p].reshape(T * N, R_dim), players[p].actor.actor_linear,
+                                           players[p].critic.critic_linear, aux, actions[:, :, p].reshape(T * N), R, gae, v, p,
+                                           rew_c if aux is not None else None, 0, scale[p], scale_aux if aux is not None else 0.0,
+                                           w_ent[p], unit_coeff=True)   # summed and differentiated as is
+                loss = loss + lp
+                stats.append(st_)
+            st = torch.stack(stats, 0) / N                                   # [A, 4]: policy, value, entropy, |aux|
         policy_loss, value_loss, entropies = (st[:, k].reshape(1, A, 1) for k in range(3))
         pred_loss = st[1, 3].reshape(1, 1) if (A > 1 and use_aux) else torch.zeros(1, 1, device=dev)
         return loss, policy_loss, value_loss, entropies, pred_loss
@@ -386,10 +423,24 @@ class Agent(object):
     def compute_grads(self, optimizer, training_mode):
         """loss -> backward into the flat gradient bucket (hipGraph-capturable: no host sync)."""
         fast = len(self.states) > 0
-        loss, policy_loss, value_loss, entropies, pred_loss = (self.loss_recompute if fast else self.loss)(training_mode)
         bucket = getattr(optimizer, "bucket", None)
+        self._want_loss_terms = bucket is not None and hasattr(bucket, "set_grads")
+        try:
+            loss, policy_loss, value_loss, entropies, pred_loss = (self.loss_recompute if fast else self.loss)(training_mode)
+        finally:
+            self._want_loss_terms = False
         if bucket is not None and hasattr(bucket, "set_grads"):
-            bucket.set_grads(torch.autograd.grad(loss, bucket.params, allow_unused=True))
+            from . import fused
+            terms = list(loss) if isinstance(loss, (tuple, list)) else [loss]
+            if self._one is None or self._one.device != terms[0].device:     # (CPU agents; GPU ones made it in __init__)
+                self._one = torch.ones((), dtype=terms[0].dtype, device=terms[0].device)
+            # the weight-gradient GEMMs of the pass register themselves and go out as one grouped launch at the end
+            with fused.deferred_weight_grads(bucket) as q:
+                grads = torch.autograd.grad(terms, bucket.params, grad_outputs=[self._one] * len(terms), allow_unused=True)
+                if q is not None:
+                    q.check(grads)
+                    q.flush()
+            bucket.set_grads(grads)
         else:
             optimizer.zero_grad()
             loss.backward()

@@ -56,19 +56,47 @@ class FlatParams(object):
         return [self.grad[off:off + p.numel()].view_as(p.data) for p, off in zip(self.params, self.offsets)]
 
     def set_grads(self, grads):
-        """Store freshly computed gradients (torch.autograd.grad output, None = unused) in the bucket with ONE batched
-        concatenation kernel — instead of zeroing the bucket and letting autograd accumulate into ~40 views one add
-        kernel at a time."""
+        """Store freshly computed gradients (torch.autograd.grad output, None = unused) in the bucket with ONE launch —
+        instead of zeroing the bucket and letting autograd accumulate into ~40 views one add kernel at a time. Gradients that
+        already ARE their slice of the bucket (the grouped weight-gradient launch writes there: fused.DeferredWeightGrads)
+        are left alone; the others go in as one segment-scatter launch (csrc/driver_hip.hip; CPU buckets: one cat)."""
         if self._views is None:
             self._views = self.grad_views()
-        flat = []
-        for g, p in zip(grads, self.params):
-            n = p.numel()
-            flat.append(g.reshape(-1) if g is not None else self._zeros[:n])
-            pad = -n % self.ALIGN
-            if pad:
-                flat.append(self._zeros[:pad])
-        torch.cat(flat, out=self.grad)
+        in_place = [g is not None and g.data_ptr() == v.data_ptr() for g, v in zip(grads, self._views)]
+        if self.grad.is_cuda:
+            import ctypes as C
+            from . import fused
+            L = fused.lib()
+            todo = [(g, off, p.numel()) for g, p, off, ip in zip(grads, self.params, self.offsets, in_place) if not ip]
+            keep = []
+            for i in range(0, len(todo), 64):
+                part = todo[i:i + 64]
+                n = len(part)
+                src, dst, cnt = (C.c_void_p * n)(), (C.c_longlong * n)(), (C.c_int * n)()
+                for q, (g, off, numel) in enumerate(part):
+                    if g is not None:
+                        g = g.detach()
+                        if g.dtype != torch.float32 or not g.is_contiguous():
+                            g = g.to(torch.float32).contiguous()
+                        keep.append(g)
+                        src[q] = g.data_ptr()
+                    else:
+                        src[q] = None
+                    dst[q], cnt[q] = off, numel
+                rc = L.atr_scatter_segments(src, dst, cnt, n, C.c_void_p(self.grad.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream(self.grad.device).cuda_stream))
+                if rc != 0:
+                    raise RuntimeError("atr_scatter_segments failed (%d)" % rc)
+        else:
+            assert not any(in_place)
+            flat = []
+            for g, p in zip(grads, self.params):
+                n = p.numel()
+                flat.append(g.reshape(-1) if g is not None else self._zeros[:n])
+                pad = -n % self.ALIGN
+                if pad:
+                    flat.append(self._zeros[:pad])
+            torch.cat(flat, out=self.grad)
         for p, v in zip(self.params, self._views):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 p.grad = v

@@ -164,14 +164,18 @@ class GraphedIteration(object):
         # thread_local: an RCCL watchdog thread polling events must not invalidate the capture
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._bind_carry()
+            player.carry_out, player.carry_written = self.carry, ()   # the rollout's epilogue kernel publishes the carry
             rollout(player, args.num_steps, fast=self.fast)
             stats = player.compute_grads(self.optimizer, mode)
             if hasattr(player.env, "generator_join"):
                 player.env.generator_join()   # the env's forked generator launches end inside the captured region
             for k, src in (("state", player.state), ("hxs", player.hxs.detach()), ("cxs", player.cxs.detach()),
                            ("done", player.done), ("eps_len", player.eps_len)):
+                if k in player.carry_written:
+                    continue
                 if self.carry[k].data_ptr() != src.data_ptr():    # (the epilogue kernel advances eps_len in place)
                     self.carry[k].copy_(src)
+            player.carry_out = None
         self._bind_carry()
         self.g_rolls[mode], self.stats_by_mode[mode] = g, stats
         self.g_roll, self.stats = g, stats          # the most recently captured pair (kept for callers/tools)
@@ -301,11 +305,15 @@ class PipelinedIteration(object):
         g_r = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_r, capture_error_mode="thread_local"):
             self._bind_carry(p)
+            p.carry_out, p.carry_written = self.carry, ()             # the rollout's epilogue kernel publishes the carry
             rollout(p, args.num_steps)
             for key, src in (("state", p.state), ("hxs", p.hxs.detach()), ("cxs", p.cxs.detach()), ("done", p.done),
                              ("eps_len", p.eps_len)):
+                if key in p.carry_written:
+                    continue
                 if self.carry[key].data_ptr() != src.data_ptr():
                     self.carry[key].copy_(src)
+            p.carry_out = None
         # the learner of THIS rollout reads the replica's own end-of-rollout tensors (last observation slot, LSTM state, done):
         # the carry belongs to the next rollout by then
         g_l = torch.cuda.CUDAGraph()

@@ -178,15 +178,16 @@ int atr_lstm_bptt(const float *dh0_heads, const float *dh1_heads, const float *k
                   const float *c_all, long long c_pstride, const float *whh0, const float *whh1, float *dg,
                   long long dg_pstride, float *dh_init, float *dc_init, int P, int T, int N, int R, void *stream);
 /* fc_action_tracker(one_hot(a_tracker)) added to the target's features over all stored steps (TAT.forward, model.py:193-194 of
- * the reference): out[r][c] = f[r][c] + w[c][actions[r * act_stride]] + b[c], w = fc_action_tracker.weight [C, A] (A <= 8, C
- * multiple of 4), actions int64. atr_embed_grad: the parameter gradients given dout = dL/dout (the gradient w.r.t. f is dout
+ * the reference): out[r][c] = f[r][c] + w[c][action of row r] + b[c], w = fc_action_tracker.weight [C, A] (A <= 8, C
+ * multiple of 4), actions int64; the action of row r is actions[(r / act_n) * act_tstride + (r % act_n) * act_stride] — a flat
+ * vector is act_n >= rows; one player's column of a [T, players, N] action store is act_n = N, act_tstride = players * N. atr_embed_grad: the parameter gradients given dout = dL/dout (the gradient w.r.t. f is dout
  * itself): dw[c][a] = sum of dout[r][c] over the rows with action a, db[c] = sum over all rows; workspace:
  * atr_embed_grad_workspace_floats(rows, C, A) floats; fixed summation order (reproducible). */
-int atr_embed_add(const float *f, const float *w, const float *b, const long long *actions, long long act_stride, float *out,
-                  long long rows, int C, int A, void *stream);
+int atr_embed_add(const float *f, const float *w, const float *b, const long long *actions, long long act_stride,
+                  long long act_n, long long act_tstride, float *out, long long rows, int C, int A, void *stream);
 long long atr_embed_grad_workspace_floats(long long rows, int C, int A);
-int atr_embed_grad(const float *dout, const long long *actions, long long act_stride, float *dw, float *db, float *workspace,
-                   long long rows, int C, int A, void *stream);
+int atr_embed_grad(const float *dout, const long long *actions, long long act_stride, long long act_n, long long act_tstride,
+                   float *dw, float *db, float *workspace, long long rows, int C, int A, void *stream);
 /* n-step returns and GAE terms of the A3C loss (player_util.py:118-141 of the reference) for all (env, agent) pairs:
  * rewards [T,N,A], values [T+1,N,A] (row T = bootstrap value), notdone [T,N] -> returns, gae [T,N,A]. */
 int atr_gae_returns(const float *rewards, const float *values, const float *notdone, float gamma, float tau,
@@ -205,12 +206,35 @@ int atr_gae_returns(const float *rewards, const float *values, const float *notd
  *     workspace: atr_heads_workspace_floats(rows, R, A) floats. Fixed reduction order (reproducible). */
 int atr_heads_values(const float *h, const float *wc, const float *bc, float *values, long long rows, int R, int vstride,
                      int voff, void *stream);
+/* ... for two players (different hidden rows and critic weights, columns voff / voff1 of the same values array) in one launch;
+ * h1 == NULL: one player. */
+int atr_heads_values2(const float *h, const float *wc, const float *bc, int voff, const float *h1, const float *wc1,
+                      const float *bc1, int voff1, float *values, long long rows, int R, int vstride, void *stream);
 long long atr_heads_workspace_floats(long long rows, int R, int A);
 int atr_heads_loss(const float *h, const long long *actions, const float *ret, const float *gae, const float *val,
                    int stride, int off, const float *r_aux, int aux_stride, int aux_off, const float *wa,
                    const float *ba, const float *wc, const float *waux, const float *baux, float scale, float scale_aux,
                    float w_ent, float *dh, float *grads_and_sums, float *workspace, long long rows, int R, int A,
                    void *stream);
+/* Both players' heads + loss terms as ONE launch + ONE reduction launch (count <= 2; same R and A): per player the arguments
+ * of atr_heads_loss, with actions read in place from the rollout's [T, players, N] store (row r: actions[(r / act_n) *
+ * act_tstride + r % act_n]; a flat vector is act_n >= rows), and stats_out (nullable, 4 floats) receiving the policy / value /
+ * entropy / |aux error| sums x stats_scale. */
+typedef struct atr_heads_loss_args {
+    const float *h;
+    const long long *actions;
+    long long act_n, act_tstride;
+    const float *ret, *gae, *val;
+    int stride, off;
+    const float *r_aux;
+    int aux_stride, aux_off;
+    const float *wa, *ba, *wc, *waux, *baux;
+    float scale, scale_aux, w_ent;
+    float *dh, *grads_and_sums, *workspace, *stats_out;
+    long long rows;
+    int R, A;
+} atr_heads_loss_args;
+int atr_heads_loss_multi(const atr_heads_loss_args *players, int count, float stats_scale, void *stream);
 
 /* C [M,N] = X1^T X2 for tall row-major X1 [K,M], X2 [K,N] (the learner's weight-gradient GEMMs: K = T*N_envs rows;
  * M, N multiples of 128), fp32 on the f32 matrix cores with split-K and a fixed-order reduction (reproducible).
@@ -220,6 +244,28 @@ int atr_heads_loss(const float *h, const long long *actions, const float *ret, c
 long long atr_gemm_tn_workspace_floats(long long K, int M, int N);
 int atr_gemm_tn(const float *x1, const float *x2, float *c, float *workspace, long long K, int M, int N,
                 const float *row_scale, float *colsum, void *stream);
+
+/* The grouped form: up to 8 such products over the SAME K rows (all weight gradients of one backward pass) as ONE launch
+ * plus ONE reduction launch. Each problem names its own destination c [M,N] (e.g. a slice of the flat gradient bucket) and up
+ * to two destinations of the column sums of its (scaled) X1 (bias_ih and bias_hh of an LSTMCell receive the same gradient).
+ * row_scale (nullable) with row_scale_shift s: row k of X1 is multiplied by row_scale[k - s] for k >= s, by 1 below — the
+ * episode mask on h_{t-1} is keep[t-1], i.e. the keep array itself shifted by one step of N rows.
+ * workspace: atr_gemm_tn_grouped_workspace_floats(problems, count, K) floats (-1: unsupported shapes or count > 8). */
+/* count <= atr_scatter_max_segments segments (src[q] (null: zeros), n[q] floats) copied to dst + dst_off[q] in one launch:
+ * autograd's per-parameter gradient tensors -> the flat gradient bucket (shared_optim.FlatParams.set_grads). */
+#define atr_scatter_max_segments 64
+int atr_scatter_segments(const float *const *src, const long long *dst_off, const int *n, int count, float *dst, void *stream);
+
+typedef struct atr_gemm_tn_problem {
+    const float *x1, *x2;
+    float *c;
+    const float *row_scale;
+    long long row_scale_shift;
+    float *colsum0, *colsum1;
+    int M, N;
+} atr_gemm_tn_problem;
+long long atr_gemm_tn_grouped_workspace_floats(const atr_gemm_tn_problem *problems, int count, long long K);
+int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int count, long long K, float *workspace, void *stream);
 
 /* The rollout driver's bookkeeping, one launch each (csrc/driver_hip.hip).
  *   atr_rollout_begin: what Agent keeps between rollouts (player_util.py:98-106: hxs/cxs [N,A,R]) -> slot 0 of the
@@ -239,6 +285,11 @@ int atr_rollout_begin(const float *hxs, const float *cxs, float *h0, float *c0, 
                       void *obs_dst, long long obs_bytes, int N, int A, int R, void *stream);
 int atr_rollout_end(const float *hT, const float *cT, long long pstride, const uint8_t *dones, float *hxs, float *cxs,
                     int *eps_len, float *keep, int T, int N, int A, int R, void *stream);
+/* ... and, in the same launch, what else the next rollout starts from: the observation after the last step (obs_bytes
+ * bytes, multiple of 4; nullable pair) -> obs_dst, and the last step's done flags -> done_dst [N] (nullable). */
+int atr_rollout_end2(const float *hT, const float *cT, long long pstride, const uint8_t *dones, float *hxs, float *cxs,
+                     int *eps_len, float *keep, int T, int N, int A, int R, const void *obs_src, void *obs_dst,
+                     long long obs_bytes, uint8_t *done_dst, void *stream);
 int atr_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq, double *state,
                   float *scalars, double lr, double beta1, double beta2, double eps, double weight_decay, int torch_eps,
                   long long n, void *stream);

@@ -218,6 +218,17 @@ def test_bootstrap_values_and_rollout_bookkeeping_kernels():
         alive = torch.flip(torch.cumprod(torch.flip(nd, [0]), 0), [0])
         assert torch.equal(player.eps_len, eps0 * alive[0] + alive.sum(0))
         assert torch.equal(player._keep, (dones == 0).float())
+        # the epilogue with a carry to publish (what the graphed drivers give it): final LSTM state, last observation and
+        # last done flags land in the carry tensors in the same launch
+        from active_tracking_rl_amd import fused
+        co = dict(state=torch.zeros_like(player.state), hxs=torch.zeros_like(player.hxs), cxs=torch.zeros_like(player.cxs),
+                  done=torch.zeros_like(player.done))
+        eps1 = eps0.clone()
+        keep1 = torch.empty_like(player._keep)
+        fused.rollout_end(cache.h_all, cache.c_all, dones, co["hxs"], co["cxs"], eps1, keep1, obs_src=player.state,
+                          obs_dst=co["state"], done_dst=co["done"])
+        assert torch.equal(co["hxs"], player.hxs) and torch.equal(co["cxs"], player.cxs) and torch.equal(keep1, player._keep)
+        assert torch.equal(co["state"], player.state) and torch.equal(co["done"], dones[-1]) and torch.equal(eps1, player.eps_len)
         # bootstrap values
         model = player.model
         v = torch.zeros((n, 2, 1), device="cuda")

@@ -256,6 +256,77 @@ def test_gemm_tn_matches_float64_reference(K, M, N):
     assert float((colsum.double() - xs.sum(0)).abs().max()) < 3e-5 * K ** 0.5 * 4
 
 
+@pytest.mark.parametrize("K", [10240, 4099])
+def test_grouped_weight_gradients_fill_the_bucket_slices(K):
+    """fused.DeferredWeightGrads (atr_gemm_tn_grouped: the weight-gradient products of one backward pass as one launch + one
+    reduction writing into slices of the flat gradient bucket) against float64: six products of the learner's shapes over the
+    same K rows, bias column sums into one and into two destinations, and the shifted episode mask of dW_hh (row k of x1
+    scaled by keep[k - N], rows below N by 1). Then FlatParams.set_grads: slices already in place are left alone, the other
+    gradients (one None) go in with the segment-scatter launch."""
+    from active_tracking_rl_amd import fused
+    from active_tracking_rl_amd.shared_optim import FlatParams
+    torch.manual_seed(K)
+    dev = "cuda"
+    shapes = [(512, 256), (512,), (512,), (512, 128), (256, 512), (256,), (256, 1024), (256,), (512, 256), (512, 128), (7, 3),
+              (1,), (5,)]
+    params = [torch.nn.Parameter(torch.randn(*sh, device=dev)) for sh in shapes]
+    bucket = FlatParams(params)
+    bucket.grad.fill_(7.0)
+    N = 512 if K % 512 == 0 else 17
+    keep = (torch.rand(K, device=dev) > 0.1).float()
+    dG = [torch.randn(K, 512, device=dev) for _ in range(2)]
+    feat, h = torch.randn(K, 256, device=dev), torch.randn(K, 128, device=dev)
+    dpre = [torch.randn(K, 256, device=dev) for _ in range(2)]
+    y0, y1 = torch.randn(K, 512, device=dev), torch.randn(K, 1024, device=dev)
+    with fused.deferred_weight_grads(bucket) as q:
+        r = [q.add(dG[0], feat, params[0], biases=(params[1], params[2])),
+             q.add(dG[0], h, params[3], row_scale=keep, shift=N),
+             q.add(dpre[0], y0, params[4], biases=(params[5],)),
+             q.add(dpre[1], y1, params[6], biases=(params[7],)),
+             q.add(dG[1], feat, params[8]),
+             q.add(dG[1], h, params[9], row_scale=keep, shift=N)]
+        assert all(x is not None for x in r)
+        assert q.add(dG[1][:, :100], h, params[10]) is None                 # not the kernel's shape class: caller's job
+        assert q.add(dG[1][:4096], h[:4096], params[9]) is None             # another K cannot join this group
+        grads = [None] * len(params)
+        for idx, x in zip((0, 3, 4, 6, 8, 9), r):
+            grads[idx] = x[0]
+        grads[1], grads[2], grads[5], grads[7] = r[0][1][0], r[0][1][1], r[2][1][0], r[3][1][0]
+        small = torch.randn(40, device=dev)
+        grads[10], grads[12] = small[3:24].view(7, 3), small[30:35]        # unaligned slices of a packed output; [11] unused
+        q.check(grads)
+        q.flush()
+    bucket.set_grads(grads)
+    torch.cuda.synchronize()
+    tol = 3e-5 * K ** 0.5 * 4
+    scale = torch.cat([torch.ones(N, device=dev), keep[:K - N]]).double().unsqueeze(1)
+    ref = {0: dG[0].double().t() @ feat.double(), 1: dG[0].double().sum(0), 2: dG[0].double().sum(0),
+           3: (dG[0].double() * scale).t() @ h.double(), 4: dpre[0].double().t() @ y0.double(), 5: dpre[0].double().sum(0),
+           6: dpre[1].double().t() @ y1.double(), 7: dpre[1].double().sum(0), 8: dG[1].double().t() @ feat.double(),
+           9: (dG[1].double() * scale).t() @ h.double(), 10: small[3:24].view(7, 3).double(), 11: torch.zeros(1, device=dev),
+           12: small[30:35].double()}
+    views = bucket.grad_views()
+    for i, want in ref.items():
+        assert float((views[i].double() - want).abs().max()) <= (tol if i < 10 else 0.0), i
+    # the padding between slots is untouched, nothing outside the slots was written
+    used = torch.zeros_like(bucket.grad, dtype=torch.bool)
+    for prm, off in zip(bucket.params, bucket.offsets):
+        used[off:off + prm.numel()] = True
+    assert bool((bucket.grad[~used] == 7.0).all())
+    # fixed reduction order: a second pass gives the same bits
+    before = bucket.grad.clone()
+    with fused.deferred_weight_grads(bucket) as q:
+        q.add(dG[0], feat, params[0], biases=(params[1], params[2]))
+        q.add(dG[0], h, params[3], row_scale=keep, shift=N)
+        q.add(dpre[0], y0, params[4], biases=(params[5],))
+        q.add(dpre[1], y1, params[6], biases=(params[7],))
+        q.add(dG[1], feat, params[8])
+        q.add(dG[1], h, params[9], row_scale=keep, shift=N)
+        q.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(before, bucket.grad)
+
+
 @pytest.mark.parametrize("M", [5, 4096])
 def test_u8_frames_give_the_float_results_bit_for_bit(M):
     """atr_stem_*_u8 (the env's byte observations decoded inside conv1's load) against the float entry points on
@@ -442,3 +513,67 @@ def test_embed_add_matches_one_hot_linear():
         torch.testing.assert_close(got[0], want[0], rtol=0, atol=0)
         torch.testing.assert_close(got[1], want[1], rtol=1e-4, atol=1e-3)
         torch.testing.assert_close(got[2], want[2], rtol=1e-4, atol=1e-3)
+    # actions read in place from the rollout's [T, players, N] store: the tracker's column as a [T, N] view (no gathered copy)
+    T, N = 20, 37
+    store = torch.randint(0, 4, (T, 2, N), device=dev)
+    lin = torch.nn.Linear(4, 256).to(dev)
+    f = torch.randn(T * N, 256, device=dev, requires_grad=True)
+    g = torch.randn(T * N, 256, device=dev)
+    for col in (0, 1):
+        view = store.transpose(1, 2)[:, :, col]                       # [T, N], strides (2 N, 1): what the learner passes
+        assert not view.is_contiguous()
+        out_v = fused.embed_add(f, lin, view)
+        out_f = fused.embed_add(f, lin, view.reshape(T * N))
+        assert torch.equal(out_v, out_f)
+        gv = torch.autograd.grad(out_v, [lin.weight, lin.bias], g)
+        gf = torch.autograd.grad(out_f, [lin.weight, lin.bias], g)
+        assert torch.equal(gv[0], gf[0]) and torch.equal(gv[1], gf[1])
+
+
+@pytest.mark.parametrize("rows_t,N,aux", [(20, 512, True), (7, 37, False)])
+def test_two_player_heads_loss_launch_equals_two_one_player_launches(rows_t, N, aux):
+    """fused.heads_loss_pair (atr_heads_loss_multi: both players' heads + loss terms in one launch + one reduction launch,
+    actions read in place from the [T, players, N] store, statistics scaled and written to one [2, 4] tensor, the objective
+    term finished inside the reduction) against two fused.heads_loss calls: terms, statistics, dL/dh and every head gradient
+    bit for bit; and fused.heads_values2 against two heads_values calls."""
+    from active_tracking_rl_amd import fused
+    dev = torch.device("cuda:0")
+    torch.manual_seed(rows_t + N)
+    T, R, A = rows_t, 128, 4
+    rows = T * N
+    actors = [torch.nn.Linear(R, A).to(dev) for _ in range(2)]
+    critics = [torch.nn.Linear(R, 1).to(dev) for _ in range(2)]
+    auxl = torch.nn.Linear(R, 1).to(dev) if aux else None
+    hs = [torch.randn(rows, R, device=dev, requires_grad=True) for _ in range(2)]
+    store = torch.randint(0, A, (T, 2, N), device=dev)
+    actions = store.transpose(1, 2)                                     # [T, N, players] view
+    ret, gae = torch.randn(T, N, 2, 1, device=dev), torch.randn(T, N, 2, 1, device=dev)
+    val = torch.zeros(T + 1, N, 2, 1, device=dev)
+    rew = torch.randn(T, N, 2, 1, device=dev)
+    v2 = torch.zeros_like(val)
+    fused.heads_values2([h.detach() for h in hs], critics, val)
+    for p in range(2):
+        fused.heads_values(hs[p].detach(), critics[p], v2, p)
+    assert torch.equal(val, v2)
+    scale, w_ent = [1.0 / N, 0.0 if not aux else 1.0 / N], [0.01, 0.2]
+    cfg = [dict(actions=actions[:, :, p], ret=ret, gae=gae, val=val, off=p, r_aux=rew if (aux and p == 1) else None, aux_off=0,
+                scale=scale[p], scale_aux=(1.0 / N if (aux and p == 1) else 0.0), w_ent=w_ent[p], stats_scale=1.0 / N)
+           for p in range(2)]
+    l0, l1, st = fused.heads_loss_pair(hs, actors, critics, [None, auxl], cfg)
+    prm = [x for p in range(2) for x in (actors[p].weight, actors[p].bias, critics[p].weight, critics[p].bias)]
+    if aux:
+        prm += [auxl.weight, auxl.bias]
+    one = torch.ones((), device=dev)
+    got = torch.autograd.grad([l0, l1], hs + prm, grad_outputs=[one, one])
+    terms, stats = [], []
+    for p in range(2):
+        lp, sp = fused.heads_loss(hs[p], actors[p], critics[p], auxl if (aux and p == 1) else None,
+                                  actions[:, :, p].reshape(rows), ret, gae, val, p, rew if (aux and p == 1) else None, 0,
+                                  scale[p], 1.0 / N if (aux and p == 1) else 0.0, w_ent[p], unit_coeff=True)
+        terms.append(lp)
+        stats.append(sp)
+    want = torch.autograd.grad(terms[0] + terms[1], hs + prm)
+    assert torch.equal(l0, terms[0]) and torch.equal(l1, terms[1])
+    assert torch.equal(st, torch.stack(stats, 0) * (1.0 / N))
+    for a_, b_ in zip(got, want):
+        assert torch.equal(a_, b_)
