@@ -443,7 +443,19 @@ def _addmm_relu(bias, x, w_t, out):
 
 
 class RolloutCache(object):
-    """Forward activations of one rollout (see A3C_Dueling.new_cache)."""
+    """Forward activations of one rollout (see A3C_Dueling.new_cache). `lazy`: per-rollout constants built on first use (a
+    launch each) — the small-shard step path never touches the stacked / transposed weight copies the batched-GEMM path reads."""
+
+    def __init__(self):
+        self.lazy = {}
+
+    def __getattr__(self, name):
+        lazy = self.__dict__.get("lazy")
+        if lazy is not None and name in lazy:
+            v = lazy.pop(name)()
+            setattr(self, name, v)
+            return v
+        raise AttributeError(name)
 
 
 class A3C_Dueling(nn.Module):
@@ -602,9 +614,12 @@ class A3C_Dueling(nn.Module):
         c.actions = torch.empty((T, 2, N), dtype=torch.int64, device=dev) if self.fused_sampling else None
         c.gates = torch.empty((2, N, 4 * R), device=dev) if N <= self.pair_gemm_max_rows else None   # scratch: pre-activations
         c.bsum = [l.bias_ih + l.bias_hh for l in (p0.lstm, p1.lstm)]
-        c.whh_t = torch.stack([l.weight_hh.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, R, 4R]
-        c.wih_t = (torch.stack([l.weight_ih.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, F, 4R]: the pair's input GEMM as one bmm
-                   if (c.f_all is not None and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape) else None)
+        c.lazy["whh_t"] = lambda: torch.stack([l.weight_hh.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, R, 4R]
+        if c.f_all is not None and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape:
+            c.lazy["wih_t"] = lambda: torch.stack([l.weight_ih.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, F, 4R]: one bmm
+            c.has_wih_t = True
+        else:
+            c.wih_t, c.has_wih_t = None, False
         if self.tat:
             fa = p1.fc_action_tracker
             c.emb = fa.weight.t() + fa.bias                        # row a = fc_action_tracker(one_hot(a))
@@ -673,7 +688,7 @@ class A3C_Dueling(nn.Module):
         mfma_step = (self.fused_actor_step and n >= self.mfma_step_min_rows and actions is not None and self._sampler._ordinal is not None
                      and fused.actor_step_supported(p0.encoder.outdim, R) and p1.encoder.outdim == p0.encoder.outdim)
         env_fused = (not mfma_step and self.fused_env_step and R == 128 and f_pair is not None and actions is not None
-                     and self._sampler._ordinal is not None and getattr(cache, "wih_t", None) is not None
+                     and self._sampler._ordinal is not None and getattr(cache, "has_wih_t", False)
                      and p0.actor.actor_linear.weight.shape == p1.actor.actor_linear.weight.shape
                      and p0.actor.actor_linear.weight.shape[0] <= 8
                      and all(t.is_contiguous() for t in (c_prev[0], c_prev[1], h_out[0], h_out[1], c_out[0], c_out[1],
@@ -708,7 +723,7 @@ class A3C_Dueling(nn.Module):
             return [actions[0], actions[1]]
         # players that do not see each other's action (maze-lstm pairs): both input projections as ONE batched GEMM on
         # the pair's feature rows and both cells + heads + draws as ONE launch — 7 launches per env step instead of 9
-        if (one_launch and not mfma_step and not self.tat and f_pair is not None and getattr(cache, "wih_t", None) is not None
+        if (one_launch and not mfma_step and not self.tat and f_pair is not None and getattr(cache, "has_wih_t", False)
                 and p0.actor.actor_linear.weight.shape == p1.actor.actor_linear.weight.shape):
             for i, p in enumerate((p0, p1)):
                 _addmm_relu(p.encoder.fc.bias, ys[i].view(n, -1), p.encoder.fc.weight.t(), f_out[i])
@@ -719,7 +734,7 @@ class A3C_Dueling(nn.Module):
         # tracker-aware pair below the MFMA-step threshold: the target's cell needs the tracker's action, its input
         # projection does not — both projections still go out as one batched GEMM, ahead of the tracker's cell
         ig_pair = None
-        if one_launch and not mfma_step and f_pair is not None and getattr(cache, "wih_t", None) is not None:
+        if one_launch and not mfma_step and f_pair is not None and getattr(cache, "has_wih_t", False):
             for i, p in enumerate((p0, p1)):
                 _addmm_relu(p.encoder.fc.bias, ys[i].view(n, -1), p.encoder.fc.weight.t(), f_out[i])
             ig_pair = torch.bmm(f_pair, cache.wih_t)

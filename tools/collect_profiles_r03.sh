@@ -15,10 +15,26 @@ bash $R/tools/prof_cfg.sh final_config1 Track2D-BlockPartialRam-v0 1024 maze-lst
 bash $R/tools/prof_cfg.sh final_config3 Track2D-MazePartialNav-v0 1024 maze-lstm none 0
 timeout 600 python $R/tools/config_sweep.py > $O/config_sweep.txt 2>&1
 timeout 600 python $R/tools/shard_sweep.py > $O/shard_sweep.txt 2>&1
+SWEEP_ORDER=sp timeout 600 python $R/tools/pipeline_sweep.py > $O/pipeline_sweep.txt 2>&1
+# --- the pipelined schedule: who waits for whom (HIP events), what slows the rollout chain next to the learner
+for n in 512 4096; do timeout 300 python $R/tools/pipe_timeline.py $n; done > $O/pipe_timeline.txt 2>&1
+timeout 300 python $R/tools/corun_kernels.py 512 > $O/corun_kernels_512.txt 2>&1
+[ -x $R/scratch_exp/two_queue ] && TWOQ_MEM=1 timeout 120 $R/scratch_exp/two_queue > $O/two_queue_microbench.txt 2>&1
 # --- the round's kernels alone
 timeout 300 python $R/tools/act_step_bench.py > $O/act_step_bench.txt 2>&1
 timeout 300 python $R/tools/pair_gemm_bench.py > $O/pair_gemm_bench.txt 2>&1
 timeout 300 python $R/tools/bptt_bench.py > $O/bptt_bench.txt 2>&1
+timeout 300 python $R/tools/gemm_group_bench.py > $O/gemm_group_bench.txt 2>&1
+# --- learning checks (tracker vs Ram, the PZR duel, tracker vs Nav in mazes) under the default (pipelined) schedule, and a main.py run
+timeout 600 python $R/tools/learning_check.py --iters 1500 > $O/learning_check_ram_tracker.txt 2>&1
+timeout 600 python $R/tools/learning_check.py --iters 1500 --schedule synchronous > $O/learning_check_ram_tracker_synchronous.txt 2>&1
+timeout 600 python $R/tools/learning_check.py --env Track2D-BlockPartialPZR-v0 --network tat-maze-lstm --train-mode -1 --iters 1500 > $O/learning_check_pzr_dueling.txt 2>&1
+timeout 600 python $R/tools/learning_check.py --env Track2D-MazePartialNav-v0 --num-envs 1024 --iters 1500 > $O/learning_check_nav_tracker.txt 2>&1
+rm -rf $O/main_logs; (cd $R && timeout 900 python main.py --shared-optimizer --split --train-mode -1 --env Track2D-BlockPartialPZR-v0 --num-envs 4096 \
+    --max-step 2000 --test-every 200 --log-dir gpurun_out/r03/main_logs/ > $O/main_py_run.txt 2>&1)
+cp $(ls -d $O/main_logs/*/*/ | head -1)logger $O/main_py_logger.txt 2>/dev/null
+tail -40 $(ls $O/main_logs/*/*/Agent:0/scalars.jsonl | head -1) > $O/main_py_scalars_tail.txt 2>/dev/null
+find $O/main_logs -name "*.dat" -delete
 # --- env-only: step kernel alone at every size (rocprofv3 stats), sweep, the other env ids, Nav split
 for n in 4096 65536 262144 1048576; do
   rm -rf /tmp/p_env; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_env -- python $R/tools/env_only_bench.py --n $n --steps 600 --warmup 100 > $O/env_only_$n.txt 2> /dev/null

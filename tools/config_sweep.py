@@ -1,5 +1,6 @@
 """End-to-end A3C throughput of the other BASELINE.json configurations at their per-GPU size on ONE MI355X (the
-headline configuration is bench.py's). Same driver as bench.py: GraphedIteration, 20-step rollouts, SharedAdam."""
+headline configuration is bench.py's). Same drivers as bench.py: the synchronous schedule (GraphedIteration) and the pipelined
+one (PipelinedIteration), 20-step rollouts, SharedAdam."""
 import time
 
 import numpy as np
@@ -7,7 +8,7 @@ import torch
 
 from active_tracking_rl_amd import registry
 from active_tracking_rl_amd.environment import VecEnv
-from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player
+from active_tracking_rl_amd.train import GraphedIteration, PipelinedIteration, default_args, make_player
 
 CASES = [
     ("configs[1] BlockPartialRam, 1024 envs, maze-lstm, train-mode 0",
@@ -21,22 +22,33 @@ CASES = [
 ]
 dev = torch.device("cuda:0")
 for name, over, special in CASES:
-    args = default_args(**over)
-    env = None
-    if special == "mixed":
-        n = args.num_envs
-        maps = np.array([registry.MAP_CODE["Block"] if i % 2 == 0 else registry.MAP_CODE["Maze"] for i in range(n)], np.uint8)
-        env = VecEnv(args.env, n, device="cuda:0", seed=args.seed, map_type_per_env=maps)
-    player, opt = make_player(args, dev, 0, 1, env=env)
-    g = GraphedIteration(player, opt, args)
-    for _ in range(5):
-        g.run()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    iters = 40
-    for _ in range(iters):
-        g.run()
-    torch.cuda.synchronize()
-    dt = (time.time() - t0) / iters
-    print("%-100s %7.3f ms/iter  %6.2f M env steps/s" % (name, dt * 1e3, args.num_envs * args.num_steps / dt / 1e6), flush=True)
-    player.env.close()
+    res = []
+    for cls in (GraphedIteration, PipelinedIteration):
+        args = default_args(**over)
+        env = None
+        if special == "mixed":
+            n = args.num_envs
+            maps = np.array([registry.MAP_CODE["Block"] if i % 2 == 0 else registry.MAP_CODE["Maze"] for i in range(n)], np.uint8)
+            env = VecEnv(args.env, n, device="cuda:0", seed=args.seed, map_type_per_env=maps)
+        player, opt = make_player(args, dev, 0, 1, env=env)
+        g = cls(player, opt, args)
+        drain = getattr(g, "finish", lambda: None)
+        if hasattr(g, "tune_streams"):
+            g.tune_streams()
+        for _ in range(5):
+            g.run()
+        drain()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        iters = 60
+        for _ in range(iters):
+            g.run()
+        drain()
+        torch.cuda.synchronize()
+        res.append((time.time() - t0) / iters)
+        player.env.close()
+        del g, player, opt
+        torch.cuda.empty_cache()
+    print("%-100s synchronous %7.3f ms/iter %6.2f M env steps/s | pipelined %7.3f ms/iter %6.2f M env steps/s" % (
+        name, res[0] * 1e3, args.num_envs * args.num_steps / res[0] / 1e6, res[1] * 1e3,
+        args.num_envs * args.num_steps / res[1] / 1e6), flush=True)
