@@ -19,3 +19,4 @@ done
 for n in 4096 262144 1048576; do for c in FETCH_SIZE WRITE_SIZE; do cp $O/env_only_pmc_${c}_$n.txt $P/r03_env_only_pmc_${c}_$n.txt; done; done
 for c in FETCH_SIZE WRITE_SIZE; do cp $O/act_step_pmc_${c}_4096.txt $P/r03_act_step_pmc_${c}_4096.txt; done
 ls $P | grep r03_ | wc -l
+python tools/make_pmc_traffic_json.py
