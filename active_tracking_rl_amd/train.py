@@ -198,6 +198,44 @@ class GraphedIteration(object):
         return self.stats
 
 
+_hip, _masked_streams = None, {}
+
+
+def cu_masked_stream(device, first_cu, n_cus, total_cus=256):
+    """A HIP stream whose kernels are dispatched only to compute units [first_cu, first_cu + n_cus) of the runtime's CU
+    enumeration (hipExtStreamCreateWithCUMask), wrapped for torch. The runtime deals the mask's bits round-robin over the
+    chip's 32 shader engines (bit k = CU k / 32 of engine k % 32), so a run of 32 m bits is m of the 8 CUs of EVERY engine of
+    every XCD: both halves of a split see all eight L2s and stay balanced under the round-robin workgroup placement; counts
+    that are not multiples of 32 leave some engines a CU short and the whole stream waits for those (measured: 120 or 136 CUs
+    are slower than 96). One stream per (device, range) per process: each masked stream takes a hardware queue of its own,
+    and a process that oversubscribes the queues gets time-sliced (measured 2-3x slower iterations)."""
+    global _hip
+    import ctypes as C
+    key = (str(device), int(first_cu), int(n_cus))
+    if key in _masked_streams:
+        return _masked_streams[key]
+    if _hip is None:
+        path = None
+        for ln in open("/proc/self/maps"):
+            if "libamdhip64" in ln:
+                path = ln.split()[-1]
+                break
+        _hip = C.CDLL(path or "libamdhip64.so")
+        _hip.hipExtStreamCreateWithCUMask.restype = C.c_int
+        _hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    words = (total_cus + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for k in range(first_cu, min(first_cu + n_cus, total_cus)):
+        mask[k // 32] |= 1 << (k % 32)
+    st = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = _hip.hipExtStreamCreateWithCUMask(C.byref(st), words, mask)
+    if rc != 0 or not st.value:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+    _masked_streams[key] = torch.cuda.ExternalStream(st.value, device=device)
+    return _masked_streams[key]
+
+
 class _BucketOnly(object):
     """What Agent.compute_grads needs of an optimizer: the flat bucket the gradients land in."""
 
@@ -272,6 +310,11 @@ class PipelinedIteration(object):
         prio = int(os.environ.get("ATR_PIPE_PRIO", "0"))
         self.sR = torch.cuda.Stream(device=dev, priority=-1 if prio == 1 else 0)
         self.sL = torch.cuda.Stream(device=dev, priority=-1 if prio == 2 else 0)
+        part = os.environ.get("ATR_PIPE_CU_SPLIT")        # force a CU partition: this many CUs for the rollout stream, the
+        self.cu_split = int(part) if part else 0          # rest for the learner's (tune_streams tries 128 / 128 by itself)
+        if self.cu_split:
+            self.sR = cu_masked_stream(dev, 256 - self.cu_split, self.cu_split)
+            self.sL = cu_masked_stream(dev, 0, 256 - self.cu_split)
         self.ev_r = [torch.cuda.Event() for _ in range(2)]
         self.ev_o = [torch.cuda.Event() for _ in range(2)]
         self.graphs = {}          # (mode, k) -> (rollout graph, learner graph, stats)
@@ -367,21 +410,39 @@ class PipelinedIteration(object):
             cur.wait_stream(self.sR)
             cur.wait_stream(self.sL)
 
-    def tune_streams(self, candidates=4, iters=8):
-        """Pick the learner stream that actually overlaps with the rollout stream. HIP multiplexes its streams onto a few
-        hardware queues (4 by default) in an order the application does not control: two streams that land on one queue
-        run the two chains back to back (measured at 512 envs: 1.73 ms per iteration against 1.33 ms on distinct queues,
-        1.62 ms synchronous), and the mapping depends on how many streams the process created before. So: `iters` real
-        iterations (they are ordinary iterations of the schedule — the weights do not depend on the stream, see `serial`)
-        per candidate, timed on the host clock, the fastest kept. Returns [(ms per iteration, chosen)] per candidate."""
+    def tune_streams(self, candidates=4, iters=8, partitions=(128,)):
+        """Pick the stream pair the two chains overlap best on. Two things are not in the application's hands and are settled
+        by trial — `iters` real iterations per candidate (ordinary iterations of the schedule: the weights do not depend on
+        the streams, see `serial`), timed on the host clock, the fastest kept:
+          * HIP multiplexes its streams onto a few hardware queues (4 by default) in an order the application does not
+            control: two streams that land on one queue run the two chains back to back (measured at 512 envs: 1.73 ms per
+            iteration against 1.33 ms on distinct queues, 1.62 ms synchronous), and the mapping depends on how many streams
+            the process created before — `candidates` alternative learner streams are tried;
+          * a CU PARTITION (`partitions`: CUs given to the rollout stream, the rest to the learner's; cu_masked_stream). On a
+            shared chip a rollout kernel's workgroups queue for CU resources behind the learner's resident workgroups (a
+            workgroup that needs 72 KB of LDS next to two 64 KB GEMM workgroups waits out the whole GEMM: tools/microbench/
+            two_queue.hip; the rollout chain runs at 40-50 % speed next to any chip-filling learner kernel: tools/
+            corun_kernels.py). With 128 CUs each neither chain ever waits for the other: both run slower (half a chip) but
+            fully concurrently — 1.15 against 1.28 ms per iteration at 512 envs; from 2048 envs up both chains are
+            throughput-bound and the shared chip wins, which is what the trial then finds.
+        Returns [(ms per iteration, chosen, label)] per candidate."""
         if self.serial:
             return []
         import time as _time
+        pairs = [(self.sR, self.sL, "as constructed")]
+        if not self.cu_split:
+            pairs += [(self.sR, torch.cuda.Stream(device=self.dev), "learner stream %d" % (c + 1)) for c in range(candidates)]
+            for r_cus in partitions:
+                try:
+                    pairs.append((cu_masked_stream(self.dev, 256 - r_cus, r_cus), cu_masked_stream(self.dev, 0, 256 - r_cus),
+                                  "CU partition %d / %d" % (r_cus, 256 - r_cus)))
+                except Exception:           # (a runtime without CU masks: the shared-chip candidates remain)
+                    pass
         trials = []
-        for sL in [self.sL] + [torch.cuda.Stream(device=self.dev) for _ in range(candidates)]:
+        for sR, sL, label in pairs:
             self.finish()
             torch.cuda.synchronize(self.dev)
-            self.sL = sL
+            self.sR, self.sL = sR, sL
             for _ in range(2):
                 self.run()
             self.finish()
@@ -391,10 +452,12 @@ class PipelinedIteration(object):
                 self.run()
             self.finish()
             torch.cuda.synchronize(self.dev)
-            trials.append(((_time.perf_counter() - t0) / iters * 1e3, sL))
+            trials.append(((_time.perf_counter() - t0) / iters * 1e3, sR, sL, label))
+        self.finish()
+        torch.cuda.synchronize(self.dev)
         best = min(trials, key=lambda t: t[0])
-        self.sL = best[1]
-        return [(ms, s is best[1]) for ms, s in trials]
+        self.sR, self.sL, self.stream_choice = best[1], best[2], best[3]
+        return [(ms, (sR is best[1] and sL is best[2]), label) for ms, sR, sL, label in trials]
 
 
 def sync_train_modes(train_modes, device, src=0):

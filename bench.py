@@ -39,6 +39,13 @@ import os
 import sys
 import time
 
+# The pipelined schedule's CU partition (train.PipelinedIteration.tune_streams) gives each chain a CU-masked stream with a
+# hardware queue of its own; iterations slow down 2-3x once a process owns more than four hardware queues (measured), so a
+# single-GPU run lets the ordinary streams share two (read by the HIP runtime at initialisation: set before torch touches the
+# GPU). Multi-rank runs keep the runtime's default — RCCL's streams want queues too, and there is no N > 1 box to measure on.
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import torch
 import torch.distributed as dist
 
@@ -190,7 +197,7 @@ def main():
         iteration, graphed, drain, trials = eager_iteration, False, (lambda: None), None
         if schedule == "pipelined":
             sched = PipelinedIteration(player, optimizer, args)
-            trials = [round(ms, 4) for ms, _ in sched.tune_streams()]
+            trials = [{"ms_per_iteration": round(ms, 4), "chosen": bool(c), "streams": lb} for ms, c, lb in sched.tune_streams()]
             iteration, graphed, drain = sched.run, True, sched.finish
         elif not a.no_graph:
             try:

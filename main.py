@@ -14,6 +14,12 @@ single-process run; under torch.distributed.run each rank uses LOCAL_RANK.
 from __future__ import print_function, division
 import os
 os.environ["OMP_NUM_THREADS"] = "1"
+# The pipelined schedule's CU partition (train.PipelinedIteration.tune_streams) gives each chain a CU-masked stream with a
+# hardware queue of its own; iterations slow down 2-3x once a process owns more than four hardware queues (measured), so a
+# single-GPU run lets the ordinary streams share two (read by the HIP runtime at initialisation: set before torch touches the
+# GPU). Multi-rank runs keep the runtime's default — RCCL's streams want queues too, and there is no N > 1 box to measure on.
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 import argparse
 import time
 from datetime import datetime

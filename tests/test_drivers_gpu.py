@@ -555,14 +555,14 @@ def test_pipelined_schedule_is_the_same_dataflow_on_one_stream_and_on_two(env_id
             torch.cuda.synchronize()
             thetas.append(opt.bucket.flat.clone())
         if not serial:                      # stream trials are ordinary iterations: run them here, mirror them below
-            trials = it.tune_streams(candidates=2, iters=3)
-            assert len(trials) == 3 and sum(c for _, c in trials) == 1
+            trials = it.tune_streams(candidates=2, iters=3, partitions=(128,))
+            assert len(trials) == 4 and sum(c for _, c, _ in trials) == 1 and "partition" in trials[-1][2]
         else:
-            for _ in range(3 * (2 + 3)):
+            for _ in range(4 * (2 + 3)):
                 it.run()
         it.finish()
         torch.cuda.synchronize()
-        assert it.i == 22
+        assert it.i == 27
         k = (it.i - 1) & 1
         assert torch.equal(it.buckets[k].flat, opt.bucket.flat)                    # O(i): theta -> F_k
         assert not torch.equal(it.buckets[1 - k].flat, opt.bucket.flat)            # the other replica is one update behind

@@ -1,6 +1,9 @@
 """End-to-end A3C throughput of the other BASELINE.json configurations at their per-GPU size on ONE MI355X (the
 headline configuration is bench.py's). Same drivers as bench.py: the synchronous schedule (GraphedIteration) and the pipelined
 one (PipelinedIteration), 20-step rollouts, SharedAdam."""
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # (see bench.py: room for the CU-partitioned stream pair)
+
 import time
 
 import numpy as np

@@ -1,5 +1,8 @@
 """Which of the learner's kernels hold up the rollout chain when they run next to it (pipelined schedule)? The rollout graph
 of an N-env shard replayed on one stream while ONE learner kernel class loops on another.   python tools/corun_kernels.py N"""
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # (see bench.py: room for the CU-partitioned stream pair)
+
 import sys
 
 import torch

@@ -1,5 +1,8 @@
 """How much does the rollout graph (the chain of small dependent launches) slow down next to a synthetic co-runner on another
 stream?  python tools/corun_probe.py N"""
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # (see bench.py: room for the CU-partitioned stream pair)
+
 import sys
 import time
 

@@ -1,5 +1,8 @@
 """Learning sanity check: train the tracker against the scripted Ram target and print the mean tracker reward per
 env-step and the done rate over time (both should improve markedly over a random-policy start)."""
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # (see bench.py: room for the CU-partitioned stream pair)
+
 import argparse
 import time
 

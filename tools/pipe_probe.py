@@ -1,5 +1,8 @@
 """PipelinedIteration: host issue time vs total time per iteration, in blocks (does the overlap hold over time?).
   python tools/pipe_probe.py N [serial]"""
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # (see bench.py: room for the CU-partitioned stream pair)
+
 import sys
 import time
 

@@ -1,6 +1,9 @@
 """Where the time of a pipelined iteration goes, without a profiler: HIP timing events around the rollout graph (stream R) and
 around learner + update (stream L) of consecutive iterations; prints per iteration the start / end of both relative to a base.
   python tools/pipe_timeline.py N"""
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # (see bench.py: room for the CU-partitioned stream pair)
+
 import sys
 
 import torch

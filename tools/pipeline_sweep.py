@@ -1,5 +1,8 @@
 """Synchronous (GraphedIteration) vs pipelined (PipelinedIteration: rollout i + 1 under learner i, one update of delay)
 iterations of the headline workload at the shard sizes.   python tools/pipeline_sweep.py [sizes...]"""
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # (see bench.py: room for the CU-partitioned stream pair)
+
 import sys
 import time
 
@@ -19,7 +22,7 @@ for n in sizes:
         player, opt = make_player(args, dev)
         g = cls(player, opt, args)
         if hasattr(g, "tune_streams") and os.environ.get("SWEEP_TUNE", "1") == "1":
-            print("  stream trials (ms/iter):", " ".join("%.3f%s" % (ms, "*" if c else "") for ms, c in g.tune_streams()), flush=True)
+            print("  stream trials (ms/iter):", " ".join("%.3f%s%s" % (ms, "*" if c else "", "(part)" if "partition" in lb else "") for ms, c, lb in g.tune_streams()), flush=True)
         for _ in range(6):
             g.run()
         if hasattr(g, "finish"):
