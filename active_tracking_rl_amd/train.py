@@ -317,6 +317,7 @@ class PipelinedIteration(object):
             self.sL = cu_masked_stream(dev, 0, 256 - self.cu_split)
         self.ev_r = [torch.cuda.Event() for _ in range(2)]
         self.ev_o = [torch.cuda.Event() for _ in range(2)]
+        self.pending = None       # (replica, learner graph) of the rollout whose learner has not been issued yet
         self.graphs = {}          # (mode, k) -> (rollout graph, learner graph, stats)
         self.g_opt = []
         for k in range(2):        # O_k: the update on theta, then theta -> F_k
@@ -384,31 +385,53 @@ class PipelinedIteration(object):
             self.master.allreduce_grads(self.optimizer)
             self.g_opt[k].replay()
         else:
+            # One call = one PHASE of the pipeline: the learner + update of the PREVIOUS rollout go out on stream L, then this
+            # rollout on stream R. (Issuing rollout i and its own learner in one call would be the same dataflow, but then a
+            # caller that synchronises after every call — bench.py brackets K = 20 env steps, i.e. one call — would wait for
+            # the learner before the next rollout could be issued, and nothing would ever overlap.)
             if self.i == 0:
                 self.sR.wait_stream(cur)
                 self.sL.wait_stream(cur)
+            self._issue_pending()
             with torch.cuda.stream(self.sR):
                 if self.i >= 2:
                     self.sR.wait_event(self.ev_o[k])      # F_k holds theta_{i-1}; the stores of replica k are free again
                 g_r.replay()
                 self.ev_r[k].record(self.sR)
-            with torch.cuda.stream(self.sL):
-                self.sL.wait_event(self.ev_r[k])
-                g_l.replay()
-                self.master.allreduce_grads(self.optimizer)   # (RCCL on this stream: under the next rollout)
-                self.g_opt[k].replay()
-                self.ev_o[k].record(self.sL)
+            self.pending = (k, g_l)
         self.master.n_steps += self.args.num_steps
         self.i += 1
         self.stats = stats
         return stats
 
-    def finish(self):
-        """Make the caller's stream wait for everything issued so far (both streams)."""
+    def _issue_pending(self):
+        """Learner, all-reduce and update of the rollout issued by the previous call, on stream L."""
+        if self.pending is None:
+            return
+        k, g_l = self.pending
+        self.pending = None
+        with torch.cuda.stream(self.sL):
+            self.sL.wait_event(self.ev_r[k])
+            g_l.replay()
+            self.master.allreduce_grads(self.optimizer)       # (RCCL on this stream: under the next rollout)
+            self.g_opt[k].replay()
+            self.ev_o[k].record(self.sL)
+
+    def sync(self):
+        """Make the caller's stream wait for everything ISSUED so far (both streams). The learner of the latest rollout is
+        not issued by this: between two calls of run() this is a phase boundary of the pipeline (what bench.py's timed
+        regions end on: every region holds K env steps of rollouts and K / T learner updates)."""
         if not self.serial and self.i > 0:
             cur = torch.cuda.current_stream(self.dev)
             cur.wait_stream(self.sR)
             cur.wait_stream(self.sL)
+
+    def finish(self):
+        """Issue what is still owed (the learner + update of the latest rollout) and make the caller's stream wait for both
+        streams: afterwards theta has received every rollout's gradient."""
+        if not self.serial and self.i > 0:
+            self._issue_pending()
+            self.sync()
 
     def tune_streams(self, candidates=4, iters=8, partitions=(128,)):
         """Pick the stream pair the two chains overlap best on. Two things are not in the application's hands and are settled
