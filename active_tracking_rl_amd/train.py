@@ -255,19 +255,22 @@ class PipelinedIteration(object):
         weights of rollout i = theta_{i-1};   g_i = gradient at theta_{i-1};   theta_{i+1} = update(theta_i, g_i)
 
     Why: at the strong-scaling shard sizes an iteration is two chains of small dependent launches (rollout: 4 per env step;
-    learner: ~100), each launch ~4.5 us before it does anything; the two chains of DIFFERENT iterations have no dependence on
+    learner: ~30 after the launch diet), each launch ~4.5 us before it does anything; the two chains of DIFFERENT iterations have no dependence on
     each other except through the weights, so they overlap (measured: two graph replays on two streams take 0.70 x their
     serial time at 512 envs, 0.81 x at 1024, 0.91 x at 4096 — tools/overlap_probe.py), and with N > 1 the gradient all-reduce
     runs under the next rollout as well.
 
     Mechanics. Two replicas of the policy (M0, M1: own flat weight buffers F0, F1, own rollout / activation stores) over
-    ONE env shard; the optimizer owns the master weights theta. Iteration i uses replica k = i & 1:
-        stream R:  [wait O(i-2)]  R_k: rollout with F_k -> stores of k; carry (obs, LSTM state, done) handed to the next rollout
-        stream L:  [wait R(i)]    L_k: loss + backward through k's stores with F_k -> gradient bucket
-                                  all-reduce (eager, RCCL) ; O_k: optimizer step on theta, then theta -> F_k
+    ONE env shard; the optimizer owns the master weights theta. Iteration i uses replica k = i & 1; one call of run() is one
+    PHASE of the pipeline:
+        stream L:  [wait R(i-1)]  L_k': loss + backward through replica k' = (i-1) & 1's stores with F_k' -> gradient bucket
+                                  all-reduce (eager, RCCL) ; O_k': optimizer step on theta, then theta -> F_k'
+        stream R:  [wait O(i-2)]  R_k: rollout i with F_k -> stores of k; carry (obs, LSTM state, done) handed to the next rollout
     F_k is next read by rollout i + 2, which waits for O(i); rollout i + 1 reads F_{1-k}, written by O(i-1): every kernel sees
     exactly the weights of the schedule above, whatever the timing (serial=True replays the same graphs in program order on
-    one stream: bit-identical weights, tests/test_drivers_gpu.py)."""
+    one stream: bit-identical weights, tests/test_drivers_gpu.py). finish() issues the learner still owed and joins both
+    streams; sync() only joins (a phase boundary). tune_streams() picks the stream pair — and whether each chain gets its own
+    half of the CUs — by trial."""
 
     def __init__(self, player, optimizer, args, warmup=2, mode=None, serial=False):
         from .player_util import Agent
@@ -305,8 +308,8 @@ class PipelinedIteration(object):
             self.buckets.append(bucket)
         self.carry = dict(state=player.state.clone(), hxs=player.hxs.detach().clone(), cxs=player.cxs.detach().clone(),
                           done=player.done.clone(), eps_len=player.eps_len.clone())
-        # the rollout is the latency chain (a launch every few us, each waiting for the one before): its stream gets the higher
-        # priority, so its workgroups are dispatched ahead of the learner's chip-filling GEMM workgroups when CUs free up
+        # (stream priorities were measured and make no difference to the overlap: ATR_PIPE_PRIO=1 / 2 raises the rollout's /
+        # the learner's stream for experiments; what matters is which hardware queues and CUs the pair gets — tune_streams)
         prio = int(os.environ.get("ATR_PIPE_PRIO", "0"))
         self.sR = torch.cuda.Stream(device=dev, priority=-1 if prio == 1 else 0)
         self.sL = torch.cuda.Stream(device=dev, priority=-1 if prio == 2 else 0)
