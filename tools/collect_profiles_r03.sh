@@ -8,6 +8,8 @@ export PYTHONPATH=$R; cd /tmp; export TMPDIR=/tmp
 timeout 1200 python $R/bench.py > $O/bench.json 2> $O/bench.err
 rm -rf /tmp/p_bench; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -- python $R/bench.py --no-cpu-baseline --no-shards > $O/bench_under_rocprof.json 2> /dev/null
 python $R/tools/summarize_prof.py stats /tmp/p_bench > $O/bench_kernel_stats.txt
+# --- the launcher + both schedules with a real process group: 2 ranks sharing the one GPU over gloo (not a scaling number)
+(cd $R && BENCH_SINGLE_DEVICE=1 BENCH_DIST_BACKEND=gloo timeout 1200 python bench.py --gpus 2 --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_selflaunch_2ranks_gloo_1gpu.json 2> /dev/null)
 # --- one replayed iteration per kernel: the headline batch and every shard size, and the other BASELINE configurations
 for n in 4096 2048 1024 512; do bash $R/tools/prof_shard.sh $n final; done
 cp $O/iter_stats_final_4096.txt $O/iteration_kernel_stats.txt

@@ -3,6 +3,7 @@
 cd "$(dirname "$0")/.."; O=gpurun_out/r03; P=profiles
 cp $O/bench.json $P/r03_bench.json
 cp $O/bench_under_rocprof.json $P/r03_bench_under_rocprof.json
+cp $O/bench_selflaunch_2ranks_gloo_1gpu.json $P/r03_bench_selflaunch_2ranks_gloo_1gpu.json
 cp $O/bench_kernel_stats.txt $P/r03_bench_kernel_stats.txt
 cp $O/iteration_kernel_stats.txt $P/r03_iteration_kernel_stats.txt
 for n in 512 1024 2048; do cp $O/iter_stats_final_$n.txt $P/r03_iteration_kernel_stats_shard$n.txt; done
