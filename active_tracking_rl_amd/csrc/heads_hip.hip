@@ -81,6 +81,9 @@ struct HeadsLoss {
 // player 0's, the rest player 1's
 struct HeadsLossMulti { HeadsLoss p[2]; };
 
+// NAx: compile-time size of the per-action arrays (4 = every registered id, 8 = the 'Moore' table): with 8 the unused half of
+// the gradient accumulators and weight rows costs 40 VGPRs, i.e. a wave per SIMD of rows in flight
+template <int NAx>
 __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(const HeadsLossMulti g)
 {
     const int pi = (int)blockIdx.x >= g.p[0].grid ? 1 : 0;
@@ -90,36 +93,53 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(const HeadsLossMulti
     const int L = a.R >> 2, A = a.A;
     const int slot = (int)threadIdx.x / L, slots = kHeadsBlock / L;
     const int j = ((int)threadIdx.x % L) * 4;
-    float4 gwa[kHeadsMaxA], gwc = make_float4(0.f, 0.f, 0.f, 0.f), gwx = gwc;
-    float gba[kHeadsMaxA], gbc = 0.f, gbx = 0.f, s_pol = 0.f, s_val = 0.f, s_ent = 0.f, s_aux = 0.f;
+    float4 gwa[NAx], gwc = make_float4(0.f, 0.f, 0.f, 0.f), gwx = gwc;
+    float gba[NAx], gbc = 0.f, gbx = 0.f, s_pol = 0.f, s_val = 0.f, s_ent = 0.f, s_aux = 0.f;
 #pragma unroll
-    for (int i = 0; i < kHeadsMaxA; i++) { gwa[i] = make_float4(0.f, 0.f, 0.f, 0.f); gba[i] = 0.f; }
-    float4 wa[kHeadsMaxA];
+    for (int i = 0; i < NAx; i++) { gwa[i] = make_float4(0.f, 0.f, 0.f, 0.f); gba[i] = 0.f; }
+    float4 wa[NAx];
 #pragma unroll
-    for (int i = 0; i < kHeadsMaxA; i++) wa[i] = i < A ? h_ld4(a.wa + i * a.R + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NAx; i++) wa[i] = i < A ? h_ld4(a.wa + i * a.R + j) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 wc = h_ld4(a.wc + j);
     const float4 wx = a.waux ? h_ld4(a.waux + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long row = (long long)bid * slots + slot; row < a.rows; row += (long long)nblk * slots) {
-        const float4 hv = h_ld4(a.h + row * a.R + j);
-        float z[kHeadsMaxA];
+    // the next row's operands are fetched under this row's arithmetic (a row is a ~5 us dependent chain of loads, butterflies
+    // and transcendentals; a CU holds only a few dozen rows at a time)
+    const long long rstride = (long long)nblk * slots;
+    long long row = (long long)bid * slots + slot;
+    float4 hv_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    float v_n = 0.f, ret_n = 0.f, gae_n = 0.f, raux_n = 0.f;
+    int act_n_ = 0;
+    auto fetch = [&](long long r) {
+        if (r < a.rows) {
+            hv_n = h_ld4(a.h + r * a.R + j);
+            const long long s_ = r * a.stride + a.off;
+            v_n = a.val[s_]; ret_n = a.ret[s_]; gae_n = a.gae[s_];
+            const long long at_ = r / a.act_n;
+            act_n_ = (int)a.actions[at_ * a.act_tstride + (r - at_ * a.act_n)];
+            if (a.r_aux) raux_n = a.r_aux[r * a.aux_stride + a.aux_off];
+        }
+    };
+    fetch(row);
+    for (; row < a.rows; row += rstride) {
+        const float4 hv = hv_n;
+        const float v = v_n, ret = ret_n, gae = gae_n, raux = raux_n;
+        const int act = act_n_;
+        fetch(row + rstride);
+        float z[NAx];
 #pragma unroll
-        for (int i = 0; i < kHeadsMaxA; i++) z[i] = i < A ? row_sum(dot4(hv, wa[i]), L) + a.ba[i] : -INFINITY;
+        for (int i = 0; i < NAx; i++) z[i] = i < A ? row_sum(dot4(hv, wa[i]), L) + a.ba[i] : -INFINITY;
         const float pred = a.waux ? row_sum(dot4(hv, wx), L) + a.baux[0] : 0.f;
-        const long long s = row * a.stride + a.off;
-        const float v = a.val[s], ret = a.ret[s], gae = a.gae[s];
-        const long long at = row / a.act_n;
-        const int act = (int)a.actions[at * a.act_tstride + (row - at * a.act_n)];
         // softmax statistics (the train branch of sample_action)
         float mx = z[0];
 #pragma unroll
-        for (int i = 1; i < kHeadsMaxA; i++) mx = fmaxf(mx, z[i]);
-        float p[kHeadsMaxA], se = 0.f;
+        for (int i = 1; i < NAx; i++) mx = fmaxf(mx, z[i]);
+        float p[NAx], se = 0.f;
 #pragma unroll
-        for (int i = 0; i < kHeadsMaxA; i++) { p[i] = i < A ? expf(z[i] - mx) : 0.f; se += p[i]; }
+        for (int i = 0; i < NAx; i++) { p[i] = i < A ? expf(z[i] - mx) : 0.f; se += p[i]; }
         const float lse = mx + logf(se);
         float ent = 0.f, logp_a = 0.f;
 #pragma unroll
-        for (int i = 0; i < kHeadsMaxA; i++) {
+        for (int i = 0; i < NAx; i++) {
             if (i < A) {
                 p[i] = p[i] / se;
                 const float lp = z[i] - lse;
@@ -132,17 +152,17 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(const HeadsLossMulti
         const float dv = a.scale * 0.5f * (v - ret);
         float dpred = 0.f, aux_abs = 0.f;
         if (a.r_aux) {
-            const float diff = pred - a.r_aux[row * a.aux_stride + a.aux_off];
+            const float diff = pred - raux;
             aux_abs = fabsf(diff);
             dpred = a.scale_aux * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
         }
-        float dz[kHeadsMaxA];
+        float dz[NAx];
 #pragma unroll
-        for (int i = 0; i < kHeadsMaxA; i++)
+        for (int i = 0; i < NAx; i++)
             dz[i] = i < A ? dlogp * ((i == act ? 1.f : 0.f) - p[i]) - dent * p[i] * ((z[i] - lse) + ent) : 0.f;
         float4 dh = make_float4(dv * wc.x + dpred * wx.x, dv * wc.y + dpred * wx.y, dv * wc.z + dpred * wx.z, dv * wc.w + dpred * wx.w);
 #pragma unroll
-        for (int i = 0; i < kHeadsMaxA; i++)
+        for (int i = 0; i < NAx; i++)
             if (i < A) {
                 dh.x = fmaf(dz[i], wa[i].x, dh.x); dh.y = fmaf(dz[i], wa[i].y, dh.y);
                 dh.z = fmaf(dz[i], wa[i].z, dh.z); dh.w = fmaf(dz[i], wa[i].w, dh.w);
@@ -168,10 +188,10 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(const HeadsLossMulti
     const int rec = (A + 2) * a.R + (A + 2) + 4;
     float *out = a.partial + (size_t)bid * rec;
 #pragma unroll
-    for (int q = 0; q < kHeadsMaxA + 2; q++) {
+    for (int q = 0; q < NAx + 2; q++) {
         if (q < A + 2) {                      // uniform: weight vector q = actor row q | critic | aux
             float4 g = gwx;
-            if (q < kHeadsMaxA && q < A) g = gwa[q < kHeadsMaxA ? q : 0];
+            if (q < NAx && q < A) g = gwa[q < NAx ? q : 0];
             else if (q == A) g = gwc;
             __syncthreads();
             wred[threadIdx.x] = g;
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(const HeadsLossMulti
     __syncthreads();
     if (j == 0) {   // row-lane 0 of every slot holds that slot's scalar partials
 #pragma unroll
-        for (int i = 0; i < kHeadsMaxA; i++) red[slot][i] = gba[i];
+        for (int i = 0; i < NAx; i++) red[slot][i] = gba[i];
         red[slot][kHeadsMaxA] = gbc; red[slot][kHeadsMaxA + 1] = gbx;
         red[slot][kHeadsMaxA + 2] = s_pol; red[slot][kHeadsMaxA + 3] = s_val;
         red[slot][kHeadsMaxA + 4] = s_ent; red[slot][kHeadsMaxA + 5] = s_aux;
@@ -327,7 +347,10 @@ extern "C" int atr_heads_loss_multi(const atr_heads_loss_args *players, int coun
     const int rec = (players[0].A + 2) * players[0].R + (players[0].A + 2) + 4;
     f.stats_scale = stats_scale; f.rec = rec; f.nb = (rec + 15) / 16; f.fold = (rec - 4) / 16 == (rec - 1) / 16 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_heads_loss, dim3((unsigned)(g.p[0].grid + g.p[1].grid)), dim3(kHeadsBlock), 0, st, g);
+    if (players[0].A <= 4)
+        hipLaunchKernelGGL(k_heads_loss<4>, dim3((unsigned)(g.p[0].grid + g.p[1].grid)), dim3(kHeadsBlock), 0, st, g);
+    else
+        hipLaunchKernelGGL(k_heads_loss<kHeadsMaxA>, dim3((unsigned)(g.p[0].grid + g.p[1].grid)), dim3(kHeadsBlock), 0, st, g);
     hipLaunchKernelGGL(k_heads_reduce, dim3((unsigned)(f.nb * count)), dim3(1024), 0, st, f);
     if (!f.fold)
         for (int i = 0; i < count; i++)
