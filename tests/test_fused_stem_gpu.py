@@ -577,3 +577,52 @@ def test_two_player_heads_loss_launch_equals_two_one_player_launches(rows_t, N, 
     assert torch.equal(st, torch.stack(stats, 0) * (1.0 / N))
     for a_, b_ in zip(got, want):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("A,aux", [(4, True), (8, False)])
+def test_heads_loss_matches_autograd_in_float64(A, aux):
+    """fused.heads_loss (csrc/heads_hip.hip; the 4-action and the 8-action ('Moore') instantiation) against the loss terms of
+    Agent.optimize written with torch ops in float64 (player_util.py:118-154 of the reference: policy term -log p(a) * gae -
+    w_ent * entropy, value term 0.5 (R - V)^2 weighted 0.5, aux |pred - r|): objective term, statistics, dL/dh and every head
+    gradient."""
+    from active_tracking_rl_amd import fused
+    dev = torch.device("cuda:0")
+    torch.manual_seed(A)
+    T, N, R = 6, 53, 128
+    rows = T * N
+    actor, critic = torch.nn.Linear(R, A).to(dev), torch.nn.Linear(R, 1).to(dev)
+    auxl = torch.nn.Linear(R, 1).to(dev) if aux else None
+    h = torch.randn(rows, R, device=dev, requires_grad=True)
+    actions = torch.randint(0, A, (rows,), device=dev)
+    ret, gae, rew = (torch.randn(T, N, 1, 1, device=dev) for _ in range(3))
+    val = torch.zeros(T + 1, N, 1, 1, device=dev)
+    fused.heads_values(h.detach(), critic, val, 0)
+    scale, scale_aux, w_ent = 1.0 / N, (1.0 / N if aux else 0.0), 0.05
+    lp, st = fused.heads_loss(h, actor, critic, auxl, actions, ret, gae, val, 0, rew if aux else None, 0, scale, scale_aux, w_ent,
+                              unit_coeff=True)
+    prm = [actor.weight, actor.bias, critic.weight, critic.bias] + ([auxl.weight, auxl.bias] if aux else [])
+    got = torch.autograd.grad(lp, [h] + prm)
+    # float64 reference
+    hd = h.detach().double().requires_grad_(True)
+    P = [p.detach().double().requires_grad_(True) for p in prm]
+    logits = hd @ P[0].t() + P[1]
+    v = (hd @ P[2].t() + P[3]).reshape(-1)
+    logp = torch.log_softmax(logits, 1)
+    prob = logp.exp()
+    ent = -(logp * prob).sum(1)
+    lpa = logp.gather(1, actions.view(-1, 1)).reshape(-1)
+    R_, G_ = ret.double().reshape(-1), gae.double().reshape(-1)
+    pol = (-lpa * G_ - w_ent * ent).sum()
+    vl = (0.5 * (R_ - v) ** 2).sum()
+    obj = scale * (pol + 0.5 * vl)
+    aux_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    if aux:
+        pred = (hd @ P[4].t() + P[5]).reshape(-1)
+        aux_sum = (pred - rew.double().reshape(-1)).abs().sum()
+        obj = obj + scale_aux * aux_sum
+    want = torch.autograd.grad(obj, [hd] + P)
+    assert abs(float(lp.detach()) - float(obj.detach())) < 1e-4 * max(1.0, abs(float(obj.detach())))
+    ref_stats = torch.stack([pol, vl, ent.sum(), aux_sum]).float()
+    torch.testing.assert_close(st, ref_stats, rtol=2e-4, atol=2e-3)
+    for g_, w_ in zip(got, want):
+        torch.testing.assert_close(g_.double().reshape(w_.shape), w_, rtol=2e-4, atol=2e-5)
