@@ -157,25 +157,43 @@ __global__ __launch_bounds__(256) void k_rmsprop_update(float *__restrict__ p, c
 // is act_n >= rows.
 __device__ __forceinline__ long long act_index(long long r, long long act_n, long long act_tstride, long long act_stride)
 {
-    const long long t = r / act_n;
-    return t * act_tstride + (r - t * act_n) * act_stride;
+    // (rows and act_n fit 32 bits — checked by the host entry points: a 64-bit division is ~150 instructions on this ISA, and
+    // these kernels do one per row and lane)
+    const unsigned t = (unsigned)r / (unsigned)(act_n > 0x7fffffffLL ? 0x7fffffffLL : act_n);
+    return (long long)t * act_tstride + (long long)((unsigned)r - t * (unsigned)(act_n > 0x7fffffffLL ? 0x7fffffffLL : act_n)) * act_stride;
 }
 
+constexpr int kEmbTabMax = 8 * 512;          // LDS table: A <= 8 rows of C <= 512 floats
 __global__ __launch_bounds__(256) void k_embed_add(const float *__restrict__ f, const float *__restrict__ w,
                                                    const float *__restrict__ b, const long long *__restrict__ act,
                                                    long long act_stride, long long act_n, long long act_tstride,
                                                    float *__restrict__ out, long long rows, int C, int A)
 {
-    const int c4 = C / 4;
-    const long long total = rows * c4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long r = i / c4;
-        const int c = (int)(i - r * c4) * 4;
+    // the A embedding rows E[a][c] = w[c][a] + b[c] (the value the sum in TAT.forward adds) built once per workgroup in LDS:
+    // per element one 16-byte LDS read instead of four strided 4-byte gathers + the bias (same values, same order of adds)
+    __shared__ __attribute__((aligned(16))) float tab[kEmbTabMax];
+    const bool use_tab = A * C <= kEmbTabMax;
+    if (use_tab)
+        for (int i = (int)threadIdx.x; i < A * C; i += (int)blockDim.x) {
+            const int a_ = i / C, c_ = i - a_ * C;
+            tab[i] = w[c_ * A + a_] + b[c_];
+        }
+    __syncthreads();
+    const unsigned c4 = (unsigned)C / 4u;
+    const unsigned total = (unsigned)rows * c4;                       // (< 2^31: checked by the host entry point)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const long long r = (long long)(i / c4);
+        const int c = (int)(i - (unsigned)r * c4) * 4;
         const int a = (int)act[act_index(r, act_n, act_tstride, act_stride)];
         float4 v = *reinterpret_cast<const float4 *>(f + r * C + c);
-        const float4 bb = *reinterpret_cast<const float4 *>(b + c);
-        v.x += w[(c + 0) * A + a] + bb.x; v.y += w[(c + 1) * A + a] + bb.y;
-        v.z += w[(c + 2) * A + a] + bb.z; v.w += w[(c + 3) * A + a] + bb.w;
+        if (use_tab) {
+            const float4 e = *reinterpret_cast<const float4 *>(tab + a * C + c);
+            v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        } else {
+            const float4 bb = *reinterpret_cast<const float4 *>(b + c);
+            v.x += w[(c + 0) * A + a] + bb.x; v.y += w[(c + 1) * A + a] + bb.y;
+            v.z += w[(c + 2) * A + a] + bb.z; v.w += w[(c + 3) * A + a] + bb.w;
+        }
         *reinterpret_cast<float4 *>(out + r * C + c) = v;
     }
 }
@@ -281,6 +299,7 @@ extern "C" int atr_embed_add(const float *f, const float *w, const float *b, con
                              long long act_n, long long act_tstride, float *out, long long rows, int C, int A, void *stream)
 {
     if (!f || !w || !b || !actions || !out || rows <= 0 || C <= 0 || (C & 3) || A < 1 || A > kEmbMaxA || act_n < 1) return 1;
+    if (rows * (C / 4) >= (1LL << 31)) return 1;
     if (((uintptr_t)f | (uintptr_t)out | (uintptr_t)b) & 15u) return 1;
     long long blocks = (rows * (C / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -301,6 +320,7 @@ extern "C" int atr_embed_grad(const float *dout, const long long *actions, long 
                               void *stream)
 {
     if (!dout || !actions || !dw || !db || !workspace || rows <= 0 || C <= 0 || A < 1 || A > kEmbMaxA || act_n < 1) return 1;
+    if (rows >= (1LL << 31)) return 1;
     const long long nwg = rows < 1024 * 64 ? (rows + 63) / 64 : 1024;
     const int rpw = (int)((rows + nwg - 1) / nwg);
     hipStream_t st = (hipStream_t)stream;

@@ -114,8 +114,8 @@ __global__ __launch_bounds__(kHeadsBlock) void k_heads_loss(const HeadsLossMulti
             hv_n = h_ld4(a.h + r * a.R + j);
             const long long s_ = r * a.stride + a.off;
             v_n = a.val[s_]; ret_n = a.ret[s_]; gae_n = a.gae[s_];
-            const long long at_ = r / a.act_n;
-            act_n_ = (int)a.actions[at_ * a.act_tstride + (r - at_ * a.act_n)];
+            const unsigned an_ = (unsigned)(a.act_n > 0x7fffffffLL ? 0x7fffffffLL : a.act_n), at_ = (unsigned)r / an_;   // (rows < 2^31)
+            act_n_ = (int)a.actions[(long long)at_ * a.act_tstride + (long long)((unsigned)r - at_ * an_)];
             if (a.r_aux) raux_n = a.r_aux[r * a.aux_stride + a.aux_off];
         }
     };
@@ -321,7 +321,7 @@ static int heads_fill(HeadsLoss &a, const atr_heads_loss_args &p)
     if (!p.h || !p.actions || !p.ret || !p.gae || !p.val || !p.wa || !p.ba || !p.wc || !p.dh || !p.grads_and_sums ||
         !p.workspace || p.rows <= 0 || p.R <= 0 || (p.R & 3) || (L != 16 && L != 32 && L != 64) || p.A < 1 || p.A > kHeadsMaxA ||
         p.stride < 1 || p.off < 0 || p.off >= p.stride || ((p.waux != nullptr) != (p.baux != nullptr)) || (p.r_aux && !p.waux) ||
-        p.act_n < 1)
+        p.act_n < 1 || p.rows >= (1LL << 31))
         return -1;
     a.h = p.h; a.actions = p.actions; a.act_n = p.act_n; a.act_tstride = p.act_tstride; a.ret = p.ret; a.gae = p.gae;
     a.val = p.val; a.stride = p.stride; a.off = p.off; a.r_aux = p.r_aux; a.aux_stride = p.aux_stride; a.aux_off = p.aux_off;
