@@ -1,6 +1,7 @@
 """One rank of tests/test_rccl_gpu.py (started by torch.distributed.run, one rank per GPU): the N>1 product path on RCCL —
 env shard keyed by the global env id, GraphedIteration (two hipGraph replays with the eager gradient all-reduce between
-them), identical SharedAdam update on every replica."""
+them) and PipelinedIteration (the all-reduce on the learner's stream beneath the next rollout), identical SharedAdam update on
+every replica."""
 import os
 import sys
 
@@ -16,7 +17,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist.init_process_group("nccl", device_id=dev)
-    from active_tracking_rl_amd.train import GraphedIteration, default_args, make_player, rollout
+    from active_tracking_rl_amd.train import GraphedIteration, PipelinedIteration, default_args, make_player, rollout
     args = default_args(num_envs=256, seed=7)
     player, opt = make_player(args, dev, rank, world)
     assert player.env.core is not None
@@ -43,6 +44,21 @@ def main():
     assert torch.isfinite(opt.bucket.flat).all()
     st = player.env.core.get_state()
     assert (st["episode"] >= 1).all()
+    # (c) the pipelined schedule on the same shard: stream trials + 5 more phases, every rank the same number of updates,
+    # replicas bit-identical afterwards (master weights AND both replica weight buffers)
+    pit = PipelinedIteration(player, opt, args)
+    trials = pit.tune_streams(candidates=1, iters=2)
+    assert sum(c for _, c, _ in trials) == 1
+    for _ in range(5):
+        pit.run()
+    pit.finish()
+    torch.cuda.synchronize(dev)
+    for t in [opt.bucket.flat] + [b.flat for b in pit.buckets]:
+        flats = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(flats, t)
+        for f in flats[1:]:
+            assert torch.equal(flats[0], f), "replicas diverged under the pipelined schedule"
+    assert torch.isfinite(opt.bucket.flat).all()
     if rank == 0:
         print("RCCL_OK world=%d elems=%d" % (world, opt.bucket.grad.numel()), flush=True)
     dist.barrier()
