@@ -22,6 +22,7 @@ SWEEP_ORDER=sp timeout 600 python $R/tools/pipeline_sweep.py > $O/pipeline_sweep
 for n in 512 4096; do timeout 300 python $R/tools/pipe_timeline.py $n; done > $O/pipe_timeline.txt 2>&1
 timeout 300 python $R/tools/corun_kernels.py 512 > $O/corun_kernels_512.txt 2>&1
 [ -x $R/scratch_exp/two_queue ] && TWOQ_MEM=1 timeout 120 $R/scratch_exp/two_queue > $O/two_queue_microbench.txt 2>&1
+[ -x $R/scratch_exp/grid_barrier ] && timeout 120 $R/scratch_exp/grid_barrier > $O/grid_barrier_microbench.txt 2>&1
 # --- the round's kernels alone
 timeout 300 python $R/tools/act_step_bench.py > $O/act_step_bench.txt 2>&1
 timeout 300 python $R/tools/pair_gemm_bench.py > $O/pair_gemm_bench.txt 2>&1

@@ -9,7 +9,7 @@ cp $O/iteration_kernel_stats.txt $P/r03_iteration_kernel_stats.txt
 for n in 512 1024 2048; do cp $O/iter_stats_final_$n.txt $P/r03_iteration_kernel_stats_shard$n.txt; done
 cp $O/iter_stats_final_config1.txt $P/r03_iteration_kernel_stats_config1.txt
 cp $O/iter_stats_final_config3.txt $P/r03_iteration_kernel_stats_config3.txt
-for f in config_sweep shard_sweep pipeline_sweep pipe_timeline corun_kernels_512 two_queue_microbench gemm_group_bench act_step_bench pair_gemm_bench bptt_bench env_only_other_configs nav_profile \
+for f in config_sweep shard_sweep pipeline_sweep pipe_timeline corun_kernels_512 two_queue_microbench grid_barrier_microbench gemm_group_bench act_step_bench pair_gemm_bench bptt_bench env_only_other_configs nav_profile \
          learning_check_ram_tracker_synchronous \
          learning_check_ram_tracker learning_check_pzr_dueling learning_check_nav_tracker main_py_logger main_py_scalars_tail; do
   [ -f $O/$f.txt ] && cp $O/$f.txt $P/r03_$f.txt
