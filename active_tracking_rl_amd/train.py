@@ -278,6 +278,12 @@ class PipelinedIteration(object):
         self.args, self.optimizer, self.master = args, optimizer, player
         self.mode0 = args.train_mode if mode is None else int(mode)
         self.serial = bool(serial)
+        # Whole-map ('Full') observations go through F.conv2d, i.e. MIOpen's kernels: replayed next to another stream's graph
+        # they were observed to hang the device (their workgroups wait on each other and need the chip to themselves). Those
+        # ids (no BASELINE configuration uses them) run the same schedule in program order on one stream.
+        from .model import CNN_maze
+        if any(isinstance(m, CNN_maze) and not m.small for m in player.model.modules()):
+            self.serial = True
         dev = self.dev = player.device
         env = player.env
         # eager warm-up on the master (allocator, GEMM workspaces), its updates rolled back

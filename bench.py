@@ -140,7 +140,7 @@ def main():
                     help="iteration schedule behind `value`: pipelined (rollout i+1 under learner i, one update of gradient "
                          "delay; train.PipelinedIteration) or synchronous (train.GraphedIteration); both = value from the "
                          "pipelined one, the synchronous numbers in the `synchronous` object")
-    ap.add_argument("--pipelined-timeout", type=float, default=600.0,
+    ap.add_argument("--pipelined-timeout", type=float, default=240.0,
                     help="seconds the pipelined measurements may take before the line is printed with the synchronous "
                          "numbers only (a watchdog: an N>1 run must not hang the driver)")
     ap.add_argument("--no-shards", action="store_true", help="skip the per-shard-size sweep of the N=1 line")

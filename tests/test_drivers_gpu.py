@@ -145,6 +145,15 @@ def test_full_observation_env_trains():
     rollout(player, args.num_steps)
     stats = player.optimize(None, opt, player.model, -1, dev)
     assert all(torch.isfinite(s).all() for s in stats)
+    # the pipelined driver keeps such ids on ONE stream (MIOpen's kernels next to another stream's graph hung the device)
+    from active_tracking_rl_amd.train import PipelinedIteration
+    it = PipelinedIteration(player, opt, args)
+    assert it.serial and it.tune_streams() == []
+    for _ in range(3):
+        it.run()
+    it.finish()
+    torch.cuda.synchronize()
+    assert torch.isfinite(opt.bucket.flat).all()
     player.env.close()
 
 
