@@ -122,14 +122,30 @@ __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
         acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
         const float *rd = At + col * kBLd + 4 * q;         // MFMA A layout: lane (row col, K slot q)
+        // the A operands run kBDepth reads ahead of the MFMAs that consume them (a ring of registers: an LDS read issued right
+        // before its use costs its full latency on a wave that has the SIMD to itself)
+        constexpr int kBDepth = 6;
+        float4 ring[kBDepth];
+#pragma unroll
+        for (int g = 0; g < kBDepth; g++) ring[g] = *reinterpret_cast<const float4 *>(rd + 16 * g);
 #pragma unroll
         for (int g = 0; g < 32; g++) {
-            const float4 av = *reinterpret_cast<const float4 *>(rd + 16 * g);
+            const float4 av = ring[g % kBDepth];
+            if (g + kBDepth < 32) ring[g % kBDepth] = *reinterpret_cast<const float4 *>(rd + 16 * (g + kBDepth));
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, B[4 * g + 0], acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, B[4 * g + 1], acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, B[4 * g + 2], acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, B[4 * g + 3], acc2, 0, 0, 0);
         }
+        // (scheduling directives for the block above: kBDepth LDS reads, then 4 MFMAs : 1 LDS read, then the remaining MFMAs — left
+        // to itself the compiler issues every read right before the MFMAs that consume it)
+        __builtin_amdgcn_sched_group_barrier(0x100, kBDepth, 0);
+#pragma unroll
+        for (int g = 0; g < 32 - kBDepth; g++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * kBDepth, 0);
         acc += acc2;
     }
 #undef BPTT_FETCH
