@@ -45,8 +45,9 @@ import time
 # hardware queue of its own; iterations slow down 2-3x once a process owns more than four hardware queues (measured), so a
 # single-GPU run lets the ordinary streams share two (read by the HIP runtime at initialisation: set before torch touches the
 # GPU). Multi-rank runs keep the runtime's default — RCCL's streams want queues too, and there is no N > 1 box to measure on.
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+_SET_HW_QUEUES = int(os.environ.get("WORLD_SIZE", "1")) == 1 and "GPU_MAX_HW_QUEUES" not in os.environ
+if _SET_HW_QUEUES:
+    os.environ["GPU_MAX_HW_QUEUES"] = "2"
 
 import torch
 import torch.distributed as dist
@@ -73,6 +74,8 @@ def self_launch(n, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
+    if _SET_HW_QUEUES:                    # (this launcher process set it for a single-GPU run: the ranks keep the runtime's default)
+        env.pop("GPU_MAX_HW_QUEUES", None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
     return subprocess.call(cmd, env=env)

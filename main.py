@@ -18,8 +18,9 @@ os.environ["OMP_NUM_THREADS"] = "1"
 # hardware queue of its own; iterations slow down 2-3x once a process owns more than four hardware queues (measured), so a
 # single-GPU run lets the ordinary streams share two (read by the HIP runtime at initialisation: set before torch touches the
 # GPU). Multi-rank runs keep the runtime's default — RCCL's streams want queues too, and there is no N > 1 box to measure on.
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+_SET_HW_QUEUES = int(os.environ.get("WORLD_SIZE", "1")) == 1 and "GPU_MAX_HW_QUEUES" not in os.environ
+if _SET_HW_QUEUES:
+    os.environ["GPU_MAX_HW_QUEUES"] = "2"
 import argparse
 import time
 from datetime import datetime
