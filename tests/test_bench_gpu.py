@@ -31,3 +31,17 @@ def test_bench_line_with_the_drivers_flags():
     assert roof["bound"] == "hbm" and roof["in_timed_region"] is True and 0.0 < roof["frac"] < 1.0
     assert roof["variant"] == "act_step_u8" and "k_act_step" in roof["kernel"]
     assert line["config"]["schedule"] == line["schedule"] and "workload" in line["config"]
+
+
+@pytest.mark.gpu
+def test_bench_watchdog_prints_the_synchronous_line_when_the_pipelined_part_does_not_come_back():
+    """--pipelined-timeout far below what the pipelined measurements need: the watchdog fires, rank 0 prints the line as
+    assembled so far (the synchronous numbers) and the process leaves with exit code 0 — an N>1 run must never hang the driver."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--envs-per-gpu", "512", "--no-shards", "--no-cpu-baseline", "--pipelined-timeout", "0.01"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["schedule"] == "synchronous" and line["value"] > 0
+    assert "did not complete" in line["pipelined"]["error"]
+    assert line["roofline"]["in_timed_region"] is True
