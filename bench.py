@@ -177,6 +177,7 @@ def main():
 
     T = 20
     steps = max(T, (a.steps + T - 1) // T * T)          # an A3C iteration is T env steps + one update
+    globals_steps = steps
     warm = max(T, (a.warmup + T - 1) // T * T)
     repeats = max(1, a.repeats)
 
@@ -185,9 +186,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def measure(envs_per_gpu, min_gpu_seconds=1.0, schedule="synchronous"):
+    def measure(envs_per_gpu, min_gpu_seconds=1.0, schedule="synchronous", region_steps=None):
         """Build the player for `envs_per_gpu` envs on this rank, warm up, then time `repeats` repeats of `steps` env
-        steps, each bracketed by barrier + synchronize; per repeat the MAX over ranks; returns the median repeat."""
+        steps (region_steps when given), each bracketed by barrier + synchronize; per repeat the MAX over ranks; returns the
+        median repeat."""
+        steps = globals_steps if region_steps is None else int(region_steps)
         args = default_args(env=a.env, network=a.network, num_envs=envs_per_gpu, num_steps=T, gpu_ids=[local_rank],
                             aux="reward" if "tat" in a.network else "none", train_mode=-1, obs_u8=not a.f32_obs)
         player, optimizer = make_player(args, device, rank, world)
@@ -255,7 +258,7 @@ def main():
             ar_us = float(tu.item())
         res = {"value": steps * envs_per_gpu * world / med, "ms_per_step": med * 1e3 / steps,
                "ms_per_iteration": med * 1e3 / (steps // T), "timed_gpu_seconds": float(sum(ts)),
-               "envs_per_gpu": envs_per_gpu, "global_envs": envs_per_gpu * world, "repeats": reps,
+               "envs_per_gpu": envs_per_gpu, "global_envs": envs_per_gpu * world, "repeats": reps, "region_steps": steps,
                "spread": {"min_ms_per_step": ts[0] * 1e3 / steps, "max_ms_per_step": ts[-1] * 1e3 / steps},
                "hipgraph": graphed, "schedule": schedule, "stream_trials_ms_per_iteration": trials, "allreduce_us": ar_us,
                "allreduce_elems": int(optimizer.bucket.grad.numel()) if hasattr(optimizer, "bucket") else None}
@@ -277,17 +280,20 @@ def main():
             shards = {"note": "headline workload at the per-GPU shard sizes of the strong form (4096 envs over 8/4/2/1 "
                               "GPUs), measured on ONE GPU; the N-GPU strong value is bounded by N x shard value, minus the "
                               "gradient all-reduce (allreduce_us of an N>1 line: %d fp32 elements)" % 0, "sizes": {}}
+            # (the shard entries are this file's own auxiliary measurement: regions of >= 200 steps whatever --steps is — a
+            # fence after every 20-step region costs a 512-env shard ~6 % — each entry says so in `region_steps`)
             for per in (a.global_envs // 8, a.global_envs // 4, a.global_envs // 2):
-                r_, p_, o_, _ = measure(per, min_gpu_seconds=0.5, schedule=schedule)
+                r_, p_, o_, _ = measure(per, min_gpu_seconds=0.5, schedule=schedule, region_steps=max(steps, 10 * T))
                 shards["sizes"][str(per)] = {k: r_[k] for k in ("value", "ms_per_iteration", "ms_per_step", "repeats",
-                                                                "spread", "stream_trials_ms_per_iteration")}
+                                                                "spread", "stream_trials_ms_per_iteration", "region_steps")}
                 p_.env.close()
                 del p_, o_
                 torch.cuda.empty_cache()
         weak, player, optimizer, args = measure(a.envs_per_gpu, schedule=schedule)
         if shards is not None:
             shards["sizes"][str(a.envs_per_gpu)] = {k: weak[k] for k in ("value", "ms_per_iteration", "ms_per_step", "repeats",
-                                                                         "spread", "stream_trials_ms_per_iteration")}
+                                                                         "spread", "stream_trials_ms_per_iteration",
+                                                                         "region_steps")}
             shards["note"] = shards["note"].replace("(allreduce_us of an N>1 line: 0 fp32 elements)",
                                                     "(allreduce_us of an N>1 line: %s fp32 elements)" % weak["allreduce_elems"])
         if strong is None:
