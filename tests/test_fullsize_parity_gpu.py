@@ -1,12 +1,14 @@
-"""-m gpu: full-size lock-step parity of the kernels the driver actually times, against the C oracle (PHILOX mode).
+"""-m gpu: full-size lock-step parity of the STAND-ALONE step kernel (`k_step2`, the C ABI's `t2d_step` / `t2d_step_u8`)
+against the C oracle (PHILOX mode), driven with externally chosen actions.
 
-For each BASELINE.json GPU configuration the EXACT product call path of the rollout driver is stepped at the full per-GPU
-shard size with the LAST rank's `env_id_base`:
-  * `environment.VecEnv.step(actions, out=slot of rollout_buffers)` — i.e. `t2d_step_u8` (byte observations written into
-    the rollout store, int64 action tensors, in-launch auto-reset, generator pass every 10th step) where the handle
-    supports it, the float path otherwise (Nav/RPF targets until they have a byte path);
-  * >= 30 steps, every env compared every step: observations, rewards (== float32(oracle float64)), done flags; final
-    positions / far counters / step counters / episode numbers.
+What this covers: `environment.VecEnv.step(actions, out=slot of rollout_buffers)` — byte observations written into a
+rollout store, int64 action tensors, in-launch auto-reset, the generator pass — at the full per-GPU shard size of every
+BASELINE.json GPU configuration with the LAST rank's `env_id_base`; >= 30 steps, every env compared every step
+(observations, rewards == float32(oracle float64), done flags) and the final positions / far counters / step counters /
+episode numbers. This is the path of `Agent.action_test`, the evaluator, `Track2DEnv` and any caller that brings its own
+actions; it is NOT the kernel bench.py's timed region runs: since round 3 the rollout ends each env step inside
+`k_act_step` (fused.act_env_step) in replayed hipGraphs — that path has its own lock-step test,
+tests/test_timed_region_parity_gpu.py.
 The oracle side is `oracle.OracleBatch` (orc_step_batch: a plain loop over the scalar oracle, test infrastructure).
 Reference semantics: envs/gym-track2d/gym_track2d/envs/track_1v1.py:71-168."""
 import numpy as np
