@@ -167,7 +167,7 @@ constexpr int kEmbTabMax = 8 * 512;          // LDS table: A <= 8 rows of C <= 5
 __global__ __launch_bounds__(256) void k_embed_add(const float *__restrict__ f, const float *__restrict__ w,
                                                    const float *__restrict__ b, const long long *__restrict__ act,
                                                    long long act_stride, long long act_n, long long act_tstride,
-                                                   float *__restrict__ out, long long rows, int C, int A)
+                                                   float *__restrict__ out, long long rows, int C, int A, long long ldf)
 {
     // the A embedding rows E[a][c] = w[c][a] + b[c] (the value the sum in TAT.forward adds) built once per workgroup in LDS:
     // per element one 16-byte LDS read instead of four strided 4-byte gathers + the bias (same values, same order of adds)
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_embed_add(const float *__restrict__ f, 
         const long long r = (long long)(i / c4);
         const int c = (int)(i - (unsigned)r * c4) * 4;
         const int a = (int)act[act_index(r, act_n, act_tstride, act_stride)];
-        float4 v = *reinterpret_cast<const float4 *>(f + r * C + c);
+        float4 v = *reinterpret_cast<const float4 *>(f + r * ldf + c);
         if (use_tab) {
             const float4 e = *reinterpret_cast<const float4 *>(tab + a * C + c);
             v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
@@ -295,16 +295,48 @@ extern "C" int atr_rollout_end2(const float *hT, const float *cT, long long pstr
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-extern "C" int atr_embed_add(const float *f, const float *w, const float *b, const long long *actions, long long act_stride,
-                             long long act_n, long long act_tstride, float *out, long long rows, int C, int A, void *stream)
+extern "C" int atr_embed_add_ld(const float *f, long long ldf, const float *w, const float *b, const long long *actions,
+                                long long act_stride, long long act_n, long long act_tstride, float *out, long long rows, int C,
+                                int A, void *stream)
 {
     if (!f || !w || !b || !actions || !out || rows <= 0 || C <= 0 || (C & 3) || A < 1 || A > kEmbMaxA || act_n < 1) return 1;
+    if (ldf < C || (ldf & 3)) return 1;
     if (rows * (C / 4) >= (1LL << 31)) return 1;
     if (((uintptr_t)f | (uintptr_t)out | (uintptr_t)b) & 15u) return 1;
     long long blocks = (rows * (C / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_embed_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f, w, b, actions, act_stride, act_n,
-                       act_tstride, out, rows, C, A);
+                       act_tstride, out, rows, C, A, ldf);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" int atr_embed_add(const float *f, const float *w, const float *b, const long long *actions, long long act_stride,
+                             long long act_n, long long act_tstride, float *out, long long rows, int C, int A, void *stream)
+{
+    return atr_embed_add_ld(f, C, w, b, actions, act_stride, act_n, act_tstride, out, rows, C, A, stream);
+}
+
+__global__ __launch_bounds__(256) void k_relu_backward_ld(const float *__restrict__ df, const float *__restrict__ f, long long ldf,
+                                                          float *__restrict__ out, long long rows, int C)
+{
+    const unsigned c4 = (unsigned)C / 4u;
+    const unsigned total = (unsigned)rows * c4;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const long long r = (long long)(i / c4);
+        const int c = (int)(i - (unsigned)r * c4) * 4;
+        const float4 a = *reinterpret_cast<const float4 *>(f + r * ldf + c);
+        float4 d = *reinterpret_cast<const float4 *>(df + r * C + c);
+        d.x = a.x > 0.f ? d.x : 0.f; d.y = a.y > 0.f ? d.y : 0.f; d.z = a.z > 0.f ? d.z : 0.f; d.w = a.w > 0.f ? d.w : 0.f;
+        *reinterpret_cast<float4 *>(out + r * C + c) = d;
+    }
+}
+
+extern "C" int atr_relu_backward_ld(const float *df, const float *f, long long ldf, float *out, long long rows, int C, void *stream)
+{
+    if (!df || !f || !out || rows <= 0 || C <= 0 || C % 4 || ldf < C || ldf % 4 || rows * (long long)(C / 4) >= (1LL << 31)) return 1;
+    const long long total = rows * (C / 4);
+    const long long blocks = total < 4096LL * 256 ? (total + 255) / 256 : 4096;
+    hipLaunchKernelGGL(k_relu_backward_ld, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, df, f, ldf, out, rows, C);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -44,6 +44,7 @@ struct TnProblem {
     float *c;                      // [M, N] destination of the reduction
     float *cs_out0, *cs_out1;      // [M] destinations of the column sums (nullable)
     long long rs_shift;
+    long long ld1, ld2;            // row strides of x1 / x2 (floats)
     int M, N;
     int tile_begin;                // first tile of this problem in the group's tile order
     int red_begin;                 // first block of this problem in the reduction launch
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const TnGroup g)
     // merge the two sources into a generic pointer and emit flat_load, which also ticks lgkmcnt and so serialises
     // the global prefetch behind every LDS wait of the MFMA loop
     const float4 *g1 = reinterpret_cast<const float4 *>(x1 + m0 + c4 * 4), *g2 = reinterpret_cast<const float4 *>(x2 + n0 + c4 * 4);
-    const long long ldm = M / 4, ldn = N / 4;                          // row strides in float4 units
+    const long long ldm = g.p[q].ld1 / 4, ldn = g.p[q].ld2 / 4;        // row strides in float4 units
     float4 ra0, ra1, rb0, rb1, ra2, ra3, rb2, rb3;
     // optional extras: row_scale[k] multiplies row k of X1 on its way into LDS (dW_hh needs the episode mask on h);
     // colsum_partial receives the column sums of X1 (the bias gradient that goes with a weight gradient) from the
@@ -256,6 +257,7 @@ static int group_tiles(const atr_gemm_tn_problem *pr, int count)
     int tiles = 0;
     for (int q = 0; q < count; q++) {
         if (!pr[q].x1 || !pr[q].x2 || !pr[q].c || pr[q].M <= 0 || pr[q].N <= 0 || pr[q].M % kTile || pr[q].N % kTile) return -1;
+        if ((pr[q].ld1 && (pr[q].ld1 < pr[q].M || pr[q].ld1 % 4)) || (pr[q].ld2 && (pr[q].ld2 < pr[q].N || pr[q].ld2 % 4))) return -1;
         tiles += (pr[q].M / kTile) * (pr[q].N / kTile);
     }
     return tiles;
@@ -293,6 +295,7 @@ extern "C" int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int coun
         const atr_gemm_tn_problem &p = problems[q];
         const long long mn = (long long)p.M * p.N;
         d.x1 = p.x1; d.x2 = p.x2; d.c = p.c; d.row_scale = p.row_scale; d.rs_shift = p.row_scale_shift; d.M = p.M; d.N = p.N;
+        d.ld1 = p.ld1 ? p.ld1 : p.M; d.ld2 = p.ld2 ? p.ld2 : p.N;
         d.cs_out0 = p.colsum0; d.cs_out1 = p.colsum1;
         d.partial = ws; ws += (size_t)g.slices * mn;
         const bool cs = p.colsum0 || p.colsum1;

@@ -199,11 +199,13 @@ __device__ __forceinline__ void nav_prefetch(const DevState &s, int e, uint32_t 
 
 // Track1v1Env.reset -> init_maze (track_1v1.py:134-168,218-240) for one env and one episode number, executed by
 // one wave on an LDS tile. All arguments are wave-uniform. `gdir` receives the Nav direction planes.
-template <bool NAV>
+// DEFER_NAV: stop before the Nav target's plans (the caller makes them: k_gen_nav spreads the three floods over three waves);
+// fi_out receives the free-cell index of the finished map either way.
+template <bool NAV, bool DEFER_NAV = false>
 __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint32_t *tile, uint32_t *mlog, int lane, uint32_t cfg,
                                                  uint32_t episode, uint32_t *gdir, uint32_t &pos, uint32_t &goals,
                                                  uint32_t &plan, uint32_t &tctr, uint32_t &navgoal, uint32_t &d2,
-                                                 uint32_t &nav2, uint32_t *stamps = nullptr)
+                                                 uint32_t &nav2, FreeIndex &fi_out, uint32_t *stamps = nullptr)
 {
     // T2D_EXP == 9 (probe build only, tools/gen_timeline_probe.py): s_memtime stamps of the generator's phases
 #define T2D_GSTAMP(i) do { if (T2D_EXP == 9 && lane == 0) stamps[i] = (uint32_t)__builtin_readcyclecounter(); } while (0)
@@ -225,6 +227,7 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
     }
     T2D_GSTAMP(1);
     const FreeIndex fi = build_free_index(tile, side, lane);
+    fi_out = fi;
     const int n = fi.total;
     T2D_GSTAMP(2);
     VStream ss;
@@ -267,7 +270,7 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
     plan = 0;
     navgoal = g1;
     if (mode == TGT_RAM) plan = ram_reset(ts);
-    if (NAV && (mode == TGT_NAV || rpf)) { // Navigator.reset (navigator.py:43-63): plan from the target spawn to goal_states[1]
+    if (NAV && (mode == TGT_NAV || rpf) && !(DEFER_NAV && !rpf)) { // Navigator.reset (navigator.py:43-63): plan from the target spawn to goal_states[1]
         NavField nf;
         nav2 = 1u << 30;                   // RPF: sample_goal(2) at reset advanced the patrol vector to 1
         nav_plan(tile, side, lane, (int)(tg & 0xffu), (int)(tg >> 8), fi, navgoal, ts, plan, nf, rpf, nav2);
@@ -298,6 +301,26 @@ __device__ __forceinline__ uint32_t window_row_bits(uint32_t w0, uint32_t w1, ui
     const uint32_t lo = j == 0 ? 0xffffffffu : (j == 1 ? w0 : (j == 2 ? w1 : W2));
     const uint32_t hi = j == 0 ? w0 : (j == 1 ? w1 : (j == 2 ? W2 : 0xffffffffu));
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(sp & 31)) & 0x1fffu;
+}
+
+// The map side of a generated next-episode slot: the tile and the window rows of the episode's first observation, so that the
+// step kernel that switches to this episode needs no dependent map fetch (k_step2 reads them speculatively when a done is
+// possible). One wave; the tile is complete in LDS.
+__device__ __forceinline__ void store_slot_map(const DevState &s, size_t so, const uint32_t *tile, int lane, uint32_t cfg, uint32_t pos)
+{
+    reinterpret_cast<uint4 *>(s.n_maps + so * kTileWords)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
+    if (lane < 2 * T2D_WIN) {
+        const int ag = lane >= T2D_WIN ? 1 : 0, y = lane - ag * T2D_WIN;
+        const int gside = side_of_cfg(cfg);
+        const int ar = (int)((pos >> (16 * ag)) & 0xffu), ac = (int)((pos >> (16 * ag + 8)) & 0xffu);
+        const int rr = ar - T2D_POB + y;
+        uint32_t bits = 0x1fffu;
+        if ((unsigned)rr < (unsigned)gside) {
+            const uint32_t *w = tile + rr * kRowWords;
+            bits = window_row_bits(w[0], w[1], w[2], gside, ac);
+        }
+        s.n_win[so * 32 + lane] = bits;
+    }
 }
 
 // Generator kernel: fills the "next episode" slot (episode[e] + 1) of every env whose slot was consumed at a step
@@ -336,32 +359,129 @@ __global__ __launch_bounds__(256) void k_gen(DevState s, uint32_t lo, uint32_t h
 #if T2D_EXP == 9
     __shared__ uint32_t gst[kWavesPerBlock][8];
     if (lane == 0) gst[wave][6] = (uint32_t)__builtin_readcyclecounter();            // kernel entry of this wave (incl. prefetch)
-    generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, target, gdir, pos, goals, plan, tctr, navgoal, d2, nav2, gst[wave]);
+    FreeIndex fi_unused;
+    generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, target, gdir, pos, goals, plan, tctr, navgoal, d2, nav2, fi_unused, gst[wave]);
     wave_lds_sync();
     if (lane == 0) { gst[wave][5] = (uint32_t)__builtin_readcyclecounter(); for (int i = 0; i < 7; i++) tile[246 + i] = gst[wave][i]; }
 #else
-    generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, target, gdir, pos, goals, plan, tctr, navgoal, d2, nav2);
+    FreeIndex fi_unused;
+    generate_episode<NAV>(s, e, tile, mlogs[wave], lane, cfg, target, gdir, pos, goals, plan, tctr, navgoal, d2, nav2, fi_unused);
 #endif
     wave_lds_sync();
-    reinterpret_cast<uint4 *>(s.n_maps + so * kTileWords)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
-    if (lane < 2 * T2D_WIN) {
-        // the window rows of the episode's first observation, so that the step kernel that switches to this episode
-        // needs no dependent map fetch (k_step2 reads them speculatively when a done is possible)
-        const int ag = lane >= T2D_WIN ? 1 : 0, y = lane - ag * T2D_WIN;
-        const int gside = side_of_cfg(cfg);
-        const int ar = (int)((pos >> (16 * ag)) & 0xffu), ac = (int)((pos >> (16 * ag + 8)) & 0xffu);
-        const int rr = ar - T2D_POB + y;
-        uint32_t bits = 0x1fffu;
-        if ((unsigned)rr < (unsigned)gside) {
-            const uint32_t *w = tile + rr * kRowWords;
-            bits = window_row_bits(w[0], w[1], w[2], gside, ac);
-        }
-        s.n_win[so * 32 + lane] = bits;
-    }
+    store_slot_map(s, so, tile, lane, cfg, pos);
     if (lane == 0) {
         s.n_pos[so] = pos; s.n_goals[so] = goals; s.n_plan[so] = plan; s.n_tctr[so] = tctr;
         s.n_navgoal[so] = navgoal; s.n_d2[so] = d2; s.gen_req[so] = 0u;
         if (NAV) s.n_nav2[so] = nav2;
+    }
+}
+
+// The generator pass of handles with Nav targets (navigator.py:5-70): ONE WORKGROUP per (slot, env) instead of one wave.
+// A generated Nav episode needs three goal-rooted floods — Navigator.reset's plan (target spawn -> goal_states[1]) and the two
+// plans queued behind it (nav_fill_queue) — and on one wave they were a serial chain behind the map (Maze: <= 110 us of growth
+// + 3 x 43 us). They only LOOK dependent: plan k + 1 starts where plan k's goal draw left the TARGET stream, and that position
+// depends on plan k's flood only when the flood FAILS (unreachable goal or goal == start: re-draws). So the common case is
+// speculated: wave 0 builds the map, picks spawns and goals and draws the two further goals as if every plan succeeded at once;
+// then waves 0 / 1 / 2 run the three floods side by side on the shared LDS tile while wave 3 writes the slot's map out; wave 0
+// validates afterwards and, if the FIRST plan failed (the only case in which the speculated draws are wrong), redoes the serial
+// chain exactly as k_gen does — the results are the oracle's either way, bit for bit (same draws in the same order).
+// PREFETCH: further blocks top up the plan queues of the running episodes, one wave per env (nav_prefetch), as in k_gen.
+template <bool PREFETCH>
+__global__ __launch_bounds__(256) void k_gen_nav(DevState s, uint32_t lo, uint32_t hi, int force)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kWavesPerBlock][kTileWords];
+    __shared__ uint32_t mlog[kMazeLogMax];
+    __shared__ uint32_t xch[16];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int b = (int)blockIdx.x;
+    if (b >= 2 * s.n) {
+        if (!PREFETCH) return;
+        const int ep = (b - 2 * s.n) * kWavesPerBlock + wave;
+        if (ep < s.n && !force && (int)((s.cfg[ep] >> 2) & 7u) == TGT_NAV) nav_prefetch(s, ep, tiles[wave], lane);
+        return;
+    }
+    const int slot = b >= s.n ? 1 : 0, e = b - slot * s.n;
+    const size_t so = (size_t)slot * s.n + e;
+    const uint32_t req = s.gen_req[so];
+    const uint32_t cfg = s.cfg[e];
+    if (!(force || (req >= lo && req <= hi && req != 0u))) return;          // (uniform over the workgroup)
+    const uint32_t cur = s.episode[e];
+    const uint32_t target = ((cur + 1u) & 1u) == (uint32_t)slot ? cur + 1u : cur + 2u;
+    uint32_t *tile = tiles[0];
+    uint32_t *gdir = s.n_dirf + so * kDirWords;
+    const int mode = (int)((cfg >> 2) & 7u), side = side_of_cfg(cfg);
+    uint32_t pos = 0u, goals = 0u, plan = 0u, tctr = 0u, navgoal = 0u, d2 = 0u, nav2 = 0u;
+    FreeIndex fi;
+    if (mode != TGT_NAV) {        // other targets of a mixed handle (and RPF): one wave, the whole episode, as k_gen
+        if (wave != 0) return;
+        generate_episode<true>(s, e, tile, mlog, lane, cfg, target, gdir, pos, goals, plan, tctr, navgoal, d2, nav2, fi);
+        wave_lds_sync();
+        store_slot_map(s, so, tile, lane, cfg, pos);
+        if (lane == 0) {
+            s.n_pos[so] = pos; s.n_goals[so] = goals; s.n_plan[so] = plan; s.n_tctr[so] = tctr;
+            s.n_navgoal[so] = navgoal; s.n_d2[so] = d2; s.gen_req[so] = 0u; s.n_nav2[so] = nav2;
+        }
+        return;
+    }
+    const uint32_t genv = s.env_base + (uint32_t)e;
+    if (wave == 0) {
+        generate_episode<true, true>(s, e, tile, mlog, lane, cfg, target, gdir, pos, goals, plan, tctr, navgoal, d2, nav2, fi);
+        // the goals of the two queued plans, drawn as nav_fill_queue will draw them if the first plan needs no re-draw
+        Stream t1;
+        t1.init(s.k0, s.k1, target, genv, STREAM_TARGET, tctr);
+        const uint32_t g2 = select_free(tile, side, fi, (int)t1.bounded((uint32_t)(fi.total - 1)), lane);
+        const uint32_t c1 = t1.ctr;
+        Stream t2;
+        t2.init(s.k0, s.k1, target, genv, STREAM_TARGET, c1);
+        const uint32_t g3 = select_free(tile, side, fi, (int)t2.bounded((uint32_t)(fi.total - 1)), lane);
+        if (lane == 0) { xch[0] = pos; xch[1] = navgoal; xch[2] = g2; xch[3] = g3; xch[4] = c1; xch[5] = t2.ctr; }
+    }
+    __syncthreads();
+    const uint32_t x_pos = xch[0], x_g1 = xch[1], x_g2 = xch[2], x_g3 = xch[3];
+    bool ok0 = false;
+    if (wave == 3) {
+        store_slot_map(s, so, tile, lane, cfg, x_pos);
+    } else {
+        // wave 0: spawn -> g1 (Navigator.reset); wave 1: g1 -> g2 (queue slot 0); wave 2: g2 -> g3 (queue slot 1)
+        const uint32_t goal = wave == 0 ? x_g1 : (wave == 1 ? x_g2 : x_g3);
+        const uint32_t start = wave == 0 ? (x_pos >> 16) : (wave == 1 ? x_g1 : x_g2);
+        const int gr = (int)(goal & 0xffu), gc = (int)((goal >> 8) & 0xffu), sr = (int)(start & 0xffu), sc = (int)((start >> 8) & 0xffu);
+        NavField nf;
+        bfs_dir_field(tile, side, lane, gr, gc, nf, false, sr, sc);
+        const bool usable = rowbits_get(nf.visA, nf.visB, sr, sc) != 0u && !(sr == gr && sc == gc);
+        if (wave == 0) {
+            ok0 = usable;
+            if (usable) store_dir_field(gdir, nf, side, lane);
+        } else {
+            store_plan_field(s.p_field + pq_index(s, target, (uint32_t)(wave - 1), e) * kPlanWords, nf, side, lane);
+            if (lane == 0) xch[8 + wave] = usable ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    uint32_t ps;
+    if (ok0) {      // the speculation held: what nav_plan + nav_fill_queue would have left behind
+        const bool u1 = xch[9] != 0u, u2 = xch[10] != 0u;
+        ps = u1 ? (2u | (u2 ? 0u : 8u)) : (1u | 8u);
+        if (lane == 0) {
+            s.p_goal[pq_index(s, target, 0u, e)] = x_g2; s.p_tctr[pq_index(s, target, 0u, e)] = xch[4];
+            s.p_goal[pq_index(s, target, 1u, e)] = x_g3; s.p_tctr[pq_index(s, target, 1u, e)] = xch[5];
+        }
+    } else {        // rare (an unreachable or coinciding first goal): the serial chain, re-draws and all
+        NavField nf;
+        VStream ts;
+        ts.init(s.k0, s.k1, target, genv, STREAM_TARGET, tctr, lane);
+        uint32_t nav2_unused = 0u;
+        nav_plan(tile, side, lane, (int)((x_pos >> 16) & 0xffu), (int)(x_pos >> 24), fi, navgoal, ts, plan, nf, false, nav2_unused);
+        if (((plan >> 28) & 1u) == 0u) store_dir_field(gdir, nf, side, lane);
+        ps = nav_fill_queue(s, e, target, tile, side, fi, lane, 0u, navgoal, ts.ctr);
+        tctr = ts.ctr;
+    }
+    if (lane == 0) {
+        s.p_state[pq_state_index(s, target, e)] = ps;
+        s.n_pos[so] = pos; s.n_goals[so] = goals; s.n_plan[so] = plan; s.n_tctr[so] = tctr;
+        s.n_navgoal[so] = navgoal; s.n_d2[so] = d2; s.gen_req[so] = 0u; s.n_nav2[so] = 0u;
     }
 }
 
@@ -851,8 +971,9 @@ struct Step2 {
     }
 
     // a_tr / a_tg: the two actions of this lane's env, already masked to the action table
-    __device__ __forceinline__ void finish(const DevState &s, int a_tr, int a_tg, int it, void *obs, float *rew,
-                                           uint8_t *done_out, uint32_t stamp)
+    // returns the done flag of this lane's env (every lane of a slot computes it from the slot's replicated state)
+    __device__ __forceinline__ int finish(const DevState &s, int a_tr, int a_tg, int it, void *obs, float *rew,
+                                          uint8_t *done_out, uint32_t stamp)
     {
         const int side = (int)(cnt >> 24);
         int c_far = (int)(cnt & 0xffu), t = (int)((cnt >> 8) & 0xffffu);
@@ -967,7 +1088,7 @@ struct Step2 {
         if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(2); }
         if (T2D_EXP == 8) {   // latency probe: level-1 loads -> rows + reward table -> one store
             if (leader) reinterpret_cast<float2 *>(rew)[e] = wall_tr ? (wall_tg ? rw_ss : rw_sm) : (wall_tg ? rw_ms : rw_mm);
-            return;
+            return 0;
         }
         if (!wall_tr) { r0 += dy0; c0 += dx0; }
         if (!wall_tg) { r1 += dy1; c1 += dx1; }
@@ -1109,6 +1230,7 @@ struct Step2 {
             T2D_STAMP(5);
             if (T2D_EXP == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T2D_STAMP(6); }
         }
+        return dn;
     }
 };
 
@@ -1229,6 +1351,7 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_a
     if (!active) return;
     if (ENV) { S.init2(s, obs, rew, done_out); S.rows(s); }   // (waits for the state only: vector loads return in order)
     int act[2] = {0, 0};
+    float4 hkeep[2];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         if (p == 1 && a.emb) {     // tracker-aware target: fc_action_tracker(one_hot(a_tracker)) projected through W_ih (model.py:193-194)
@@ -1237,6 +1360,7 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_a
             for (int g = 0; g < 4; g++) pre[1][g] = fma4(1.0f, ld4(em + g * R), pre[1][g]);
         }
         const CellOut o = cell4(pre[p][0], pre[p][1], pre[p][2], pre[p][3], cp[p], k);
+        hkeep[p] = o.h;
         if (live) {
             st4(a.h_out[p] + (size_t)e * R + j, o.h);
             st4(a.c_out[p] + (size_t)e * R + j, o.c);
@@ -1273,7 +1397,18 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_a
         }
         act[p] = __shfl(mine, lane & 32, 64);
     }
-    if (ENV) S.finish(s, act[0] & s.amask, act[1] & s.amask, 0, obs, rew, done_out, stamp);
+    if (ENV) {
+        const int dn = S.finish(s, act[0] & s.amask, act[1] & s.amask, 0, obs, rew, done_out, stamp);
+        // the hidden rows as the NEXT step's LSTMCell GEMM reads them: zero for an env whose episode just ended (the reset() of
+        // train.py:73-74 -> player_util.py:98-102), written into the h columns of that step's [features | k h] rows
+        if (a.hm_out[0] && live) {
+            const float km = dn ? 0.0f : 1.0f;
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+                st4(a.hm_out[p] + (size_t)e * a.hm_ld + j,
+                    make_float4(km * hkeep[p].x, km * hkeep[p].y, km * hkeep[p].z, km * hkeep[p].w));
+        }
+    }
 }
 
 __global__ void k_build_reward_lut(float2 *lut)
@@ -1494,6 +1629,12 @@ static inline dim3 env_grid(int n) { return dim3((unsigned)((n + kWavesPerBlock 
 static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t lo, uint32_t hi, int force, bool prefetch = false)
 {
     const dim3 grid = env_grid(2 * h->s.n);        // one wave per (slot, env)
+    if (h->has_navmode) {                          // Nav targets: one workgroup per (slot, env) (+ the queue top-up blocks)
+        const unsigned blocks = 2u * (unsigned)h->s.n + (prefetch ? (unsigned)((h->s.n + kWavesPerBlock - 1) / kWavesPerBlock) : 0u);
+        if (prefetch) hipLaunchKernelGGL((k_gen_nav<true>), dim3(blocks), dim3(256), 0, st, h->s, lo, hi, force);
+        else hipLaunchKernelGGL((k_gen_nav<false>), dim3(blocks), dim3(256), 0, st, h->s, lo, hi, force);
+        return;
+    }
     if (h->has_nav && prefetch) hipLaunchKernelGGL((k_gen<true, true>), env_grid(3 * h->s.n), dim3(256), 0, st, h->s, lo, hi, force);
     else if (h->has_nav) hipLaunchKernelGGL((k_gen<true, false>), grid, dim3(256), 0, st, h->s, lo, hi, force);
     else hipLaunchKernelGGL((k_gen<false, false>), grid, dim3(256), 0, st, h->s, lo, hi, force);
@@ -1745,6 +1886,10 @@ extern "C" int atr_act_env_step(t2d_handle *h, const atr_act_step *args, void *o
             return fail(T2D_ERR_INVALID, "atr_act_env_step: null policy buffer (player %d)", p);
     if (!a.actions_out || !a.counter || a.R != 128 || (a.A != 4 && a.A != 8))
         return fail(T2D_ERR_INVALID, "atr_act_env_step: needs R = 128, A = 4 or 8, actions_out, counter");
+    if ((a.hm_out[0] != nullptr) != (a.hm_out[1] != nullptr) || (a.hm_out[0] && (a.hm_ld < a.R || (a.hm_ld & 3) ||
+                                                                                 (((uintptr_t)a.hm_out[0] | (uintptr_t)a.hm_out[1]) & 15u))))
+        return fail(T2D_ERR_INVALID, "atr_act_env_step: hm_out needs both players, 16-byte aligned, hm_ld >= R and a multiple of 4");
+    if (a.hm_out[0] && !h) return fail(T2D_ERR_INVALID, "atr_act_env_step: hm_out (masked hidden rows) needs the env step");
     hipStream_t st = (hipStream_t)stream;
     if (!h) {   // policy half only (the learner's bootstrap step: one more actor step, no env step)
         if (a.N <= 0) return fail(T2D_ERR_INVALID, "atr_act_env_step: N must be > 0 without an env handle");

@@ -27,7 +27,15 @@ class ActStepArgs(C.Structure):
                 ("h_out", C.c_void_p * 2), ("c_out", C.c_void_p * 2), ("acts", C.c_void_p * 2),
                 ("actor_w", C.c_void_p * 2), ("actor_b", C.c_void_p * 2), ("emb", C.c_void_p), ("done_prev", C.c_void_p),
                 ("actions_out", C.c_void_p), ("counter", C.c_void_p), ("seed", C.c_ulonglong), ("ordinal", C.c_uint),
-                ("A", C.c_int), ("N", C.c_int), ("R", C.c_int)]
+                ("A", C.c_int), ("N", C.c_int), ("R", C.c_int), ("hm_out", C.c_void_p * 2), ("hm_ld", C.c_longlong)]
+
+
+class LinearArgs(C.Structure):
+    """atr_linear_args of include/atr_policy.h."""
+    _fields_ = [("a", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("c", C.c_void_p), ("lda", C.c_longlong),
+                ("ldw", C.c_longlong), ("ldc", C.c_longlong), ("stride_a", C.c_longlong), ("stride_w", C.c_longlong),
+                ("stride_c", C.c_longlong), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batch", C.c_int),
+                ("relu", C.c_int), ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong)]
 
 
 class PairLinearArgs(C.Structure):
@@ -52,7 +60,7 @@ class GemmTnProblem(C.Structure):
     """atr_gemm_tn_problem of include/atr_policy.h."""
     _fields_ = [("x1", C.c_void_p), ("x2", C.c_void_p), ("c", C.c_void_p), ("row_scale", C.c_void_p),
                 ("row_scale_shift", C.c_longlong), ("colsum0", C.c_void_p), ("colsum1", C.c_void_p), ("M", C.c_int),
-                ("N", C.c_int)]
+                ("N", C.c_int), ("ld1", C.c_longlong), ("ld2", C.c_longlong)]
 
 
 def lib():
@@ -85,6 +93,18 @@ def lib():
                                                  C.c_ulonglong, C.c_uint, i32, i32, vp]
         L.atr_embed_add.restype = i32
         L.atr_embed_add.argtypes = [vp, vp, vp, vp, ll, ll, ll, vp, ll, i32, i32, vp]
+        L.atr_embed_add_ld.restype = i32
+        L.atr_embed_add_ld.argtypes = [vp, ll, vp, vp, vp, ll, ll, ll, vp, ll, i32, i32, vp]
+        L.atr_relu_backward_ld.restype = i32
+        L.atr_relu_backward_ld.argtypes = [vp, vp, ll, vp, ll, i32, vp]
+        L.atr_lt_init.restype = i32
+        L.atr_lt_init.argtypes = [C.c_char_p]
+        L.atr_linear.restype = i32
+        L.atr_linear.argtypes = [C.POINTER(LinearArgs), vp]
+        L.atr_linear_plan_info.restype = i32
+        L.atr_linear_plan_info.argtypes = [C.POINTER(LinearArgs), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
+                                           C.POINTER(C.c_float)]
+        L.atr_lt_last_error.restype = C.c_char_p
         L.atr_embed_grad_workspace_floats.restype = ll
         L.atr_embed_grad_workspace_floats.argtypes = [ll, i32, i32]
         L.atr_embed_grad.restype = i32
@@ -260,7 +280,10 @@ class _LinearReluCached(torch.autograd.Function):
     @staticmethod
     def backward(ctx, df):
         x, w, f, b = ctx.saved_tensors
-        dpre = torch.ops.aten.threshold_backward(df.contiguous(), f, 0.0)
+        if f.is_cuda and not f.is_contiguous() and f.dim() == 2 and f.stride(1) == 1 and f.stride(0) % 4 == 0 and f.shape[1] % 4 == 0:
+            dpre = relu_backward_ld(df.contiguous(), f)     # (f is a column block of the rollout's [features | k h] rows)
+        else:
+            dpre = torch.ops.aten.threshold_backward(df.contiguous(), f, 0.0)
         r = _deferred.add(dpre, x, w, biases=(b,)) if _deferred is not None else None
         if r is not None:                  # joins the backward pass's grouped weight-gradient launch
             dw, (db,) = r
@@ -271,6 +294,85 @@ class _LinearReluCached(torch.autograd.Function):
 
 def linear_relu_cached(x, linear, f):
     return _LinearReluCached.apply(x, linear.weight, linear.bias, f)
+
+
+@torch.no_grad()
+def relu_backward_ld(df, f):
+    """df * (f > 0) for a dense df [rows, C] and an activation f [rows, C] whose rows are f.stride(0) floats apart."""
+    rows, Cc = df.shape
+    out = torch.empty_like(df)
+    rc = lib().atr_relu_backward_ld(_p(df), _p(f), f.stride(0), _p(out), rows, Cc, _stream(df))
+    if rc != 0:
+        raise RuntimeError("atr_relu_backward_ld failed (%d)" % rc)
+    return out
+
+
+_lt_ready = False
+
+
+def _lt_init():
+    """Hand csrc/lt_gemm.cpp the libhipblaslt.so PyTorch itself uses (it resolves the entry points from that copy)."""
+    global _lt_ready
+    if _lt_ready:
+        return
+    import os
+    cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "libhipblaslt.so")]
+    try:
+        for ln in open("/proc/self/maps"):
+            if "libhipblaslt" in ln:
+                cands.insert(0, ln.split()[-1])
+                break
+    except OSError:
+        pass
+    L = lib()
+    for path in cands:
+        if os.path.exists(path) and L.atr_lt_init(path.encode()) == 0:
+            _lt_ready = True
+            return
+    raise RuntimeError("atr_lt_init failed: %s" % L.atr_lt_last_error().decode())
+
+
+def _linear_args(a, w, out, bias, relu, workspace):
+    g = LinearArgs()
+    if a.dim() == 2:
+        a, w, out = a.unsqueeze(0), w.unsqueeze(0), out.unsqueeze(0)
+    B, M, K = a.shape
+    N = w.shape[1]
+    assert w.shape == (B, N, K) and out.shape == (B, M, N)
+    for t in (a, w, out):
+        assert t.is_cuda and t.dtype == torch.float32 and t.stride(2) == 1 and t.data_ptr() % 16 == 0
+    g.a, g.w, g.c = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.lda, g.ldw, g.ldc = a.stride(1), w.stride(1), out.stride(1)
+    g.stride_a, g.stride_w, g.stride_c = a.stride(0), w.stride(0), out.stride(0)
+    g.bias = bias.data_ptr() if bias is not None else None
+    assert bias is None or (B == 1 and bias.is_contiguous() and bias.numel() == N)
+    g.M, g.N, g.K, g.batch, g.relu = M, N, K, B, 1 if relu else 0
+    if workspace is not None:
+        g.workspace, g.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    return g
+
+
+@torch.no_grad()
+def linear_lt(a, w, out, bias=None, relu=False, workspace=None):
+    """out = act(a @ w.T + bias) through hipBLASLt called directly (atr_linear, csrc/lt_gemm.cpp): a [M, K], w [N, K] (nn.Linear
+    layout), out [M, N] — or a batch of them as 3-D tensors (no bias then). Rows may be strided (a column block of wider rows:
+    the fc output inside the rollout's [features | k h] rows). workspace: a uint8 device tensor private to the calling chain
+    of launches (two streams must not share one); None = the library's own."""
+    _lt_init()
+    g = _linear_args(a, w, out, bias, relu, workspace)
+    L = lib()
+    if L.atr_linear(C.byref(g), _stream(a)) != 0:
+        raise RuntimeError("atr_linear failed: %s" % L.atr_lt_last_error().decode())
+    return out
+
+
+def linear_lt_info(a, w, out, bias=None, relu=False, workspace=None):
+    """(candidates, chosen index, tuned?, best us) of the kernel choice for this problem (after its first linear_lt call)."""
+    g = _linear_args(a, w, out, bias, relu, workspace)
+    cand, ch, tu, us = C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(0)
+    if lib().atr_linear_plan_info(C.byref(g), C.byref(cand), C.byref(ch), C.byref(tu), C.byref(us)) != 0:
+        return None
+    return dict(candidates=cand.value, chosen=ch.value, tuned=bool(tu.value), best_us=us.value)
 
 
 def rows169(x):
@@ -627,12 +729,14 @@ def pair_linear(a1, w1, out, bias=None, a2=None, w2=None, done=None, relu=False)
 
 @torch.no_grad()
 def act_env_step(env_core, ig, hg, biases, c_prev, done, h_out, c_out, acts, sampler, actors, actions_out, emb=None,
-                 env_out=None):
+                 env_out=None, hm_out=None):
     """The END of a rollout step as ONE launch (atr_act_env_step, csrc/track2d_hip.hip k_act_step): both players' cells +
     actor heads + draws (tracker first; emb [A,4R] adds emb[a_tracker] to the target's pre-activations) and, with
     env_core (a vec_env.VecTrack2D) and env_out = (obs [N,2,13,13] u8 | f32, rew [N,2], done [N] u8), the env step with
     those actions. ig / hg: per-player [N,4R] contiguous (hg[p] None: ig[p] is the whole pre-activation); biases (b0, b1)
     [4R] or None; c_prev / h_out / c_out per-player [N,R]; acts per-player [N,4R] or None; actions_out int64 [2,N].
+    hm_out (with the env step only): per-player [N,R] views with a common row stride — they receive the fresh hidden rows
+    zeroed where this step's done flag is set (what the next step's LSTMCell GEMM reads).
     Same results as lstm_cell_act_into x 2 + env.step. Only valid inside sampler.begin_block(); consumes two ordinals."""
     N, R = c_prev[0].shape
     assert sampler._ordinal is not None and actions_out.is_contiguous() and actions_out.shape == (2, N)
@@ -653,6 +757,10 @@ def act_env_step(env_core, ig, hg, biases, c_prev, done, h_out, c_out, acts, sam
     a.ordinal = sampler._ordinal + 1
     sampler._ordinal += 2
     a.A, a.N, a.R = actors[0].weight.shape[0], N, R
+    if hm_out is not None:
+        assert env_core is not None and hm_out[0].shape == (N, R) and hm_out[1].shape == (N, R)
+        assert hm_out[0].stride(1) == 1 and hm_out[1].stride(1) == 1 and hm_out[0].stride(0) == hm_out[1].stride(0)
+        a.hm_out[0], a.hm_out[1], a.hm_ld = hm_out[0].data_ptr(), hm_out[1].data_ptr(), hm_out[0].stride(0)
     L = lib()
     if env_core is None:
         rc = L.atr_act_env_step(None, C.byref(a), None, 0, None, None, _stream(ig[0]))
@@ -878,13 +986,15 @@ class _EmbedAdd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, f, w, b, actions):
-        f = f.contiguous()
+        if not (f.stride(1) == 1 and f.stride(0) >= f.shape[1] and f.stride(0) % 4 == 0):
+            f = f.contiguous()       # (rows may be strided: the features as a column block of the rollout's [features | k h] rows)
         rows, Cc = f.shape
         A = w.shape[1]
         wc, bc = w.contiguous(), b.contiguous()
-        out = torch.empty_like(f)
+        out = torch.empty((rows, Cc), dtype=f.dtype, device=f.device)
         acts, act_n, act_ts = _act_layout(actions, rows)
-        rc = lib().atr_embed_add(_p(f), _p(wc), _p(bc), _p(acts), 1, act_n, act_ts, _p(out), rows, Cc, A, _stream(f))
+        rc = lib().atr_embed_add_ld(_p(f), f.stride(0), _p(wc), _p(bc), _p(acts), 1, act_n, act_ts, _p(out), rows, Cc, A,
+                                    _stream(f))
         if rc != 0:
             raise RuntimeError("atr_embed_add failed (%d)" % rc)
         ctx.save_for_backward(acts)
@@ -951,7 +1061,8 @@ class DeferredWeightGrads(object):
         if (dst is None or any(v is None for v in bv) or len(bv) > 2 or len(self.problems) >= self.MAX
                 or (self.K is not None and K != self.K) or K < 4096 or M % 128 or N % 128
                 or not (x1.is_cuda and x1.dtype == torch.float32 and x2.dtype == torch.float32
-                        and x1.is_contiguous() and x2.is_contiguous())
+                        and x1.is_contiguous() and x2.stride(1) == 1 and x2.stride(0) >= N and x2.stride(0) % 4 == 0
+                        and x2.data_ptr() % 16 == 0)
                 or tuple(dst.shape) != (M, N) or (row_scale is not None and not row_scale.is_contiguous())):
             return None
         self.K = K
@@ -980,6 +1091,7 @@ class DeferredWeightGrads(object):
             arr[q].colsum0 = bv[0].data_ptr() if len(bv) > 0 else None
             arr[q].colsum1 = bv[1].data_ptr() if len(bv) > 1 else None
             arr[q].M, arr[q].N = M, N
+            arr[q].ld1, arr[q].ld2 = M, x2.stride(0)
         L = lib()
         x0 = self.problems[0][0]
         ws = torch.empty(L.atr_gemm_tn_grouped_workspace_floats(arr, n, self.K), dtype=torch.float32, device=x0.device)

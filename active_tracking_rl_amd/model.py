@@ -528,6 +528,8 @@ class A3C_Dueling(nn.Module):
     env_step_fused_seen = False   # (diagnostic: some step of this model ran its env step inside k_act_step)
     fused_env_step = True    # ... and end the step with ONE launch: both cells + heads + draws + the env step (k_act_step)
     pair_gemm_max_rows = int(__import__('os').environ.get('ATR_PAIR_GEMM_MAX_ROWS', '1024'))  # up to here: GEMM pairs as one launch
+    # above: the LSTMCell's two GEMMs as ONE library product over [features | k h_prev] rows (fused.linear_lt, K = F + R)
+    cat_gate_gemm = __import__('os').environ.get('ATR_CAT_GATE_GEMM', '1') != '0'
     # atr_actor_step (both LSTMCell GEMMs + cell as one MFMA kernel per player, then two draw launches and the step launch)
     # is kept as an option: since k_act_step the GEMM pair + ONE fused cell/draw/env launch is faster at every batch size
     # measured (4096 rows: 6.15 vs 6.21 ms per iteration); ATR_MFMA_MIN_ROWS=3072 restores round 2's choice
@@ -601,7 +603,22 @@ class A3C_Dueling(nn.Module):
         c = RolloutCache()
         c.T, c.N, c.frames = T, N, frames
         c.y = [torch.empty((T, N * f, 512), device=dev) for f in frames]
-        if p0.encoder.outdim == p1.encoder.outdim:      # one [2, T, N, F] store: a step's pair of rows is one strided batch
+        c.fh_all = None
+        same_f = p0.encoder.outdim == p1.encoder.outdim
+        if (same_f and self.cat_gate_gemm and N > self.pair_gemm_max_rows and self.fused_env_step and self.fused_sampling
+                and R == 128 and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape and p0.encoder.outdim % 4 == 0):
+            # Above the pair-kernel sizes the LSTMCell's two GEMMs are ONE product over rows [features | k h_prev] (K = F + R):
+            # slot t of this store holds step t's fc features (written by the fc GEMM with row stride F + R) next to the
+            # previous step's hidden row, already zeroed where that step ended an episode (written by k_act_step); slot T is
+            # the bootstrap step's. The learner reads the features in place (strided).
+            Fd = p0.encoder.outdim
+            c.fh_all = torch.empty((2, T + 1, N, Fd + R), device=dev)
+            c.f_all = c.fh_all[:, :T, :, :Fd]
+            c.f = [c.f_all[0], c.f_all[1]]
+            c.lazy["w_cat"] = lambda: torch.stack([torch.cat([l.weight_ih, l.weight_hh], 1) for l in (p0.lstm, p1.lstm)], 0)
+            if getattr(self, "_lt_ws", None) is None or self._lt_ws.device != dev:
+                self._lt_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)   # this model's chain of launches only
+        elif same_f:      # one [2, T, N, F] store: a step's pair of rows is one strided batch
             c.f_all = torch.empty((2, T, N, p0.encoder.outdim), device=dev)
             c.f = [c.f_all[0], c.f_all[1]]
         else:
@@ -612,7 +629,7 @@ class A3C_Dueling(nn.Module):
         c.h_all = torch.empty((2, T + 1, N, R), device=dev)
         c.c_all = torch.empty((2, T + 1, N, R), device=dev)
         c.actions = torch.empty((T, 2, N), dtype=torch.int64, device=dev) if self.fused_sampling else None
-        c.gates = torch.empty((2, N, 4 * R), device=dev) if N <= self.pair_gemm_max_rows else None   # scratch: pre-activations
+        c.gates = torch.empty((2, N, 4 * R), device=dev) if (N <= self.pair_gemm_max_rows or c.fh_all is not None) else None   # scratch: pre-activations
         c.bsum = [l.bias_ih + l.bias_hh for l in (p0.lstm, p1.lstm)]
         c.lazy["whh_t"] = lambda: torch.stack([l.weight_hh.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, R, 4R]
         if c.f_all is not None and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape:
@@ -636,7 +653,8 @@ class A3C_Dueling(nn.Module):
                               cache.feat1[t] if cache.feat1 is not None else None,
                               cache.h_all[:, t], cache.c_all[:, t], cache.h_all[:, t + 1], cache.c_all[:, t + 1],
                               cache.acts[:, t], cache.actions[t] if cache.actions is not None else None, done,
-                              f_pair=cache.f_all[:, t] if cache.f_all is not None else None, env_out=env_out)
+                              f_pair=cache.f_all[:, t] if cache.f_all is not None else None, env_out=env_out,
+                              fh=(cache.fh_all[:, t], cache.fh_all[:, t + 1]) if cache.fh_all is not None else None)
 
     @torch.no_grad()
     def boot_values(self, states, cache, done, v_out):
@@ -650,7 +668,10 @@ class A3C_Dueling(nn.Module):
             b = cache.boot = RolloutCache()
             dev, N, R = states.device, cache.N, cache.h_all.shape[-1]
             b.y = [torch.empty_like(cache.y[i][0]) for i in range(2)]
-            b.f_all = torch.empty_like(cache.f_all[:, 0]) if cache.f_all is not None else None
+            if cache.fh_all is not None:       # slot T of the [features | k h] store is the bootstrap step's
+                b.f_all = cache.fh_all[:, cache.T, :, :cache.f_all.shape[-1]]
+            else:
+                b.f_all = torch.empty_like(cache.f_all[:, 0]) if cache.f_all is not None else None
             b.f = [b.f_all[0], b.f_all[1]] if b.f_all is not None else [torch.empty_like(cache.f[i][0]) for i in range(2)]
             b.feat1 = torch.empty_like(cache.feat1[0]) if cache.feat1 is not None else None
             b.h, b.c = torch.empty((2, N, R), device=dev), torch.empty((2, N, R), device=dev)
@@ -658,12 +679,12 @@ class A3C_Dueling(nn.Module):
             b.actions = torch.empty((2, N), dtype=torch.int64, device=dev) if cache.actions is not None else None
         T = cache.T
         self._act_step(states, cache, b.y, b.f, b.feat1, cache.h_all[:, T], cache.c_all[:, T], b.h, b.c, b.acts, b.actions,
-                       done, f_pair=b.f_all)
+                       done, f_pair=b.f_all, fh=(cache.fh_all[:, T], None) if cache.fh_all is not None else None)
         fused.heads_values2([b.h[0], b.h[1]], (self.player0.critic.critic_linear, self.player1.critic.critic_linear), v_out)
         return v_out
 
     def _act_step(self, states, cache, y, f_out, feat1, h_prev, c_prev, h_out, c_out, acts, actions, done, f_pair=None,
-                  env_out=None):
+                  env_out=None, fh=None):
         """One actor step of both players on explicit buffers: y / f_out per-player stem and fc outputs, h_prev / c_prev
         [2,N,R] (un-masked; `done` [N] uint8 of the previous step is applied inside), h_out / c_out [2,N,R], acts
         [2,N,4R] (activated gates), actions [2,N] int64 or None."""
@@ -694,7 +715,9 @@ class A3C_Dueling(nn.Module):
                      and all(t.is_contiguous() for t in (c_prev[0], c_prev[1], h_out[0], h_out[1], c_out[0], c_out[1],
                                                          acts[0], acts[1], h_prev[0], h_prev[1])))
         pair_gemm = env_fused and n <= self.pair_gemm_max_rows and getattr(cache, "gates", None) is not None
-        hgs = None if (mfma_step or pair_gemm) else torch.bmm(h_prev, cache.whh_t)
+        # fh = (this step's [2, N, F + R] rows of the [features | k h_prev] store, the next step's): one gate GEMM, K = F + R
+        cat_gemm = env_fused and not pair_gemm and fh is not None and getattr(cache, "gates", None) is not None
+        hgs = None if (mfma_step or pair_gemm or cat_gemm) else torch.bmm(h_prev, cache.whh_t)
         one_launch = (actions is not None and self._sampler._ordinal is not None and R // 4 in (16, 32, 64)
                       and p0.actor.actor_linear.weight.shape[0] <= 8 and p1.actor.actor_linear.weight.shape[0] <= 8)
         # Below the MFMA-step threshold: both input projections as ONE batched GEMM on the pair's feature rows, then both
@@ -711,13 +734,30 @@ class A3C_Dueling(nn.Module):
                 fused.pair_linear([f_out[0], f_out[1]], [p0.lstm.weight_ih, p1.lstm.weight_ih], [g[0], g[1]], bias=cache.bsum,
                                   a2=[h_prev[0], h_prev[1]], w2=[p0.lstm.weight_hh, p1.lstm.weight_hh], done=done)
                 ig, hg_, bs = g, None, None
+                hm = None
+            elif cat_gemm:
+                # fc + ReLU straight into the feature columns of this step's rows (ldc = F + R), then both LSTMCell GEMMs of both
+                # players as ONE batched product over those rows: 5 launches per step, one gate tensor (the bias is added in
+                # k_act_step: the library has no per-batch bias). k_act_step writes the NEXT step's k h columns itself — it
+                # knows this step's done flags — so the mask on h is already in the rows; `done` still masks c_prev.
+                fh_t, fh_next = fh
+                Fd = f_out[0].shape[-1]
+                for i, p in enumerate((p0, p1)):
+                    fused.linear_lt(ys[i].view(n, -1), p.encoder.fc.weight, fh_t[i][:, :Fd], bias=p.encoder.fc.bias, relu=True,
+                                    workspace=self._lt_ws)
+                g = cache.gates
+                fused.linear_lt(fh_t, cache.w_cat, g, workspace=self._lt_ws)
+                ig, hg_, bs = g, None, cache.bsum
+                hm = [fh_next[0][:, Fd:], fh_next[1][:, Fd:]] if (fh_next is not None and env_out is not None) else None
             else:
+                hm = None
                 for i, p in enumerate((p0, p1)):
                     _addmm_relu(p.encoder.fc.bias, ys[i].view(n, -1), p.encoder.fc.weight.t(), f_out[i])
                 ig, hg_, bs = torch.bmm(f_pair, cache.wih_t), hgs, cache.bsum
             fused.act_env_step(core, ig, hg_, bs, c_prev, done, h_out, c_out, acts, self._sampler,
                                (p0.actor.actor_linear, p1.actor.actor_linear), actions,
-                               emb=cache.emb_ih if self.tat else None, env_out=env_out[1:] if env_out is not None else None)
+                               emb=cache.emb_ih if self.tat else None, env_out=env_out[1:] if env_out is not None else None,
+                               hm_out=hm)
             self.env_stepped = env_out is not None
             self.env_step_fused_seen = self.env_step_fused_seen or self.env_stepped
             return [actions[0], actions[1]]

@@ -143,6 +143,12 @@ class Agent(object):
         self._cache = None
         self._keep = None
         sampler = getattr(self.model, "_sampler", None)
+        if (sampler is None and getattr(self.model, "fused_sampling", False) and hasattr(self.model, "new_cache")
+                and torch.is_tensor(self.state) and self.state.is_cuda):
+            # made here and not lazily inside the first step: without an open draw block the first rollout of a model would
+            # take the slower per-player launches instead of the path every later rollout takes
+            from . import fused
+            sampler = self.model._sampler = fused.ActionSampler(self.state.device)
         if sampler is not None:
             sampler.begin_block()                                 # one counter bump per rollout, ordinals inside
         if num_steps is not None and self.cache_rollout and hasattr(self.model, "new_cache") and self.num_agents == 2:
@@ -156,9 +162,11 @@ class Agent(object):
                 from . import fused                               # both copies + the observation's in one launch
                 fused.rollout_begin(self.hxs, self.cxs, self._cache.h_all, self._cache.c_all, obs0,
                                     self._buf[0][0] if obs0 is not None else None)
+                self._seed_fh()
                 return
             self._cache.h_all[:, 0].copy_(self.hxs.transpose(0, 1))
             self._cache.c_all[:, 0].copy_(self.cxs.transpose(0, 1))
+            self._seed_fh()
             if obs0 is not None:
                 self._buf[0][0].copy_(obs0)
             return
@@ -168,6 +176,14 @@ class Agent(object):
         self._cs = [c.contiguous() for c in self.cxs.unbind(1)]
         if hasattr(self.model, "begin_act"):
             self.model.begin_act()
+
+    def _seed_fh(self):
+        """The h columns of slot 0 of the cache's [features | k h_prev] rows (the one-GEMM LSTMCell path of model._act_step):
+        the state the rollout starts from — masked by the previous rollout's last done flags already (end_rollout)."""
+        fh = getattr(self._cache, "fh_all", None)
+        if fh is not None:
+            R = self._cache.h_all.shape[-1]
+            fh[:, 0, :, fh.shape[-1] - R:].copy_(self._cache.h_all[:, 0])
 
     def end_rollout(self):
         """Publish the per-player LSTM states back as hxs/cxs [N,A,R] and the episode-length counters."""
@@ -380,7 +396,12 @@ class Agent(object):
                 model.boot_values(self.state, self._cache, self.done, v[T])
                 sampler.end_block()
             else:
-                boot, _, _, _, _, _ = model((self.state, (self.hxs, self.cxs)))
+                # (the LSTM state the rollout ended on, from THIS rollout's own store: under the graphed drivers self.hxs /
+                # self.cxs alias the carry, which the next rollout may already be overwriting on another stream)
+                k_end = (self.done == 0).to(torch.float32).view(N, 1, 1)
+                hx_end = self._cache.h_all[:, T].transpose(0, 1) * k_end
+                cx_end = self._cache.c_all[:, T].transpose(0, 1) * k_end
+                boot, _, _, _, _, _ = model((self.state, (hx_end, cx_end)))
                 v[T].copy_(boot)
             R, gae = fused.gae_returns(rewards.contiguous(), v, nd, args.gamma, args.tau)
         use_aux = 'reward' in args.aux and getattr(model, "tat", False) and getattr(model.player1, "sub_task", False)
@@ -481,6 +502,10 @@ class Agent(object):
         self.allreduce_grads(optimizer)
         max_norm = getattr(self.args, "max_grad_norm", None)
         if max_norm:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm)
+            if getattr(optimizer, "bucket", None) is not None:
+                from .train import clip_flat_grad_           # the same expression the graphed drivers capture
+                clip_flat_grad_(optimizer, max_norm)
+            else:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm)
         optimizer.step()
         return stats

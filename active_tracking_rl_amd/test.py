@@ -4,8 +4,10 @@ GPU (argmax policy, Agent.action_test) instead of one env in a side process.
 Kept from the reference: evaluation on `--env-base` (default Track2D-BlockPartialNav-v0, main.py:27), the summary line
 ("ave eps reward / ave eps length / reward step", test.py:101-109), the checkpoint names and contents
 (`all-best-{n_iter}.dat` / `all-new.dat`, and with --split `tracker-{best,new}.dat`, `target-{best,new}.dat`:
-state_dicts with the reference's keys, test.py:111-127), the train_modes schedule (test.py:84-92) and the stop sentinel
--100 once n_iter > max_step (test.py:129-134). Success = episode length >= 500 (gym_eval.py:114-115).
+state_dicts with the reference's keys, test.py:111-127), the train_modes schedule (test.py:84-92, including the
+--train-mode 2 tracker / target alternation, which needs the --adv-step flag the reference forgot to define), the
+`test/reward{i}`, `test/fps`, `test/eps_len` scalars (test.py:93-97; one record per evaluation episode, as there) and the
+stop sentinel -100 once n_iter > max_step (test.py:129-134). Success = episode length >= 500 (gym_eval.py:114-115).
 """
 import logging
 import os
@@ -17,7 +19,7 @@ import torch
 from .environment import create_env
 from .model import build_model
 from .player_util import Agent
-from .utils import check_path, setup_logger
+from .utils import ScalarWriter, check_path, setup_logger
 
 
 @torch.no_grad()
@@ -45,6 +47,31 @@ def evaluate(model, env_id, args, device, episodes, seed=None):
     if was_training:
         model.train()
     return rsum[:episodes].cpu().numpy(), length[:episodes].cpu().numpy()
+
+
+def schedule_train_modes(args, train_modes, n_iter, state):
+    """test.py:84-92, verbatim semantics: tracker only while n_iter < --init-step; with --train-mode 2 the mode of every rank
+    flips (1 - mode) whenever more than `iter_th` iterations have passed since the last flip — iter_th starts at --init-step
+    and becomes --init-step after a flip to the tracker, --adv-step after a flip away from it — and is otherwise reset to
+    --train-mode. `state` carries last_iter / iter_th between calls (locals of the reference's one long loop). The reference
+    applies this at the end of every evaluation episode; here it runs once per evaluation round (all episodes of a round
+    finish together)."""
+    state.setdefault("last_iter", 0)
+    state.setdefault("iter_th", args.init_step)
+    for rank in range(len(train_modes)):
+        if n_iter < args.init_step:
+            train_modes[rank] = 0
+        elif args.train_mode == 2 and n_iter - state["last_iter"] > state["iter_th"]:
+            train_modes[rank] = 1 - train_modes[rank]
+            state["last_iter"] = n_iter
+            adv_step = getattr(args, "adv_step", None)
+            if adv_step is None:
+                raise AttributeError("--train-mode 2 needs --adv-step (test.py:90 of the reference reads args.adv_step, which "
+                                     "its main.py never defines)")
+            state["iter_th"] = args.init_step if train_modes[rank] == 0 else adv_step
+        else:
+            train_modes[rank] = args.train_mode
+    return train_modes
 
 
 def save_checkpoints(model, args, n_iter, best):
@@ -83,17 +110,27 @@ def test(args, shared_model, train_modes, n_iters, rounds=None, state=None):
         for k, v in vars(args).items():
             log.info('{0}: {1}'.format(k, v))
         state.update(started=True, start_time=time.time(), max_score=-100)
+    if state.get("writer") is None:
+        state["writer"] = ScalarWriter(os.path.join(args.log_dir, 'Test'))          # test.py:19
+    writer = state["writer"]
     env_id = args.env if args.env_base is None else args.env_base
     start_time, max_score = state["start_time"], state["max_score"]
     done_rounds = 0
     while rounds is None or done_rounds < rounds:
+        t0 = time.time()
         rsum, length = evaluate(shared_model, env_id, args, device, args.test_eps)
         n_iter = int(sum(n_iters))
-        for rank in range(len(n_iters)):                     # test.py:84-92
-            if n_iter < args.init_step:
-                train_modes[rank] = 0
-            else:
-                train_modes[rank] = args.train_mode
+        schedule_train_modes(args, train_modes, n_iter, state)                       # test.py:84-92
+        # test.py:93-97: one record per evaluation episode at step n_iter. test/fps in the reference is the env steps per
+        # second of the evaluator's one env; here the episodes of a round run as one batch, so it is the round's env steps
+        # (all episodes) over its wall time
+        fps = float(length.sum()) / max(time.time() - t0, 1e-9)
+        for ep in range(len(length)):
+            for i in range(rsum.shape[1]):
+                writer.add_scalar('test/reward' + str(i), rsum[ep, i], n_iter)
+            writer.add_scalar('test/fps', fps, n_iter)
+            writer.add_scalar('test/eps_len', length[ep], n_iter)
+        writer.flush()
         ave_reward_sum = rsum[:, :2].sum(0) / args.test_eps
         len_mean = length.sum() / args.test_eps
         reward_step = rsum[:, :2].sum(0) / max(length.sum(), 1)

@@ -32,7 +32,7 @@ def default_args(**over):
              amsgrad=True, load_model_dir=None, log_dir='logs/', network='tat-maze-lstm', aux='reward', gpu_ids=[0],
              obs='img', single=False, gray=False, crop=False, inv=False, rescale=False, render=False,
              shared_optimizer=True, split=False, train_mode=-1, stack_frames=1, input_size=80, rnn_out=128,
-             sleep_time=0, max_step=150000, init_step=-1, num_envs=4096, max_grad_norm=None, obs_u8=True)
+             sleep_time=0, max_step=150000, init_step=-1, adv_step=None, num_envs=4096, max_grad_norm=None, obs_u8=True)
     d.update(over)
     return argparse.Namespace(**d)
 
@@ -90,6 +90,18 @@ def rollout(player, num_steps, fast=True):
         player.env.flush()
 
 
+def clip_flat_grad_(optimizer, max_norm, eps=1e-6):
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) (what player_util.py:157 asks for; a no-op in the reference, SURVEY
+    quirk 5, hence off unless --max-grad-norm is given) on the flat gradient bucket: the total norm over all parameters is the
+    norm of the one flat tensor (the bucket's padding stays zero). No host synchronisation: capturable in the update graph."""
+    bucket = getattr(optimizer, "bucket", None)
+    if not max_norm or bucket is None:
+        return
+    g = bucket.grad
+    coef = (float(max_norm) / (g.norm(2) + eps)).clamp(max=1.0)
+    g.mul_(coef)
+
+
 class GraphedIteration(object):
     """One A3C iteration (20-step rollout -> loss -> backward | all-reduce | SharedAdam) replayed as two hipGraphs.
 
@@ -131,6 +143,7 @@ class GraphedIteration(object):
         self._capture(self.mode0)
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
+            clip_flat_grad_(optimizer, getattr(args, "max_grad_norm", None))
             optimizer.step()
         if saved is not None:          # (capturing a graph does not execute it; restore anyway in case a backend ran it)
             with torch.no_grad():
@@ -199,18 +212,40 @@ class GraphedIteration(object):
 
 
 _hip, _masked_streams = None, {}
+MODEL_SWITCHES = ("fused_sampling", "fused_actor_step", "fused_env_step", "pair_gemm_max_rows", "mfma_step_min_rows",
+                  "cat_gate_gemm")
 
 
-def cu_masked_stream(device, first_cu, n_cus, total_cus=256):
+def device_cus(device):
+    """Compute units of `device` as the HIP runtime enumerates them (hipDeviceProp.multiProcessorCount: 256 on an MI355X)."""
+    return int(torch.cuda.get_device_properties(device).multi_processor_count)
+
+
+def cu_partition(device):
+    """(first CU, CUs) of the rollout half and of the learner half of an even CU split, or None when this part cannot be
+    split evenly over its shader engines: the runtime deals a mask's bits round-robin over the chip's 32 shader engines, so
+    only runs that are multiples of 32 CUs give every engine the same share (cu_masked_stream)."""
+    total = device_cus(device)
+    if total < 64 or total % 64 != 0:
+        return None
+    return (total // 2, total // 2), (0, total // 2)
+
+
+def cu_masked_stream(device, first_cu, n_cus, total_cus=None):
     """A HIP stream whose kernels are dispatched only to compute units [first_cu, first_cu + n_cus) of the runtime's CU
     enumeration (hipExtStreamCreateWithCUMask), wrapped for torch. The runtime deals the mask's bits round-robin over the
     chip's 32 shader engines (bit k = CU k / 32 of engine k % 32), so a run of 32 m bits is m of the 8 CUs of EVERY engine of
     every XCD: both halves of a split see all eight L2s and stay balanced under the round-robin workgroup placement; counts
     that are not multiples of 32 leave some engines a CU short and the whole stream waits for those (measured: 120 or 136 CUs
-    are slower than 96). One stream per (device, range) per process: each masked stream takes a hardware queue of its own,
-    and a process that oversubscribes the queues gets time-sliced (measured 2-3x slower iterations)."""
+    are slower than 96). total_cus: the device's CU count (read from the device properties when None). One stream per
+    (device, range) per process: each masked stream takes a hardware queue of its own, and a process that oversubscribes
+    the queues gets time-sliced (measured 2-3x slower iterations)."""
     global _hip
     import ctypes as C
+    if total_cus is None:
+        total_cus = device_cus(device)
+    if n_cus <= 0 or first_cu < 0 or first_cu + n_cus > total_cus:
+        raise ValueError("CU range [%d, %d) does not fit a %d-CU device" % (first_cu, first_cu + n_cus, total_cus))
     key = (str(device), int(first_cu), int(n_cus))
     if key in _masked_streams:
         return _masked_streams[key]
@@ -302,6 +337,11 @@ class PipelinedIteration(object):
             m = build_model(env.observation_space, env.action_space, args, dev).to(dev)
             m.load_state_dict(player.model.state_dict())
             m.train()
+            for attr, val in vars(player.model).items():     # instance-level kernel switches set on the master (A/B runs:
+                if attr in MODEL_SWITCHES:                    # bench.py --actor-step) hold for the replicas that do the work
+                    setattr(m, attr, val)
+            if getattr(player.model, "_lt_ws", None) is not None:       # library-GEMM scratch of this replica's own chain of
+                m._lt_ws = torch.empty_like(player.model._lt_ws)        # launches (allocated here, outside any capture)
             bucket = FlatParams(select_params(m, args.train_mode))
             assert bucket.flat.numel() == optimizer.bucket.flat.numel()
             # a draw stream of its own: the learner's bootstrap step reads the replica's counter, which only the replica's
@@ -322,8 +362,9 @@ class PipelinedIteration(object):
         part = os.environ.get("ATR_PIPE_CU_SPLIT")        # force a CU partition: this many CUs for the rollout stream, the
         self.cu_split = int(part) if part else 0          # rest for the learner's (tune_streams tries 128 / 128 by itself)
         if self.cu_split:
-            self.sR = cu_masked_stream(dev, 256 - self.cu_split, self.cu_split)
-            self.sL = cu_masked_stream(dev, 0, 256 - self.cu_split)
+            total = device_cus(dev)
+            self.sR = cu_masked_stream(dev, total - self.cu_split, self.cu_split, total)
+            self.sL = cu_masked_stream(dev, 0, total - self.cu_split, total)
         self.ev_r = [torch.cuda.Event() for _ in range(2)]
         self.ev_o = [torch.cuda.Event() for _ in range(2)]
         self.pending = None       # (replica, learner graph) of the rollout whose learner has not been issued yet
@@ -332,6 +373,7 @@ class PipelinedIteration(object):
         for k in range(2):        # O_k: the update on theta, then theta -> F_k
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                clip_flat_grad_(optimizer, getattr(args, "max_grad_norm", None))
                 optimizer.step()
                 self.buckets[k].flat.copy_(optimizer.bucket.flat)
             self.g_opt.append(g)
@@ -367,6 +409,8 @@ class PipelinedIteration(object):
                 if self.carry[key].data_ptr() != src.data_ptr():
                     self.carry[key].copy_(src)
             p.carry_out = None
+            if hasattr(p.env, "generator_join"):
+                p.env.generator_join()        # the env's forked generator launches (opt-in) end inside the captured region
         # the learner of THIS rollout reads the replica's own end-of-rollout tensors (last observation slot, LSTM state, done):
         # the carry belongs to the next rollout by then
         g_l = torch.cuda.CUDAGraph()
@@ -442,35 +486,78 @@ class PipelinedIteration(object):
             self._issue_pending()
             self.sync()
 
-    def tune_streams(self, candidates=4, iters=8, partitions=(128,)):
+    def _schedule_tensors(self):
+        """Every tensor an update of this schedule writes: master weights, optimizer state, the replicas' weight copies."""
+        opt = self.optimizer
+        seen, out = set(), []
+        for t in [opt.bucket.flat, opt.bucket.grad] + [v for v in vars(opt).values() if isinstance(v, torch.Tensor)] \
+                + [b.flat for b in self.buckets]:
+            if t.data_ptr() not in seen and t.numel() > 0:
+                seen.add(t.data_ptr())
+                out.append(t)
+        return out
+
+    def tune_streams(self, candidates=4, iters=8, partitions=("half",), keep_updates=False):
         """Pick the stream pair the two chains overlap best on. Two things are not in the application's hands and are settled
-        by trial — `iters` real iterations per candidate (ordinary iterations of the schedule: the weights do not depend on
-        the streams, see `serial`), timed on the host clock, the fastest kept:
+        by trial — `iters` iterations of the schedule per candidate, timed on the host clock, the fastest kept:
           * HIP multiplexes its streams onto a few hardware queues (4 by default) in an order the application does not
             control: two streams that land on one queue run the two chains back to back (measured at 512 envs: 1.73 ms per
             iteration against 1.33 ms on distinct queues, 1.62 ms synchronous), and the mapping depends on how many streams
             the process created before — `candidates` alternative learner streams are tried;
-          * a CU PARTITION (`partitions`: CUs given to the rollout stream, the rest to the learner's; cu_masked_stream). On a
+          * a CU PARTITION (`partitions`: "half" = an even split, or a CU count for the rollout stream, the rest to the
+            learner's; cu_masked_stream; skipped on parts whose CU count does not split evenly over the shader engines). On a
             shared chip a rollout kernel's workgroups queue for CU resources behind the learner's resident workgroups (a
             workgroup that needs 72 KB of LDS next to two 64 KB GEMM workgroups waits out the whole GEMM: tools/microbench/
             two_queue.hip; the rollout chain runs at 40-50 % speed next to any chip-filling learner kernel: tools/
-            corun_kernels.py). With 128 CUs each neither chain ever waits for the other: both run slower (half a chip) but
+            corun_kernels.py). With half the CUs each neither chain ever waits for the other: both run slower but
             fully concurrently — 1.15 against 1.28 ms per iteration at 512 envs; from 2048 envs up both chains are
             throughput-bound and the shared chip wins, which is what the trial then finds.
+        The trial iterations are NOT training: unless keep_updates is set, the master weights, the optimizer state (step
+        counter, moments), the replicas' weight copies, the phase counter and the step count are restored afterwards, so that
+        iteration 0 of the caller's run is its first (the env shard and the carried LSTM state simply continue — experience
+        nobody learned from). Multi-rank runs: every trial holds all-reduces, so all ranks must run the SAME candidate list
+        (a rank whose CU-masked streams cannot be made would otherwise run fewer collectives and hang the job: the partition
+        candidates are kept only if every rank has them, all-reduce MIN) and must KEEP the same pair (the per-candidate times
+        are all-reduced MAX — an iteration is as slow as its slowest rank — before the argmin).
         Returns [(ms per iteration, chosen, label)] per candidate."""
         if self.serial:
             return []
         import time as _time
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         pairs = [(self.sR, self.sL, "as constructed")]
         if not self.cu_split:
             pairs += [(self.sR, torch.cuda.Stream(device=self.dev), "learner stream %d" % (c + 1)) for c in range(candidates)]
-            for r_cus in partitions:
+            total = device_cus(self.dev)
+            for part in partitions:
+                made = None
                 try:
-                    pairs.append((cu_masked_stream(self.dev, 256 - r_cus, r_cus), cu_masked_stream(self.dev, 0, 256 - r_cus),
-                                  "CU partition %d / %d" % (r_cus, 256 - r_cus)))
-                except Exception:           # (a runtime without CU masks: the shared-chip candidates remain)
-                    pass
-        trials = []
+                    if part == "half":
+                        halves = cu_partition(self.dev)
+                        if halves is not None:
+                            (r0, rn), (l0, ln) = halves
+                            made = (cu_masked_stream(self.dev, r0, rn, total), cu_masked_stream(self.dev, l0, ln, total),
+                                    "CU partition %d / %d" % (rn, ln))
+                    elif 0 < int(part) < total:
+                        r_cus = int(part)
+                        made = (cu_masked_stream(self.dev, total - r_cus, r_cus, total),
+                                cu_masked_stream(self.dev, 0, total - r_cus, total), "CU partition %d / %d" % (r_cus, total - r_cus))
+                except (RuntimeError, OSError, AttributeError, ValueError):   # a runtime without CU masks
+                    made = None
+                if multi:       # the candidate exists on every rank or on none
+                    ok = torch.tensor([1 if made is not None else 0], dtype=torch.int32, device=self.dev)
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    if int(ok.item()) == 0:
+                        made = None
+                if made is not None:
+                    pairs.append(made)
+        self.finish()
+        torch.cuda.synchronize(self.dev)
+        tensors = None if keep_updates else self._schedule_tensors()
+        saved = [t.clone() for t in tensors] if tensors is not None else None
+        i0, n0 = self.i, self.master.n_steps
+        iters += iters & 1              # whole pairs of phases per candidate: the replica parity is the same afterwards
+        times = []
         for sR, sL, label in pairs:
             self.finish()
             torch.cuda.synchronize(self.dev)
@@ -484,12 +571,23 @@ class PipelinedIteration(object):
                 self.run()
             self.finish()
             torch.cuda.synchronize(self.dev)
-            trials.append(((_time.perf_counter() - t0) / iters * 1e3, sR, sL, label))
+            times.append((_time.perf_counter() - t0) / iters * 1e3)
         self.finish()
         torch.cuda.synchronize(self.dev)
-        best = min(trials, key=lambda t: t[0])
-        self.sR, self.sL, self.stream_choice = best[1], best[2], best[3]
-        return [(ms, (sR is best[1] and sL is best[2]), label) for ms, sR, sL, label in trials]
+        if multi:
+            tt = torch.tensor(times, dtype=torch.float64, device=self.dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            times = tt.tolist()
+        best = min(range(len(pairs)), key=lambda j: times[j])
+        self.sR, self.sL, self.stream_choice = pairs[best][0], pairs[best][1], pairs[best][2]
+        if saved is not None:
+            with torch.no_grad():
+                for t, v in zip(tensors, saved):
+                    t.copy_(v)
+            assert (self.i - i0) % 2 == 0      # (each candidate ran 2 + iters phases: replica i0 & 1 is next, as before)
+            self.i, self.master.n_steps = i0, n0
+            torch.cuda.synchronize(self.dev)
+        return [(times[j], j == best, pairs[j][2]) for j in range(len(pairs))]
 
 
 def sync_train_modes(train_modes, device, src=0):

@@ -123,6 +123,11 @@ typedef struct atr_act_step {
     unsigned long long seed;
     unsigned ordinal;
     int A, N, R;
+    /* with an env handle only (nullable): hm_out[p] + e * hm_ld receives (done[e] == 0 ? h_out row : 0) — the hidden row as
+     * the NEXT step's LSTMCell GEMM wants it (episode-boundary mask applied, player_util.py:98-102), written next to that
+     * step's features so that the cell's two GEMMs are one product over rows [features | k h] (atr_linear, K = 256 + 128) */
+    float *hm_out[2];
+    long long hm_ld;
 } atr_act_step;
 struct t2d_handle;
 /* env == NULL: the policy half alone (N rows; the learner's bootstrap step). Otherwise N must equal the handle's env count,
@@ -139,6 +144,30 @@ int atr_act_env_step(struct t2d_handle *env, const atr_act_step *args, void *obs
  * GEMMs of nn.LSTMCell for both players in one pass (model.py:110,137,172,203: A1 = features, W1 = weight_ih, A2 = previous
  * hidden state masked by the previous step's done flags, W2 = weight_hh, bias = b_ih + b_hh). N and every k multiples of
  * 32, (k1 + k2) >= 128, 16-byte aligned pointers, strides multiples of 4. Returns 0, -1 (bad argument), -2 (launch failure). */
+/* A plain Linear layer (batch of them) through hipBLASLt called directly (csrc/lt_gemm.cpp):
+ *     C[b] = act(A[b] W[b]^T + bias),  b < batch;  A [M, K] (row stride lda), W [N, K] (nn.Linear layout, row stride ldw),
+ *     C [M, N] (row stride ldc >= N: the output may be a column block of wider rows), bias [N] (nullable, batch == 1 only),
+ *     relu != 0 applies max(., 0); stride_* = floats between consecutive batch members.
+ * Uses: CNN_maze's fc + ReLU (perception.py:81,90 of the reference) written into the first 256 columns of the rollout's
+ * [features | k h_prev] rows, and both GEMMs of nn.LSTMCell for both players (model.py:110,137,172,203) as ONE batched
+ * product over those rows (K = 384) -> one gate tensor. Each distinct problem is timed once over the library's candidate
+ * kernels (first call outside a stream capture) and keeps the fastest for the life of the process.
+ * atr_lt_init: once per process, with the path of the libhipblaslt.so PyTorch itself loads (this library does not link one).
+ * Return 0 or -1 (atr_lt_last_error()). */
+typedef struct atr_linear_args {
+    const float *a, *w, *bias;
+    float *c;
+    long long lda, ldw, ldc;
+    long long stride_a, stride_w, stride_c;
+    int M, N, K, batch, relu;
+    void *workspace;              /* device scratch for split-K style kernels (16-byte aligned; NULL = the library's own, which */
+    long long workspace_bytes;    /* callers on DIFFERENT streams must not share: give each concurrent chain its own) */
+} atr_linear_args;
+int atr_lt_init(const char *libhipblaslt_path);
+int atr_linear(const atr_linear_args *args, void *stream);
+int atr_linear_plan_info(const atr_linear_args *args, int *candidates, int *chosen, int *tuned, float *best_us);
+const char *atr_lt_last_error(void);
+
 typedef struct atr_pair_linear_args {
     const float *a1[2], *w1[2], *a2[2], *w2[2], *bias[2];
     float *c[2];
@@ -185,6 +214,13 @@ int atr_lstm_bptt(const float *dh0_heads, const float *dh1_heads, const float *k
  * atr_embed_grad_workspace_floats(rows, C, A) floats; fixed summation order (reproducible). */
 int atr_embed_add(const float *f, const float *w, const float *b, const long long *actions, long long act_stride,
                   long long act_n, long long act_tstride, float *out, long long rows, int C, int A, void *stream);
+/* ... with f's rows ldf floats apart (the features as a column block of the rollout's [features | k h] rows); out stays dense */
+int atr_embed_add_ld(const float *f, long long ldf, const float *w, const float *b, const long long *actions,
+                     long long act_stride, long long act_n, long long act_tstride, float *out, long long rows, int C, int A,
+                     void *stream);
+/* ReLU backward against a stored activation: out[r][c] = f[r * ldf + c] > 0 ? df[r][c] : 0 (df, out dense [rows, C]; C a
+ * multiple of 4, 16-byte aligned rows) — aten::threshold_backward for a strided activation, one vectorised pass. */
+int atr_relu_backward_ld(const float *df, const float *f, long long ldf, float *out, long long rows, int C, void *stream);
 long long atr_embed_grad_workspace_floats(long long rows, int C, int A);
 int atr_embed_grad(const float *dout, const long long *actions, long long act_stride, long long act_n, long long act_tstride,
                    float *dw, float *db, float *workspace, long long rows, int C, int A, void *stream);
@@ -263,6 +299,7 @@ typedef struct atr_gemm_tn_problem {
     long long row_scale_shift;
     float *colsum0, *colsum1;
     int M, N;
+    long long ld1, ld2;      /* row strides of x1 / x2 in floats (0 = dense: M / N); multiples of 4 */
 } atr_gemm_tn_problem;
 long long atr_gemm_tn_grouped_workspace_floats(const atr_gemm_tn_problem *problems, int count, long long K);
 int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int count, long long K, float *workspace, void *stream);

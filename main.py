@@ -14,13 +14,6 @@ single-process run; under torch.distributed.run each rank uses LOCAL_RANK.
 from __future__ import print_function, division
 import os
 os.environ["OMP_NUM_THREADS"] = "1"
-# The pipelined schedule's CU partition (train.PipelinedIteration.tune_streams) gives each chain a CU-masked stream with a
-# hardware queue of its own; iterations slow down 2-3x once a process owns more than four hardware queues (measured), so a
-# single-GPU run lets the ordinary streams share two (read by the HIP runtime at initialisation: set before torch touches the
-# GPU). Multi-rank runs keep the runtime's default — RCCL's streams want queues too, and there is no N > 1 box to measure on.
-_SET_HW_QUEUES = int(os.environ.get("WORLD_SIZE", "1")) == 1 and "GPU_MAX_HW_QUEUES" not in os.environ
-if _SET_HW_QUEUES:
-    os.environ["GPU_MAX_HW_QUEUES"] = "2"
 import argparse
 import time
 from datetime import datetime
@@ -77,11 +70,27 @@ parser.add_argument('--no-graph', action='store_true', help='run iterations eage
 parser.add_argument('--schedule', choices=('pipelined', 'synchronous'), default='pipelined',
                     help='pipelined: rollout i+1 overlaps learner i on a second HIP stream (gradients one update late); '
                          'synchronous: rollout, learner, update in sequence')
-parser.add_argument('--log-every', type=int, default=10, metavar='LE', help='training iterations between train/* scalar records')
+parser.add_argument('--log-every', type=int, default=100, metavar='LE',
+                    help='training iterations between train/* scalar records (each record joins both streams of the pipelined '
+                         'schedule and reads ~10 scalars back: keep it well above 1)')
+parser.add_argument('--adv-step', type=int, default=None, metavar='AS',
+                    help="--train-mode 2 only: iterations the TARGET trains before the evaluator hands back to the tracker "
+                         "(test.py:88-91 of the reference reads args.adv_step, which its own main.py never defines)")
 
 if __name__ == '__main__':
     args = parser.parse_args()
+    if args.train_mode == 2 and args.adv_step is None:
+        parser.error("--train-mode 2 (tracker / target alternation, test.py:88-91) needs --adv-step: the reference reads "
+                     "args.adv_step there without defining the flag and stops with an AttributeError at the first switch")
+    if args.max_grad_norm is not None and args.max_grad_norm <= 0:
+        parser.error("--max-grad-norm must be positive")
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # The pipelined schedule's CU partition (train.PipelinedIteration.tune_streams) gives each chain a CU-masked stream with a
+    # hardware queue of its own; iterations slow down 2-3x once a process owns more than four hardware queues (measured), so
+    # the ordinary streams share two. Read by the HIP runtime at initialisation, i.e. set here, before anything touches the
+    # GPU — and only for the schedule that needs it. (N > 1: measured with a 1-rank RCCL group, profiles/r04_multirank_*.)
+    if args.schedule == 'pipelined' and not args.no_graph and world == 1 and "GPU_MAX_HW_QUEUES" not in os.environ:
+        os.environ["GPU_MAX_HW_QUEUES"] = "2"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(args.gpu_ids[0])))
     if world > 1:

@@ -157,21 +157,34 @@ def test_full_observation_env_trains():
     player.env.close()
 
 
-@pytest.mark.parametrize("train_mode", [-1, 0, 1])
-def test_cached_rollout_learner_matches_the_recompute_learner(train_mode):
+@pytest.mark.parametrize("train_mode,cat_gemm", [(-1, False), (0, False), (1, False), (-1, True), (1, True)])
+def test_cached_rollout_learner_matches_the_recompute_learner(train_mode, cat_gemm):
     """Actor/learner with the rollout cache (forward evaluated once, in the rollout: model.act_cached +
     forward_sequence_cached) against the recompute learner (forward_sequence) on the SAME rollout: loss terms and
     every parameter gradient agree to fp32 round-off (different GEMM shapes -> different summation orders). Train-mode
     0 / 1: the cached learner does not back-propagate the untrained player's recurrence — its parameters get no (or an
-    all-zero) gradient from either learner."""
+    all-zero) gradient from either learner. cat_gemm: the large-batch form of the rollout step (fc + ReLU written into
+    [features | k h_prev] rows by atr_linear, both LSTMCell GEMMs as one K = 384 product, the masked hidden rows written by
+    k_act_step) forced at a small batch — the learner then reads the features in place, strided (atr_relu_backward_ld,
+    atr_embed_add_ld, the grouped weight-gradient launch with a row stride)."""
     from active_tracking_rl_amd.train import default_args, make_player, rollout
-    args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=256, num_steps=6, network="tat-maze-lstm", seed=11,
-                        train_mode=train_mode)
+    args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=1024 if cat_gemm else 256, num_steps=6,
+                        network="tat-maze-lstm", seed=11, train_mode=train_mode)
     args.gpu_ids = [0]
     player, optimizer = make_player(args, torch.device("cuda:0"), 0, 1)
     assert player.cache_rollout
+    if cat_gemm:
+        player.model.pair_gemm_max_rows = 0
     rollout(player, args.num_steps, fast=True)
-    assert player._cache is not None
+    assert player._cache is not None and (player._cache.fh_all is not None) == cat_gemm
+    if cat_gemm:      # the rows the one-GEMM path reads: features next to the PREVIOUS step's hidden row, masked by its done flag
+        cch, T_ = player._cache, args.num_steps
+        keep = (player._buf[2] == 0).float()                                          # [T, N]
+        for t in range(1, T_ + 1):
+            want = cch.h_all[:, t] * keep[t - 1].view(1, -1, 1)
+            assert torch.equal(cch.fh_all[:, t, :, 256:], want), t
+        assert torch.equal(cch.fh_all[:, 0, :, 256:], cch.h_all[:, 0])
+        assert not cch.f[0].is_contiguous() and cch.f[0].stride(-2) == 384
     outs = []
     cache = player._cache
     for cached, fused_heads in ((True, True), (True, False), (False, False)):
@@ -564,14 +577,14 @@ def test_pipelined_schedule_is_the_same_dataflow_on_one_stream_and_on_two(env_id
             torch.cuda.synchronize()
             thetas.append(opt.bucket.flat.clone())
         if not serial:                      # stream trials are ordinary iterations: run them here, mirror them below
-            trials = it.tune_streams(candidates=2, iters=3, partitions=(128,))
+            trials = it.tune_streams(candidates=2, iters=4, partitions=(128,), keep_updates=True)
             assert len(trials) == 4 and sum(c for _, c, _ in trials) == 1 and "partition" in trials[-1][2]
         else:
-            for _ in range(4 * (2 + 3)):
+            for _ in range(4 * (2 + 4)):
                 it.run()
         it.finish()
         torch.cuda.synchronize()
-        assert it.i == 27
+        assert it.i == 31
         k = (it.i - 1) & 1
         assert torch.equal(it.buckets[k].flat, opt.bucket.flat)                    # O(i): theta -> F_k
         assert not torch.equal(it.buckets[1 - k].flat, opt.bucket.flat)            # the other replica is one update behind
@@ -580,6 +593,18 @@ def test_pipelined_schedule_is_the_same_dataflow_on_one_stream_and_on_two(env_id
         st = player.env.core.get_state()
         res.append((thetas + [opt.bucket.flat.clone()], [b.flat.clone() for b in it.buckets],
                     {k_: v.clone() for k_, v in it.carry.items()}, st["pos"].copy(), [s.clone() for s in it.stats]))
+        if not serial:
+            # by default the stream trials are NOT training: master weights, optimizer state, replica weights, phase and step
+            # counters come back as they were (main.py tunes before iteration 0: the first logged iteration is the first update)
+            snap = [t.clone() for t in it._schedule_tensors()]
+            i_before, n_before = it.i, it.master.n_steps
+            trials = it.tune_streams(candidates=1, iters=3)
+            assert sum(c for _, c, _ in trials) == 1
+            assert all(torch.equal(a, b) for a, b in zip(snap, it._schedule_tensors()))
+            assert (it.i, it.master.n_steps) == (i_before, n_before)
+            it.run(); it.run(); it.finish()
+            torch.cuda.synchronize()
+            assert torch.isfinite(opt.bucket.flat).all() and not torch.equal(snap[0], opt.bucket.flat)
         player.env.close()
     (ta, fa, ca, pa, sa), (tb, fb, cb, pb, sb) = res
     assert all(torch.equal(a, b) for a, b in zip(ta, tb))
