@@ -548,34 +548,46 @@ __device__ __forceinline__ int bfs_dir_field(const uint32_t *tile, int side, int
     }
     f.visA = frA; f.visB = frB;
     for (;;) {
+        // Rows 64 .. side-1 (set B, 17-18 of the 81-82 rows) take no part in a level unless the frontier stands in them or in
+        // row 63: a wave-uniform test per level skips their share of the work (about 40 % of a level's instructions) for the
+        // larger part of most floods — a lone wave's instruction count is its latency.
+        const bool actB = __ballot((frB.w[0] | frB.w[1] | frB.w[2]) != 0u || (lane == 63 && (frA.w[0] | frA.w[1] | frA.w[2]) != 0u)) != 0ull;
         RowBits upA, dnA, upB, dnB;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const uint32_t a_prev = from_prev_lane(frA.w[j]);       // row lane-1 (set A)
             const uint32_t a_next = from_next_lane(frA.w[j]);       // row lane+1 (set A)
-            const uint32_t b_prev = from_prev_lane(frB.w[j]);
-            const uint32_t b_next = from_next_lane(frB.w[j]);
-            const uint32_t a_last = __builtin_amdgcn_readlane(frA.w[j], 63);  // row 63
-            const uint32_t b_first = __builtin_amdgcn_readlane(frB.w[j], 0);  // row 64
             upA.w[j] = lane == 0 ? 0u : a_prev;                     // frontier cell above  -> action 0 (up)
-            dnA.w[j] = lane == 63 ? b_first : a_next;               // frontier cell below  -> action 1 (down)
-            upB.w[j] = lane == 0 ? a_last : b_prev;
-            dnB.w[j] = lane == 63 ? 0u : b_next;
+            dnA.w[j] = a_next;                                      // frontier cell below  -> action 1 (down)
+            upB.w[j] = 0u; dnB.w[j] = 0u;
+        }
+        if (actB) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const uint32_t b_prev = from_prev_lane(frB.w[j]);
+                const uint32_t b_next = from_next_lane(frB.w[j]);
+                const uint32_t a_last = __builtin_amdgcn_readlane(frA.w[j], 63);  // row 63
+                const uint32_t b_first = __builtin_amdgcn_readlane(frB.w[j], 0);  // row 64
+                if (lane == 63) dnA.w[j] = b_first;
+                upB.w[j] = lane == 0 ? a_last : b_prev;
+                dnB.w[j] = lane == 63 ? 0u : b_next;
+            }
         }
         const RowBits lfA = row_shl1(frA), rtA = row_shr1(frA);     // frontier cell to the left / right
-        const RowBits lfB = row_shl1(frB), rtB = row_shr1(frB);
         uint32_t any = 0u;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            {
-                const uint32_t open = freeA.w[j] & ~f.visA.w[j];
-                const uint32_t u = upA.w[j] & open, d = dnA.w[j] & open & ~u;
-                const uint32_t l = lfA.w[j] & open & ~(u | d), r = rtA.w[j] & open & ~(u | d | l);
-                const uint32_t nw = u | d | l | r;
-                f.d0A.w[j] |= d | r; f.d1A.w[j] |= l | r;
-                f.visA.w[j] |= nw; frA.w[j] = nw; any |= nw;
-            }
-            {
+            const uint32_t open = freeA.w[j] & ~f.visA.w[j];
+            const uint32_t u = upA.w[j] & open, d = dnA.w[j] & open & ~u;
+            const uint32_t l = lfA.w[j] & open & ~(u | d), r = rtA.w[j] & open & ~(u | d | l);
+            const uint32_t nw = u | d | l | r;
+            f.d0A.w[j] |= d | r; f.d1A.w[j] |= l | r;
+            f.visA.w[j] |= nw; frA.w[j] = nw; any |= nw;
+        }
+        if (actB) {
+            const RowBits lfB = row_shl1(frB), rtB = row_shr1(frB);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
                 const uint32_t open = freeB.w[j] & ~f.visB.w[j];
                 const uint32_t u = upB.w[j] & open, d = dnB.w[j] & open & ~u;
                 const uint32_t l = lfB.w[j] & open & ~(u | d), r = rtB.w[j] & open & ~(u | d | l);

@@ -425,8 +425,16 @@ __global__ __launch_bounds__(256) void k_gen_nav(DevState s, uint32_t lo, uint32
         return;
     }
     const uint32_t genv = s.env_base + (uint32_t)e;
+#if T2D_EXP == 9     // probe build (tools/gen_nav_timeline_probe.py): s_memtime stamps of wave 0, left in the slot's spare tile words
+    __shared__ uint32_t gst[16];
+#define T2D_NSTAMP(i) do { if (wave == 0 && lane == 0) gst[i] = (uint32_t)__builtin_readcyclecounter(); } while (0)
+#else
+    uint32_t *gst = nullptr;
+#define T2D_NSTAMP(i) do { } while (0)
+#endif
+    T2D_NSTAMP(6);
     if (wave == 0) {
-        generate_episode<true, true>(s, e, tile, mlog, lane, cfg, target, gdir, pos, goals, plan, tctr, navgoal, d2, nav2, fi);
+        generate_episode<true, true>(s, e, tile, mlog, lane, cfg, target, gdir, pos, goals, plan, tctr, navgoal, d2, nav2, fi, gst);
         // the goals of the two queued plans, drawn as nav_fill_queue will draw them if the first plan needs no re-draw
         Stream t1;
         t1.init(s.k0, s.k1, target, genv, STREAM_TARGET, tctr);
@@ -437,6 +445,7 @@ __global__ __launch_bounds__(256) void k_gen_nav(DevState s, uint32_t lo, uint32
         const uint32_t g3 = select_free(tile, side, fi, (int)t2.bounded((uint32_t)(fi.total - 1)), lane);
         if (lane == 0) { xch[0] = pos; xch[1] = navgoal; xch[2] = g2; xch[3] = g3; xch[4] = c1; xch[5] = t2.ctr; }
     }
+    T2D_NSTAMP(7);
     __syncthreads();
     const uint32_t x_pos = xch[0], x_g1 = xch[1], x_g2 = xch[2], x_g3 = xch[3];
     bool ok0 = false;
@@ -458,7 +467,9 @@ __global__ __launch_bounds__(256) void k_gen_nav(DevState s, uint32_t lo, uint32
             if (lane == 0) xch[8 + wave] = usable ? 1u : 0u;
         }
     }
+    T2D_NSTAMP(8);
     __syncthreads();
+    T2D_NSTAMP(9);
     if (wave != 0) return;
     uint32_t ps;
     if (ok0) {      // the speculation held: what nav_plan + nav_fill_queue would have left behind
@@ -483,6 +494,13 @@ __global__ __launch_bounds__(256) void k_gen_nav(DevState s, uint32_t lo, uint32
         s.n_pos[so] = pos; s.n_goals[so] = goals; s.n_plan[so] = plan; s.n_tctr[so] = tctr;
         s.n_navgoal[so] = navgoal; s.n_d2[so] = d2; s.gen_req[so] = 0u; s.n_nav2[so] = 0u;
     }
+#if T2D_EXP == 9
+    if (lane == 0) {
+        gst[5] = (uint32_t)__builtin_readcyclecounter();
+        for (int i = 0; i < 10; i++) s.n_maps[so * kTileWords + 246 + i] = gst[i];
+    }
+#endif
+#undef T2D_NSTAMP
 }
 
 __global__ __launch_bounds__(256) void k_nav_prefetch(DevState s)
@@ -1625,11 +1643,16 @@ extern "C" int t2d_destroy(t2d_handle *h)
 }
 
 static inline dim3 env_grid(int n) { return dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)); }
+constexpr int kGenNavMaxEnvs = 2048;
 
 static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t lo, uint32_t hi, int force, bool prefetch = false)
 {
     const dim3 grid = env_grid(2 * h->s.n);        // one wave per (slot, env)
-    if (h->has_navmode) {                          // Nav targets: one workgroup per (slot, env) (+ the queue top-up blocks)
+    // Nav targets, small shards: one WORKGROUP per (slot, env), the three floods of a generated episode on three waves
+    // (k_gen_nav: the pass is as long as its slowest generation — 238 -> 206 us at 1024 Maze + Nav envs). A large batch has
+    // thousands of generations per pass and is bound by their throughput, where four waves per generation lose to one
+    // (8192 envs: 927 against 784 us per pass): those keep k_gen.
+    if (h->has_navmode && h->s.n <= kGenNavMaxEnvs) {
         const unsigned blocks = 2u * (unsigned)h->s.n + (prefetch ? (unsigned)((h->s.n + kWavesPerBlock - 1) / kWavesPerBlock) : 0u);
         if (prefetch) hipLaunchKernelGGL((k_gen_nav<true>), dim3(blocks), dim3(256), 0, st, h->s, lo, hi, force);
         else hipLaunchKernelGGL((k_gen_nav<false>), dim3(blocks), dim3(256), 0, st, h->s, lo, hi, force);
