@@ -480,6 +480,56 @@ extern "C" int t2d_np_target_action(t2d_np *e, int32_t *action)
     return 0;
 }
 
+// ---- many envs at once: the per-env calls above spread over host threads (each env owns its stream: no shared state) ----
+#include <atomic>
+#include <thread>
+
+template <class F> static int for_each_env(int count, int threads, F &&body)
+{
+    if (count <= 0) return 0;
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > count) nt = count;
+    std::atomic<int> next(0), err(0);
+    char first_err[sizeof(g_err)] = "";
+    std::atomic<bool> have_err(false);
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= count) return;
+            const int rc = body(i);
+            if (rc != 0) {
+                err.store(rc);
+                bool expected = false;
+                if (have_err.compare_exchange_strong(expected, true)) snprintf(first_err, sizeof(first_err), "env %d: %s", i, g_err);
+            }
+        }
+    };
+    if (nt == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; t++) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+    }
+    if (err.load() != 0) { snprintf(g_err, sizeof(g_err), "%s", first_err); return err.load(); }
+    return 0;
+}
+
+extern "C" int t2d_np_reset_many(t2d_np *const *envs, int count, uint8_t *mazes, int32_t *sides, int32_t *pos, int32_t *goals,
+                                 int threads)
+{
+    if (!envs || !mazes || !sides || !pos || !goals) return fail(-1, "t2d_np_reset_many: null argument");
+    return for_each_env(count, threads, [&](int i) {
+        return t2d_np_reset(envs[i], mazes + (size_t)i * 82 * 82, sides + i, pos + 4 * i, goals + 4 * i);
+    });
+}
+
+extern "C" int t2d_np_target_actions(t2d_np *const *envs, int count, int32_t *actions, int threads)
+{
+    if (!envs || !actions) return fail(-1, "t2d_np_target_actions: null argument");
+    return for_each_env(count, threads, [&](int i) { return t2d_np_target_action(envs[i], actions + i); });
+}
+
 extern "C" int t2d_np_get_plan(const t2d_np *e, int32_t *plan, int32_t max_len, int32_t *len, int32_t *cursor,
                                int32_t navgoal[2])
 {

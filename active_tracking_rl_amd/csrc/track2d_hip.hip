@@ -1459,6 +1459,8 @@ struct t2d_handle {
     DevState s;
     int device;
     bool reset_done;   // every env has a current episode
+    std::vector<uint8_t> has_episode;   // per env: given one by t2d_inject (which may come env by env)
+    int n_has_episode = 0;
     bool primed;       // every env has a valid next slot
     bool has_nav;
     bool has_ram;      // some env has the scripted Ram target (selects the step kernel variant with the plan code)
@@ -2104,7 +2106,10 @@ extern "C" int t2d_inject(t2d_handle *h, int first, int count, int side, const u
         for (int k3 = 0; k3 < 3; k3++)
             HIP_TRY(hipMemcpyAsync(s.p_state + (size_t)k3 * s.n + first, zero.data(), nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (first == 0 && count == s.n) h->reset_done = true;
+    if (h->has_episode.size() != (size_t)s.n) { h->has_episode.assign((size_t)s.n, 0); h->n_has_episode = 0; }
+    for (int i = 0; i < count; i++)
+        if (!h->has_episode[(size_t)(first + i)]) { h->has_episode[(size_t)(first + i)] = 1; h->n_has_episode++; }
+    if (h->n_has_episode == s.n) h->reset_done = true;      // (all at once or env by env)
     return T2D_OK;
 }
 

@@ -177,6 +177,72 @@ class VecEnv(object):
         raise NotImplementedError("matplotlib rendering (track_1v1.py:170-216) is out of scope")
 
 
+class NumpyVecEnv(object):
+    """N envs in the REFERENCE-EXACT mode at once (VecEnv's batched protocol, rng="numpy"): env i's maps, spawns, goals and
+    scripted Ram / Nav / RPF target come from its own numpy-legacy stream seeded np.random.seed(seeds[i]) — host C++
+    (np_mode.NpBatchSource: MT19937, numpy's draws, heapq-faithful A*, spread over host threads) — and go to the device through
+    t2d_inject / as the step's target action; the device does the per-step work for all N in one launch. An env that finishes
+    is reset at once from ITS stream (the next episode of that seed, as the reference's worker loop does: train.py:73-74) and
+    reports the new episode's first observation, like VecEnv. Per env the episodes are the reference's from the seed alone.
+    env_ids: one id or one per env (same observation type; map type, target mode and level may differ per env).
+    Costs a host round trip per step (done flags down, target actions / new episodes up): a parity tool, not the
+    throughput path."""
+
+    def __init__(self, env_ids, seeds, device="cuda:0", threads=0):
+        from .np_mode import NpBatchSource
+        n = len(seeds)
+        ids = [env_ids] * n if isinstance(env_ids, str) else list(env_ids)
+        assert len(ids) == n
+        sp = [registry.spec(i) for i in ids]
+        assert len(set(x["obs_type"] for x in sp)) == 1, "one observation type per handle"
+        self.num_envs, self.env_ids = n, ids
+        self.src = NpBatchSource([x["map_type"] for x in sp], [x["target_mode"] for x in sp], [x["level"] for x in sp], seeds,
+                                 threads)
+        modes = np.array([registry.TARGET_CODE["Ext"] if self.src.scripted[i] else registry.TARGET_CODE[sp[i]["target_mode"]]
+                          for i in range(n)], np.uint8)           # scripted targets are driven from the host (T2D_TGT_EXT)
+        self.core = VecTrack2D(ids[0], num_envs=n, device=device, seed=int(seeds[0]), auto_reset=False,
+                               map_type_per_env=np.array([registry.MAP_CODE[x["map_type"]] for x in sp], np.uint8),
+                               target_mode_per_env=modes, level_per_env=np.array([x["level"] for x in sp], np.uint8),
+                               obs_type=sp[0]["obs_type"])
+        self.device = self.core.device
+        self.observation_space, self.action_space = _spaces(self.core.obs_hw, self.core.num_actions)
+        self._scripted_idx = np.nonzero(self.src.scripted)[0]
+
+    def _inject(self, idx, mazes, sides, pos, goals):
+        for j, i in enumerate(idx):                    # (per env: sides differ between Maze and Block / Empty maps)
+            s_ = int(sides[j])
+            self.core.inject(np.ascontiguousarray(mazes[j, :s_, :s_]), pos[j], goals[j], first=int(i))
+
+    def reset(self, mask=None):
+        """New episodes for every env (or those where mask is set) from their streams; returns all observations."""
+        idx = np.arange(self.num_envs) if mask is None else np.nonzero(np.asarray(mask))[0]
+        self._inject(idx, *self.src.reset(idx))
+        return self.core.observe()
+
+    def step(self, actions):
+        """actions: [a_tracker [N], a_target [N]] (device or host integers; the target's entry is ignored where the target is
+        scripted) -> (obs [N,2,h,w] f32, rewards [N,2] f32, done [N] u8, info {'distance': [N] f64})."""
+        dev = self.device
+        a0 = torch.as_tensor(actions[0], dtype=torch.int64, device=dev).reshape(-1).contiguous()
+        a1 = torch.as_tensor(actions[1], dtype=torch.int64, device=dev).reshape(-1).clone()
+        if len(self._scripted_idx):                    # track_1v1.py:80-84: the scripted target overrides action[1]
+            ta = self.src.target_actions(self._scripted_idx)
+            a1[torch.as_tensor(self._scripted_idx, device=dev)] = torch.as_tensor(ta, dtype=torch.int64, device=dev)
+        obs, rew, done = self.core.step(a0, a1.contiguous())
+        d2 = self.core.get_state()["d2"].astype(np.float64)
+        fin = np.nonzero(done.cpu().numpy())[0]
+        if len(fin):
+            self._inject(fin, *self.src.reset(fin))
+            fresh = self.core.observe()
+            sel = torch.as_tensor(fin, device=dev)
+            obs[sel] = fresh[sel]
+        return obs, rew, done, {"distance": np.sqrt(d2)}
+
+    def close(self):
+        self.core.close()
+        self.src.close()
+
+
 class Track2DEnv(object):
     """One env behind the reference's exact gym protocol (TimeLimit + frame_stack included).
 

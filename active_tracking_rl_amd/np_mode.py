@@ -8,7 +8,8 @@ import numpy as np
 from . import registry, vec_env
 
 NP_SYMBOLS = ("t2d_np_create", "t2d_np_destroy", "t2d_np_last_error", "t2d_np_seed", "t2d_np_reset",
-              "t2d_np_target_action", "t2d_np_get_plan", "t2d_np_astar", "t2d_np_draw")
+              "t2d_np_target_action", "t2d_np_get_plan", "t2d_np_astar", "t2d_np_draw", "t2d_np_reset_many",
+              "t2d_np_target_actions")
 _ready = False
 
 
@@ -34,6 +35,10 @@ def _lib():
         L.t2d_np_astar.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp]
         L.t2d_np_draw.restype = i32
         L.t2d_np_draw.argtypes = [vp, i32, u32, u32, vp]
+        L.t2d_np_reset_many.restype = i32
+        L.t2d_np_reset_many.argtypes = [vp, i32, vp, vp, vp, vp, i32]
+        L.t2d_np_target_actions.restype = i32
+        L.t2d_np_target_actions.argtypes = [vp, i32, vp, i32]
         _ready = True
     return L
 
@@ -99,6 +104,47 @@ class NpEpisodeSource(object):
         out = np.zeros(max(int(arg) if kind == 2 else int(count), 1), np.float64)
         _check(self.L.t2d_np_draw(self.h, int(kind), int(arg), int(count), _ptr(out)))
         return out[:int(arg) if kind == 2 else int(count)]
+
+
+class NpBatchSource(object):
+    """The random side of N envs, each with its own numpy-legacy stream (np.random.seed(seeds[i]) semantics), advanced
+    together on host threads (t2d_np_reset_many / t2d_np_target_actions). map_types / target_modes / levels: one value or
+    one per env."""
+
+    def __init__(self, map_types, target_modes, levels, seeds, threads=0):
+        n = len(seeds)
+        expand = lambda v: list(v) if isinstance(v, (list, tuple, np.ndarray)) else [v] * n
+        self.map_types, self.target_modes, self.levels = expand(map_types), expand(target_modes), [int(x) for x in expand(levels)]
+        assert len(self.map_types) == n and len(self.target_modes) == n and len(self.levels) == n
+        self.n, self.threads, self.L = n, int(threads), _lib()
+        self.src = [NpEpisodeSource(self.map_types[i], self.target_modes[i], self.levels[i], int(seeds[i])) for i in range(n)]
+        self.scripted = np.array([s.scripted for s in self.src], bool)
+
+    def close(self):
+        for s in self.src:
+            s.close()
+
+    def _handles(self, idx):
+        return (C.c_void_p * len(idx))(*[self.src[i].h for i in idx])
+
+    def reset(self, idx=None):
+        """Episodes for the envs in idx (all when None) -> (mazes u8 [k, 82, 82], sides int32 [k], pos int32 [k, 2, 2],
+        goals int32 [k, 2, 2])."""
+        idx = list(range(self.n)) if idx is None else [int(i) for i in idx]
+        k = len(idx)
+        mazes = np.zeros((k, 82, 82), np.uint8)
+        sides, pos, goals = np.zeros(k, np.int32), np.zeros((k, 4), np.int32), np.zeros((k, 4), np.int32)
+        if k:
+            _check(self.L.t2d_np_reset_many(self._handles(idx), k, _ptr(mazes), _ptr(sides), _ptr(pos), _ptr(goals), self.threads))
+        return mazes, sides, pos.reshape(k, 2, 2), goals.reshape(k, 2, 2)
+
+    def target_actions(self, idx):
+        """The scripted targets' actions for the next step of the envs in idx (each must have a Ram / Nav / RPF target)."""
+        idx = [int(i) for i in idx]
+        a = np.zeros(len(idx), np.int32)
+        if idx:
+            _check(self.L.t2d_np_target_actions(self._handles(idx), len(idx), _ptr(a), self.threads))
+        return a
 
 
 def astar(maze, start, goal, max_len=8192):

@@ -478,7 +478,11 @@ class Agent(object):
     def allreduce_grads(self, optimizer):
         """The ONE collective of the path: flat fp32 gradient bucket, mean over ranks (RCCL over xGMI). Replaces
         ensure_shared_grads + the shared-memory model (utils.py:36-44)."""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        # (a 1-rank group issues nothing unless ATR_FORCE_ALLREDUCE=1: tools/multirank_probe.py measures the collective's
+        # stream hand-overs on the one leased GPU that way)
+        if dist.get_world_size() == 1 and __import__("os").environ.get("ATR_FORCE_ALLREDUCE") != "1":
             return
         world = dist.get_world_size()
         bucket = getattr(optimizer, "bucket", None)

@@ -90,6 +90,17 @@ def rollout(player, num_steps, fast=True):
         player.env.flush()
 
 
+def capture_allreduce_default():
+    """Whether the gradient all-reduce is captured INSIDE the update graph (one graph replay per update: all-reduce, clip,
+    optimizer step) or issued eagerly between the learner's graph and the update graph. ATR_CAPTURE_ALLREDUCE=1 / 0 overrides;
+    the default is the measured winner (profiles/r04_multirank_1gpu.txt)."""
+    v = os.environ.get("ATR_CAPTURE_ALLREDUCE")
+    return CAPTURE_ALLREDUCE_DEFAULT if v is None else v == "1"
+
+
+CAPTURE_ALLREDUCE_DEFAULT = False
+
+
 def clip_flat_grad_(optimizer, max_norm, eps=1e-6):
     """torch.nn.utils.clip_grad_norm_(params, max_norm) (what player_util.py:157 asks for; a no-op in the reference, SURVEY
     quirk 5, hence off unless --max-grad-norm is given) on the flat gradient bucket: the total norm over all parameters is the
@@ -141,8 +152,11 @@ class GraphedIteration(object):
                           cxs=player.cxs.detach().clone(), done=player.done.clone(), eps_len=player.eps_len.clone())
         self.g_rolls, self.stats_by_mode = {}, {}
         self._capture(self.mode0)
+        self.capture_allreduce = capture_allreduce_default()
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
+            if self.capture_allreduce:
+                player.allreduce_grads(optimizer)
             clip_flat_grad_(optimizer, getattr(args, "max_grad_norm", None))
             optimizer.step()
         if saved is not None:          # (capturing a graph does not execute it; restore anyway in case a backend ran it)
@@ -204,7 +218,8 @@ class GraphedIteration(object):
         if g is None:
             g = self._capture(mode)
         g.replay()
-        self.player.allreduce_grads(self.optimizer)
+        if not self.capture_allreduce:
+            self.player.allreduce_grads(self.optimizer)
         self.g_opt.replay()
         self.player.n_steps += self.args.num_steps
         self.stats = self.stats_by_mode[mode]
@@ -367,12 +382,15 @@ class PipelinedIteration(object):
             self.sL = cu_masked_stream(dev, 0, total - self.cu_split, total)
         self.ev_r = [torch.cuda.Event() for _ in range(2)]
         self.ev_o = [torch.cuda.Event() for _ in range(2)]
+        self.capture_allreduce = capture_allreduce_default()
         self.pending = None       # (replica, learner graph) of the rollout whose learner has not been issued yet
         self.graphs = {}          # (mode, k) -> (rollout graph, learner graph, stats)
         self.g_opt = []
         for k in range(2):        # O_k: the update on theta, then theta -> F_k
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                if self.capture_allreduce:
+                    player.allreduce_grads(optimizer)
                 clip_flat_grad_(optimizer, getattr(args, "max_grad_norm", None))
                 optimizer.step()
                 self.buckets[k].flat.copy_(optimizer.bucket.flat)
@@ -435,7 +453,8 @@ class PipelinedIteration(object):
             # is the same dataflow as the two-stream schedule below
             g_r.replay()
             g_l.replay()
-            self.master.allreduce_grads(self.optimizer)
+            if not self.capture_allreduce:
+                self.master.allreduce_grads(self.optimizer)
             self.g_opt[k].replay()
         else:
             # One call = one PHASE of the pipeline: the learner + update of the PREVIOUS rollout go out on stream L, then this
@@ -466,7 +485,8 @@ class PipelinedIteration(object):
         with torch.cuda.stream(self.sL):
             self.sL.wait_event(self.ev_r[k])
             g_l.replay()
-            self.master.allreduce_grads(self.optimizer)       # (RCCL on this stream: under the next rollout)
+            if not self.capture_allreduce:
+                self.master.allreduce_grads(self.optimizer)   # (RCCL on this stream: under the next rollout)
             self.g_opt[k].replay()
             self.ev_o[k].record(self.sL)
 

@@ -47,6 +47,13 @@ int t2d_np_reset(t2d_np *e, uint8_t *maze, int32_t *side, int32_t pos[4], int32_
  * does not depend on the tracker). Error for the policy-driven modes (Adv / PZR / Far). */
 int t2d_np_target_action(t2d_np *e, int32_t *action);
 
+/* The two per-step / per-episode calls for MANY envs (a batch replayed against the reference: each env keeps its own stream,
+ * so the calls are independent and are spread over `threads` host threads; 0 = one per hardware thread). envs[i] -> entry i of
+ * every output: mazes [count][82*82], sides [count], pos / goals [count][4]; actions [count]. Returns 0 or the first failing
+ * env's code (t2d_np_last_error names it). */
+int t2d_np_reset_many(t2d_np *const *envs, int count, uint8_t *mazes, int32_t *sides, int32_t *pos, int32_t *goals, int threads);
+int t2d_np_target_actions(t2d_np *const *envs, int count, int32_t *actions, int threads);
+
 /* The target's current plan (plan_actions, a_i) and, for Nav / RPF, its goal: for tests against the reference's
  * plan0 / navgoal0. plan: caller buffer of max_len ints; *len = full length (may exceed max_len). */
 int t2d_np_get_plan(const t2d_np *e, int32_t *plan, int32_t max_len, int32_t *len, int32_t *cursor, int32_t navgoal[2]);

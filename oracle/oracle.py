@@ -58,6 +58,7 @@ def lib():
         L.orc_get_obs.argtypes = [vp, pu8]
         L.orc_get_plan.restype = i32
         L.orc_get_plan.argtypes = [vp, pi, pi]
+        L.orc_get_nav.argtypes = [vp, pi, pi, pi]
         L.orc_episode.restype = u32
         L.orc_episode.argtypes = [vp]
         L.orc_step_batch.restype = i32
@@ -163,6 +164,13 @@ class OracleEnv(object):
         o = np.zeros_like(self._obs)
         self.L.orc_get_obs(self.h, _p(o, C.c_uint8))
         return o
+
+    def nav(self):
+        """(goal [2], plan B?, plan length) of a Nav / RPF target."""
+        g = np.zeros(2, np.int32)
+        pb, ln = C.c_int(0), C.c_int(0)
+        self.L.orc_get_nav(self.h, _p(g, C.c_int), C.byref(pb), C.byref(ln))
+        return g, bool(pb.value), ln.value
 
     def plan(self):
         buf = np.zeros(1024, np.int32)

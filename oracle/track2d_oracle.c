@@ -819,6 +819,14 @@ int orc_get_plan(const orc_env *e, int *plan, int *cursor)
     return e->plan_len;
 }
 uint32_t orc_episode(const orc_env *e) { return e->episode; }
+/* Nav / RPF target: the Navigator's current goal (re-drawn when the first one was unreachable, navigator.py:50-56), whether it
+ * fell back to plan B (:58-59) and the length of its plan (NP mode: the A* action list; PHILOX mode: the BFS distance). */
+void orc_get_nav(const orc_env *e, int *nav_goal, int *planb, int *plan_len)
+{
+    if (nav_goal) { nav_goal[0] = e->nav_goal[0]; nav_goal[1] = e->nav_goal[1]; }
+    if (planb) *planb = e->nav_planb;
+    if (plan_len) *plan_len = e->nav_planb ? e->plan_len : (e->rng_mode == ORC_RNG_NP ? e->plan_len : e->remaining);
+}
 
 /* Lock-step helper for the full-size parity tests: n envs, one step each, and — as the vectorised product does inside its
  * step launch — a finished env is reset at once and reports the FIRST observation of its next episode (the reference worker

@@ -79,6 +79,7 @@ void orc_get_state(const orc_env *e, int *pos /*[2][2]*/, int *goals /*[2][2]*/,
                    int *c_far, int *t, int64_t *d2);
 void orc_get_obs(const orc_env *e, uint8_t *obs);
 int orc_get_plan(const orc_env *e, int *plan /* up to 1024 */, int *cursor);
+void orc_get_nav(const orc_env *e, int *nav_goal /*[2]*/, int *planb, int *plan_len);
 uint32_t orc_episode(const orc_env *e);
 
 /* n envs in lock step (same obs size each): actions int[n][2] -> obs u8[n][obs_size], rewards f64[n][2], done u8[n];

@@ -299,6 +299,74 @@ def edge_cases():
     print("edges:", names)
 
 
+def _dist_worker(job):
+    """One worker of distributions(): `count` resets of the REFERENCE env on one np.random.seed, statistics only."""
+    map_type, mode, seed, count = job
+    np.random.seed(seed)
+    env = Track1v1Env(map_type=map_type, target_mode=mode, level=0)
+    S = 82 if map_type == "Block" else 81
+    st = dict(walls=np.zeros(64, np.int64), wall_rows=np.zeros(S, np.int64), wall_cols=np.zeros(S, np.int64),
+              offs=np.zeros(4, np.int64), tr_rows=np.zeros(S, np.int64), tr_cols=np.zeros(S, np.int64),
+              g0_rows=np.zeros(S, np.int64), g1_cols=np.zeros(S, np.int64), plan_len=np.zeros(32, np.int64),
+              first_act=np.zeros(4, np.int64), flags=np.zeros(4, np.int64))
+    for _ in range(count):
+        env.reset()
+        m = (np.array(env.maze) != 0)
+        inner = m[1:-1, 1:-1]
+        k = int(inner.sum())
+        # Block: K = int(0.15 U * 6400) in [0, 959] -> 64 bins of 15; Maze: interior wall cells, 64 bins of 16 (clipped)
+        st["walls"][min(63, k // (15 if map_type == "Block" else 16))] += 1
+        st["wall_rows"] += m.sum(1); st["wall_cols"] += m.sum(0)
+        (r0, c0), (r1, c1) = [list(map(int, x)) for x in env.init_states]
+        st["offs"][(r1 - r0 + 1) * 2 + (c1 - c0 + 1)] += 1          # (-1,-1) (-1,0) (0,-1) (0,0)
+        st["tr_rows"][r0] += 1; st["tr_cols"][c0] += 1
+        st["g0_rows"][int(env.goal_states[0][0])] += 1; st["g1_cols"][int(env.goal_states[1][1])] += 1
+        if mode == "Ram":
+            plan = np.asarray(env.Target[0].plan_actions)
+            st["plan_len"][len(plan)] += 1
+            st["first_act"][int(plan[0])] += 1
+        if mode == "Nav":
+            tgt = env.Target[0]
+            plan_b = isinstance(tgt.plan_actions, np.ndarray)        # np.random.choice(..., 10): plan B (navigator.py:58-59)
+            st["flags"][0] += int(plan_b)
+            st["flags"][1] += int(list(map(int, tgt.goal_states)) != list(map(int, env.goal_states[1])))   # goal re-drawn
+            if not plan_b:
+                st["plan_len"][min(31, len(tgt.plan_actions) // 8)] += 1     # A* path length, 32 bins of 8 cells
+                st["first_act"][int(tgt.plan_actions[0])] += 1
+    st["flags"][3] = count
+    return (map_type, mode, seed), st
+
+
+def distributions():
+    """What the reference's generators DRAW, as histograms over >= 20 000 resets per case: the device's
+    Philox generators are a different bit source by design, so 'same episodes' can only mean 'same distributions' — these
+    counts are what tests/test_generator_distributions*.py hold the device (and the oracle's PHILOX mode) to. Two halves
+    (different seeds) are stored separately so that a test can scale its bound by the reference's own half-vs-half noise.
+    Reference: generators.py:38-94,115-176; navigator.py:43-63,73-93; track_1v1.py:218-240."""
+    import multiprocessing as mp
+    cases = [("Block", "Ram"), ("Maze", "Ram"), ("Block", "Nav"), ("Maze", "Nav")]
+    per_job, jobs_per_half = 1250, 8                                # 2 halves x 8 jobs x 1250 = 20 000 resets per case
+    jobs = []
+    for ci, (mt, md) in enumerate(cases):
+        for h in range(2):
+            for j in range(jobs_per_half):
+                jobs.append((mt, md, 900000 + ci * 1000 + h * 100 + j, per_job))
+    with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
+        res = pool.map(_dist_worker, jobs, chunksize=1)
+    out = {}
+    for (mt, md, seed), st in res:
+        h = (seed // 100) % 10
+        for k, v in st.items():
+            key = "%s_%s/h%d/%s" % (mt, md, h, k)
+            out[key] = out.get(key, 0) + v
+    out["cases"] = np.array(["%s_%s" % c for c in cases])
+    np.savez_compressed(os.path.join(HERE, "distributions.npz"), **out)
+    for mt, md in cases:
+        a = out["%s_%s/h0/flags" % (mt, md)]
+        print("distributions", mt, md, "resets per half", int(a[3]), "offsets", out["%s_%s/h0/offs" % (mt, md)].tolist(),
+              "planB / re-drawn", a[:2].tolist())
+
+
 def astar_cases():
     out = {}
     rs = np.random.RandomState(123)
@@ -466,6 +534,9 @@ if __name__ == "__main__":
         model_fixture()
         loss_fixture()
         sys.exit(0)
+    if "--distributions-only" in sys.argv:
+        distributions()
+        sys.exit(0)
     episodes()
     full_obs_episodes()
     rpf_episodes()
@@ -475,3 +546,4 @@ if __name__ == "__main__":
     registry()
     model_fixture()
     loss_fixture()
+    distributions()

@@ -59,6 +59,33 @@ def main():
         for f in flats[1:]:
             assert torch.equal(flats[0], f), "replicas diverged under the pipelined schedule"
     assert torch.isfinite(opt.bucket.flat).all()
+    # (d) the all-reduce captured INSIDE the update graph (ATR_CAPTURE_ALLREDUCE=1; off by default: measured within 1 % of
+    # the eager call on one rank, profiles/r04_multirank_1gpu.txt, and never run on a real multi-GPU node): with one rank
+    # the collective is forced so that the capture holds it; with more ranks only when asked for (a first run of a captured
+    # RCCL collective across GPUs belongs in a session that can watch it)
+    if world > 1 and os.environ.get("ATR_TEST_CAPTURED_ALLREDUCE") != "1":
+        if rank == 0:
+            print("RCCL_OK world=%d elems=%d" % (world, opt.bucket.grad.numel()), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    os.environ["ATR_CAPTURE_ALLREDUCE"] = "1"
+    if world == 1:
+        os.environ["ATR_FORCE_ALLREDUCE"] = "1"
+    try:
+        git = GraphedIteration(player, opt, args)
+        assert git.capture_allreduce
+        for _ in range(3):
+            git.run()
+        torch.cuda.synchronize(dev)
+        flats = [torch.zeros_like(opt.bucket.flat) for _ in range(world)]
+        dist.all_gather(flats, opt.bucket.flat)
+        for f in flats[1:]:
+            assert torch.equal(flats[0], f), "replicas diverged with the captured all-reduce"
+        assert torch.isfinite(opt.bucket.flat).all()
+    finally:
+        os.environ.pop("ATR_CAPTURE_ALLREDUCE", None)
+        os.environ.pop("ATR_FORCE_ALLREDUCE", None)
     if rank == 0:
         print("RCCL_OK world=%d elems=%d" % (world, opt.bucket.grad.numel()), flush=True)
     dist.barrier()

@@ -612,3 +612,71 @@ def test_pipelined_schedule_is_the_same_dataflow_on_one_stream_and_on_two(env_id
     assert all(torch.equal(ca[k_], cb[k_]) for k_ in ca)
     assert np.array_equal(pa, pb)
     assert all(torch.equal(a, b) for a, b in zip(sa, sb))
+
+
+def test_numpy_rng_batch_replays_all_reference_episodes_concurrently_in_one_handle():
+    """environment.NumpyVecEnv — the reference-exact mode for a BATCH: all 16 multi-episode cases of episodes.npz (Block / Maze /
+    Empty maps x PZR / Adv / Far / Ram / Nav targets x levels 0 / 1, each captured from the reference env on its own seed), four
+    copies of each = 64 envs in ONE device handle, advanced in lock step from (env id, seed, the recorded policy actions) alone:
+    every env's maps / spawns / scripted-target actions come from its own numpy-legacy stream on host threads (the reference's
+    own A* paths for Nav), the device steps all 64 per launch. Every step's observations, float64 rewards, done flags and
+    info['distance'] must equal the reference's, and so must the first observation of every following episode (the stream
+    goes on across episodes exactly as in the reference's worker loop, train.py:73-74)."""
+    import time
+    from conftest import GOLDEN
+    from active_tracking_rl_amd.environment import NumpyVecEnv
+    g = np.load(os.path.join(GOLDEN, "episodes.npz"))
+    names = [str(n) for n in g["names"]] * 4
+    ids, seeds, eps = [], [], []
+    for name in names:
+        mp, mode, lvl, seed, _ = [str(x) for x in g[name + "/meta"]]
+        ids.append("Track2D-%sPartial%s-v%s" % (mp, mode, lvl))
+        seeds.append(int(seed))
+        eps.append([{k: g["%s/ep%d_%s" % (name, e, k)] for k in ("obs0", "act_in", "obs", "rew", "done", "pos")}
+                    for e in range(int(g[name + "/n_eps"]))])
+    n = len(names)
+    assert n == 64
+    env = NumpyVecEnv(ids, seeds)
+    obs = env.reset().cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(obs[i], eps[i][0]["obs0"].astype(np.float32)), (names[i], "first reset")
+    cur = [[0, 0] for _ in range(n)]              # (episode, step) of every env; episode == len(eps[i]): finished
+    steps = 0
+    t0 = time.time()
+    while any(c[0] < len(eps[i]) for i, c in enumerate(cur)):
+        act = np.zeros((2, n), np.int64)
+        for i, (e, t) in enumerate(cur):
+            if e < len(eps[i]):
+                act[:, i] = eps[i][e]["act_in"][t]
+        obs, rew, done, info = env.step([act[0], act[1]])
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        cut = np.zeros(n, bool)
+        for i, (e, t) in enumerate(cur):
+            if e >= len(eps[i]):
+                continue
+            E = eps[i][e]
+            last = t == len(E["act_in"]) - 1
+            assert bool(done[i]) == bool(E["done"][t]), (names[i], e, t, "done")
+            assert np.array_equal(rew[i].astype(np.float64), E["rew"][t].astype(np.float32).astype(np.float64)), (names[i], e, t)
+            dr = E["pos"][t, 1] - E["pos"][t, 0]
+            assert abs(info["distance"][i] - float(np.sqrt(float((dr * dr).sum())))) < 1e-12
+            if not done[i]:
+                assert np.array_equal(obs[i], E["obs"][t].astype(np.float32)), (names[i], e, t, "obs")
+            elif e + 1 < len(eps[i]):             # finished: the env restarted from its stream inside step()
+                assert last
+                assert np.array_equal(obs[i], eps[i][e + 1]["obs0"].astype(np.float32)), (names[i], e + 1, "obs0 after done")
+            steps += 1
+            if last:
+                cur[i] = [e + 1, 0]
+                cut[i] = not done[i] and e + 1 < len(eps[i])       # the capture stopped this episode early: reset() as it did
+            else:
+                cur[i][1] = t + 1
+        if cut.any():
+            fresh = env.reset(cut).cpu().numpy()
+            for i in np.nonzero(cut)[0]:
+                assert np.array_equal(fresh[i], eps[i][cur[i][0]]["obs0"].astype(np.float32)), (names[i], cur[i][0], "obs0")
+    dt = time.time() - t0
+    env.close()
+    assert steps > 5000
+    print("numpy-rng batch: %d env steps of 64 concurrent reference replays in %.2f s (%.0f env steps/s incl. the checks)"
+          % (steps, dt, steps / dt))
