@@ -528,8 +528,11 @@ class A3C_Dueling(nn.Module):
     env_step_fused_seen = False   # (diagnostic: some step of this model ran its env step inside k_act_step)
     fused_env_step = True    # ... and end the step with ONE launch: both cells + heads + draws + the env step (k_act_step)
     pair_gemm_max_rows = int(__import__('os').environ.get('ATR_PAIR_GEMM_MAX_ROWS', '1024'))  # up to here: GEMM pairs as one launch
-    # above: the LSTMCell's two GEMMs as ONE library product over [features | k h_prev] rows (fused.linear_lt, K = F + R)
+    # from cat_gemm_min_rows up: the LSTMCell's two GEMMs as ONE library product over [features | k h_prev] rows
+    # (fused.linear_lt, K = F + R; measured in a replayed graph: 9.9 us against 13.4 for the pair kernel at 1024 rows, 7.3
+    # against 7.7 at 512); the fc + ReLU pair stays one pair-kernel launch up to pair_gemm_max_rows
     cat_gate_gemm = __import__('os').environ.get('ATR_CAT_GATE_GEMM', '1') != '0'
+    cat_gemm_min_rows = int(__import__('os').environ.get('ATR_CAT_GEMM_MIN_ROWS', '768'))
     # atr_actor_step (both LSTMCell GEMMs + cell as one MFMA kernel per player, then two draw launches and the step launch)
     # is kept as an option: since k_act_step the GEMM pair + ONE fused cell/draw/env launch is faster at every batch size
     # measured (4096 rows: 6.15 vs 6.21 ms per iteration); ATR_MFMA_MIN_ROWS=3072 restores round 2's choice
@@ -605,9 +608,9 @@ class A3C_Dueling(nn.Module):
         c.y = [torch.empty((T, N * f, 512), device=dev) for f in frames]
         c.fh_all = None
         same_f = p0.encoder.outdim == p1.encoder.outdim
-        if (same_f and self.cat_gate_gemm and N > self.pair_gemm_max_rows and self.fused_env_step and self.fused_sampling
+        if (same_f and self.cat_gate_gemm and N >= self.cat_gemm_min_rows and self.fused_env_step and self.fused_sampling
                 and R == 128 and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape and p0.encoder.outdim % 4 == 0):
-            # Above the pair-kernel sizes the LSTMCell's two GEMMs are ONE product over rows [features | k h_prev] (K = F + R):
+            # From cat_gemm_min_rows up the LSTMCell's two GEMMs are ONE product over rows [features | k h_prev] (K = F + R):
             # slot t of this store holds step t's fc features (written by the fc GEMM with row stride F + R) next to the
             # previous step's hidden row, already zeroed where that step ended an episode (written by k_act_step); slot T is
             # the bootstrap step's. The learner reads the features in place (strided).
@@ -714,9 +717,9 @@ class A3C_Dueling(nn.Module):
                      and p0.actor.actor_linear.weight.shape[0] <= 8
                      and all(t.is_contiguous() for t in (c_prev[0], c_prev[1], h_out[0], h_out[1], c_out[0], c_out[1],
                                                          acts[0], acts[1], h_prev[0], h_prev[1])))
-        pair_gemm = env_fused and n <= self.pair_gemm_max_rows and getattr(cache, "gates", None) is not None
         # fh = (this step's [2, N, F + R] rows of the [features | k h_prev] store, the next step's): one gate GEMM, K = F + R
-        cat_gemm = env_fused and not pair_gemm and fh is not None and getattr(cache, "gates", None) is not None
+        cat_gemm = env_fused and fh is not None and getattr(cache, "gates", None) is not None
+        pair_gemm = env_fused and not cat_gemm and n <= self.pair_gemm_max_rows and getattr(cache, "gates", None) is not None
         hgs = None if (mfma_step or pair_gemm or cat_gemm) else torch.bmm(h_prev, cache.whh_t)
         one_launch = (actions is not None and self._sampler._ordinal is not None and R // 4 in (16, 32, 64)
                       and p0.actor.actor_linear.weight.shape[0] <= 8 and p1.actor.actor_linear.weight.shape[0] <= 8)
@@ -742,9 +745,13 @@ class A3C_Dueling(nn.Module):
                 # knows this step's done flags — so the mask on h is already in the rows; `done` still masks c_prev.
                 fh_t, fh_next = fh
                 Fd = f_out[0].shape[-1]
-                for i, p in enumerate((p0, p1)):
-                    fused.linear_lt(ys[i].view(n, -1), p.encoder.fc.weight, fh_t[i][:, :Fd], bias=p.encoder.fc.bias, relu=True,
-                                    workspace=self._lt_ws)
+                if n <= self.pair_gemm_max_rows:      # (both encoders' fc + ReLU as one pair-kernel launch, row stride F + R)
+                    fused.pair_linear([ys[0].view(n, -1), ys[1].view(n, -1)], [p0.encoder.fc.weight, p1.encoder.fc.weight],
+                                      [fh_t[0][:, :Fd], fh_t[1][:, :Fd]], bias=[p0.encoder.fc.bias, p1.encoder.fc.bias], relu=True)
+                else:
+                    for i, p in enumerate((p0, p1)):
+                        fused.linear_lt(ys[i].view(n, -1), p.encoder.fc.weight, fh_t[i][:, :Fd], bias=p.encoder.fc.bias,
+                                        relu=True, workspace=self._lt_ws)
                 g = cache.gates
                 fused.linear_lt(fh_t, cache.w_cat, g, workspace=self._lt_ws)
                 ig, hg_, bs = g, None, cache.bsum

@@ -24,12 +24,19 @@ torch.distributed.run on 127.0.0.1, the role main.py:102-116 plays in the refere
 the process group really has N ranks (checked with an all-reduce of ones and an all-gather of the device ids).
 
 Extra objects on the same JSON line:
-  roofline     the step/observe kernel (k_step2): algorithmic bytes (1723 B x envs per launch)
-               / average launch duration, measured with HIP events on the launch stream over back-to-back
-               policy-shaped launches in a hipGraph (the kernel alone; the per-step figure with the generator pass
-               every 10th step is reported next to it); peak 8 TB/s (HBM3E). `traffic` is read from the committed
-               rocprofv3 --pmc passes (profiles/r02_pmc_traffic.json).
-  env_only     the same kernel driven with on-device random actions (no policy): launches/s -> env steps/s, per
+  roofline     SURVEY 8(d)'s figure for the env kernel OF THE TIMED REGION: algorithmic bytes per env-step (709 B with byte
+               observations, 1723 B with float ones) x envs per launch / that kernel's duration IN SITU. Since round 3 the rollout
+               ends every env step inside k_act_step (both LSTM cells + heads + draws + env step + observation), so its duration
+               is measured where it runs: a whole 20-step rollout of the player is captured into a hipGraph twice — as it is,
+               and with the k_act_step launches left out — and replayed alternately with HIP events on the launch stream; the
+               difference / 20 is the kernel's in-situ cost (`avg_launch_us`; rocprofv3's average for the kernel in a replayed
+               iteration, profiles/r04_iteration_kernel_stats.txt, rides along as `rocprof_in_iteration_us` and must agree).
+               `frac` = that figure / 8 TB/s. The same duration priced with EVERYTHING the fused kernel moves (gate
+               pre-activations, cell / hidden state, activated gates parked for the learner) is reported under its own name,
+               `policy_state_included`, never as `frac`. `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc
+               passes (profiles/r04_pmc_traffic.json). `other_variants`: the stand-alone step kernel (k_step2; what t2d_step /
+               t2d_step_u8 launch for callers that bring their own actions), measured alone in a 9-launch graph.
+  env_only     the stand-alone step kernel driven with on-device random actions (no policy): launches/s -> env steps/s, per
                launch and in the persistent mode (t2d_rollout_random: up to 10 steps per launch).
   policy_stem  informational f32-MFMA roofline of the conv-stem kernels (the largest single kernels of the iteration).
   cpu_baseline reference-shaped 16-worker (+1 evaluator) CPU A3C on the oracle (oracle/cpu_a3c.py --suite), rank 0, N=1
@@ -95,7 +102,7 @@ def init_ranks(a):
     if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     use_cuda = torch.cuda.is_available()
-    info = {"backend": backend if world > 1 else None, "rccl_ranks": 1, "devices": [local_rank]}
+    info = {"backend": backend if world > 1 else None, "ranks": 1, "devices": [local_rank]}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -114,7 +121,7 @@ def init_ranks(a):
         if dist.get_world_size() != a.gpus or n_comm != a.gpus:
             raise SystemExit("bench.py: communicator has %d ranks (world_size %d), expected %d"
                              % (n_comm, dist.get_world_size(), a.gpus))
-        info.update(rccl_ranks=n_comm, devices=[int(t.item()) for t in ids])
+        info.update(ranks=n_comm, devices=[int(t.item()) for t in ids])
     return world, rank, local_rank, info
 
 
@@ -173,7 +180,8 @@ def main():
         dist.barrier()
     from active_tracking_rl_amd import gemm_tuning
     tuned = gemm_tuning.enable() and os.environ.get("ATR_DISABLE_GEMM_TUNING") != "1"
-    from active_tracking_rl_amd.train import GraphedIteration, PipelinedIteration, default_args, make_player, rollout
+    from active_tracking_rl_amd.train import (GraphedIteration, PipelinedIteration, capture_allreduce_default, default_args,
+                                              make_player, rollout)
 
     T = 20
     steps = max(T, (a.steps + T - 1) // T * T)          # an A3C iteration is T env steps + one update
@@ -384,30 +392,35 @@ def main():
             torch.cuda.synchronize(device)
             tot += e0.elapsed_time(e1)
         k8_us = tot * 1e3 / (40 * 9)
-    # the fused end-of-step kernel (k_act_step: both players' cells + heads + draws + env step), when the timed region uses it
-    # at this batch size: the same 9-launch graph, gate pre-activations of the shape the rollout feeds it
+    # the fused end-of-step kernel (k_act_step: both players' cells + heads + draws + env step), which the timed region uses at
+    # every batch size: (1) alone, a 9-launch graph with gate tensors of the shape the rollout feeds it; (2) IN SITU
     fused_in_region = bool(getattr(player.model, "env_step_fused_seen", False))
-    ka_us, ka_bytes = None, None
+    ka_us, ka_bytes, ka_situ_us, situ_detail = None, None, None, None
+    one_gate = masked_h = False
     if getattr(core, "supports_u8", False) and n % 2 == 0:
         from active_tracking_rl_amd import fused as fz
         mdl = player.model
         R = args.rnn_out
-        pairg = n <= getattr(mdl, "pair_gemm_max_rows", 0)
+        one_gate = n <= getattr(mdl, "pair_gemm_max_rows", 0) or (getattr(mdl, "cat_gate_gemm", False)
+                                                                  and n >= getattr(mdl, "cat_gemm_min_rows", 1 << 30))
+        masked_h = getattr(mdl, "cat_gate_gemm", False) and n >= getattr(mdl, "cat_gemm_min_rows", 1 << 30)
         gts = torch.randn(2, n, 4 * R, device=device)
-        hgt = None if pairg else torch.randn(2, n, 4 * R, device=device)
+        hgt = None if one_gate else torch.randn(2, n, 4 * R, device=device)
         cprev, hout, cout = (torch.zeros(2, n, R, device=device) for _ in range(3))
         actst = torch.empty(2, n, 4 * R, device=device)
         actn = torch.empty(2, n, dtype=torch.int64, device=device)
+        rows_next = torch.empty(2, n, 256 + R, device=device) if masked_h else None
         smp = fz.ActionSampler(device, seed=5)
         heads = (mdl.player0.actor.actor_linear, mdl.player1.actor.actor_linear)
-        bsum = None if pairg else [torch.zeros(4 * R, device=device) for _ in range(2)]
+        bsum = [torch.zeros(4 * R, device=device) for _ in range(2)]
         embt = torch.randn(4, 4 * R, device=device) if getattr(mdl, "tat", False) else None
         out8 = (torch.empty((n, 2, 13, 13), dtype=torch.uint8, device=device), out[1], out[2])
 
         def act_launch():
             fz.act_env_step(core, [gts[0], gts[1]], [hgt[0], hgt[1]] if hgt is not None else None, bsum,
                             [cprev[0], cprev[1]], out[2], [hout[0], hout[1]], [cout[0], cout[1]], [actst[0], actst[1]], smp,
-                            heads, actn, emb=embt, env_out=out8)
+                            heads, actn, emb=embt, env_out=out8,
+                            hm_out=[rows_next[0][:, 256:], rows_next[1][:, 256:]] if masked_h else None)
         core.flush()
         smp.begin_block()
         with torch.cuda.stream(side):
@@ -429,11 +442,54 @@ def main():
             torch.cuda.synchronize(device)
             tot += e0.elapsed_time(e1)
         ka_us = tot * 1e3 / (40 * 9)
-        # algorithmic bytes per env-step of the fused kernel: the env's 709 B (u8 observations) + per player: gate
-        # pre-activations read (4R floats, twice when ig / hg arrive separately), c_prev read, h / c written, activated gates
-        # written (the learner's cache), + actions 16 B + previous done 1 B
-        per_player = 4 * R * 4 * (1 if pairg else 2) + 3 * R * 4 + 4 * R * 4
+        # everything the fused kernel moves per env-step: the env's 709 B (u8 observations) + per player: gate pre-activations
+        # read (4R floats; twice when ig / hg arrive separately), c_prev read, h / c written, activated gates written (the
+        # learner's cache), the masked hidden row for the next step's GEMM (one-GEMM path), + actions 16 B + previous done 1 B
+        per_player = 4 * R * 4 * (1 if one_gate else 2) + 3 * R * 4 + 4 * R * 4 + (R * 4 if masked_h else 0)
         ka_bytes = B_STEP_U8 + 2 * per_player + 17
+        # (2) in situ: a whole T-step rollout of the player as a hipGraph, with and without the k_act_step launches; replayed
+        # alternately, HIP events on the launch stream around each replay; difference / T = what the kernel costs where it runs
+        if fused_in_region:
+            def capture_rollout(skip_act):
+                real = fz.act_env_step
+
+                def no_act(env_core, ig, hg, biases, c_prev, done, h_out, c_out, acts, sampler, actors, actions_out, **kw):
+                    sampler._ordinal += 2          # (the launch is left out; the draw bookkeeping of the block goes on)
+                    return actions_out
+                if skip_act:
+                    fz.act_env_step = no_act
+                try:
+                    core.flush()
+                    torch.cuda.synchronize(device)
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                        rollout(player, T)
+                        player.clear_actions()
+                        if hasattr(player.model, "cache_dense"):
+                            player.model.cache_dense(False)
+                finally:
+                    fz.act_env_step = real
+                return gr
+            g_full, g_skip = capture_rollout(False), capture_rollout(True)
+            for gg in (g_full, g_skip):
+                gg.replay()
+            torch.cuda.synchronize(device)
+            t_full = t_skip = 0.0
+            REP = 30
+            for _ in range(REP):
+                for which, gg in (("full", g_full), ("skip", g_skip)):
+                    e0.record()
+                    gg.replay()
+                    e1.record()
+                    torch.cuda.synchronize(device)
+                    if which == "full":
+                        t_full += e0.elapsed_time(e1)
+                    else:
+                        t_skip += e0.elapsed_time(e1)
+            ka_situ_us = (t_full - t_skip) * 1e3 / (REP * T)
+            situ_detail = {"rollout_graph_us": t_full * 1e3 / REP, "rollout_graph_without_k_act_step_us": t_skip * 1e3 / REP,
+                           "launches": T, "replays_each": REP}
+            del g_full, g_skip
     core.reset()
     achieved = B_STEP * n / (k_us * 1e-6) / 1e9
     # env-only loop with on-device random actions
@@ -496,35 +552,43 @@ def main():
         stem_roof = {"error": repr(ex)}
 
     traffic, traffic_src, traffic_u8, traffic_u8_src, traffic_act, traffic_act_src = None, None, None, None, None, None
-    for fname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for fname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:   # HBM traffic of the same kernels from the committed rocprofv3 --pmc passes (cannot be taken inside this run)
             pm = json.load(open(os.path.join(ROOT, "profiles", fname)))
             if pm.get("n_envs") == n and traffic is None:
                 traffic = pm["traffic_bytes_per_launch"]
                 traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % fname
             if pm.get("n_envs") == n and traffic_act is None and pm.get("act_step") is not None:
-                traffic_act = pm["act_step"]["traffic_bytes_per_launch"]
-                traffic_act_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, k_act_step with ig + hg)" % fname
+                # (only the passes of the kernel in the form the timed region runs it: one gate tensor since round 4)
+                if bool(pm["act_step"].get("one_gate_tensor", False)) == bool(one_gate):
+                    traffic_act = pm["act_step"]["traffic_bytes_per_launch"]
+                    traffic_act_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %s)" % (fname, pm["act_step"]["kernel"])
             if pm.get("n_envs") == n and traffic_u8 is None and pm.get("traffic_bytes_per_launch_u8") is not None:
                 traffic_u8 = pm["traffic_bytes_per_launch_u8"]
                 traffic_u8_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, k_step2<OBS_U8>)" % fname
         except Exception:
             pass
-    kernel_sum = None
-    try:   # sum of the kernel durations of one replayed iteration from the committed rocprofv3 table of this workload
-        for ln in open(os.path.join(ROOT, "profiles", "r03_iteration_kernel_stats.txt")):
-            if ln.startswith("# total kernel time"):
-                tot_ms = float(ln.split()[4])
-            if ln.startswith("# iterations"):
-                kernel_sum = {"ms": tot_ms / float(ln.split()[2]), "source": "profiles/r03_iteration_kernel_stats.txt "
-                              "(rocprofv3 --kernel-trace --stats of tools/iter_profile.py: total kernel time / iterations)"}
-    except Exception:
-        pass
-    note_k = ("avg_launch_us = the kernel alone: a hipGraph of 9 policy-shaped launches captured right after a generator pass "
-              "(no k_gen inside) replayed 40x, HIP events on the launch stream around each replay; it contains the in-graph "
-              "kernel boundaries, so it sits a few tenths of a us above rocprofv3's average for the kernel "
-              "(profiles/r03_*kernel_stats*.txt); the generator pass every 10th step is reported separately "
-              "(avg_step_us_incl_generator)")
+    kernel_sum, rocprof_act_us = None, None
+    for fname in ("r04_iteration_kernel_stats.txt", "r03_iteration_kernel_stats.txt"):
+        try:   # one replayed iteration under rocprofv3 --kernel-trace --stats (tools/iter_profile.py), committed: the sum of its
+            # kernel durations, and the in-iteration average of the env kernel the in-situ figure below must agree with
+            tot_ms = its = None
+            for ln in open(os.path.join(ROOT, "profiles", fname)):
+                if ln.startswith("# total kernel time"):
+                    tot_ms = float(ln.split()[4])
+                if ln.startswith("# iterations"):
+                    its = float(ln.split()[2])
+                if "k_act_step<2, false, true" in ln and rocprof_act_us is None:
+                    rocprof_act_us = {"us": float(ln.split()[-2]), "source": "profiles/%s" % fname}
+            if tot_ms is not None and its:
+                kernel_sum = {"ms": tot_ms / its, "source": "profiles/%s (rocprofv3 --kernel-trace --stats of "
+                              "tools/iter_profile.py: total kernel time / iterations)" % fname}
+                break
+        except Exception:
+            pass
+    note_k = ("step_f32 / step_u8 (other_variants): the stand-alone step kernel alone — a hipGraph of 9 policy-shaped launches "
+              "captured right after a generator pass (no k_gen inside) replayed 40x, HIP events on the launch stream around each "
+              "replay; the generator pass is reported separately (avg_step_us_incl_generator)")
     f32_variant = {"kernel": "t2d::k_step2<..., OBS_F32_VEC4> (t2d_step: float32 observations, SURVEY 8(d) B_step = 1723 B)",
                    "in_timed_region": not getattr(player.env, "obs_u8", False) and not fused_in_region,
                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -537,21 +601,37 @@ def main():
         "achieved": B_STEP_U8 * n / (k8_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": B_STEP_U8 * n / (k8_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_u8, "traffic_source": traffic_u8_src,
         "bytes_per_launch": B_STEP_U8 * n, "avg_launch_us": k8_us}
-    act_variant = None if ka_us is None else {
-        "kernel": "t2d::k_act_step<OBS_U8> (atr_act_env_step: both players' LSTM cells + heads + draws + env step + "
-                  "observation in one launch)",
-        "in_timed_region": fused_in_region,
-        "achieved": ka_bytes * n / (ka_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": ka_bytes * n / (ka_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-        "traffic": traffic_act if not pairg else None, "traffic_source": traffic_act_src if not pairg else None,
-        "bytes_per_launch": ka_bytes * n,
-        "bytes_per_env_step": ka_bytes, "avg_launch_us": ka_us,
-        "bytes_note": "env 709 B (u8 observations) + per player: gate pre-activations read, c_prev read, h / c written, "
-                      "activated gates written for the learner + actions + previous done"}
+    act_variant = None
+    if ka_us is not None:
+        # interface-mandated env traffic only (709 B per env-step with byte observations) over the kernel's duration
+        # where it runs; the figure that also counts the policy state the fused kernel moves goes under its own name
+        dur = ka_situ_us if ka_situ_us else ka_us
+        b8d = B_STEP_U8 if getattr(player.env, "obs_u8", False) else B_STEP
+        act_variant = {
+            "kernel": "t2d::k_act_step<%s> (atr_act_env_step: both players' LSTM cells + heads + draws + env step + "
+                      "observation in one launch)" % ("OBS_U8" if getattr(player.env, "obs_u8", False) else "OBS_F32"),
+            "in_timed_region": fused_in_region,
+            "achieved": b8d * n / (dur * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": b8d * n / (dur * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "frac_8d": b8d * n / (dur * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "bytes_per_launch": b8d * n, "bytes_per_env_step": b8d,
+            "avg_launch_us": dur,
+            "avg_launch_us_source": ("in situ: (20-step rollout graph) - (the same graph without the k_act_step launches), "
+                                     "/ 20, HIP events on the launch stream" if ka_situ_us else
+                                     "alone: 9-launch graph (the timed region did not run this kernel)"),
+            "in_situ": situ_detail, "alone_us": ka_us, "rocprof_in_iteration_us": rocprof_act_us,
+            "traffic": traffic_act, "traffic_source": traffic_act_src,
+            "policy_state_included": {
+                "bytes_per_env_step": ka_bytes, "bytes_per_launch": ka_bytes * n,
+                "achieved": ka_bytes * n / (dur * 1e-6) / 1e9, "frac_of_peak": ka_bytes * n / (dur * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "alone": {"avg_launch_us": ka_us, "frac_of_peak": ka_bytes * n / (ka_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                "note": "NOT SURVEY 8(d)'s figure: the env's 709 B + per player gate pre-activations read (one tensor: the "
+                        "LSTMCell's two GEMMs are one product since round 4), c_prev read, h / c written, activated gates "
+                        "written for the learner, the masked hidden row for the next step's GEMM, + actions + previous done"}}
     # `roofline` = the env kernel of the TIMED REGION at this batch size; the other variants ride along, each with its flag
-    variants = {"step_f32": f32_variant, "step_u8": u8_variant, "act_step_u8": act_variant}
-    pick = "act_step_u8" if (fused_in_region and act_variant) else ("step_u8" if (u8_variant and u8_variant["in_timed_region"])
-                                                                    else "step_f32")
+    variants = {"step_f32": f32_variant, "step_u8": u8_variant, "act_step": act_variant}
+    pick = "act_step" if (fused_in_region and act_variant) else ("step_u8" if (u8_variant and u8_variant["in_timed_region"])
+                                                                 else "step_f32")
     roofline = dict(variants[pick])
     roofline.update(bound="hbm", variant=pick, note=note_k,
                     other_variants={k: v for k, v in variants.items() if k != pick and v is not None})
@@ -562,7 +642,12 @@ def main():
         "ms_per_step": weak["ms_per_step"], "ms_per_iteration": weak["ms_per_iteration"],
         "timed_gpu_seconds": weak["timed_gpu_seconds"], "repeats_run": weak["repeats"], "kernel_sum_per_iteration": kernel_sum,
         "shards": shards, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "rccl_ranks": comm["rccl_ranks"], "devices": comm["devices"], "dist_backend": comm["backend"],
+        "ranks": comm["ranks"], "rccl_ranks": comm["ranks"] if (comm["backend"] == "nccl" or world == 1) else None,
+        "devices": comm["devices"], "dist_backend": comm["backend"],
+        "allreduce": {"mode": "captured in the update graph" if capture_allreduce_default() else
+                              "eager, between the learner's graph and the update graph",
+                      "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
+                      "basis": "profiles/r04_multirank_1gpu.txt (1-rank RCCL group, collective forced)"},
         "allreduce_us": weak["allreduce_us"], "allreduce_elems": weak["allreduce_elems"],
         "weak": {k: weak[k] for k in ("value", "ms_per_step", "envs_per_gpu", "global_envs", "allreduce_us")},
         "strong": {k: strong[k] for k in ("value", "ms_per_step", "envs_per_gpu", "global_envs", "allreduce_us",

@@ -29,7 +29,13 @@ def test_bench_line_with_the_drivers_flags():
     assert set(sizes) == {"128", "256", "512"} and all(v["value"] > 0 for v in sizes.values())
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["in_timed_region"] is True and 0.0 < roof["frac"] < 1.0
-    assert roof["variant"] == "act_step_u8" and "k_act_step" in roof["kernel"]
+    assert roof["variant"] == "act_step" and "k_act_step" in roof["kernel"]
+    # SURVEY 8(d)'s figure: 709 B per env-step (byte observations) over the kernel's in-situ duration; the wider byte count
+    # (policy state the fused kernel also moves) only under its own name
+    assert roof["bytes_per_env_step"] == 709 and roof["frac"] == roof["frac_8d"]
+    assert roof["in_situ"] is not None and roof["avg_launch_us"] > 0 and roof["alone_us"] > 0
+    assert roof["policy_state_included"]["bytes_per_env_step"] > 709
+    assert "step_f32" in roof["other_variants"] and line["ranks"] == 1
     assert line["config"]["schedule"] == line["schedule"] and "workload" in line["config"]
 
 

@@ -21,7 +21,7 @@ def test_plain_command_self_launches_n_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
     assert len(lines) == 1, r.stdout                        # rank 0 only
-    assert lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2 and len(lines[0]["devices"]) == 2
+    assert lines[0]["n_gpus"] == 2 and lines[0]["ranks"] == 2 and len(lines[0]["devices"]) == 2
 
 
 def test_refuses_a_rank_count_that_differs_from_gpus():
@@ -36,4 +36,4 @@ def test_single_rank_needs_no_process_group():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][0])
-    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1
+    assert line["n_gpus"] == 1 and line["ranks"] == 1
