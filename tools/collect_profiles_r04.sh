@@ -1,0 +1,58 @@
+#!/bin/bash
+# Round 4 evidence, regenerated under gpurun_out/r04/ on the GPU box (tools/publish_profiles_r04.sh copies what is to be judged
+# to profiles/):   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/collect_profiles_r04.sh'
+# PMC passes are separate runs with no trace domains besides the counter collection (pool rule).
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O
+export PYTHONPATH=$R GPU_MAX_HW_QUEUES=2; cd /tmp; export TMPDIR=/tmp
+# --- the bench line (driver flags and defaults), and the same command under the profiler
+timeout 1200 python $R/bench.py > $O/bench.json 2> $O/bench.err
+timeout 600 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_flags.json 2> /dev/null
+rm -rf /tmp/p_bench; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -- python $R/bench.py --no-cpu-baseline --no-shards > $O/bench_under_rocprof.json 2> /dev/null
+python $R/tools/summarize_prof.py stats /tmp/p_bench > $O/bench_kernel_stats.txt
+(cd $R && BENCH_SINGLE_DEVICE=1 BENCH_DIST_BACKEND=gloo timeout 1200 python bench.py --gpus 2 --steps 100 --warmup 20 --no-cpu-baseline --no-shards > $O/bench_selflaunch_2ranks_gloo_1gpu.json 2> /dev/null)
+# --- one replayed iteration per kernel: the headline batch and every shard size, and the other BASELINE configurations
+prof_iter() {   # name, then iter_profile.py arguments
+  rm -rf /tmp/p_it; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_it -- python $R/tools/iter_profile.py 50 "${@:2}" > /dev/null 2>&1
+  python $R/tools/summarize_prof.py stats /tmp/p_it 52 > $O/$1.txt
+}
+prof_iter iteration_kernel_stats
+for n in 2048 1024 512; do prof_iter iteration_kernel_stats_shard$n Track2D-BlockPartialPZR-v0 $n tat-maze-lstm reward -1; done
+prof_iter iteration_kernel_stats_config1 Track2D-BlockPartialRam-v0 1024 maze-lstm none 0
+prof_iter iteration_kernel_stats_config3 Track2D-MazePartialNav-v0 1024 maze-lstm none 0
+(cd $R && timeout 600 python tools/config_sweep.py > $O/config_sweep.txt 2>&1)
+# --- the round's pieces alone
+(cd $R && timeout 300 python tools/lt_gemm_bench.py > $O/lt_gemm_bench.txt 2>&1)
+(cd $R && timeout 300 python tools/act_step_bench.py > $O/act_step_bench.txt 2>&1)
+(cd $R && ACT_BENCH_MODE=one timeout 300 python tools/act_step_bench.py 512 1024 2048 4096 >> $O/act_step_bench.txt 2>&1)
+# --- multi-rank settings under a 1-rank RCCL group
+(cd $R && bash tools/multirank_probe.sh > /dev/null 2>&1; cp gpurun_out/r04_multirank_1gpu.txt $O/multirank_1gpu.txt)
+# --- Nav / Maze: generator pass (kernel stats at 1024 / 8192 random-policy envs), its timeline (probe build, if present)
+for n in 1024 8192; do
+  rm -rf /tmp/p_nav; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_nav -- python $R/tools/env_only_bench.py --env Track2D-MazePartialNav-v0 --n $n --steps 600 --warmup 100 > $O/nav_env_only_$n.txt 2>/dev/null
+  python $R/tools/summarize_prof.py stats /tmp/p_nav > $O/nav_kernel_stats_$n.txt
+done
+[ -f $R/scratch_exp/libexp9.so ] && (cd $R && T2D_LIB_PATH=scratch_exp/libexp9.so timeout 300 python tools/gen_nav_timeline_probe.py > $O/generator_nav_timeline.txt 2>&1)
+# --- env-only: the stand-alone step kernel at every size (rocprofv3 stats)
+for n in 4096 65536 262144 1048576; do
+  rm -rf /tmp/p_env; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_env -- python $R/tools/env_only_bench.py --n $n --steps 600 --warmup 100 > $O/env_only_$n.txt 2> /dev/null
+  python $R/tools/summarize_prof.py stats /tmp/p_env > $O/env_only_kernel_stats_$n.txt
+done
+# --- HBM traffic (PMC): FETCH_SIZE and WRITE_SIZE in separate passes — the stand-alone step kernel at 4096 envs, and the fused
+# end-of-step kernel in the form the timed region runs it (one gate tensor, bias, masked hidden rows)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p_pmc; timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_pmc -- python $R/tools/env_only_bench.py --n 4096 --steps 300 --warmup 50 > /dev/null 2>&1
+  python $R/tools/summarize_prof.py pmc /tmp/p_pmc k_step2 > $O/env_only_pmc_${c}_4096.txt
+  rm -rf /tmp/p_pmc; (cd $R && ACT_BENCH_MODE=one timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_pmc -- python tools/act_step_bench.py 4096 > /dev/null 2>&1)
+  python $R/tools/summarize_prof.py pmc /tmp/p_pmc k_act_step > $O/act_step_pmc_${c}_4096.txt
+done
+# --- learning checks under the default (pipelined) schedule, and a main.py run with the evaluator's scalars
+(cd $R && timeout 600 python tools/learning_check.py --iters 1500 > $O/learning_check_ram_tracker.txt 2>&1)
+(cd $R && timeout 600 python tools/learning_check.py --env Track2D-BlockPartialPZR-v0 --network tat-maze-lstm --train-mode -1 --iters 1500 > $O/learning_check_pzr_dueling.txt 2>&1)
+(cd $R && timeout 600 python tools/learning_check.py --env Track2D-MazePartialNav-v0 --num-envs 1024 --iters 1500 > $O/learning_check_nav_tracker.txt 2>&1)
+rm -rf $O/main_logs; (cd $R && timeout 900 python main.py --shared-optimizer --split --train-mode -1 --env Track2D-BlockPartialPZR-v0 --num-envs 4096 \
+    --max-step 1000 --test-every 250 --log-dir gpurun_out/r04/main_logs/ > $O/main_py_run.txt 2>&1)
+cp $(ls -d $O/main_logs/*/*/ | head -1)logger $O/main_py_logger.txt 2>/dev/null
+tail -30 $(ls $O/main_logs/*/*/Agent:0/scalars.jsonl | head -1) > $O/main_py_scalars_tail.txt 2>/dev/null
+tail -12 $(ls $O/main_logs/*/*/Test/scalars.jsonl | head -1) > $O/main_py_test_scalars_tail.txt 2>/dev/null
+find $O/main_logs -name "*.dat" -delete
+ls -la $O
