@@ -55,7 +55,7 @@ struct Plan {
     hipblasLtMatmulAlgo_t algo;
     size_t ws_bytes = 0;
     bool tuned = false;
-    int candidates = 0, chosen = -1;
+    int candidates = 0, chosen = -1, preset = -1;
     float best_us = 0.f;
 };
 
@@ -186,6 +186,18 @@ int plan_for(const atr_linear_args &a, hipStream_t st, Plan **out)
         it = g.plans.emplace(k, p).first;
     }
     Plan &p = it->second;
+    if (p.preset >= 0 && p.chosen < 0) {       // a recorded choice (atr_linear_set_choice): candidate number `preset`, no timing
+        std::vector<hipblasLtMatmulHeuristicResult_t> res;
+        if (candidates(a, p, res) != 0) return -1;
+        p.candidates = (int)res.size();
+        if (p.preset < (int)res.size() && res[p.preset].state == HIPBLAS_STATUS_SUCCESS && res[p.preset].workspaceSize <= ws_size(a)) {
+            p.algo = res[p.preset].algo;
+            p.ws_bytes = res[p.preset].workspaceSize;
+            p.chosen = p.preset;
+            p.tuned = true;                    // (as good as tuned: the choice was timed when it was recorded)
+        }
+        p.preset = -1;
+    }
     if (p.chosen < 0 || (!p.tuned && !capturing(st))) {
         std::vector<hipblasLtMatmulHeuristicResult_t> res;
         if (candidates(a, p, res) != 0) return -1;
@@ -272,6 +284,23 @@ extern "C" int atr_linear(const atr_linear_args *a, void *stream)
     if (p->ws_bytes > ws_size(*a)) return fail("atr_linear: workspace smaller than the one this problem was tuned with", 0);
     const int rc = run(*a, *p, p->algo, p->ws_bytes, st);
     return rc == 0 ? 0 : fail("hipblasLtMatmul", rc);
+}
+
+// Use candidate number `index` of the library's list for this problem instead of timing the list on first use (a choice
+// recorded by an earlier run: lt_tuning_gfx950.json). Ignored if the list turns out shorter or the candidate unusable.
+extern "C" int atr_linear_set_choice(const atr_linear_args *a, int index)
+{
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (check_args(a) != 0) return -1;
+    const Key k = key_of(*a);
+    auto it = g.plans.find(k);
+    if (it == g.plans.end()) {
+        Plan p;
+        if (build_plan(*a, p) != 0) return -1;
+        it = g.plans.emplace(k, p).first;
+    }
+    if (it->second.chosen < 0) it->second.preset = index;
+    return 0;
 }
 
 extern "C" int atr_linear_plan_info(const atr_linear_args *a, int *candidates_out, int *chosen_out, int *tuned_out, float *best_us_out)

@@ -104,6 +104,8 @@ def lib():
         L.atr_linear_plan_info.restype = i32
         L.atr_linear_plan_info.argtypes = [C.POINTER(LinearArgs), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
                                            C.POINTER(C.c_float)]
+        L.atr_linear_set_choice.restype = i32
+        L.atr_linear_set_choice.argtypes = [C.POINTER(LinearArgs), i32]
         L.atr_lt_last_error.restype = C.c_char_p
         L.atr_embed_grad_workspace_floats.restype = ll
         L.atr_embed_grad_workspace_floats.argtypes = [ll, i32, i32]
@@ -352,6 +354,43 @@ def _linear_args(a, w, out, bias, relu, workspace):
     return g
 
 
+LT_TUNING_FILE = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)),
+                                            "lt_tuning_gfx950.json")
+_lt_choices, _lt_seen = None, {}
+
+
+def _lt_key(g):
+    return "M%d_N%d_K%d_b%d_lda%d_ldw%d_ldc%d_sa%d_sw%d_sc%d_relu%d_bias%d" % (
+        g.M, g.N, g.K, g.batch, g.lda, g.ldw, g.ldc, g.stride_a, g.stride_w, g.stride_c, g.relu, 1 if g.bias else 0)
+
+
+def lt_choices():
+    """{problem key: candidate index} recorded by tools/tune_lt.py (lt_tuning_gfx950.json next to this file; ATR_LT_TUNING=0
+    ignores it): the kernel choices of csrc/lt_gemm.cpp are then the same in every run — what tunableop_gfx950.csv is for
+    torch's GEMMs — and nothing is timed at first use."""
+    global _lt_choices
+    if _lt_choices is None:
+        import json
+        import os
+        _lt_choices = {}
+        if os.environ.get("ATR_LT_TUNING", "1") != "0" and os.path.exists(LT_TUNING_FILE):
+            try:
+                _lt_choices = {k: int(v) for k, v in json.load(open(LT_TUNING_FILE)).get("choices", {}).items()}
+            except (ValueError, OSError):
+                _lt_choices = {}
+    return _lt_choices
+
+
+def lt_chosen():
+    """{problem key: (candidate index, candidates, best us)} of every problem this process has run (for tools/tune_lt.py)."""
+    out = {}
+    for k, g in _lt_seen.items():
+        cand, ch, tu, us = C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(0)
+        if lib().atr_linear_plan_info(C.byref(g), C.byref(cand), C.byref(ch), C.byref(tu), C.byref(us)) == 0 and tu.value:
+            out[k] = (ch.value, cand.value, us.value)
+    return out
+
+
 @torch.no_grad()
 def linear_lt(a, w, out, bias=None, relu=False, workspace=None):
     """out = act(a @ w.T + bias) through hipBLASLt called directly (atr_linear, csrc/lt_gemm.cpp): a [M, K], w [N, K] (nn.Linear
@@ -361,6 +400,12 @@ def linear_lt(a, w, out, bias=None, relu=False, workspace=None):
     _lt_init()
     g = _linear_args(a, w, out, bias, relu, workspace)
     L = lib()
+    key = _lt_key(g)
+    if key not in _lt_seen:
+        _lt_seen[key] = g
+        idx = lt_choices().get(key)
+        if idx is not None:
+            L.atr_linear_set_choice(C.byref(g), idx)
     if L.atr_linear(C.byref(g), _stream(a)) != 0:
         raise RuntimeError("atr_linear failed: %s" % L.atr_lt_last_error().decode())
     return out
