@@ -31,6 +31,9 @@ for n in 1024 8192; do
   rm -rf /tmp/p_nav; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_nav -- python $R/tools/env_only_bench.py --env Track2D-MazePartialNav-v0 --n $n --steps 600 --warmup 100 > $O/nav_env_only_$n.txt 2>/dev/null
   python $R/tools/summarize_prof.py stats /tmp/p_nav > $O/nav_kernel_stats_$n.txt
 done
+# (the probe build of the library, -DT2D_EXP=9, compiled here from the sources of this very tree)
+mkdir -p $R/scratch_exp; (cd $R/active_tracking_rl_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -ldl -Wno-unused-result -DT2D_EXP=9 \
+    -o $R/scratch_exp/libexp9.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
 [ -f $R/scratch_exp/libexp9.so ] && (cd $R && T2D_LIB_PATH=scratch_exp/libexp9.so timeout 300 python tools/gen_nav_timeline_probe.py > $O/generator_nav_timeline.txt 2>&1)
 # --- env-only: the stand-alone step kernel at every size (rocprofv3 stats)
 for n in 4096 65536 262144 1048576; do
