@@ -12,6 +12,7 @@
 //                       or torch.optim.Adam's form of it; atr_rmsprop_step: SharedRMSprop / torch.optim.RMSprop
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/atr_policy.h"
 
@@ -27,9 +28,26 @@ struct RolloutBegin {
     int N, A, R;
 };
 
-__global__ __launch_bounds__(256) void k_rollout_begin(RolloutBegin a)
+// The per-rollout constants of the actor (the weights do not change inside a rollout), made in the rollout's first launch
+// instead of ~8 tiny ones (two bias adds, the tracker-action embedding table and its projection through W_ih, the
+// concatenated LSTMCell weight, the draw counter's bump, the first rows' hidden columns): at 512 envs those were 2 % of an
+// iteration. All optional (null = not wanted).
+struct RolloutConsts {
+    const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];   // nn.LSTMCell parameters of the two players ([4R,F], [4R,R], [4R], [4R])
+    float *bsum;                     // [2, 4R] = b_ih + b_hh
+    float *w_cat;                    // [2, 4R, F + R] = [W_ih | W_hh] (the one-GEMM LSTMCell's weight)
+    const float *fa_w, *fa_b;        // fc_action_tracker [F, A], [F] (tracker-aware target)
+    float *emb_ih;                   // [A, 4R] = (fa_w^T + fa_b) W_ih[1]^T
+    unsigned long long *counter;     // the action sampler's stream counter: += 1
+    float *fh0;                      // slot 0 of the [features | k h] rows of player 0: hidden columns <- hxs; player p at + p * fh_pstride
+    long long fh_pstride, fh_ld;     // (row stride; the hidden columns start at fh_ld - R)
+    int F, A_act;
+};
+
+__global__ __launch_bounds__(256) void k_rollout_begin(RolloutBegin a, RolloutConsts k)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
     const long long nstate = (long long)a.N * a.A * (a.R / 4);
     if (i < nstate) {
         const int r4 = (int)(i % (a.R / 4));
@@ -40,9 +58,57 @@ __global__ __launch_bounds__(256) void k_rollout_begin(RolloutBegin a)
         const long long o = (long long)p * a.pstride + n * a.R + 4 * r4;
         *reinterpret_cast<float4 *>(a.h0 + o) = h;
         *reinterpret_cast<float4 *>(a.c0 + o) = c;
+        if (k.fh0) *reinterpret_cast<float4 *>(k.fh0 + (long long)p * k.fh_pstride + n * k.fh_ld + (k.fh_ld - a.R) + 4 * r4) = h;
     }
     if (a.obs_src != nullptr)
-        for (long long j = i; j < a.obs_words; j += (long long)gridDim.x * blockDim.x) a.obs_dst[j] = a.obs_src[j];
+        for (long long j = i; j < a.obs_words; j += nthreads) a.obs_dst[j] = a.obs_src[j];
+    const int G = 4 * a.R;                       // gate rows
+    if (k.counter && i == 0) *k.counter += 1ull;
+    if (k.bsum && i < 2LL * G / 4) {
+        const int p = (int)(i / (G / 4)), j4 = (int)(i % (G / 4));
+        const float4 x = reinterpret_cast<const float4 *>(k.b_ih[p])[j4], y = reinterpret_cast<const float4 *>(k.b_hh[p])[j4];
+        reinterpret_cast<float4 *>(k.bsum)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+    if (k.w_cat) {
+        const int K4 = (k.F + a.R) / 4, F4 = k.F / 4;
+        const long long total = 2LL * G * K4;
+        for (long long j = i; j < total; j += nthreads) {
+            const int c4 = (int)(j % K4);
+            const long long row = j / K4;             // p * G + g
+            const int p = (int)(row / G), g = (int)(row % G);
+            const float4 v = c4 < F4 ? reinterpret_cast<const float4 *>(k.w_ih[p] + (long long)g * k.F)[c4]
+                                     : reinterpret_cast<const float4 *>(k.w_hh[p] + (long long)g * a.R)[c4 - F4];
+            reinterpret_cast<float4 *>(k.w_cat)[j] = v;
+        }
+    }
+    // emb_ih[a][g] = sum_c (fa_w[c][a] + fa_b[c]) * W_ih[1][g][c]: one WAVE per gate row g (coalesced reads of the row, the
+    // A embedding rows from an LDS table, butterfly sums), the first G / 4 workgroups
+    if (k.emb_ih && (int)blockIdx.x < G / 4) {
+        __shared__ float etab[8 * 256];
+        const int F = k.F, A = k.A_act;
+        for (int t = (int)threadIdx.x; t < A * F; t += (int)blockDim.x) {
+            const int act = t / F, c = t - act * F;
+            etab[t] = k.fa_w[c * A + act] + k.fa_b[c];
+        }
+        __syncthreads();
+        const int lane = (int)threadIdx.x & 63, g = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+        const float *wr = k.w_ih[1] + (long long)g * F;
+        float acc[8];
+#pragma unroll
+        for (int a_ = 0; a_ < 8; a_++) acc[a_] = 0.f;
+        for (int c = lane; c < F; c += 64) {
+            const float w = wr[c];
+#pragma unroll
+            for (int a_ = 0; a_ < 8; a_++)
+                if (a_ < A) acc[a_] = fmaf(etab[a_ * F + c], w, acc[a_]);
+        }
+#pragma unroll
+        for (int a_ = 0; a_ < 8; a_++) {
+            float v = acc[a_];
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (a_ < A && lane == 0) k.emb_ih[a_ * G + g] = v;
+        }
+    }
 }
 
 struct RolloutEnd {
@@ -263,11 +329,39 @@ extern "C" int atr_rollout_begin(const float *hxs, const float *cxs, float *h0, 
     if (!hxs || !cxs || !h0 || !c0 || N <= 0 || A <= 0 || R <= 0 || (R & 3) || (obs_bytes & 3) || (pstride & 3)) return 1;
     if (((uintptr_t)hxs | (uintptr_t)cxs | (uintptr_t)h0 | (uintptr_t)c0) & 15u) return 1;
     if (obs_src && (((uintptr_t)obs_src | (uintptr_t)obs_dst) & 3u)) return 1;
+    return atr_rollout_begin2(hxs, cxs, h0, c0, pstride, obs_src, obs_dst, obs_bytes, N, A, R, nullptr, stream);
+}
+
+extern "C" int atr_rollout_begin2(const float *hxs, const float *cxs, float *h0, float *c0, long long pstride,
+                                  const void *obs_src, void *obs_dst, long long obs_bytes, int N, int A, int R,
+                                  const atr_rollout_consts *consts, void *stream)
+{
+    if (!hxs || !cxs || !h0 || !c0 || N <= 0 || A <= 0 || R <= 0 || (R & 3) || (obs_bytes & 3) || (pstride & 3)) return 1;
+    if (((uintptr_t)hxs | (uintptr_t)cxs | (uintptr_t)h0 | (uintptr_t)c0) & 15u) return 1;
+    if (obs_src && (((uintptr_t)obs_src | (uintptr_t)obs_dst) & 3u)) return 1;
     RolloutBegin a{hxs, cxs, h0, c0, pstride, (const uint32_t *)obs_src, (uint32_t *)obs_dst, obs_bytes / 4, N, A, R};
+    RolloutConsts k;
+    memset(&k, 0, sizeof(k));
     const long long work = (long long)N * A * (R / 4);
     long long blocks = (work + 255) / 256;
     if (obs_src && blocks < 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_rollout_begin, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (consts) {
+        const atr_rollout_consts &c = *consts;
+        if (A != 2 || c.F <= 0 || (c.F & 3)) return 1;
+        const bool need_w = c.bsum || c.w_cat || c.emb_ih;
+        for (int p = 0; p < 2 && need_w; p++)
+            if (!c.w_ih[p] || !c.w_hh[p] || !c.b_ih[p] || !c.b_hh[p] ||
+                (((uintptr_t)c.w_ih[p] | (uintptr_t)c.w_hh[p] | (uintptr_t)c.b_ih[p] | (uintptr_t)c.b_hh[p]) & 15u)) return 1;
+        if (c.emb_ih && (!c.fa_w || !c.fa_b || c.A_act < 1 || c.A_act > 8 || c.F > 256)) return 1;
+        if (((uintptr_t)c.bsum | (uintptr_t)c.w_cat | (uintptr_t)c.fh0) & 15u) return 1;
+        if (c.fh0 && (c.fh_ld < R || (c.fh_ld & 3) || (c.fh_pstride & 3))) return 1;
+        for (int p = 0; p < 2; p++) { k.w_ih[p] = c.w_ih[p]; k.w_hh[p] = c.w_hh[p]; k.b_ih[p] = c.b_ih[p]; k.b_hh[p] = c.b_hh[p]; }
+        k.bsum = c.bsum; k.w_cat = c.w_cat; k.fa_w = c.fa_w; k.fa_b = c.fa_b; k.emb_ih = c.emb_ih;
+        k.counter = c.counter; k.fh0 = c.fh0; k.fh_pstride = c.fh_pstride; k.fh_ld = c.fh_ld; k.F = c.F; k.A_act = c.A_act;
+        if (c.emb_ih && blocks < R) blocks = R;           // (G / 4 = R workgroups make emb_ih: one wave per gate row)
+        if (c.w_cat && blocks < 384) blocks = 384;
+    }
+    hipLaunchKernelGGL(k_rollout_begin, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, k);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -453,8 +453,12 @@ class ActionSampler(object):
         self._ordinal = None
 
     @torch.no_grad()
-    def begin_block(self):
-        """Advance the counter once (in stream order); the following calls use ordinals 1, 2, ... until end_block."""
+    def begin_block(self, launch=True):
+        """Advance the counter once (in stream order); the following calls use ordinals 1, 2, ... until end_block.
+        launch=False: the caller's next launch bumps the counter itself (fused.rollout_begin(counter=...))."""
+        if not launch:
+            self._ordinal = 0
+            return
         dummy = self.counter
         rc = lib().atr_sample_actions(_p(dummy), _p(dummy), _p(dummy), _p(dummy), _p(self.counter), self.seed, 0, 1,
                                       0, 4, 1, _stream(self.counter))
@@ -1190,9 +1194,29 @@ def gemm_tn(x1, x2, row_scale=None, colsum=False):
     return (c, x1.sum(0)) if colsum else c
 
 
+class RolloutConsts(C.Structure):
+    """atr_rollout_consts of include/atr_policy.h."""
+    _fields_ = [("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2),
+                ("bsum", C.c_void_p), ("w_cat", C.c_void_p), ("fa_w", C.c_void_p), ("fa_b", C.c_void_p), ("emb_ih", C.c_void_p),
+                ("counter", C.c_void_p), ("fh0", C.c_void_p), ("fh_pstride", C.c_longlong), ("fh_ld", C.c_longlong),
+                ("F", C.c_int), ("A_act", C.c_int)]
+
+
+def rollout_consts_ok(consts):
+    """Whether atr_rollout_begin2 can make these constants (contiguous, 16-byte aligned parameters)."""
+    ts = []
+    for l in consts["lstm"]:
+        ts += [l.weight_ih, l.weight_hh, l.bias_ih, l.bias_hh]
+    if "fa" in consts:
+        ts += [consts["fa"].weight, consts["fa"].bias]
+    return all(t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.data_ptr() % 16 == 0 for t in ts)
+
+
 @torch.no_grad()
-def rollout_begin(hxs, cxs, h_all, c_all, obs_src=None, obs_dst=None):
-    """hxs/cxs [N,A,R] -> h_all/c_all[:, 0] ([A,T+1,N,R] rollout stores); optionally obs_src -> obs_dst (same bytes)."""
+def rollout_begin(hxs, cxs, h_all, c_all, obs_src=None, obs_dst=None, consts=None, counter=None):
+    """hxs/cxs [N,A,R] -> h_all/c_all[:, 0] ([A,T+1,N,R] rollout stores); optionally obs_src -> obs_dst (same bytes).
+    consts (model.new_cache(defer_consts=True).consts) + counter (the action sampler's): the per-rollout constants of the actor
+    and the counter bump in the same launch (atr_rollout_begin2)."""
     N, A, R = hxs.shape
     assert hxs.is_contiguous() and cxs.is_contiguous() and h_all.is_contiguous() and c_all.is_contiguous()
     assert h_all.shape[0] == A and h_all.shape[2] == N and h_all.shape[3] == R and hxs.dtype == torch.float32
@@ -1201,10 +1225,35 @@ def rollout_begin(hxs, cxs, h_all, c_all, obs_src=None, obs_dst=None):
         assert obs_src.is_contiguous() and obs_dst.is_contiguous()
         nbytes = obs_src.numel() * obs_src.element_size()
         assert nbytes == obs_dst.numel() * obs_dst.element_size() and nbytes % 4 == 0
-    rc = lib().atr_rollout_begin(_p(hxs), _p(cxs), _p(h_all), _p(c_all), h_all.stride(0), _pn(obs_src), _pn(obs_dst), nbytes,
-                                 N, A, R, _stream(hxs))
+    if consts is None:
+        rc = lib().atr_rollout_begin(_p(hxs), _p(cxs), _p(h_all), _p(c_all), h_all.stride(0), _pn(obs_src), _pn(obs_dst), nbytes,
+                                     N, A, R, _stream(hxs))
+        if rc != 0:
+            raise RuntimeError("atr_rollout_begin failed (%d)" % rc)
+        return
+    k = RolloutConsts()
+    for p, l in enumerate(consts["lstm"]):
+        k.w_ih[p], k.w_hh[p] = l.weight_ih.data_ptr(), l.weight_hh.data_ptr()
+        k.b_ih[p], k.b_hh[p] = l.bias_ih.data_ptr(), l.bias_hh.data_ptr()
+    k.bsum = consts["bsum"].data_ptr()
+    k.F = int(consts["F"])
+    if "w_cat" in consts:
+        k.w_cat = consts["w_cat"].data_ptr()
+        fh = consts["fh_all"]
+        k.fh0, k.fh_pstride, k.fh_ld = fh.data_ptr(), fh.stride(0), fh.stride(2)
+    if "emb_ih" in consts:
+        fa = consts["fa"]
+        k.fa_w, k.fa_b, k.emb_ih, k.A_act = fa.weight.data_ptr(), fa.bias.data_ptr(), consts["emb_ih"].data_ptr(), fa.weight.shape[1]
+    if counter is not None:
+        k.counter = counter.data_ptr()
+    L = lib()
+    L.atr_rollout_begin2.restype = C.c_int
+    L.atr_rollout_begin2.argtypes = [C.c_void_p] * 4 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int,
+                                                        C.c_int, C.POINTER(RolloutConsts), C.c_void_p]
+    rc = L.atr_rollout_begin2(_p(hxs), _p(cxs), _p(h_all), _p(c_all), h_all.stride(0), _pn(obs_src), _pn(obs_dst), nbytes,
+                              N, A, R, C.byref(k), _stream(hxs))
     if rc != 0:
-        raise RuntimeError("atr_rollout_begin failed (%d)" % rc)
+        raise RuntimeError("atr_rollout_begin2 failed (%d)" % rc)
 
 
 @torch.no_grad()

@@ -586,7 +586,7 @@ class A3C_Dueling(nn.Module):
         return [a0, a1], [h0, h1], [c0, c1]
 
     # ---- rollout cache: the learner back-propagates through the forward pass the actor already evaluated -------
-    def new_cache(self, num_steps, states):
+    def new_cache(self, num_steps, states, defer_consts=False):
         """Storage for one rollout's forward activations (per player: stem outputs, fc features, LSTM gates / cell /
         hidden states for every step), filled by act_cached and consumed by forward_sequence_cached — the reference
         also evaluates the forward pass once, inside the rollout (player_util.py:46-73). None when the fused GPU path
@@ -618,7 +618,8 @@ class A3C_Dueling(nn.Module):
             c.fh_all = torch.empty((2, T + 1, N, Fd + R), device=dev)
             c.f_all = c.fh_all[:, :T, :, :Fd]
             c.f = [c.f_all[0], c.f_all[1]]
-            c.lazy["w_cat"] = lambda: torch.stack([torch.cat([l.weight_ih, l.weight_hh], 1) for l in (p0.lstm, p1.lstm)], 0)
+            if not defer_consts:
+                c.lazy["w_cat"] = lambda: torch.stack([torch.cat([l.weight_ih, l.weight_hh], 1) for l in (p0.lstm, p1.lstm)], 0)
             if getattr(self, "_lt_ws", None) is None or self._lt_ws.device != dev:
                 self._lt_ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)   # this model's chain of launches only
         elif same_f:      # one [2, T, N, F] store: a step's pair of rows is one strided batch
@@ -633,7 +634,17 @@ class A3C_Dueling(nn.Module):
         c.c_all = torch.empty((2, T + 1, N, R), device=dev)
         c.actions = torch.empty((T, 2, N), dtype=torch.int64, device=dev) if self.fused_sampling else None
         c.gates = torch.empty((2, N, 4 * R), device=dev) if (N <= self.pair_gemm_max_rows or c.fh_all is not None) else None   # scratch: pre-activations
-        c.bsum = [l.bias_ih + l.bias_hh for l in (p0.lstm, p1.lstm)]
+        defer_consts = bool(defer_consts) and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape and p0.encoder.outdim % 4 == 0
+        c.consts = None
+        if defer_consts:
+            bs = torch.empty((2, 4 * R), device=dev)
+            c.bsum = [bs[0], bs[1]]
+            c.consts = dict(lstm=(p0.lstm, p1.lstm), bsum=bs, F=p0.encoder.outdim)
+            if c.fh_all is not None:
+                c.w_cat = torch.empty((2, 4 * R, p0.encoder.outdim + R), device=dev)
+                c.consts.update(w_cat=c.w_cat, fh_all=c.fh_all)
+        else:
+            c.bsum = [l.bias_ih + l.bias_hh for l in (p0.lstm, p1.lstm)]
         c.lazy["whh_t"] = lambda: torch.stack([l.weight_hh.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, R, 4R]
         if c.f_all is not None and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape:
             c.lazy["wih_t"] = lambda: torch.stack([l.weight_ih.t() for l in (p0.lstm, p1.lstm)], 0)  # [2, F, 4R]: one bmm
@@ -642,9 +653,34 @@ class A3C_Dueling(nn.Module):
             c.wih_t, c.has_wih_t = None, False
         if self.tat:
             fa = p1.fc_action_tracker
-            c.emb = fa.weight.t() + fa.bias                        # row a = fc_action_tracker(one_hot(a))
-            c.emb_ih = c.emb @ p1.lstm.weight_ih.t()               # ... projected through W_ih: [n_act, 4R]
+            if defer_consts and fa.weight.shape[1] <= 8:
+                c.lazy["emb"] = lambda: fa.weight.t() + fa.bias     # (only the per-player fallback launches read it)
+                c.emb_ih = torch.empty((fa.weight.shape[1], 4 * R), device=dev)
+                c.consts.update(fa=fa, emb_ih=c.emb_ih)
+            else:
+                c.emb = fa.weight.t() + fa.bias                    # row a = fc_action_tracker(one_hot(a))
+                c.emb_ih = c.emb @ p1.lstm.weight_ih.t()           # ... projected through W_ih: [n_act, 4R]
         return c
+
+    @torch.no_grad()
+    def fill_consts(self, cache):
+        """The deferred per-rollout constants of new_cache(defer_consts=True) with tensor ops (when the rollout's first launch
+        does not make them)."""
+        k = cache.consts
+        if k is None:
+            return
+        l0, l1 = k["lstm"]
+        torch.add(l0.bias_ih, l0.bias_hh, out=k["bsum"][0])
+        torch.add(l1.bias_ih, l1.bias_hh, out=k["bsum"][1])
+        if "w_cat" in k:
+            F_ = k["F"]
+            for p, l in enumerate((l0, l1)):
+                k["w_cat"][p, :, :F_].copy_(l.weight_ih)
+                k["w_cat"][p, :, F_:].copy_(l.weight_hh)
+        if "emb_ih" in k:
+            fa = k["fa"]
+            torch.mm(fa.weight.t() + fa.bias, l1.weight_ih.t(), out=k["emb_ih"])
+        cache.consts = None
 
     @torch.no_grad()
     def act_cached(self, states, cache, t, done=None, env_out=None):

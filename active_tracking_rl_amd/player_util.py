@@ -149,20 +149,35 @@ class Agent(object):
             # take the slower per-player launches instead of the path every later rollout takes
             from . import fused
             sampler = self.model._sampler = fused.ActionSampler(self.state.device)
-        if sampler is not None:
-            sampler.begin_block()                                 # one counter bump per rollout, ordinals inside
-        if num_steps is not None and self.cache_rollout and hasattr(self.model, "new_cache") and self.num_agents == 2:
-            self._cache = self.model.new_cache(num_steps, self.state)
-        self._actions_buf = getattr(self._cache, "actions", None)
         obs0 = self.state.reshape(self._buf[0][0].shape) if self._buf is not None else None
+        want_cache = num_steps is not None and self.cache_rollout and hasattr(self.model, "new_cache") and self.num_agents == 2
+        # the rollout's first launch (atr_rollout_begin2) moves the LSTM state and the observation into the stores AND makes the
+        # per-rollout constants of the actor + the draw counter's bump: one launch instead of ~8
+        one_launch = (want_cache and self.fused_bookkeeping and torch.is_tensor(self.hxs) and self.hxs.is_cuda
+                      and self.hxs.is_contiguous() and self.cxs.is_contiguous() and sampler is not None
+                      and (obs0 is None or (obs0.dtype == self._buf[0].dtype and obs0.is_contiguous()
+                                            and (obs0.numel() * obs0.element_size()) % 4 == 0)))
+        if want_cache:
+            self._cache = self.model.new_cache(num_steps, self.state, defer_consts=one_launch)
+        self._actions_buf = getattr(self._cache, "actions", None)
+        consts = getattr(self._cache, "consts", None)
+        if consts is not None:
+            from . import fused
+            if not (one_launch and fused.rollout_consts_ok(consts)):
+                self.model.fill_consts(self._cache)               # (tensor ops; the launch below then only moves state)
+                consts = None
+        if sampler is not None:
+            sampler.begin_block(launch=consts is None)            # one counter bump per rollout, ordinals inside
         if self._cache is not None:                               # LSTM state lives in the cache: slot t -> t+1
-            if (self.fused_bookkeeping and self.hxs.is_cuda and self.hxs.is_contiguous() and self.cxs.is_contiguous()
-                    and (obs0 is None or (obs0.dtype == self._buf[0].dtype and obs0.is_contiguous()
-                                          and (obs0.numel() * obs0.element_size()) % 4 == 0))):
+            if one_launch:
                 from . import fused                               # both copies + the observation's in one launch
                 fused.rollout_begin(self.hxs, self.cxs, self._cache.h_all, self._cache.c_all, obs0,
-                                    self._buf[0][0] if obs0 is not None else None)
-                self._seed_fh()
+                                    self._buf[0][0] if obs0 is not None else None, consts=consts,
+                                    counter=sampler.counter if consts is not None else None)
+                if consts is None:
+                    self._seed_fh()
+                else:
+                    self._cache.consts = None
                 return
             self._cache.h_all[:, 0].copy_(self.hxs.transpose(0, 1))
             self._cache.c_all[:, 0].copy_(self.cxs.transpose(0, 1))

@@ -323,6 +323,22 @@ int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int count, long lon
  *     torch.optim.RMSprop with the same settings. */
 int atr_rollout_begin(const float *hxs, const float *cxs, float *h0, float *c0, long long pstride, const void *obs_src,
                       void *obs_dst, long long obs_bytes, int N, int A, int R, void *stream);
+/* ... and, in the same launch, the per-rollout constants of the actor (weights are fixed inside a rollout; every output
+ * optional): bsum [2,4R] = b_ih + b_hh; w_cat [2,4R,F+R] = [W_ih | W_hh] (the one-GEMM LSTMCell); emb_ih [A,4R] =
+ * (fc_action_tracker.weight^T + bias) W_ih[1]^T (model.py:193-194 projected through the target's input weights); the action
+ * sampler's counter += 1; the hidden columns of slot 0 of the [features | k h] rows <- hxs. A (players) must be 2. */
+typedef struct atr_rollout_consts {
+    const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];
+    float *bsum, *w_cat;
+    const float *fa_w, *fa_b;
+    float *emb_ih;
+    unsigned long long *counter;
+    float *fh0;
+    long long fh_pstride, fh_ld;
+    int F, A_act;
+} atr_rollout_consts;
+int atr_rollout_begin2(const float *hxs, const float *cxs, float *h0, float *c0, long long pstride, const void *obs_src,
+                       void *obs_dst, long long obs_bytes, int N, int A, int R, const atr_rollout_consts *consts, void *stream);
 int atr_rollout_end(const float *hT, const float *cT, long long pstride, const uint8_t *dones, float *hxs, float *cxs,
                     int *eps_len, float *keep, int T, int N, int A, int R, void *stream);
 /* ... and, in the same launch, what else the next rollout starts from: the observation after the last step (obs_bytes
