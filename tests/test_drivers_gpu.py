@@ -680,3 +680,43 @@ def test_numpy_rng_batch_replays_all_reference_episodes_concurrently_in_one_hand
     assert steps > 5000
     print("numpy-rng batch: %d env steps of 64 concurrent reference replays in %.2f s (%.0f env steps/s incl. the checks)"
           % (steps, dt, steps / dt))
+
+
+def test_max_grad_norm_is_applied_inside_the_captured_update_graphs():
+    """--max-grad-norm under the graphed drivers: the clip (clip_grad_norm_ on the flat bucket, player_util.py:157's intent) is
+    captured in the update graph of GraphedIteration and PipelinedIteration — the gradient the last update consumed has at most
+    that norm under every driver (eager loop, synchronous graphs, pipelined graphs), the unclipped run's is larger and its
+    weights differ, and the clipped eager and graphed runs stay close (same update rule on near-identical rollouts)."""
+    from active_tracking_rl_amd.train import GraphedIteration, PipelinedIteration, default_args, make_player, rollout
+    dev = torch.device("cuda:0")
+
+    def run(kind, max_norm):
+        args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=256, seed=13, max_grad_norm=max_norm)
+        player, opt = make_player(args, dev)
+        if kind == "eager":
+            for _ in range(2):
+                rollout(player, args.num_steps)
+                player.optimize(None, opt, player.model, args.train_mode, dev)
+        elif kind == "graph":
+            it = GraphedIteration(player, opt, args, warmup=0)
+            for _ in range(2):
+                it.run()
+        else:
+            it = PipelinedIteration(player, opt, args, warmup=0, serial=True)
+            for _ in range(2):
+                it.run()
+            it.finish()
+        torch.cuda.synchronize()
+        w = opt.bucket.flat.clone()
+        gn = float(opt.bucket.grad.norm())
+        player.env.close()
+        return w, gn
+    w_eager, gn = run("eager", 0.05)
+    assert gn <= 0.05 * 1.0001, gn                      # the gradient the last update saw was clipped
+    w_graph, gn_g = run("graph", 0.05)
+    assert gn_g <= 0.05 * 1.0001
+    assert (w_eager - w_graph).abs().max() < 5e-3
+    w_free, gn_free = run("graph", None)
+    assert gn_free > 0.05 and not torch.equal(w_free, w_graph)
+    w_pipe, gn_p = run("pipelined", 0.05)               # (one update of delay: another trajectory, but clipped all the same)
+    assert gn_p <= 0.05 * 1.0001 and torch.isfinite(w_pipe).all()
