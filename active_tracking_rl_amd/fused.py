@@ -334,6 +334,25 @@ def _lt_init():
     raise RuntimeError("atr_lt_init failed: %s" % L.atr_lt_last_error().decode())
 
 
+_lt_state = None
+
+
+def lt_available():
+    """Whether atr_linear can be used (PyTorch's libhipblaslt.so found and initialised). False only on an unexpected
+    runtime: the model then keeps round 3's rollout step (library GEMMs through torch + two gate tensors) — slower, still the
+    HIP path — and says so once on stderr."""
+    global _lt_state
+    if _lt_state is None:
+        try:
+            _lt_init()
+            _lt_state = True
+        except (RuntimeError, OSError) as ex:
+            import sys
+            print("active_tracking_rl_amd: hipBLASLt direct path unavailable (%s); using the torch GEMM path" % (ex,), file=sys.stderr)
+            _lt_state = False
+    return _lt_state
+
+
 def _linear_args(a, w, out, bias, relu, workspace):
     g = LinearArgs()
     if a.dim() == 2:

@@ -608,7 +608,9 @@ class A3C_Dueling(nn.Module):
         c.y = [torch.empty((T, N * f, 512), device=dev) for f in frames]
         c.fh_all = None
         same_f = p0.encoder.outdim == p1.encoder.outdim
+        from . import fused as _fz
         if (same_f and self.cat_gate_gemm and N >= self.cat_gemm_min_rows and self.fused_env_step and self.fused_sampling
+                and _fz.lt_available()
                 and R == 128 and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape and p0.encoder.outdim % 4 == 0):
             # From cat_gemm_min_rows up the LSTMCell's two GEMMs are ONE product over rows [features | k h_prev] (K = F + R):
             # slot t of this store holds step t's fc features (written by the fc GEMM with row stride F + R) next to the
