@@ -331,8 +331,12 @@ def create_env(env_id, args, num_envs=None, device=None, env_id_base=0, obs_u8=N
     seed = getattr(args, "seed", 1)
     if obs_u8 is None:
         obs_u8 = bool(getattr(args, "obs_u8", False))
+    rng = rng if rng is not None else getattr(args, "rng", "philox")
+    if n > 1 and rng == "numpy":      # the reference-exact mode for a batch: env i on np.random.seed(seed + env_id_base + i)
+        if stack != 1 or rescale:
+            raise NotImplementedError("rng='numpy' with num_envs > 1 returns raw float32 observations (no frame stack / rescale)")
+        return NumpyVecEnv(env_id, [int(seed) + int(env_id_base) + i for i in range(n)], device=device)
     if n > 1:
         return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base, rescale=rescale,
                       obs_u8=obs_u8, inv=inv)
-    rng = rng if rng is not None else getattr(args, "rng", "philox")
     return Track2DEnv(env_id, device=device, seed=seed, stack_frames=stack, rescale=rescale, rng=rng, inv=inv)

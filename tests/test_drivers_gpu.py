@@ -682,6 +682,41 @@ def test_numpy_rng_batch_replays_all_reference_episodes_concurrently_in_one_hand
           % (steps, dt, steps / dt))
 
 
+def test_create_env_numpy_rng_batch_equals_single_numpy_envs():
+    """create_env(..., num_envs=4, rng="numpy") is the batch form of the reference-exact mode: env i runs np.random.seed(seed + i),
+    i.e. what four single create_env(..., rng="numpy") envs seeded seed + i do (the reference worker's env.seed(seed + rank),
+    train.py:23), observation for observation and reward for reward."""
+    import argparse
+    from active_tracking_rl_amd.environment import NumpyVecEnv, create_env
+    mk = lambda seed: argparse.Namespace(stack_frames=1, seed=seed, rescale=False, gpu_ids=[0])
+    batch = create_env("Track2D-BlockPartialNav-v0", mk(31), num_envs=4, rng="numpy")
+    assert isinstance(batch, NumpyVecEnv)
+    singles = [create_env("Track2D-BlockPartialNav-v0", mk(31 + i), num_envs=1, rng="numpy") for i in range(4)]
+    ob = batch.reset().cpu().numpy()
+    so = [e.reset() for e in singles]
+    so = [x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x) for x in so]
+    for i in range(4):
+        assert np.array_equal(ob[i], so[i].reshape(ob[i].shape).astype(np.float32)), i
+    rs = np.random.RandomState(3)
+    for t in range(120):
+        a = rs.randint(0, 7, size=(2, 4))
+        ob, rew, done, _ = batch.step([a[0], a[1]])
+        ob, rew, done = ob.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        for i, e in enumerate(singles):
+            o1, r1, d1, _ = e.step([int(a[0, i]), int(a[1, i])])
+            o1 = o1.cpu().numpy() if torch.is_tensor(o1) else np.asarray(o1)
+            r1 = r1.cpu().numpy() if torch.is_tensor(r1) else np.asarray(r1)
+            assert bool(d1) == bool(done[i]), (t, i)
+            assert np.array_equal(np.asarray(r1, np.float32).reshape(-1), rew[i].reshape(-1)), (t, i)
+            if d1:
+                o1 = e.reset()
+                o1 = o1.cpu().numpy() if torch.is_tensor(o1) else np.asarray(o1)
+            assert np.array_equal(ob[i], o1.reshape(ob[i].shape).astype(np.float32)), (t, i)
+    batch.close()
+    for e in singles:
+        e.close()
+
+
 def test_max_grad_norm_is_applied_inside_the_captured_update_graphs():
     """--max-grad-norm under the graphed drivers: the clip (clip_grad_norm_ on the flat bucket, player_util.py:157's intent) is
     captured in the update graph of GraphedIteration and PipelinedIteration — the gradient the last update consumed has at most

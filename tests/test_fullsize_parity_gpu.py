@@ -98,6 +98,12 @@ def test_config3_1024_maze_nav_last_rank():
     _lockstep("Track2D-MazePartialNav-v0", 1024, 0, 60, policy="chase")
 
 
+def test_maze_nav_4096_single_gpu_generator_path():
+    """MazePartialNav above 2048 envs on one GPU: the generator pass is `k_gen<NAV>` there (one wave per generated episode;
+    up to 2048 envs it is `k_gen_nav`, one workgroup per episode, covered above) — same draws, same episodes."""
+    _lockstep("Track2D-MazePartialNav-v0", 4096, 4096, 45, min_done=400)
+
+
 def test_config4_2048_adv_mixed_maps_last_rank():
     """BASELINE configs[4]: Track2D-BlockPartialAdv-v0, 16384 envs over 8 GPUs, Block/Maze 50/50 per batch — rank 7's shard."""
     mts = ["Block" if i % 2 == 0 else "Maze" for i in range(2048)]
