@@ -19,6 +19,11 @@
 //     reduction writes straight into the destinations the caller names (slices of the flat gradient bucket), the bias
 //     gradient into up to two of them (bias_ih and bias_hh receive the same sums).
 // fp32 MFMA is an exact fmaf chain, so this is the reference's arithmetic type.
+// Where it stands (round 4, tools/gemm_tn_timeline.py + SQ counters): 114-116 TFLOP/s on the learner's group at 4096 envs;
+// SQ_VALU_MFMA_BUSY_CYCLES = 0.765 of the kernel's cycles. Under this sustained f32-MFMA load the shader clock sits at
+// 1.93-2.0 GHz (s_memtime against the 100 MHz wall clock; the 157 TFLOP/s figure is 2.4 GHz), i.e. a clock-adjusted peak of
+// ~128 TFLOP/s. K chunks of 16 / 24 rows (ATR_TN_KC: 4 / 3 workgroups per CU) run the same at 4096 envs and 3-4 % faster at
+// 1024; operands resident in L2 / MALL gain 3 % — neither occupancy nor HBM is what holds it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -29,8 +34,15 @@ namespace atr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTile = 128, kKC = 32, kLd = 128;   // tile side, K-chunk rows, LDS row length (floats)
+#ifndef ATR_TN_KC
+#define ATR_TN_KC 32
+#endif
+#ifndef ATR_TN_PROBE
+#define ATR_TN_PROBE 0     // 1: probe build only (tools/gemm_tn_timeline.py): per-workgroup start / end stamps
+#endif
+constexpr int kTile = 128, kKC = ATR_TN_KC, kLd = 128;   // tile side, K-chunk rows, LDS row length (floats)
 constexpr int kGemmThreads = 256;
+constexpr int kWgPerCu = kKC == 32 ? 2 : kKC == 24 ? 3 : 4;
 
 struct GemmLds { float a[2][kKC][kLd]; float b[2][kKC][kLd]; };   // 64 KB: two workgroups per CU
 
@@ -57,10 +69,17 @@ struct TnGroup {
     int red_blocks;                // matrix blocks of the reduction launch; column-sum blocks follow
 };
 
-__global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const TnGroup g)
+#if ATR_TN_PROBE
+__device__ unsigned long long g_tn_stamps[8192 * 4];
+#endif
+
+__global__ __launch_bounds__(kGemmThreads, kWgPerCu) void k_gemm_tn(const TnGroup g)
 {
     __shared__ __attribute__((aligned(16))) GemmLds s;
     const int tid = (int)threadIdx.x, l = tid & 63, wave = tid >> 6;
+#if ATR_TN_PROBE
+    const unsigned long long st_rt = wall_clock64(), st_cy = __builtin_readcyclecounter();
+#endif
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware order: workgroup i runs on XCD i % 8; give each XCD whole K-slices (all their tiles, of every problem, back
     // to back): an operand slice is fetched from HBM once and re-read from that XCD's L2 by the other tiles — and by the other
@@ -90,6 +109,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const TnGroup g)
     const float4 *g1 = reinterpret_cast<const float4 *>(x1 + m0 + c4 * 4), *g2 = reinterpret_cast<const float4 *>(x2 + n0 + c4 * 4);
     const long long ldm = g.p[q].ld1 / 4, ldn = g.p[q].ld2 / 4;        // row strides in float4 units
     float4 ra0, ra1, rb0, rb1, ra2, ra3, rb2, rb3;
+    float rs0 = 1.f, rs1 = 1.f, rs2 = 1.f, rs3 = 1.f;
     // optional extras: row_scale[k] multiplies row k of X1 on its way into LDS (dW_hh needs the episode mask on h);
     // colsum_partial receives the column sums of X1 (the bias gradient that goes with a weight gradient) from the
     // workgroups of the first tile column, which add up their staged chunks
@@ -102,28 +122,34 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const TnGroup g)
         ra0 = zero4; ra1 = zero4; rb0 = zero4; rb1 = zero4; ra2 = zero4; ra3 = zero4; rb2 = zero4; rb3 = zero4; \
         if (ka_ < k_end) { ra0 = g1[ka_ * ldm]; rb0 = g2[ka_ * ldn]; }         \
         if (kb_ < k_end) { ra1 = g1[kb_ * ldm]; rb1 = g2[kb_ * ldn]; }         \
-        if (kc_ < k_end) { ra2 = g1[kc_ * ldm]; rb2 = g2[kc_ * ldn]; }         \
-        if (kd_ < k_end) { ra3 = g1[kd_ * ldm]; rb3 = g2[kd_ * ldn]; }         \
-        if (row_scale) {                                                       \
-            float s0_ = 1.f, s1_ = 1.f, s2_ = 1.f, s3_ = 1.f;   /* (rows past k_end hold zeros already) */              \
-            if (ka_ >= rs_shift && ka_ < k_end) s0_ = row_scale[ka_ - rs_shift];                                       \
-            if (kb_ >= rs_shift && kb_ < k_end) s1_ = row_scale[kb_ - rs_shift];                                       \
-            if (kc_ >= rs_shift && kc_ < k_end) s2_ = row_scale[kc_ - rs_shift];                                       \
-            if (kd_ >= rs_shift && kd_ < k_end) s3_ = row_scale[kd_ - rs_shift];                                       \
-            ra0.x *= s0_; ra0.y *= s0_; ra0.z *= s0_; ra0.w *= s0_; ra1.x *= s1_; ra1.y *= s1_; ra1.z *= s1_; ra1.w *= s1_; \
-            ra2.x *= s2_; ra2.y *= s2_; ra2.z *= s2_; ra2.w *= s2_; ra3.x *= s3_; ra3.y *= s3_; ra3.z *= s3_; ra3.w *= s3_; \
+        if (kKC >= 24 && kc_ < k_end) { ra2 = g1[kc_ * ldm]; rb2 = g2[kc_ * ldn]; }         \
+        if (kKC == 32 && kd_ < k_end) { ra3 = g1[kd_ * ldm]; rb3 = g2[kd_ * ldn]; }         \
+        if (row_scale) {      /* the factors ride along with the chunk; applied on the way into LDS (GEMM_TN_STAGE) */     \
+            rs0 = 1.f; rs1 = 1.f; rs2 = 1.f; rs3 = 1.f;        /* (rows past k_end hold zeros already) */               \
+            if (ka_ >= rs_shift && ka_ < k_end) rs0 = row_scale[ka_ - rs_shift];                                       \
+            if (kb_ >= rs_shift && kb_ < k_end) rs1 = row_scale[kb_ - rs_shift];                                       \
+            if (kKC >= 24 && kc_ >= rs_shift && kc_ < k_end) rs2 = row_scale[kc_ - rs_shift];                         \
+            if (kKC == 32 && kd_ >= rs_shift && kd_ < k_end) rs3 = row_scale[kd_ - rs_shift];                         \
         }                                                                      \
     }
 #define GEMM_TN_STAGE(buf_)                                                    \
     {                                                                          \
+        if (row_scale) {                                                       \
+            ra0.x *= rs0; ra0.y *= rs0; ra0.z *= rs0; ra0.w *= rs0; ra1.x *= rs1; ra1.y *= rs1; ra1.z *= rs1; ra1.w *= rs1; \
+            ra2.x *= rs2; ra2.y *= rs2; ra2.z *= rs2; ra2.w *= rs2; ra3.x *= rs3; ra3.y *= rs3; ra3.z *= rs3; ra3.w *= rs3; \
+        }                                                                      \
         *reinterpret_cast<float4 *>(&s.a[buf_][r][c4 * 4]) = ra0;              \
         *reinterpret_cast<float4 *>(&s.a[buf_][r + 8][c4 * 4]) = ra1;          \
         *reinterpret_cast<float4 *>(&s.b[buf_][r][c4 * 4]) = rb0;              \
         *reinterpret_cast<float4 *>(&s.b[buf_][r + 8][c4 * 4]) = rb1;          \
-        *reinterpret_cast<float4 *>(&s.a[buf_][r + 16][c4 * 4]) = ra2;         \
-        *reinterpret_cast<float4 *>(&s.a[buf_][r + 24][c4 * 4]) = ra3;         \
-        *reinterpret_cast<float4 *>(&s.b[buf_][r + 16][c4 * 4]) = rb2;         \
-        *reinterpret_cast<float4 *>(&s.b[buf_][r + 24][c4 * 4]) = rb3;         \
+        if (kKC >= 24) {                                                       \
+        *reinterpret_cast<float4 *>(&s.a[buf_][(r + 16) % kKC][c4 * 4]) = ra2;         \
+        *reinterpret_cast<float4 *>(&s.b[buf_][(r + 16) % kKC][c4 * 4]) = rb2;         \
+        }                                                                      \
+        if (kKC == 32) {                                                       \
+        *reinterpret_cast<float4 *>(&s.a[buf_][(r + 24) % kKC][c4 * 4]) = ra3;         \
+        *reinterpret_cast<float4 *>(&s.b[buf_][(r + 24) % kKC][c4 * 4]) = rb3;         \
+        }                                                                      \
     }
     f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
@@ -147,6 +173,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const TnGroup g)
                 na0 = pa[(kp + 1) * 2 * kLd]; na1 = pa[(kp + 1) * 2 * kLd + 32];
                 nb0 = pb[(kp + 1) * 2 * kLd]; nb1 = pb[(kp + 1) * 2 * kLd + 32];
             }
+            // keep these reads ABOVE the MFMAs: left alone, the scheduler sinks them below and waits for them at once
+            // (ds_read, s_waitcnt lgkmcnt(0), 4 MFMAs per k-pair: the matrix pipe idles for an LDS latency every 256 cycles —
+            // 107 -> 114 TFLOP/s on the learner's group at 4096 envs)
+            __builtin_amdgcn_sched_barrier(0);
             acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
             acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
             acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
@@ -181,6 +211,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void k_gemm_tn(const TnGroup g)
         }
     };
     store(acc00, 0, 0); store(acc01, 0, 1); store(acc10, 1, 0); store(acc11, 1, 1);
+#if ATR_TN_PROBE
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned long long *o = &g_tn_stamps[(size_t)blockIdx.x * 4];
+        o[0] = st_rt; o[1] = wall_clock64(); o[2] = __builtin_readcyclecounter() - st_cy;
+        o[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
+#endif
 }
 
 // C = sum over slices, fixed order — all problems of a group in one launch: blocks [red_begin, ...) of a problem cover its
@@ -227,7 +264,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const TnGroup g)
 
 // slices (a multiple of the 8 XCDs) for `tiles` output tiles in all: the estimate is rounds of 256-CU occupancy x rows per
 // workgroup, plus a fixed cost per round (prologue / epilogue of a workgroup ~ 64 rows of work)
-static void gemm_tn_plan(long long K, int tiles, int *slices, int *chunks_per_slice)
+struct TnPlan { int slices, chunks_per_slice; };
+
+static TnPlan gemm_tn_plan(long long K, int tiles)
 {
     // Two workgroups fit a CU (64 KB LDS each) and run best in pairs (one's MFMAs cover the other's load latency): count
     // rounds of 512 co-resident workgroups at pair efficiency, a tail of <= 256 as a round of lone workgroups at solo
@@ -241,15 +280,22 @@ static void gemm_tn_plan(long long K, int tiles, int *slices, int *chunks_per_sl
         if (s > chunks && s > 8) break;
         const long long cps = (chunks + s - 1) / s, wgs = (long long)tiles * s;
         const double rows = (double)cps * kKC + 64.0;
-        const long long full = wgs / 512, rem = wgs - full * 512;
-        double cost = (double)full * 2.0 * rows / eff_pair;
-        if (rem > 256) cost += 2.0 * rows / eff_pair;
+        const long long round = 256 * kWgPerCu;
+        const long long full = wgs / round, rem = wgs - full * round;
+        double cost = (double)full * kWgPerCu * rows / eff_pair;
+        if (rem > 256) cost += (double)((rem + 255) / 256) * rows / eff_pair;
         else if (rem > 0) cost += rows / eff_solo;
         if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
     if (forced >= 8 && forced % 8 == 0 && forced <= chunks) best = forced;
-    *slices = best;
-    *chunks_per_slice = (int)((chunks + best - 1) / best);
+    TnPlan p;
+    p.chunks_per_slice = (int)((chunks + best - 1) / best);
+    p.slices = best;
+    // (Equal workgroups do not take equal time — 300-510 us for the same 80 chunks at 4096 envs, tools/gemm_tn_timeline.py:
+    // power management, the neighbour on the CU — and every CU gets the same number of them, so the CUs finish ~7 % apart.
+    // Cutting the last 8 slices into 2-4x as many short ones to fill that ragged end was measured: 1-3 % SLOWER, the extra
+    // partial tiles cost more than the tail returns.)
+    return p;
 }
 
 static int group_tiles(const atr_gemm_tn_problem *pr, int count)
@@ -267,13 +313,19 @@ static int group_tiles(const atr_gemm_tn_problem *pr, int count)
 
 using namespace atr;
 
+#if ATR_TN_PROBE
+extern "C" int atr_tn_stamps(unsigned long long *host, int wgs)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tn_stamps), (size_t)wgs * 4 * sizeof(unsigned long long));
+}
+#endif
+
 extern "C" long long atr_gemm_tn_grouped_workspace_floats(const atr_gemm_tn_problem *problems, int count, long long K)
 {
     if (!problems || count < 1 || count > kMaxProblems || K <= 0) return -1;
     const int tiles = group_tiles(problems, count);
     if (tiles < 0) return -1;
-    int s, c;
-    gemm_tn_plan(K, tiles, &s, &c);
+    const int s = gemm_tn_plan(K, tiles).slices;
     long long total = 0;
     for (int q = 0; q < count; q++) total += (long long)s * problems[q].M * problems[q].N + (long long)s * problems[q].M;
     return total;
@@ -285,7 +337,8 @@ extern "C" int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int coun
     const int tiles = group_tiles(problems, count);
     if (tiles < 0) return -1;
     TnGroup g;
-    gemm_tn_plan(K, tiles, &g.slices, &g.chunks_per_slice);
+    const TnPlan plan = gemm_tn_plan(K, tiles);
+    g.slices = plan.slices; g.chunks_per_slice = plan.chunks_per_slice;
     g.K = K; g.count = count; g.tiles_total = tiles;
     float *ws = workspace;
     int tile_begin = 0, red_begin = 0, cs_blocks = 0;
