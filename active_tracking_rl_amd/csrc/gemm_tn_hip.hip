@@ -5,7 +5,7 @@
 // TFLOP/s on all of them, 2.5% of an A3C iteration saved; also tighter error than the library's split-K order):
 //   * 128 x 128 output tile per workgroup (4 waves, each a 64 x 64 quadrant = 2 x 2 v_mfma_f32_32x32x2_f32 tiles,
 //     64 accumulator VGPRs), the K range split over many workgroups (split-K) so that ~512 workgroups exist;
-//   * both operands are consumed in their natural row-major layout: a 32-row chunk of X1 and of X2 is staged in LDS
+//   * both operands are consumed in their natural row-major layout: a 16- or 32-row chunk of X1 and of X2 (by K: tn_kc) is staged in LDS
 //     (unpadded rows: the two k-rows an MFMA operand read touches are served in different LDS passes; padding them
 //     apart was measured 3-10 % slower) and an MFMA operand is ONE ds_read_b32 per lane (A[i = m][k] = X1[k][m], B[k][j] = X2[k][n]: lane l reads row k0 + (l>>5),
 //     column base + (l & 31)); the next chunk's global loads are in flight while the current one is multiplied;
@@ -22,8 +22,7 @@
 // Where it stands (round 4, tools/gemm_tn_timeline.py + SQ counters): 114-116 TFLOP/s on the learner's group at 4096 envs;
 // SQ_VALU_MFMA_BUSY_CYCLES = 0.765 of the kernel's cycles. Under this sustained f32-MFMA load the shader clock sits at
 // 1.93-2.0 GHz (s_memtime against the 100 MHz wall clock; the 157 TFLOP/s figure is 2.4 GHz), i.e. a clock-adjusted peak of
-// ~128 TFLOP/s. K chunks of 16 / 24 rows (ATR_TN_KC: 4 / 3 workgroups per CU) run the same at 4096 envs and 3-4 % faster at
-// 1024; operands resident in L2 / MALL gain 3 % — neither occupancy nor HBM is what holds it.
+// ~128 TFLOP/s. Operands resident in L2 / MALL gain 3 %; chunk size / occupancy: see tn_kc below.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -34,17 +33,25 @@ namespace atr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef ATR_TN_KC
-#define ATR_TN_KC 32
-#endif
 #ifndef ATR_TN_PROBE
 #define ATR_TN_PROBE 0     // 1: probe build only (tools/gemm_tn_timeline.py): per-workgroup start / end stamps
 #endif
-constexpr int kTile = 128, kKC = ATR_TN_KC, kLd = 128;   // tile side, K-chunk rows, LDS row length (floats)
+constexpr int kTile = 128, kLd = 128;   // tile side, LDS row length (floats)
 constexpr int kGemmThreads = 256;
-constexpr int kWgPerCu = kKC == 32 ? 2 : kKC == 24 ? 3 : 4;
+// Rows per K chunk — a template parameter of the kernel: 32 (64 KB of LDS, 2 workgroups per CU) or 16 (32 KB, 4 per CU).
+// The learner's group, 16 / 24 / 32 rows: 179 / 180 / 198 us at 512 envs, 309 / 309 / 334 at 1024, 571 / 570 / 575 at 2048,
+// 1078 / 1083 / 1094 at 4096 (stand-alone); next to the other replica's rollout (pipelined schedule, 4096 envs) the 32-row
+// form leaves it more room: 15.58-15.60 M env steps/s against 15.43-15.46. So: 16 rows up to kSmallK rows of K, 32 above.
+constexpr long long kSmallK = 20 * 1024 + 1;
+constexpr int tn_wg_per_cu(int kc) { return kc == 32 ? 2 : kc == 24 ? 3 : 4; }
+static int tn_kc(long long K)
+{
+    static const int forced = getenv("ATR_GEMM_TN_KC") ? atoi(getenv("ATR_GEMM_TN_KC")) : 0;   // (tuning experiments)
+    if (forced == 16 || forced == 32) return forced;
+    return K < kSmallK ? 16 : 32;
+}
 
-struct GemmLds { float a[2][kKC][kLd]; float b[2][kKC][kLd]; };   // 64 KB: two workgroups per CU
+template <int kKC> struct GemmLds { float a[2][kKC][kLd]; float b[2][kKC][kLd]; };
 
 constexpr int kMaxProblems = 8;
 
@@ -73,9 +80,10 @@ struct TnGroup {
 __device__ unsigned long long g_tn_stamps[8192 * 4];
 #endif
 
-__global__ __launch_bounds__(kGemmThreads, kWgPerCu) void k_gemm_tn(const TnGroup g)
+template <int kKC>
+__global__ __launch_bounds__(kGemmThreads, tn_wg_per_cu(kKC)) void k_gemm_tn(const TnGroup g)
 {
-    __shared__ __attribute__((aligned(16))) GemmLds s;
+    __shared__ __attribute__((aligned(16))) GemmLds<kKC> s;
     const int tid = (int)threadIdx.x, l = tid & 63, wave = tid >> 6;
 #if ATR_TN_PROBE
     const unsigned long long st_rt = wall_clock64(), st_cy = __builtin_readcyclecounter();
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(kGemmThreads, kWgPerCu) void k_gemm_tn(const TnGrou
     __syncthreads();
     int buf = 0;
     const int kr = l >> 5, col = l & 31;
-    // (a second register set, i.e. two chunks of prefetch distance, was measured: no faster — with two workgroups per
+    // (a second register set, i.e. two chunks of prefetch distance, was measured: no faster — with several workgroups per
     // CU the other one's MFMAs already cover the load latency)
     for (long long k0 = k_begin; k0 < k_end; k0 += kKC, buf ^= 1) {
         const bool more = k0 + kKC < k_end;
@@ -268,8 +276,9 @@ struct TnPlan { int slices, chunks_per_slice; };
 
 static TnPlan gemm_tn_plan(long long K, int tiles)
 {
-    // Two workgroups fit a CU (64 KB LDS each) and run best in pairs (one's MFMAs cover the other's load latency): count
-    // rounds of 512 co-resident workgroups at pair efficiency, a tail of <= 256 as a round of lone workgroups at solo
+    const int kKC = tn_kc(K), kWgPerCu = tn_wg_per_cu(kKC);
+    // kWgPerCu workgroups fit a CU (LDS) and run best together (one's MFMAs cover the others' load latency): count
+    // rounds of 256 * kWgPerCu co-resident workgroups at that efficiency, a tail of <= 256 as a round of lone workgroups at solo
     // efficiency; every workgroup pays a fixed prologue / epilogue worth ~64 rows
     const long long chunks = (K + kKC - 1) / kKC;
     const double eff_pair = 0.85, eff_solo = 0.6;
@@ -359,7 +368,8 @@ extern "C" int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int coun
     }
     g.red_blocks = red_begin;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)(g.slices * tiles)), dim3(kGemmThreads), 0, st, g);
+    if (tn_kc(K) == 16) hipLaunchKernelGGL(k_gemm_tn<16>, dim3((unsigned)(g.slices * tiles)), dim3(kGemmThreads), 0, st, g);
+    else hipLaunchKernelGGL(k_gemm_tn<32>, dim3((unsigned)(g.slices * tiles)), dim3(kGemmThreads), 0, st, g);
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)(red_begin + cs_blocks)), dim3(256), 0, st, g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

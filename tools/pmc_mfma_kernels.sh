@@ -9,7 +9,7 @@ f = glob.glob("/tmp/p_m/**/*counter_collection.csv", recursive=True)[0]
 d = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    for tag in ("k_actor_step", "k_gemm_tn(", "k_stem_fwd", "k_stem_bwd", "k_step2"):
+    for tag in ("k_actor_step", "k_gemm_tn<", "k_stem_fwd", "k_stem_bwd", "k_step2"):
         if tag in k:
             d[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("# pass:", sys.argv[1])
