@@ -24,6 +24,11 @@ prof_iter iteration_kernel_stats_config3 Track2D-MazePartialNav-v0 1024 maze-lst
 (cd $R && timeout 300 python tools/lt_gemm_bench.py > $O/lt_gemm_bench.txt 2>&1)
 (cd $R && timeout 300 python tools/act_step_bench.py > $O/act_step_bench.txt 2>&1)
 (cd $R && ACT_BENCH_MODE=one timeout 300 python tools/act_step_bench.py 512 1024 2048 4096 >> $O/act_step_bench.txt 2>&1)
+# --- the learner's grouped weight-gradient GEMM alone, and its per-workgroup timeline (probe build -DATR_TN_PROBE=1, compiled here)
+(cd $R && timeout 300 python tools/gemm_group_bench.py 512 1024 2048 4096 > $O/gemm_group_bench.txt 2>&1)
+mkdir -p $R/scratch_exp; (cd $R/active_tracking_rl_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -ldl -Wno-unused-result -DATR_TN_PROBE=1 \
+    -o $R/scratch_exp/libtnprobe.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
+[ -f $R/scratch_exp/libtnprobe.so ] && (cd $R && T2D_LIB_PATH=scratch_exp/libtnprobe.so timeout 300 python tools/gemm_tn_timeline.py 4096 1536 > $O/gemm_tn_timeline.txt 2>&1)
 # --- multi-rank settings under a 1-rank RCCL group
 (cd $R && bash tools/multirank_probe.sh > /dev/null 2>&1; cp gpurun_out/r04_multirank_1gpu.txt $O/multirank_1gpu.txt)
 # --- Nav / Maze: generator pass (kernel stats at 1024 / 8192 random-policy envs), its timeline (probe build, if present)

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."; O=gpurun_out/r04; P=profiles
 for f in bench.json bench_driver_flags.json bench_under_rocprof.json bench_selflaunch_2ranks_gloo_1gpu.json; do [ -s $O/$f ] && cp $O/$f $P/r04_$f; done
 for f in bench_kernel_stats iteration_kernel_stats iteration_kernel_stats_shard2048 iteration_kernel_stats_shard1024 iteration_kernel_stats_shard512 \
-         iteration_kernel_stats_config1 iteration_kernel_stats_config3 config_sweep lt_gemm_bench act_step_bench multirank_1gpu \
+         iteration_kernel_stats_config1 iteration_kernel_stats_config3 config_sweep lt_gemm_bench act_step_bench gemm_group_bench gemm_tn_timeline multirank_1gpu \
          nav_env_only_1024 nav_env_only_8192 nav_kernel_stats_1024 nav_kernel_stats_8192 generator_nav_timeline \
          learning_check_ram_tracker learning_check_pzr_dueling learning_check_nav_tracker main_py_logger main_py_scalars_tail \
          main_py_test_scalars_tail; do
