@@ -19,10 +19,14 @@
 //     reduction writes straight into the destinations the caller names (slices of the flat gradient bucket), the bias
 //     gradient into up to two of them (bias_ih and bias_hh receive the same sums).
 // fp32 MFMA is an exact fmaf chain, so this is the reference's arithmetic type.
-// Where it stands (round 4, tools/gemm_tn_timeline.py + SQ counters): 114-116 TFLOP/s on the learner's group at 4096 envs;
-// SQ_VALU_MFMA_BUSY_CYCLES = 0.765 of the kernel's cycles. Under this sustained f32-MFMA load the shader clock sits at
-// 1.93-2.0 GHz (s_memtime against the 100 MHz wall clock; the 157 TFLOP/s figure is 2.4 GHz), i.e. a clock-adjusted peak of
-// ~128 TFLOP/s. Operands resident in L2 / MALL gain 3 %; chunk size / occupancy: see tn_kc below.
+// Where it stands (round 4): 124-127 TFLOP/s = 0.79-0.81 of the 157 TFLOP/s f32-MFMA peak on the learner's group at 4096 envs
+// (1014-1035 us; round 3: 1184 us). What moved it: the operand prefetch kept above the MFMAs (107 -> 114-118), operands DMA'd
+// straight into LDS (-> 124-127). Measured on the way (tools/gemm_tn_timeline.py, SQ counters): SQ_VALU_MFMA_BUSY_CYCLES =
+// 0.765 of the kernel's cycles before the DMA path; the shader clock holds 2.4 GHz in steady state (s_memtime against the
+// 100 MHz wall clock; the first launches after idle run at 1.9-2.0); equal workgroups take 287-390 us and the CUs finish
+// 0.95 full; operands resident in L2 / MALL gain 3 %; LDS bank conflicts 0. Tried and dropped: cutting the last slices short to
+// fill the ragged end (1-3 % slower: more partial tiles), wave-private staging with no barrier at all (15 % slower: twice the
+// staging traffic costs more than the barriers), the LDS writes of the next chunk moved into the MFMA loop (no change).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -33,6 +37,9 @@ namespace atr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef ATR_TN_DIRECT
+#define ATR_TN_DIRECT 1    // 0: staging through registers only (A/B builds)
+#endif
 #ifndef ATR_TN_PROBE
 #define ATR_TN_PROBE 0     // 1: probe build only (tools/gemm_tn_timeline.py): per-workgroup start / end stamps
 #endif
@@ -80,7 +87,9 @@ struct TnGroup {
 __device__ unsigned long long g_tn_stamps[8192 * 4];
 #endif
 
-template <int kKC>
+// kMixed = false: the host has checked that EVERY workgroup of the launch takes the direct path (no row factors anywhere in the
+// group, K a whole number of chunks) and the register-staged path is compiled out.
+template <int kKC, bool kMixed>
 __global__ __launch_bounds__(kGemmThreads, tn_wg_per_cu(kKC)) void k_gemm_tn(const TnGroup g)
 {
     __shared__ __attribute__((aligned(16))) GemmLds<kKC> s;
@@ -162,16 +171,8 @@ __global__ __launch_bounds__(kGemmThreads, tn_wg_per_cu(kKC)) void k_gemm_tn(con
     f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
     for (int q = 0; q < 16; q++) { acc00[q] = 0.f; acc01[q] = 0.f; acc10[q] = 0.f; acc11[q] = 0.f; }
-    GEMM_TN_FETCH(k_begin);
-    GEMM_TN_STAGE(0);
-    __syncthreads();
-    int buf = 0;
     const int kr = l >> 5, col = l & 31;
-    // (a second register set, i.e. two chunks of prefetch distance, was measured: no faster — with several workgroups per
-    // CU the other one's MFMAs already cover the load latency)
-    for (long long k0 = k_begin; k0 < k_end; k0 += kKC, buf ^= 1) {
-        const bool more = k0 + kKC < k_end;
-        if (more) GEMM_TN_FETCH(k0 + kKC);               // next chunk's loads fly under this chunk's MFMAs
+    auto compute = [&](int buf) {
         const float *pa = &s.a[buf][kr][wm * 64 + col], *pb = &s.b[buf][kr][wn * 64 + col];
         float a0 = pa[0], a1 = pa[32], b0 = pb[0], b1 = pb[32];
 #pragma unroll
@@ -196,8 +197,48 @@ __global__ __launch_bounds__(kGemmThreads, tn_wg_per_cu(kKC)) void k_gemm_tn(con
 #pragma unroll
             for (int q = 0; q < kKC / 2; q++) cs += pc[q * kLd];
         }
-        if (more) GEMM_TN_STAGE(buf ^ 1);                // the other buffer was last read one iteration ago
+    };
+    // Whole chunks and no row factors (the learner's own groups at every BASELINE size): the operands go from global memory
+    // STRAIGHT into LDS (global_load_lds_dwordx4: lane l of a wave lands at base + 16 l, i.e. a wave fills two 128-float rows
+    // per instruction) — no staging registers, no ds_write, nothing for the wave to do between issuing the loads of chunk
+    // c + 1 (into the buffer everybody left at the last barrier) and the barrier that ends chunk c.
+    // (a mixed launch with 16-row chunks keeps to the register-staged path: both paths together do not fit its 128 VGPRs)
+    const bool direct = !kMixed || (kKC == 32 && ATR_TN_DIRECT && row_scale == nullptr && k_end > k_begin && (k_end - k_begin) % kKC == 0);
+    if (direct) {
+        auto dma = [&](long long k0, int buf) {
+#pragma unroll
+            for (int j = 0; j < kKC / 8; j++) {
+                const long long kk = k0 + r + 8 * j;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g1 + kk * ldm),
+                                                 (__attribute__((address_space(3))) void *)(&s.a[buf][2 * wave + 8 * j][0]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g2 + kk * ldn),
+                                                 (__attribute__((address_space(3))) void *)(&s.b[buf][2 * wave + 8 * j][0]), 16, 0, 0);
+            }
+        };
+        dma(k_begin, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
         __syncthreads();
+        int buf = 0;
+        for (long long k0 = k_begin; k0 < k_end; k0 += kKC, buf ^= 1) {
+            if (k0 + kKC < k_end) dma(k0 + kKC, buf ^ 1);
+            compute(buf);
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // the next chunk has landed (issued a whole chunk of MFMAs ago)
+            __syncthreads();
+        }
+    } else if (kMixed) {
+        GEMM_TN_FETCH(k_begin);
+        GEMM_TN_STAGE(0);
+        __syncthreads();
+        int buf = 0;
+        // (a second register set, i.e. two chunks of prefetch distance, was measured: no faster — with several workgroups per
+        // CU the other one's MFMAs already cover the load latency)
+        for (long long k0 = k_begin; k0 < k_end; k0 += kKC, buf ^= 1) {
+            const bool more = k0 + kKC < k_end;
+            if (more) GEMM_TN_FETCH(k0 + kKC);           // next chunk's loads fly under this chunk's MFMAs
+            compute(buf);
+            if (more) GEMM_TN_STAGE(buf ^ 1);            // the other buffer was last read one iteration ago
+            __syncthreads();
+        }
     }
     if (do_colsum) {
         float *red = &s.a[0][0][0];
@@ -368,8 +409,17 @@ extern "C" int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int coun
     }
     g.red_blocks = red_begin;
     hipStream_t st = (hipStream_t)stream;
-    if (tn_kc(K) == 16) hipLaunchKernelGGL(k_gemm_tn<16>, dim3((unsigned)(g.slices * tiles)), dim3(kGemmThreads), 0, st, g);
-    else hipLaunchKernelGGL(k_gemm_tn<32>, dim3((unsigned)(g.slices * tiles)), dim3(kGemmThreads), 0, st, g);
+    const dim3 grid((unsigned)(g.slices * tiles)), block(kGemmThreads);
+    const int kc = tn_kc(K);
+    bool all_direct = ATR_TN_DIRECT && K % kc == 0;
+    for (int q = 0; q < count; q++) all_direct = all_direct && problems[q].row_scale == nullptr;
+    if (kc == 16) {
+        if (all_direct) hipLaunchKernelGGL((k_gemm_tn<16, false>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((k_gemm_tn<16, true>), grid, block, 0, st, g);
+    } else {
+        if (all_direct) hipLaunchKernelGGL((k_gemm_tn<32, false>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((k_gemm_tn<32, true>), grid, block, 0, st, g);
+    }
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)(red_begin + cs_blocks)), dim3(256), 0, st, g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -646,6 +646,7 @@ class _LstmSeqCached(torch.autograd.Function):
         whh = h_all.new_empty(0) if fused_path else torch.stack([w.t() for w in whh_l], 0).contiguous()
         ctx.save_for_backward(keep.contiguous(), h_all, c_all, acts, whh, *feats, *wih, *whh_l, *fw[3 * P:5 * P])
         ctx.P = P
+        need, ctx.hm = need                       # (lstm_sequence_cached packs the two non-tensor arguments together)
         ctx.need = tuple(bool(x) for x in need) if need is not None else (True,) * P
         return tuple(h_all[p, 1:] for p in range(P))
 
@@ -677,8 +678,12 @@ class _LstmSeqCached(torch.autograd.Function):
                     # both products of this player contract dG: registered with the grouped launch. dW_hh^T = dG^T (k h):
                     # the mask on h_{t-1} is keep[t-1] = the keep array shifted by one step of N rows, applied to dG's rows
                     r1 = q.add(dG[i], feats[p], wih[p], biases=(bih[p], bhh[p]))
-                    r2 = q.add(dG[i], h_all[p, :T].reshape(T * N, R), whh_nn[p], row_scale=keep, shift=N) \
-                        if r1 is not None else None
+                    if r1 is None:
+                        r2 = None
+                    elif ctx.hm is not None:       # (k h rows stored by the rollout: nothing to mask)
+                        r2 = q.add(dG[i], ctx.hm[p], whh_nn[p])
+                    else:
+                        r2 = q.add(dG[i], h_all[p, :T].reshape(T * N, R), whh_nn[p], row_scale=keep, shift=N)
                     if r1 is not None and r2 is not None:
                         dwih[p], (dbi, dbh) = r1
                         dwhh_l[p] = r2[0]
@@ -698,13 +703,15 @@ class _LstmSeqCached(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + db_hh
 
 
-def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts, need=None):
+def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts, need=None, hm=None):
     """feats: per-player [T*N, F] (with grad); lstms: the nn.LSTMCells; stored activations from the rollout.
-    need: per player, whether anything upstream of its hidden sequence is trained (None = all)."""
+    need: per player, whether anything upstream of its hidden sequence is trained (None = all).
+    hm: per player the MASKED previous hidden rows k_{t-1} h_{t-1} as [T*N, R] (row-strided views are fine) when the rollout
+    stored them (model._act_step's one-GEMM path) — dW_hh then needs no row factors."""
     P = len(lstms)
     args = list(feats) + [l.weight_ih for l in lstms] + [l.weight_hh for l in lstms] + \
         [l.bias_ih for l in lstms] + [l.bias_hh for l in lstms]
-    return _LstmSeqCached.apply(keep, h_all, c_all, acts, need, *args)
+    return _LstmSeqCached.apply(keep, h_all, c_all, acts, (need, hm), *args)
 
 
 @torch.no_grad()

@@ -607,6 +607,7 @@ class A3C_Dueling(nn.Module):
         c.T, c.N, c.frames = T, N, frames
         c.y = [torch.empty((T, N * f, 512), device=dev) for f in frames]
         c.fh_all = None
+        c.hm_written = 0
         same_f = p0.encoder.outdim == p1.encoder.outdim
         from . import fused as _fz
         if (same_f and self.cat_gate_gemm and N >= self.cat_gemm_min_rows and self.fused_env_step and self.fused_sampling
@@ -803,6 +804,8 @@ class A3C_Dueling(nn.Module):
                                (p0.actor.actor_linear, p1.actor.actor_linear), actions,
                                emb=cache.emb_ih if self.tat else None, env_out=env_out[1:] if env_out is not None else None,
                                hm_out=hm)
+            if hm is not None:            # slot t + 1 of the [features | k h] rows now holds k_t h_t (the learner's dW_hh reads
+                cache.hm_written = getattr(cache, "hm_written", 0) + 1        # them when every step of the rollout wrote one)
             self.env_stepped = env_out is not None
             self.env_step_fused_seen = self.env_step_fused_seen or self.env_stepped
             return [actions[0], actions[1]]
@@ -877,7 +880,13 @@ class A3C_Dueling(nn.Module):
                     a_tr = actions_seq[:, :, 0].reshape(T * N)
                     f = f + p.fc_action_tracker(F.one_hot(a_tr, self.action_dim_tracker).to(f.dtype))
             feats.append(f)
-        return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, cache.acts, need)
+        # the masked hidden rows k_{t-1} h_{t-1} the rollout left next to the features (one-GEMM LSTMCell path): dW_hh contracts
+        # them as they are — no mask to apply inside the weight-gradient kernel, whose operands then go straight into LDS
+        hm = None
+        if getattr(cache, "fh_all", None) is not None and getattr(cache, "hm_written", 0) >= T:
+            Fd = cache.f_all.shape[-1]
+            hm = [cache.fh_all[i, :T, :, Fd:].view(T * N, -1) for i in range(2)]
+        return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, cache.acts, need, hm=hm)
 
     def forward_sequence_cached(self, cache, states_seq, actions_seq, keep):
         """forward_sequence over a cached rollout: only the heads are evaluated forward; the backward pass is the
