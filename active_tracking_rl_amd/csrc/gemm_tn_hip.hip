@@ -215,8 +215,8 @@ __global__ __launch_bounds__(kGemmThreads, tn_wg_per_cu(kKC)) void k_gemm_tn(con
                                                  (__attribute__((address_space(3))) void *)(&s.b[buf][2 * wave + 8 * j][0]), 16, 0, 0);
             }
         };
-        dma(k_begin, 0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+        if (k_begin < k_end) dma(k_begin, 0);            // (a slice past the end of K — the planner's last ones when the chunk
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // count does not divide — loads nothing and stores zeros); vmcnt(0)
         __syncthreads();
         int buf = 0;
         for (long long k0 = k_begin; k0 < k_end; k0 += kKC, buf ^= 1) {

@@ -235,9 +235,14 @@ def test_actor_cell_kernel_cell_embedding_and_draw():
     torch.testing.assert_close(outs[0], h_ref, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("K,M,N", [(81920, 256, 512), (20480, 512, 256), (4099, 128, 384), (8192, 128, 128)])
+@pytest.mark.parametrize("K,M,N", [(81920, 256, 512), (20480, 512, 256), (4099, 128, 384), (8192, 128, 128),
+                                   (4160, 128, 128), (20800, 128, 256), (41600, 256, 128), (4112, 128, 128)])
 def test_gemm_tn_matches_float64_reference(K, M, N):
     """atr_gemm_tn (x1^T x2 for tall operands, csrc/gemm_tn_hip.hip) against a float64 matmul; ragged K tail included.
+    The sizes cover both chunk sizes (16 rows below 20 481 rows of K, 32 above), the operands-straight-into-LDS path (K a
+    whole number of chunks, no row factors: the first call) and the register-staged one (ragged K; row factors: the second
+    call), and chunk counts that leave the planner's last K-slices EMPTY (4160 = 260 chunks over 256 slices of 2; 20 800 and
+    41 600 likewise with 32-row chunks): those workgroups must store zeros without touching memory past the operands.
     Tolerance: fp32 accumulation over K products of N(0,1) operands."""
     from active_tracking_rl_amd import fused
     torch.manual_seed(K + M)
