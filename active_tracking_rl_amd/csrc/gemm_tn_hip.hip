@@ -51,12 +51,22 @@ constexpr int kGemmThreads = 256;
 // form leaves it more room: 15.58-15.60 M env steps/s against 15.43-15.46. So: 16 rows up to kSmallK rows of K, 32 above.
 constexpr long long kSmallK = 20 * 1024 + 1;
 constexpr int tn_wg_per_cu(int kc) { return kc == 32 ? 2 : kc == 24 ? 3 : 4; }
+// Co-run mode (atr_gemm_tn_set_corun; the pipelined schedule's learner, train.PipelinedIteration): the launch is padded with
+// dynamic LDS until ONE workgroup fits a CU — 4 waves, one per SIMD, 32 KB of LDS — and the kernel takes ~1.4x as long, but
+// the other replica's rollout on the second stream, a chain of short latency-bound kernels, keeps moving next to it instead
+// of queueing behind co-resident dW workgroups that run for hundreds of microseconds each: the pipelined iteration at 4096
+// envs 15.75 -> 16.6-16.75 M env steps/s, 11.3 -> 11.7 at 1024, 13.95 -> 14.5 at 2048 (two or three workgroups per CU: no
+// gain at all; the same cap on k_stem_bwd: +1 % alone, a loss together with this one).
+static int g_tn_corun = 0;
 static int tn_kc(long long K)
 {
     static const int forced = getenv("ATR_GEMM_TN_KC") ? atoi(getenv("ATR_GEMM_TN_KC")) : 0;   // (tuning experiments)
     if (forced == 16 || forced == 32) return forced;
+    if (g_tn_corun) return 16;
     return K < kSmallK ? 16 : 32;
 }
+static int tn_wg_per_cu_now(int kc) { return g_tn_corun ? 1 : tn_wg_per_cu(kc); }
+constexpr unsigned kCorunLdsPad = 50000;     // 32 KB static (16-row chunks) + this > half of a CU's 160 KB
 
 template <int kKC> struct GemmLds { float a[2][kKC][kLd]; float b[2][kKC][kLd]; };
 
@@ -317,7 +327,7 @@ struct TnPlan { int slices, chunks_per_slice; };
 
 static TnPlan gemm_tn_plan(long long K, int tiles)
 {
-    const int kKC = tn_kc(K), kWgPerCu = tn_wg_per_cu(kKC);
+    const int kKC = tn_kc(K), kWgPerCu = tn_wg_per_cu_now(kKC);
     // kWgPerCu workgroups fit a CU (LDS) and run best together (one's MFMAs cover the others' load latency): count
     // rounds of 256 * kWgPerCu co-resident workgroups at that efficiency, a tail of <= 256 as a round of lone workgroups at solo
     // efficiency; every workgroup pays a fixed prologue / epilogue worth ~64 rows
@@ -411,17 +421,36 @@ extern "C" int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int coun
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)(g.slices * tiles)), block(kGemmThreads);
     const int kc = tn_kc(K);
+    static const unsigned forced_pad = getenv("ATR_GEMM_TN_LDS_PAD") ? (unsigned)atoi(getenv("ATR_GEMM_TN_LDS_PAD")) : 0u;   // (occupancy experiments)
+    const unsigned lds_pad = forced_pad ? forced_pad : (g_tn_corun && kc == 16 ? kCorunLdsPad : 0u);
+    static bool attr_set = false;
+    if (lds_pad && !attr_set) {              // (static + dynamic LDS beyond 64 KB needs the opt-in)
+        const int lim = 96 * 1024;
+        if (hipFuncSetAttribute((const void *)k_gemm_tn<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_gemm_tn<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_gemm_tn<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_gemm_tn<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess)
+            return -2;
+        attr_set = true;
+    }
     bool all_direct = ATR_TN_DIRECT && K % kc == 0;
     for (int q = 0; q < count; q++) all_direct = all_direct && problems[q].row_scale == nullptr;
     if (kc == 16) {
-        if (all_direct) hipLaunchKernelGGL((k_gemm_tn<16, false>), grid, block, 0, st, g);
-        else hipLaunchKernelGGL((k_gemm_tn<16, true>), grid, block, 0, st, g);
+        if (all_direct) hipLaunchKernelGGL((k_gemm_tn<16, false>), grid, block, lds_pad, st, g);
+        else hipLaunchKernelGGL((k_gemm_tn<16, true>), grid, block, lds_pad, st, g);
     } else {
-        if (all_direct) hipLaunchKernelGGL((k_gemm_tn<32, false>), grid, block, 0, st, g);
-        else hipLaunchKernelGGL((k_gemm_tn<32, true>), grid, block, 0, st, g);
+        if (all_direct) hipLaunchKernelGGL((k_gemm_tn<32, false>), grid, block, lds_pad, st, g);
+        else hipLaunchKernelGGL((k_gemm_tn<32, true>), grid, block, lds_pad, st, g);
     }
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)(red_begin + cs_blocks)), dim3(256), 0, st, g);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int atr_gemm_tn_set_corun(int on)
+{
+    const int was = g_tn_corun;
+    g_tn_corun = on ? 1 : 0;
+    return was;
 }
 
 extern "C" long long atr_gemm_tn_workspace_floats(long long K, int M, int N)

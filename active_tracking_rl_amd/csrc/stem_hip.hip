@@ -23,6 +23,7 @@
 // D[i = 4*(l>>4) + r][j = l&15] in accumulator register r.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/atr_policy.h"
 
@@ -503,7 +504,8 @@ static int stem_backward_impl(const XT *x, long long x_stride, const float *y, c
 {
     if (!x || !y || !dy || !w1 || !b1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !workspace || M <= 0 || x_stride < 169)
         return -1;
-    const int grid = stem_grid(M, kBwdBlocksPerCu);
+    static const int bpc = getenv("ATR_STEM_BWD_BLOCKS") ? atoi(getenv("ATR_STEM_BWD_BLOCKS")) : kBwdBlocksPerCu;   // (occupancy experiments)
+    const int grid = stem_grid(M, bpc >= 1 && bpc <= kBwdBlocksPerCu ? bpc : kBwdBlocksPerCu);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((k_stem_bwd<XT>), dim3((unsigned)grid), dim3(kThreads), 0, st, x, y, dy, w1, b1, w2, workspace, M,
                        x_stride);

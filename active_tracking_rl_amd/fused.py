@@ -138,6 +138,8 @@ def lib():
         L.atr_gemm_tn.argtypes = [vp, vp, vp, vp, ll, i32, i32, vp, vp, vp]
         L.atr_gemm_tn_grouped_workspace_floats.restype = ll
         L.atr_gemm_tn_grouped_workspace_floats.argtypes = [C.POINTER(GemmTnProblem), i32, ll]
+        L.atr_gemm_tn_set_corun.restype = i32
+        L.atr_gemm_tn_set_corun.argtypes = [i32]
         L.atr_gemm_tn_grouped.restype = i32
         L.atr_gemm_tn_grouped.argtypes = [C.POINTER(GemmTnProblem), i32, ll, vp, vp]
         L.atr_scatter_segments.restype = i32
@@ -1196,6 +1198,23 @@ class deferred_weight_grads(object):
 
 
 @torch.no_grad()
+class gemm_tn_corun(object):
+    """`with fused.gemm_tn_corun(True):` — the weight-gradient launches issued (or captured) inside are planned for ONE workgroup
+    per CU (atr_gemm_tn_set_corun, csrc/gemm_tn_hip.hip): ~1.4x the kernel's own time, but a chain of short kernels on another
+    stream keeps running beside it. The pipelined schedule captures its learner graphs like this (train.PipelinedIteration)."""
+
+    def __init__(self, on=True):
+        self.on, self.was = bool(on), None
+
+    def __enter__(self):
+        self.was = lib().atr_gemm_tn_set_corun(1 if self.on else 0)
+        return self
+
+    def __exit__(self, *exc):
+        lib().atr_gemm_tn_set_corun(self.was)
+        return False
+
+
 def gemm_tn(x1, x2, row_scale=None, colsum=False):
     """x1.t() @ x2 for tall row-major x1 [K,M], x2 [K,N] — the weight-gradient GEMMs (csrc/gemm_tn_hip.hip) when the
     shape fits the kernel (CUDA fp32, contiguous, M and N multiples of 128), otherwise the library GEMM.

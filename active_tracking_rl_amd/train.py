@@ -99,6 +99,7 @@ def capture_allreduce_default():
 
 
 CAPTURE_ALLREDUCE_DEFAULT = False
+CORUN_MIN_ENVS = 1024      # PipelinedIteration: the learner's dW kernel in its one-workgroup-per-CU form from this shard size up
 
 
 def clip_flat_grad_(optimizer, max_norm, eps=1e-6):
@@ -382,6 +383,14 @@ class PipelinedIteration(object):
             self.sL = cu_masked_stream(dev, 0, total - self.cu_split, total)
         self.ev_r = [torch.cuda.Event() for _ in range(2)]
         self.ev_o = [torch.cuda.Event() for _ in range(2)]
+        # The learner's grouped weight-gradient GEMM is captured in its co-run form (one workgroup per CU: fused.gemm_tn_corun)
+        # from 1024 envs up, where learner and rollout share the whole chip: it runs a fifth of the learner's time, its
+        # workgroups live for hundreds of microseconds, and two of them per CU leave the other replica's short rollout kernels
+        # queueing (4096 envs: 15.75 -> 16.6-16.75 M env steps/s, 2048: 13.95 -> 14.5, 1024: 11.3 -> 11.7). Below that the CU
+        # partition of tune_streams does the separating and the kernel keeps its full occupancy (512 envs: 9.1 M against 8.4).
+        # ATR_PIPE_CORUN=0 / 1 overrides.
+        env_corun = os.environ.get("ATR_PIPE_CORUN")
+        self.corun = (int(env_corun) != 0) if env_corun is not None else (int(args.num_envs) >= CORUN_MIN_ENVS and not self.cu_split)
         self.capture_allreduce = capture_allreduce_default()
         self.pending = None       # (replica, learner graph) of the rollout whose learner has not been issued yet
         self.graphs = {}          # (mode, k) -> (rollout graph, learner graph, stats)
@@ -432,7 +441,8 @@ class PipelinedIteration(object):
         # the learner of THIS rollout reads the replica's own end-of-rollout tensors (last observation slot, LSTM state, done):
         # the carry belongs to the next rollout by then
         g_l = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_l, capture_error_mode="thread_local"):
+        from . import fused
+        with fused.gemm_tn_corun(self.corun), torch.cuda.graph(g_l, capture_error_mode="thread_local"):
             stats = p.compute_grads(_BucketOnly(self.buckets[k]), mode)
             self.optimizer.bucket.grad.copy_(self.buckets[k].grad)
         self.graphs[(mode, k)] = (g_r, g_l, stats)

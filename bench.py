@@ -674,7 +674,9 @@ def main():
                   "pipelined": "rollout i+1 on a second HIP stream while learner + all-reduce + update i run "
                                "(train.PipelinedIteration; main.py's default): the same kernels and the same work per "
                                "iteration, every gradient applied exactly one update late — the bounded form of the "
-                               "reference's Hogwild worker asynchrony (main.py:86-116, train.py:71-95)"}
+                               "reference's Hogwild worker asynchrony (main.py:86-116, train.py:71-95). From 1024 envs "
+                               "per GPU up the learner's grouped weight-gradient GEMM is captured in its co-run form (one "
+                               "workgroup per CU: slower alone, but the other replica's rollout keeps moving beside it)"}
     line["schedule"] = first
     line["schedule_note"] = sched_note[first]
     line["config"]["schedule"] = first

@@ -305,6 +305,12 @@ typedef struct atr_gemm_tn_problem {
     long long ld1, ld2;      /* row strides of x1 / x2 in floats (0 = dense: M / N); multiples of 4 */
 } atr_gemm_tn_problem;
 long long atr_gemm_tn_grouped_workspace_floats(const atr_gemm_tn_problem *problems, int count, long long K);
+/* Co-run mode of the weight-gradient kernel, process-wide, returns the previous setting: while on, launches (and the workspace
+ * sizes that go with them) are planned for ONE workgroup per CU, so that a chain of short kernels on another stream keeps
+ * running beside them (the pipelined schedule captures its learner graphs in this mode; results stay a fixed-order sum, the
+ * K split differs from the default mode's). Not a per-stream setting: set it around the launches (or the graph capture) that
+ * want it, from the thread that issues them. */
+int atr_gemm_tn_set_corun(int on);
 int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int count, long long K, float *workspace, void *stream);
 
 /* The rollout driver's bookkeeping, one launch each (csrc/driver_hip.hip).

@@ -261,6 +261,36 @@ def test_gemm_tn_matches_float64_reference(K, M, N):
     assert float((colsum.double() - xs.sum(0)).abs().max()) < 3e-5 * K ** 0.5 * 4
 
 
+@pytest.mark.parametrize("K,M,N", [(81920, 256, 512), (20480, 512, 384), (4160, 128, 128), (4099, 128, 256)])
+def test_gemm_tn_corun_mode_computes_the_same_products(K, M, N):
+    """fused.gemm_tn_corun (atr_gemm_tn_set_corun: the launch planned for ONE workgroup per CU, which the pipelined schedule's
+    learner graphs are captured with): the same products against float64 — 16-row chunks at every K, padded dynamic LDS, its own
+    K split and workspace size — bit-reproducible, and the mode is back to what it was afterwards (also after an exception)."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(K + N)
+    x1, x2 = torch.randn(K, M, device="cuda"), torch.randn(K, N, device="cuda")
+    ref = x1.double().t() @ x2.double()
+    tol = 3e-5 * K ** 0.5 * 4
+    c0 = fused.gemm_tn(x1, x2)
+    with fused.gemm_tn_corun(True):
+        c1, cs1 = fused.gemm_tn(x1, x2, colsum=True)
+        c2, _ = fused.gemm_tn(x1, x2, colsum=True)
+        scale = (torch.rand(K, device="cuda") > 0.2).float()
+        c3 = fused.gemm_tn(x1, x2, row_scale=scale)
+    assert float((c1.double() - ref).abs().max()) < tol and float((c0.double() - ref).abs().max()) < tol
+    assert torch.equal(c1, c2)
+    assert float((cs1.double() - x1.double().sum(0)).abs().max()) < tol
+    assert float((c3.double() - (x1.double() * scale.double().unsqueeze(1)).t() @ x2.double()).abs().max()) < tol
+    assert fused.lib().atr_gemm_tn_set_corun(0) == 0                     # the context manager restored "off"
+    try:
+        with fused.gemm_tn_corun(True):
+            raise KeyError("x")
+    except KeyError:
+        pass
+    assert fused.lib().atr_gemm_tn_set_corun(0) == 0
+    assert torch.equal(fused.gemm_tn(x1, x2), c0)                        # and the default mode computes what it did before
+
+
 @pytest.mark.parametrize("K", [10240, 4099])
 def test_grouped_weight_gradients_fill_the_bucket_slices(K):
     """fused.DeferredWeightGrads (atr_gemm_tn_grouped: the weight-gradient products of one backward pass as one launch + one
