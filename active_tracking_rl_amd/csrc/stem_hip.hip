@@ -448,7 +448,16 @@ static int stem_grid(long long M, int blocks_per_cu)
 }
 constexpr int kFwdBlocksPerCu = 3, kBwdBlocksPerCu = 2;
 
-extern "C" long long atr_stem_workspace_floats(long long M) { return (long long)stem_grid(M, kBwdBlocksPerCu) * kPartial; }
+// (workgroups per CU of the backward. Measured under the pipelined schedule at 4096 envs, where the question is how the other
+// replica's rollout fares beside this kernel: 1 per CU +1 % alone but a loss once the dW GEMM runs in its co-run form,
+// 4 / 8 / 16 per CU — shorter-lived workgroups, more partial records — 16.55 / 16.50 / 16.42 M env steps/s against 16.73 with 2)
+static int stem_bwd_blocks()
+{
+    static const int bpc = getenv("ATR_STEM_BWD_BLOCKS") ? atoi(getenv("ATR_STEM_BWD_BLOCKS")) : kBwdBlocksPerCu;   // (occupancy experiments)
+    return bpc >= 1 && bpc <= 16 ? bpc : kBwdBlocksPerCu;
+}
+
+extern "C" long long atr_stem_workspace_floats(long long M) { return (long long)stem_grid(M, stem_bwd_blocks()) * kPartial; }
 
 static StemProblem make_problem(const void *x, long long x_stride, const float *w1, const float *b1, const float *w2,
                                 const float *b2, float *y, long long M)
@@ -504,8 +513,7 @@ static int stem_backward_impl(const XT *x, long long x_stride, const float *y, c
 {
     if (!x || !y || !dy || !w1 || !b1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !workspace || M <= 0 || x_stride < 169)
         return -1;
-    static const int bpc = getenv("ATR_STEM_BWD_BLOCKS") ? atoi(getenv("ATR_STEM_BWD_BLOCKS")) : kBwdBlocksPerCu;   // (occupancy experiments)
-    const int grid = stem_grid(M, bpc >= 1 && bpc <= kBwdBlocksPerCu ? bpc : kBwdBlocksPerCu);
+    const int grid = stem_grid(M, stem_bwd_blocks());
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL((k_stem_bwd<XT>), dim3((unsigned)grid), dim3(kThreads), 0, st, x, y, dy, w1, b1, w2, workspace, M,
                        x_stride);
