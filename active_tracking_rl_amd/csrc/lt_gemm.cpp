@@ -286,8 +286,9 @@ extern "C" int atr_linear(const atr_linear_args *a, void *stream)
     return rc == 0 ? 0 : fail("hipblasLtMatmul", rc);
 }
 
-// Use candidate number `index` of the library's list for this problem instead of timing the list on first use (a choice
-// recorded by an earlier run: lt_tuning_gfx950.json). Ignored if the list turns out shorter or the candidate unusable.
+// Use candidate number `index` of the library's list for this problem instead of timing the list (a choice recorded by an
+// earlier run: lt_tuning_gfx950.json; or another one for launches that will run next to other work). If the list turns out
+// shorter or the candidate unusable, the next call times the list as if nothing had been selected.
 extern "C" int atr_linear_set_choice(const atr_linear_args *a, int index)
 {
     std::lock_guard<std::mutex> lock(g.mu);
@@ -299,7 +300,9 @@ extern "C" int atr_linear_set_choice(const atr_linear_args *a, int index)
         if (build_plan(*a, p) != 0) return -1;
         it = g.plans.emplace(k, p).first;
     }
-    if (it->second.chosen < 0) it->second.preset = index;
+    it->second.preset = index;                 // (also over an earlier choice: the next call resolves the candidate list again)
+    it->second.chosen = -1;
+    it->second.tuned = false;
     return 0;
 }
 

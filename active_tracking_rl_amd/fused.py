@@ -1197,7 +1197,6 @@ class deferred_weight_grads(object):
 
 
 
-@torch.no_grad()
 class gemm_tn_corun(object):
     """`with fused.gemm_tn_corun(True):` — the weight-gradient launches issued (or captured) inside are planned for ONE workgroup
     per CU (atr_gemm_tn_set_corun, csrc/gemm_tn_hip.hip): ~1.4x the kernel's own time, but a chain of short kernels on another
@@ -1215,6 +1214,7 @@ class gemm_tn_corun(object):
         return False
 
 
+@torch.no_grad()
 def gemm_tn(x1, x2, row_scale=None, colsum=False):
     """x1.t() @ x2 for tall row-major x1 [K,M], x2 [K,N] — the weight-gradient GEMMs (csrc/gemm_tn_hip.hip) when the
     shape fits the kernel (CUDA fp32, contiguous, M and N multiples of 128), otherwise the library GEMM.

@@ -57,6 +57,11 @@ def k_gemm_tn():
         q.flush()
 
 
+def k_gemm_tn_corun():
+    with fused.gemm_tn_corun(True):
+        k_gemm_tn()
+
+
 def k_bptt():
     fused._lstm_bptt(None, keep, h_all, c_all, acts, dhs, whh_nn=whh, want_dwhh=False)
 
@@ -79,7 +84,8 @@ def k_relu_bwd():
 
 
 E = lambda: torch.cuda.Event(enable_timing=True)
-for name, load in (("nothing", None), ("grouped weight-gradient GEMM (k_gemm_tn + reduce)", k_gemm_tn), ("k_lstm_bptt", k_bptt),
+for name, load in (("nothing", None), ("grouped weight-gradient GEMM (k_gemm_tn + reduce)", k_gemm_tn),
+                   ("the same in its co-run form (1 workgroup per CU)", k_gemm_tn_corun), ("k_lstm_bptt", k_bptt),
                    ("k_stem_bwd (+ reduce)", k_stem_bwd), ("dX GEMM of the LSTM (library)", k_dx_lstm),
                    ("dX GEMM of the target's fc (library)", k_dx_fc), ("ReLU backward (torch elementwise)", k_relu_bwd)):
     if load is not None:
