@@ -166,8 +166,9 @@ typedef struct atr_linear_args {
 int atr_lt_init(const char *libhipblaslt_path);
 int atr_linear(const atr_linear_args *args, void *stream);
 int atr_linear_plan_info(const atr_linear_args *args, int *candidates, int *chosen, int *tuned, float *best_us);
-/* Pre-select candidate `index` of the library's list for this problem (a choice an earlier run timed and recorded) instead of
- * timing the list at first use. */
+/* Select candidate `index` of the library's list for this problem (a choice an earlier run timed and recorded) instead of
+ * timing the list at first use; called again later it replaces the earlier choice (the next atr_linear call resolves it; an
+ * unusable index falls back to timing the list). */
 int atr_linear_set_choice(const atr_linear_args *args, int index);
 const char *atr_lt_last_error(void);
 
