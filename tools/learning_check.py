@@ -17,10 +17,11 @@ ap.add_argument("--num-envs", type=int, default=4096)
 ap.add_argument("--network", default="maze-lstm")
 ap.add_argument("--train-mode", type=int, default=0)
 ap.add_argument("--schedule", choices=("synchronous", "pipelined"), default="pipelined")
+ap.add_argument("--seed", type=int, default=None, help="default: default_args' seed")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 args = default_args(env=a.env, network=a.network, aux="reward" if "tat" in a.network else "none", train_mode=a.train_mode,
-                    num_envs=a.num_envs)
+                    num_envs=a.num_envs, **({"seed": a.seed} if a.seed is not None else {}))
 player, opt = make_player(args, dev)
 pipelined = a.schedule == "pipelined"
 it = PipelinedIteration(player, opt, args) if pipelined else GraphedIteration(player, opt, args)
