@@ -587,21 +587,24 @@ class PipelinedIteration(object):
         saved = [t.clone() for t in tensors] if tensors is not None else None
         i0, n0 = self.i, self.master.n_steps
         iters += iters & 1              # whole pairs of phases per candidate: the replica parity is the same afterwards
-        times = []
-        for sR, sL, label in pairs:
-            self.finish()
-            torch.cuda.synchronize(self.dev)
-            self.sR, self.sL = sR, sL
-            for _ in range(2):
-                self.run()
-            self.finish()
-            torch.cuda.synchronize(self.dev)
-            t0 = _time.perf_counter()
-            for _ in range(iters):
-                self.run()
-            self.finish()
-            torch.cuda.synchronize(self.dev)
-            times.append((_time.perf_counter() - t0) / iters * 1e3)
+        # two passes over the list, the better of a candidate's two times counts: one 8-iteration sample is noisy enough to
+        # lose the CU partition its trial at 512 envs in two runs of six (8.2 M env steps/s instead of 8.9)
+        times = [float("inf")] * len(pairs)
+        for _pass in range(2):
+            for j, (sR, sL, label) in enumerate(pairs):
+                self.finish()
+                torch.cuda.synchronize(self.dev)
+                self.sR, self.sL = sR, sL
+                for _ in range(2):
+                    self.run()
+                self.finish()
+                torch.cuda.synchronize(self.dev)
+                t0 = _time.perf_counter()
+                for _ in range(iters):
+                    self.run()
+                self.finish()
+                torch.cuda.synchronize(self.dev)
+                times[j] = min(times[j], (_time.perf_counter() - t0) / iters * 1e3)
         self.finish()
         torch.cuda.synchronize(self.dev)
         if multi:
@@ -614,7 +617,7 @@ class PipelinedIteration(object):
             with torch.no_grad():
                 for t, v in zip(tensors, saved):
                     t.copy_(v)
-            assert (self.i - i0) % 2 == 0      # (each candidate ran 2 + iters phases: replica i0 & 1 is next, as before)
+            assert (self.i - i0) % 2 == 0      # (each candidate ran 2 x (2 + iters) phases: replica i0 & 1 is next, as before)
             self.i, self.master.n_steps = i0, n0
             torch.cuda.synchronize(self.dev)
         return [(times[j], j == best, pairs[j][2]) for j in range(len(pairs))]

@@ -580,11 +580,11 @@ def test_pipelined_schedule_is_the_same_dataflow_on_one_stream_and_on_two(env_id
             trials = it.tune_streams(candidates=2, iters=4, partitions=(128,), keep_updates=True)
             assert len(trials) == 4 and sum(c for _, c, _ in trials) == 1 and "partition" in trials[-1][2]
         else:
-            for _ in range(4 * (2 + 4)):
+            for _ in range(4 * 2 * (2 + 4)):                # (4 candidates, two passes, 2 warm-up + 4 timed phases each)
                 it.run()
         it.finish()
         torch.cuda.synchronize()
-        assert it.i == 31
+        assert it.i == 7 + 48
         k = (it.i - 1) & 1
         assert torch.equal(it.buckets[k].flat, opt.bucket.flat)                    # O(i): theta -> F_k
         assert not torch.equal(it.buckets[1 - k].flat, opt.bucket.flat)            # the other replica is one update behind
