@@ -555,6 +555,43 @@ def test_act_env_step_equals_cells_draws_and_env_step(env_id, n, u8, tat):
 
 
 @pytest.mark.gpu
+def test_pipelined_learner_in_the_dw_kernels_corun_form_computes_the_same_updates():
+    """From 1024 envs up PipelinedIteration captures its learner graphs with the grouped weight-gradient GEMM in its co-run
+    form (fused.gemm_tn_corun: one workgroup per CU, 16-row chunks, its own K split). Same seed, same rollouts, program order
+    on one stream (serial=True): the master weights after four updates with the form on and off agree to fp32 summation-order
+    noise, the env shard went through the same states (the rollouts of the first two iterations do not depend on any update),
+    and the form is what the default picks at this size and not below it."""
+    from active_tracking_rl_amd import train
+    from active_tracking_rl_amd.train import PipelinedIteration, default_args, make_player
+    dev = torch.device("cuda:0")
+    out = []
+    for corun in ("1", "0"):
+        os.environ["ATR_PIPE_CORUN"] = corun
+        try:
+            args = default_args(num_envs=1024, seed=5)
+            player, opt = make_player(args, dev)
+            it = PipelinedIteration(player, opt, args, serial=True)
+            assert it.corun == (corun == "1")
+            for _ in range(4):
+                it.run()
+            it.finish()
+            torch.cuda.synchronize()
+            out.append((opt.bucket.flat.clone(), player.env.core.get_state()["pos"].copy()))
+            player.env.close()
+        finally:
+            os.environ.pop("ATR_PIPE_CORUN", None)
+    (w1, pos1), (w0, pos0) = out
+    assert torch.isfinite(w1).all()
+    assert float((w1 - w0).abs().max()) < 2e-4, float((w1 - w0).abs().max())
+    assert np.mean(np.all(pos1 == pos0, axis=tuple(range(1, pos1.ndim)))) > 0.9      # (sampling diverges only through the weights)
+    for n, want in ((1024, True), (512, False)):
+        args = default_args(num_envs=n, seed=5)
+        player, opt = make_player(args, dev)
+        assert PipelinedIteration(player, opt, args, serial=True).corun == want and train.CORUN_MIN_ENVS == 1024
+        player.env.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env_id,network,mode", [("Track2D-BlockPartialPZR-v0", "tat-maze-lstm", -1),
                                                  ("Track2D-BlockPartialNav-v0", "maze-lstm", 0)])
 def test_pipelined_schedule_is_the_same_dataflow_on_one_stream_and_on_two(env_id, network, mode):
