@@ -103,9 +103,13 @@ def lib():
         L.atr_linear.argtypes = [C.POINTER(LinearArgs), vp]
         L.atr_linear_plan_info.restype = i32
         L.atr_linear_plan_info.argtypes = [C.POINTER(LinearArgs), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
-                                           C.POINTER(C.c_float)]
+                                           C.POINTER(C.c_float), C.POINTER(i32), C.POINTER(i32)]
         L.atr_linear_set_choice.restype = i32
-        L.atr_linear_set_choice.argtypes = [C.POINTER(LinearArgs), i32]
+        L.atr_linear_set_choice.argtypes = [C.POINTER(LinearArgs), i32, i32]
+        L.atr_lt_library_info.restype = i32
+        L.atr_lt_library_info.argtypes = [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]
+        L.atr_linear_kernel_name.restype = i32
+        L.atr_linear_kernel_name.argtypes = [C.POINTER(LinearArgs), C.c_char_p, i32]
         L.atr_lt_last_error.restype = C.c_char_p
         L.atr_embed_grad_workspace_floats.restype = ll
         L.atr_embed_grad_workspace_floats.argtypes = [ll, i32, i32]
@@ -377,38 +381,98 @@ def _linear_args(a, w, out, bias, relu, workspace):
 
 LT_TUNING_FILE = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)),
                                             "lt_tuning_gfx950.json")
-_lt_choices, _lt_seen = None, {}
+LT_SOURCES = {0: "none", 1: "timed", 2: "recorded", 3: "first-usable", 4: "refused", 5: "refused-timed"}
+_lt_choices, _lt_seen, _lt_status = None, {}, "not loaded"
 
 
 def _lt_key(g):
-    return "M%d_N%d_K%d_b%d_lda%d_ldw%d_ldc%d_sa%d_sw%d_sc%d_relu%d_bias%d" % (
-        g.M, g.N, g.K, g.batch, g.lda, g.ldw, g.ldc, g.stride_a, g.stride_w, g.stride_c, g.relu, 1 if g.bias else 0)
+    # everything that selects a kernel, including the workspace limit handed to the heuristic (another limit = another list)
+    return "M%d_N%d_K%d_b%d_lda%d_ldw%d_ldc%d_sa%d_sw%d_sc%d_relu%d_bias%d_ws%d" % (
+        g.M, g.N, g.K, g.batch, g.lda, g.ldw, g.ldc, g.stride_a, g.stride_w, g.stride_c, g.relu, 1 if g.bias else 0,
+        g.workspace_bytes if g.workspace else 0)
+
+
+def lt_library():
+    """{'version', 'git', 'header_version'} of the hipBLASLt build csrc/lt_gemm.cpp loaded (PyTorch's copy) and of the header it
+    was compiled against."""
+    _lt_init()
+    v, hv, rev = C.c_int(0), C.c_int(0), C.create_string_buffer(256)
+    if lib().atr_lt_library_info(C.byref(v), C.byref(hv), rev, 256) != 0:
+        raise RuntimeError("atr_lt_library_info failed")
+    return dict(version=v.value, git=rev.value.decode(errors="replace"), header_version=hv.value)
 
 
 def lt_choices():
-    """{problem key: candidate index} recorded by tools/tune_lt.py (lt_tuning_gfx950.json next to this file; ATR_LT_TUNING=0
-    ignores it): the kernel choices of csrc/lt_gemm.cpp are then the same in every run — what tunableop_gfx950.csv is for
-    torch's GEMMs — and nothing is timed at first use."""
-    global _lt_choices
+    """{problem key: (candidate index, solution index)} recorded by tools/tune_lt.py (lt_tuning_gfx950.json next to this file;
+    ATR_LT_TUNING=0 ignores it): the kernel choices of csrc/lt_gemm.cpp are then the same in every run — what
+    tunableop_gfx950.csv is for torch's GEMMs — and nothing is timed at first use. The record is only used when it was made
+    with the hipBLASLt build that is loaded now (version + revision, as TunableOp's validators do): a position in the
+    heuristic's list means nothing on another build. On a mismatch the file is ignored, every problem is timed at first use
+    (outside capture) and lt_tuning_status() says so; within a matching build csrc/lt_gemm.cpp still checks each record's
+    solution index against the list it gets."""
+    global _lt_choices, _lt_status
     if _lt_choices is None:
         import json
         import os
         _lt_choices = {}
-        if os.environ.get("ATR_LT_TUNING", "1") != "0" and os.path.exists(LT_TUNING_FILE):
+        if os.environ.get("ATR_LT_TUNING", "1") == "0":
+            _lt_status = "timed at first use (ATR_LT_TUNING=0)"
+        elif not os.path.exists(LT_TUNING_FILE):
+            _lt_status = "timed at first use (no tuning file)"
+        else:
             try:
-                _lt_choices = {k: int(v) for k, v in json.load(open(LT_TUNING_FILE)).get("choices", {}).items()}
-            except (ValueError, OSError):
+                rec = json.load(open(LT_TUNING_FILE))
+                have = lt_library()
+                want = rec.get("hipblaslt") or {}
+                if want.get("version") != have["version"] or want.get("git") != have["git"]:
+                    _lt_status = ("timed at first use (tuning file made with hipBLASLt %s %s, loaded %s %s)"
+                                  % (want.get("version"), want.get("git"), have["version"], have["git"]))
+                else:
+                    for k, v in rec.get("choices", {}).items():
+                        idx, sol = int(v["index"]), int(v.get("solution", -1))
+                        if idx >= 0:
+                            _lt_choices[k] = (idx, sol)
+                    _lt_status = "recorded (hipBLASLt %s %s, %d problems)" % (have["version"], have["git"], len(_lt_choices))
+            except (ValueError, OSError, KeyError, TypeError, AttributeError) as ex:
                 _lt_choices = {}
+                _lt_status = "timed at first use (unreadable tuning file: %s)" % (ex,)
     return _lt_choices
 
 
+def lt_tuning_status():
+    """One line for the bench record: where the direct-hipBLASLt kernel choices of this process come from, and how many of the
+    problems seen so far run a recorded / timed / refused choice."""
+    if _lt_state is False:
+        return "torch GEMM path (direct hipBLASLt unavailable)"
+    if _lt_choices is None:
+        return "not used"
+    counts = {}
+    for k, g in _lt_seen.items():
+        info = _plan_info(g)
+        if info is not None:
+            counts[LT_SOURCES.get(info["source"], "?")] = counts.get(LT_SOURCES.get(info["source"], "?"), 0) + 1
+    tail = ", ".join("%d %s" % (n, k) for k, n in sorted(counts.items()))
+    return _lt_status + ("; in use: " + tail if tail else "")
+
+
+def _plan_info(g):
+    cand, ch, tu, us, sol, src = C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(0), C.c_int(-1), C.c_int(0)
+    if lib().atr_linear_plan_info(C.byref(g), C.byref(cand), C.byref(ch), C.byref(tu), C.byref(us), C.byref(sol), C.byref(src)) != 0:
+        return None
+    return dict(candidates=cand.value, chosen=ch.value, tuned=bool(tu.value), best_us=us.value, solution=sol.value,
+                source=src.value)
+
+
 def lt_chosen():
-    """{problem key: (candidate index, candidates, best us)} of every problem this process has run (for tools/tune_lt.py)."""
+    """{problem key: plan info + kernel name} of every problem this process has run and timed (for tools/tune_lt.py)."""
     out = {}
     for k, g in _lt_seen.items():
-        cand, ch, tu, us = C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(0)
-        if lib().atr_linear_plan_info(C.byref(g), C.byref(cand), C.byref(ch), C.byref(tu), C.byref(us)) == 0 and tu.value:
-            out[k] = (ch.value, cand.value, us.value)
+        info = _plan_info(g)
+        if info is not None and info["tuned"]:
+            name = C.create_string_buffer(512)
+            lib().atr_linear_kernel_name(C.byref(g), name, 512)
+            info["kernel"] = name.value.decode(errors="replace")
+            out[k] = info
     return out
 
 
@@ -424,9 +488,9 @@ def linear_lt(a, w, out, bias=None, relu=False, workspace=None):
     key = _lt_key(g)
     if key not in _lt_seen:
         _lt_seen[key] = g
-        idx = lt_choices().get(key)
-        if idx is not None:
-            L.atr_linear_set_choice(C.byref(g), idx)
+        rec = lt_choices().get(key)
+        if rec is not None:
+            L.atr_linear_set_choice(C.byref(g), rec[0], rec[1])
     if L.atr_linear(C.byref(g), _stream(a)) != 0:
         raise RuntimeError("atr_linear failed: %s" % L.atr_lt_last_error().decode())
     return out
@@ -434,11 +498,17 @@ def linear_lt(a, w, out, bias=None, relu=False, workspace=None):
 
 def linear_lt_info(a, w, out, bias=None, relu=False, workspace=None):
     """(candidates, chosen index, tuned?, best us) of the kernel choice for this problem (after its first linear_lt call)."""
+    return _plan_info(_linear_args(a, w, out, bias, relu, workspace))
+
+
+def linear_lt_set_choice(a, w, out, index, solution=-1, bias=None, relu=False, workspace=None):
+    """Pre-select candidate `index` (and, with solution >= 0, insist that it is that solution) for this problem: what
+    lt_choices() does from the tuning file, by hand (tests, A/B runs)."""
+    _lt_init()
     g = _linear_args(a, w, out, bias, relu, workspace)
-    cand, ch, tu, us = C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(0)
-    if lib().atr_linear_plan_info(C.byref(g), C.byref(cand), C.byref(ch), C.byref(tu), C.byref(us)) != 0:
-        return None
-    return dict(candidates=cand.value, chosen=ch.value, tuned=bool(tu.value), best_us=us.value)
+    _lt_seen.setdefault(_lt_key(g), g)
+    if lib().atr_linear_set_choice(C.byref(g), int(index), int(solution)) != 0:
+        raise RuntimeError("atr_linear_set_choice failed: %s" % lib().atr_lt_last_error().decode())
 
 
 def rows169(x):

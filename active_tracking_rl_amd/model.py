@@ -586,11 +586,15 @@ class A3C_Dueling(nn.Module):
         return [a0, a1], [h0, h1], [c0, c1]
 
     # ---- rollout cache: the learner back-propagates through the forward pass the actor already evaluated -------
-    def new_cache(self, num_steps, states, defer_consts=False):
+    def new_cache(self, num_steps, states, defer_consts=False, env_fused=False):
         """Storage for one rollout's forward activations (per player: stem outputs, fc features, LSTM gates / cell /
         hidden states for every step), filled by act_cached and consumed by forward_sequence_cached — the reference
         also evaluates the forward pass once, inside the rollout (player_util.py:46-73). None when the fused GPU path
-        does not apply (CPU tensors, non-maze encoders, fused kernels switched off)."""
+        does not apply (CPU tensors, non-maze encoders, fused kernels switched off).
+        env_fused: every step of this rollout will hand act_cached an env_out (the env step runs inside k_act_step, which
+        then knows the step's done flags and writes the next step's masked hidden rows). Only then is the one-GEMM LSTMCell
+        store [features | k h_prev] built: with a separate env.step (RPF / Nav-less 'Full' ids, --rescale, --stack-frames > 1,
+        NumpyVecEnv) nobody would write those hidden columns."""
         p0, p1 = self.player0, self.player1
         ok = (states.is_cuda and states.dtype in (torch.float32, torch.uint8) and fused_lstm and not self.single
               and all(isinstance(p.encoder, CNN_maze) and p.encoder.small and p.encoder.use_fused
@@ -610,8 +614,8 @@ class A3C_Dueling(nn.Module):
         c.hm_written = 0
         same_f = p0.encoder.outdim == p1.encoder.outdim
         from . import fused as _fz
-        if (same_f and self.cat_gate_gemm and N >= self.cat_gemm_min_rows and self.fused_env_step and self.fused_sampling
-                and _fz.lt_available()
+        if (same_f and env_fused and self.cat_gate_gemm and N >= self.cat_gemm_min_rows and self.fused_env_step
+                and self.fused_sampling and _fz.lt_available()
                 and R == 128 and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape and p0.encoder.outdim % 4 == 0):
             # From cat_gemm_min_rows up the LSTMCell's two GEMMs are ONE product over rows [features | k h_prev] (K = F + R):
             # slot t of this store holds step t's fc features (written by the fc GEMM with row stride F + R) next to the
@@ -784,6 +788,11 @@ class A3C_Dueling(nn.Module):
                 # knows this step's done flags — so the mask on h is already in the rows; `done` still masks c_prev.
                 fh_t, fh_next = fh
                 Fd = f_out[0].shape[-1]
+                if fh_next is not None and env_out is None:
+                    # (only the bootstrap step has no next slot; every other step's masked hidden row is written by k_act_step
+                    # from the done flags of the env step it runs itself)
+                    raise RuntimeError("one-GEMM LSTMCell rows need the env step inside k_act_step: new_cache(env_fused=True) "
+                                       "was promised an env_out for every step of the rollout")
                 if n <= self.pair_gemm_max_rows:      # (both encoders' fc + ReLU as one pair-kernel launch, row stride F + R)
                     fused.pair_linear([ys[0].view(n, -1), ys[1].view(n, -1)], [p0.encoder.fc.weight, p1.encoder.fc.weight],
                                       [fh_t[0][:, :Fd], fh_t[1][:, :Fd]], bias=[p0.encoder.fc.bias, p1.encoder.fc.bias], relu=True)

@@ -158,7 +158,12 @@ class Agent(object):
                       and (obs0 is None or (obs0.dtype == self._buf[0].dtype and obs0.is_contiguous()
                                             and (obs0.numel() * obs0.element_size()) % 4 == 0)))
         if want_cache:
-            self._cache = self.model.new_cache(num_steps, self.state, defer_consts=one_launch)
+            # will every step's env.step run inside the policy step's last launch? (action_rollout asks the same question per
+            # step; envs that decline — RPF targets, 'Full' observations, --rescale, stacked frames, NumpyVecEnv — step on
+            # their own, and the cache must then not take the form whose hidden rows only k_act_step writes)
+            env_fused = (self._buf is not None and hasattr(self.env, "fused_step_out") and num_steps >= 1
+                         and self.env.fused_step_out((self._buf[0][1], self._buf[1][0], self._buf[2][0])) is not None)
+            self._cache = self.model.new_cache(num_steps, self.state, defer_consts=one_launch, env_fused=env_fused)
         self._actions_buf = getattr(self._cache, "actions", None)
         consts = getattr(self._cache, "consts", None)
         if consts is not None:

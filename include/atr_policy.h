@@ -165,11 +165,27 @@ typedef struct atr_linear_args {
 } atr_linear_args;
 int atr_lt_init(const char *libhipblaslt_path);
 int atr_linear(const atr_linear_args *args, void *stream);
-int atr_linear_plan_info(const atr_linear_args *args, int *candidates, int *chosen, int *tuned, float *best_us);
+/* where a problem's kernel choice came from (atr_linear_plan_info's `source`) */
+#define ATR_LT_SOURCE_NONE 0
+#define ATR_LT_SOURCE_TIMED 1          /* the candidate list was timed at first use */
+#define ATR_LT_SOURCE_RECORDED 2       /* atr_linear_set_choice's record, verified against the list */
+#define ATR_LT_SOURCE_FIRST_USABLE 3   /* first call came inside a stream capture: first usable candidate, timed later */
+#define ATR_LT_SOURCE_REFUSED 4        /* (transient) a record that did not match the loaded library's list */
+#define ATR_LT_SOURCE_REFUSED_TIMED 5  /* ... and the list was timed instead */
+/* solution: the library's solution index of the kernel in use (hipblaslt_ext::getIndexFromAlgo; -1 if it does not say). */
+int atr_linear_plan_info(const atr_linear_args *args, int *candidates, int *chosen, int *tuned, float *best_us, int *solution,
+                         int *source);
 /* Select candidate `index` of the library's list for this problem (a choice an earlier run timed and recorded) instead of
- * timing the list at first use; called again later it replaces the earlier choice (the next atr_linear call resolves it; an
- * unusable index falls back to timing the list). */
-int atr_linear_set_choice(const atr_linear_args *args, int index);
+ * timing the list at first use; called again later it replaces the earlier choice (the next atr_linear call resolves it).
+ * `solution` >= 0 is the recorded kernel's solution index: a position means nothing on another build of the library, so the
+ * candidate at `index` is only taken when it IS that solution, else the list is searched for it; an out-of-range index, an
+ * unusable candidate or an absent solution REFUSES the record and the list is timed instead (source = REFUSED_TIMED). */
+int atr_linear_set_choice(const atr_linear_args *args, int index, int solution);
+/* The loaded library's hipblasLtGetVersion and revision, and the version of the header csrc/lt_gemm.cpp was compiled against
+ * (they may differ: PyTorch ships its own copy; atr_lt_init's functional self-test — one small RELU_BIAS product against host
+ * loops — is what decides whether the direct path is used). 0, or -1 before atr_lt_init. */
+int atr_lt_library_info(int *version, int *header_version, char *gitrev, int len);
+int atr_linear_kernel_name(const atr_linear_args *args, char *out, int len);
 const char *atr_lt_last_error(void);
 
 typedef struct atr_pair_linear_args {

@@ -212,6 +212,58 @@ def test_cached_rollout_learner_matches_the_recompute_learner(train_mode, cat_ge
         _check_grads(ga, gb)
 
 
+@pytest.mark.parametrize("env_id,kw", [("Track2D-BlockPartialRPF-v0", {}), ("Track2D-BlockPartialPZR-v0", {"rescale": True}),
+                                       ("Track2D-BlockPartialPZR-v0", {"stack_frames": 2})])
+def test_large_batch_rollout_with_a_separate_env_step_keeps_the_two_gemm_cell(env_id, kw):
+    """Envs whose step cannot run inside k_act_step (RPF targets, --rescale, stacked frames: VecEnv.fused_step_out is None)
+    at a batch above cat_gemm_min_rows: nobody would write the masked hidden columns of the one-GEMM [features | k h_prev]
+    rows, so the cache must keep the two-GEMM form — and the cached learner must agree with the recompute learner, which
+    re-runs the recurrence from the rollout's first LSTM state and shares nothing with the cache."""
+    from active_tracking_rl_amd.train import default_args, make_player, rollout
+    args = default_args(env=env_id, num_envs=1024, num_steps=6, network="tat-maze-lstm", seed=7, train_mode=-1, **kw)
+    args.gpu_ids = [0]
+    player, optimizer = make_player(args, torch.device("cuda:0"), 0, 1)
+    assert player.model.cat_gate_gemm and args.num_envs >= player.model.cat_gemm_min_rows
+    rollout(player, args.num_steps, fast=True)
+    if player._cache is None:            # (stacked frames: no in-place rollout store, the recompute learner is the only one)
+        assert kw.get("stack_frames", 1) > 1 or kw.get("rescale")
+        player.env.close()
+        return
+    assert player._cache.fh_all is None
+    assert not player.model.env_stepped
+    outs = []
+    cache = player._cache
+    for cached in (True, False):
+        player._cache = cache if cached else None
+        torch.manual_seed(5)
+        if getattr(player.model, "_sampler", None) is not None:
+            player.model._sampler.counter.zero_()
+            player.model._sampler._last = None
+        loss, pl, vl, ent, pred = player.loss_recompute(args.train_mode)
+        player._cache = cache
+        grads = torch.autograd.grad(loss, list(player.model.parameters()), allow_unused=True)
+        outs.append((loss.detach(), grads))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-5)
+    _check_grads(outs[0][1], outs[1][1])
+    player.env.close()
+
+
+def test_one_gemm_cell_refuses_a_step_without_the_fused_env_step():
+    """model._act_step on a cache of the one-GEMM form without an env_out: a loud error, not stale hidden rows."""
+    from active_tracking_rl_amd.train import default_args, make_player, rollout
+    args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=1024, num_steps=3, network="tat-maze-lstm", seed=7)
+    args.gpu_ids = [0]
+    player, _ = make_player(args, torch.device("cuda:0"), 0, 1)
+    rollout(player, args.num_steps, fast=True)
+    cache = player._cache
+    assert cache.fh_all is not None
+    player.model._sampler.reopen_block()
+    with pytest.raises(RuntimeError, match="env step inside k_act_step"):
+        player.model.act_cached(player.state, cache, 0, None, env_out=None)
+    player.model._sampler.end_block()
+    player.env.close()
+
+
 def test_bootstrap_values_and_rollout_bookkeeping_kernels():
     """The learner's bootstrap V(s_T) through the rollout's fused kernels (model.boot_values: one more actor step into
     scratch + critic heads) against the plain model pieces evaluated with the tracker action it drew; the rollout

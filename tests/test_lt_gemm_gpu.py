@@ -193,3 +193,73 @@ def test_rollout_first_launch_makes_the_per_rollout_constants(n):
         assert c.fh_all is None
     player.end_rollout() if False else None
     player.env.close()
+
+
+def _problem(m=640, seed=0):
+    torch.manual_seed(seed)
+    dev = "cuda"
+    a = torch.randn(m, 512, device=dev)
+    w = torch.randn(256, 512, device=dev)
+    b = torch.randn(256, device=dev)
+    rows = torch.zeros(m, 384, device=dev)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
+    return a, w, b, rows, ws
+
+
+def test_recorded_choice_is_checked_against_the_loaded_library():
+    """A recorded kernel choice is (position in the heuristic's list, solution index). An out-of-range position is refused
+    (the list is timed instead); a position whose kernel is not the recorded solution is not believed — the list is searched
+    for the solution; a solution the list does not hold is refused. The product is right in every case."""
+    from active_tracking_rl_amd import fused
+    # (shapes no other test or the tuning file uses: the plans below start from nothing)
+    a, w, b, rows, ws = _problem(m=608)
+    want = F.relu(a @ w.t() + b)
+    fused.linear_lt_set_choice(a, w, rows[:, :256], index=100000, bias=b, relu=True, workspace=ws)
+    fused.linear_lt(a, w, rows[:, :256], bias=b, relu=True, workspace=ws)
+    info = fused.linear_lt_info(a, w, rows[:, :256], bias=b, relu=True, workspace=ws)
+    assert fused.LT_SOURCES[info["source"]] == "refused-timed" and 0 <= info["chosen"] < info["candidates"] and info["tuned"]
+    torch.testing.assert_close(rows[:, :256], want, rtol=2e-4, atol=2e-3)
+    if info["solution"] < 0:
+        pytest.skip("this hipBLASLt build does not export hipblaslt_ext::getIndexFromAlgo")
+    best_idx, best_sol = info["chosen"], info["solution"]
+    # the right solution recorded under a wrong position: found by its identity
+    wrong_pos = (best_idx + 1) % info["candidates"]
+    fused.linear_lt_set_choice(a, w, rows[:, :256], index=wrong_pos, solution=best_sol, bias=b, relu=True, workspace=ws)
+    rows.zero_()
+    fused.linear_lt(a, w, rows[:, :256], bias=b, relu=True, workspace=ws)
+    info = fused.linear_lt_info(a, w, rows[:, :256], bias=b, relu=True, workspace=ws)
+    assert fused.LT_SOURCES[info["source"]] == "recorded" and info["solution"] == best_sol and info["chosen"] == best_idx
+    torch.testing.assert_close(rows[:, :256], want, rtol=2e-4, atol=2e-3)
+    # a solution this list does not hold: refused, timed
+    fused.linear_lt_set_choice(a, w, rows[:, :256], index=0, solution=2 ** 30, bias=b, relu=True, workspace=ws)
+    rows.zero_()
+    fused.linear_lt(a, w, rows[:, :256], bias=b, relu=True, workspace=ws)
+    info = fused.linear_lt_info(a, w, rows[:, :256], bias=b, relu=True, workspace=ws)
+    assert fused.LT_SOURCES[info["source"]] == "refused-timed" and info["solution"] != 2 ** 30
+    torch.testing.assert_close(rows[:, :256], want, rtol=2e-4, atol=2e-3)
+
+
+def test_tuning_file_of_another_library_build_is_ignored(tmp_path, monkeypatch):
+    """lt_tuning_gfx950.json is only believed when it was made with the hipBLASLt build that is loaded (version + revision);
+    otherwise every problem is timed at first use and the status line says why. The committed file must match this image."""
+    import json
+    from active_tracking_rl_amd import fused
+    have = fused.lt_library()
+    assert have["version"] > 0
+    committed = json.load(open(fused.LT_TUNING_FILE))
+    assert committed["hipblaslt"] == {"version": have["version"], "git": have["git"]}, \
+        "regenerate lt_tuning_gfx950.json with tools/tune_lt.py for this image's hipBLASLt"
+    a, w, b, rows, ws = _problem(m=672)
+    g = fused._linear_args(a, w, rows[:, :256], b, True, ws)
+    key = fused._lt_key(g)
+    for hip, expect in (({"version": have["version"] + 1, "git": have["git"]}, False),
+                        ({"version": have["version"], "git": have["git"] + "x"}, False),
+                        ({"version": have["version"], "git": have["git"]}, True)):
+        f = tmp_path / "lt.json"
+        f.write_text(json.dumps({"hipblaslt": hip, "choices": {key: {"index": 0, "solution": -1}}}))
+        monkeypatch.setattr(fused, "LT_TUNING_FILE", str(f))
+        monkeypatch.setattr(fused, "_lt_choices", None)
+        ch = fused.lt_choices()
+        assert (key in ch) == expect
+        assert fused.lt_tuning_status().startswith("recorded" if expect else "timed at first use (tuning file made with")
+    monkeypatch.setattr(fused, "_lt_choices", None)

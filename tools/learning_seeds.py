@@ -1,0 +1,80 @@
+"""Learning sanity across seeds and schedules in ONE process (VERDICT r04 "Next round" 2): for every (schedule, seed) a fresh
+player trains `--iters` iterations; the mean tracker reward per env step over windows of 100 iterations is recorded at every
+`--every` iterations. Schedules: synchronous (GraphedIteration), pipelined (PipelinedIteration on two streams),
+pipelined-serial (the same double-buffered dataflow in program order on one stream).
+
+    python tools/learning_seeds.py --env Track2D-MazePartialNav-v0 --num-envs 1024 --network maze-lstm --train-mode 0 \
+        --iters 3000 --seeds 1 2 3 4 5 6 7 8 > profiles/r05_learning_seeds_nav_mode0.txt
+"""
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # (see bench.py: room for the CU-partitioned stream pair)
+
+import argparse
+import time
+
+import torch
+
+from active_tracking_rl_amd.train import GraphedIteration, PipelinedIteration, default_args, make_player
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--env", default="Track2D-MazePartialNav-v0")
+ap.add_argument("--iters", type=int, default=3000)
+ap.add_argument("--every", type=int, default=500)
+ap.add_argument("--num-envs", type=int, default=1024)
+ap.add_argument("--network", default="maze-lstm")
+ap.add_argument("--train-mode", type=int, default=0)
+ap.add_argument("--seeds", type=int, nargs="+", default=[1, 2, 3, 4, 5, 6, 7, 8])
+ap.add_argument("--schedules", nargs="+", default=["synchronous", "pipelined", "pipelined-serial"])
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+print("# %s  %d envs  %s  train-mode %d  %d iterations; mean tracker (target) reward per env step over the 100 iterations before "
+      "each checkpoint" % (a.env, a.num_envs, a.network, a.train_mode, a.iters), flush=True)
+marks = list(range(a.every, a.iters + 1, a.every))
+print("# schedule seed " + " ".join("@%d" % m for m in marks), flush=True)
+final = {}
+for sched in a.schedules:
+    for seed in a.seeds:
+        args = default_args(env=a.env, network=a.network, aux="reward" if "tat" in a.network else "none",
+                            train_mode=a.train_mode, num_envs=a.num_envs, seed=seed)
+        player, opt = make_player(args, dev)
+        pipelined = sched != "synchronous"
+        if pipelined:
+            it = PipelinedIteration(player, opt, args, serial=(sched == "pipelined-serial"))
+            if not it.serial:
+                it.tune_streams()
+        else:
+            it = GraphedIteration(player, opt, args)
+        rew_acc = torch.zeros(2, device=dev)
+        row, t0 = [], time.time()
+        for i in range(1, a.iters + 1):
+            it.run()
+            in_window = any(m - 100 < i <= m for m in marks)
+            if in_window:
+                if pipelined:     # the replica that just rolled out, read on the stream its rollout ran on
+                    src = it.players[(it.i - 1) & 1]
+                    if it.serial:
+                        rew_acc += src.reward.mean(0)
+                    else:
+                        with torch.cuda.stream(it.sR):
+                            rew_acc += src.reward.mean(0)
+                else:
+                    rew_acc += player.reward.mean(0)
+            if i in marks:
+                if pipelined:
+                    it.finish()
+                torch.cuda.synchronize()
+                row.append((rew_acc[0].item() / 100, rew_acc[1].item() / 100))
+                rew_acc.zero_()
+                torch.cuda.synchronize()
+        if pipelined:
+            it.finish()
+        torch.cuda.synchronize()
+        print("%-17s %2d  " % (sched, seed) + "  ".join("%+.3f (%+.3f)" % r for r in row) + "   [%.0fs]" % (time.time() - t0),
+              flush=True)
+        final.setdefault(sched, []).append(row[-1][0])
+        player.env.close()
+        del it, player, opt
+        torch.cuda.empty_cache()
+print("# final tracker reward, mean / min / max over seeds")
+for sched, v in final.items():
+    print("# %-17s %+.3f / %+.3f / %+.3f" % (sched, sum(v) / len(v), min(v), max(v)))

@@ -26,10 +26,15 @@ for over in CASES:
     del player, opt
     torch.cuda.empty_cache()
 ch = fused.lt_chosen()
-out = {"note": "candidate index (position in hipblasLtMatmulAlgoGetHeuristic's list for the problem, 512 requested) of the kernel "
-               "csrc/lt_gemm.cpp timed fastest; written by tools/tune_lt.py on an MI355X",
-       "torch": torch.__version__, "choices": {k: v[0] for k, v in sorted(ch.items())},
-       "timing_us": {k: round(v[2], 2) for k, v in sorted(ch.items())}, "candidates": {k: v[1] for k, v in sorted(ch.items())}}
+libinfo = fused.lt_library()
+out = {"note": "per problem: the kernel csrc/lt_gemm.cpp timed fastest — its position in hipblasLtMatmulAlgoGetHeuristic's list (512 "
+               "requested, the workspace limit is part of the key) AND its solution index (hipblaslt_ext::getIndexFromAlgo). Only used "
+               "when `hipblaslt` equals the loaded library's version + revision (fused.lt_choices); written by tools/tune_lt.py on an MI355X",
+       "torch": torch.__version__, "hipblaslt": {"version": libinfo["version"], "git": libinfo["git"]},
+       "header_version": libinfo["header_version"],
+       "choices": {k: {"index": v["chosen"], "solution": v["solution"], "candidates": v["candidates"], "us": round(v["best_us"], 2),
+                       "kernel": v["kernel"]} for k, v in sorted(ch.items())}}
 json.dump(out, open(fused.LT_TUNING_FILE, "w"), indent=1)
+print("hipBLASLt %s %s (header %s)" % (libinfo["version"], libinfo["git"], libinfo["header_version"]))
 for k, v in sorted(ch.items()):
-    print("%-90s candidate %3d of %3d  %.2f us" % (k, v[0], v[1], v[2]))
+    print("%-100s candidate %3d of %3d  solution %6d  %.2f us  %s" % (k, v["chosen"], v["candidates"], v["solution"], v["best_us"], v["kernel"][:60]))
