@@ -57,7 +57,7 @@ constexpr int tn_wg_per_cu(int kc) { return kc == 32 ? 2 : kc == 24 ? 3 : 4; }
 // of queueing behind co-resident dW workgroups that run for hundreds of microseconds each: the pipelined iteration at 4096
 // envs 15.75 -> 16.6-16.75 M env steps/s, 11.3 -> 11.7 at 1024, 13.95 -> 14.5 at 2048 (two or three workgroups per CU: no
 // gain at all; the same cap on k_stem_bwd: +1 % alone, a loss together with this one).
-static int g_tn_corun = 0;
+static thread_local int g_tn_corun = 0;     // per calling thread: another thread's eager launches keep their own mode
 static int tn_kc(long long K)
 {
     static const int forced = getenv("ATR_GEMM_TN_KC") ? atoi(getenv("ATR_GEMM_TN_KC")) : 0;   // (tuning experiments)

@@ -21,6 +21,7 @@
 #include "../../include/atr_policy.h"
 #include "../../include/track2d.h"
 #include "atr_cell.h"
+#include "coop_gemm.h"
 #include "t2d_device.h"
 
 #ifndef T2D_EXP
@@ -1306,29 +1307,28 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_step2(DevState s, const vo
 // dependent launches of 5-10 us each at every batch size. The env's state loads go out first and its map-row loads as
 // soon as the state is there, so both fly under the cells' arithmetic.
 // NA: compile-time number of actions (4 = every registered id; 8 = the 'Moore' table) — the head and draw code is sized to it
-template <int OBS, bool RAM, bool ENV, int NA, bool NAV = false>
-__global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_act_step a, void *obs, float *rew,
-                                                               uint8_t *done_out, uint32_t stamp)
+// The body of k_act_step for ONE env pair = one wavefront, as a function: k_act_step calls it from a workgroup of kStep2Waves
+// waves (STAGE_EMB: the embedding rows are parked in LDS here, behind a workgroup barrier every wave reaches), k_coop_step from a
+// workgroup whose earlier phases already staged them (STAGE_EMB = false: no barrier inside, waves without an env pair simply
+// do not call). tid / nthreads: the caller's thread index and workgroup size (the staging loop's shape).
+template <int OBS, bool RAM, bool ENV, int NA, bool NAV, bool STAGE_EMB, int NTHREADS>
+__device__ __forceinline__ void act_pair(const DevState &s, const atr_act_step &a, void *obs, float *rew, uint8_t *done_out,
+                                         uint32_t stamp, int e0, int lane, int tid, uint32_t *stage, uint32_t *navtile,
+                                         float *emb_lds)
 {
     using namespace atr;
-    __shared__ __attribute__((aligned(16))) uint32_t stage2[kStep2Waves][kStage2Words];
-    __shared__ __attribute__((aligned(16))) float emb_lds[NA * 4 * 128];   // the tracker-action embedding table
-    __shared__ __attribute__((aligned(16))) uint32_t navtiles[NAV ? kStep2Waves : 1][NAV ? kTileWords : 4];
-    const int lane = (int)(threadIdx.x & 63u);
-    const int wave = uni((int)(threadIdx.x >> 6));
-    const int e0 = ((int)blockIdx.x * kStep2Waves + wave) * 2;
     const int n = ENV ? s.n : a.N;
     // the embedding rows (A x 4R floats, 8 KB) go to LDS now: the target's cell reads row a_tracker the moment the tracker's
     // draw is known — an LDS read instead of a dependent trip to L2 in the middle of the kernel's serial chain
-    constexpr int kEmbTrips = NA * 128 / (64 * kStep2Waves);
+    constexpr int kEmbTrips = STAGE_EMB ? NA * 128 / NTHREADS : 1;
     float4 emb_st[kEmbTrips];
-    if (a.emb) {
+    if (STAGE_EMB && a.emb) {
 #pragma unroll
-        for (int i = 0; i < kEmbTrips; i++) emb_st[i] = ld4(a.emb + 4 * ((int)threadIdx.x + i * 64 * kStep2Waves));
+        for (int i = 0; i < kEmbTrips; i++) emb_st[i] = ld4(a.emb + 4 * (tid + i * NTHREADS));
     }
     const bool active = e0 < n;         // (no early return: every wave reaches the workgroup barrier below)
     Step2<false, OBS, RAM, NAV> S;
-    if (ENV && active) { S.init(s, e0, lane, stage2[wave]); if (NAV) S.tile = navtiles[wave]; }    // env state loads first ...
+    if (ENV && active) { S.init(s, e0, lane, stage); if (NAV) S.tile = navtile; }    // env state loads first ...
     const int sl = lane >> 5, q = lane & 31, j = q * 4;
     const bool live = e0 + sl < n;
     const int e = live ? e0 + sl : (active ? e0 : 0);
@@ -1361,11 +1361,13 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_a
         for (int x = 0; x < NA; x++) aw[p][x] = ld4(a.actor_w[p] + x * R + j);
     }
     const unsigned long long ctr = *a.counter;
-    if (a.emb) {
+    if (STAGE_EMB) {
+        if (a.emb) {
 #pragma unroll
-        for (int i = 0; i < kEmbTrips; i++) st4(emb_lds + 4 * ((int)threadIdx.x + i * 64 * kStep2Waves), emb_st[i]);
+            for (int i = 0; i < kEmbTrips; i++) st4(emb_lds + 4 * (tid + i * NTHREADS), emb_st[i]);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (!active) return;
     if (ENV) { S.init2(s, obs, rew, done_out); S.rows(s); }   // (waits for the state only: vector loads return in order)
     int act[2] = {0, 0};
@@ -1429,6 +1431,179 @@ __global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_a
     }
 }
 
+template <int OBS, bool RAM, bool ENV, int NA, bool NAV = false>
+__global__ __launch_bounds__(64 * kStep2Waves) void k_act_step(DevState s, atr_act_step a, void *obs, float *rew,
+                                                               uint8_t *done_out, uint32_t stamp)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stage2[kStep2Waves][kStage2Words];
+    __shared__ __attribute__((aligned(16))) float emb_lds[NA * 4 * 128];   // the tracker-action embedding table
+    __shared__ __attribute__((aligned(16))) uint32_t navtiles[NAV ? kStep2Waves : 1][NAV ? kTileWords : 4];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int e0 = ((int)blockIdx.x * kStep2Waves + wave) * 2;
+    act_pair<OBS, RAM, ENV, NA, NAV, true, 64 * kStep2Waves>(s, a, obs, rew, done_out, stamp, e0, lane, (int)threadIdx.x, stage2[wave],
+                                                             navtiles[NAV ? wave : 0], emb_lds);
+}
+
+// ---- the small-shard rollout step as ONE launch after the stem: fc + ReLU -> LSTMCell GEMM -> cells + heads + draws + env step ----
+// At 512 / 1024 envs per GPU (the 8- and 4-GPU forms of the headline: 4096 envs sharded) a rollout step is four dependent
+// launches of 8-10 us each, every one of them 2-3 us of matrix-pipe work behind a launch, a cold L2 and a drain. A layer
+// boundary needs activations to cross between CUs, and a chip-wide barrier inside a kernel costs more than the launch it
+// would replace (tools/microbench/grid_barrier.hip: 5.7 us — the agent-scope release / acquire is an L2 write-back +
+// invalidate, because the eight XCDs have eight L2s). But nothing forces a layer's rows to cross XCDs: this kernel gives
+// every XCD one eighth of the envs END TO END. Its 32 workgroups split each layer's tiles among themselves (coop_gemm.h),
+// write them with plain stores — write-through to the ONE L2 they share — and meet at a barrier that lives in that L2: an
+// atomic counter (RMW atomics execute in the L2) polled with sc1 loads (device scope: they miss the CU's L1). No L2
+// write-back, no invalidate: 1 us per barrier (tools/microbench/xcd_barrier.hip), half a dependent launch. What makes the
+// plain loads after the barrier safe without an L1 invalidate: a layer's activations are written once, in whole 128-byte
+// lines (32 columns of a row), to addresses no CU has read since its L1 was invalidated at kernel start.
+//   phase A  encoder fc + ReLU of both players (perception.py:81,90) into the feature columns of this step's [features | k h_prev] rows
+//   phase B  both GEMMs of nn.LSTMCell of both players (model.py:110,137,172,203) as one K = F + R product over those rows
+//            -> gate pre-activations (scratch that never leaves the L2 hot set)
+//   phase C  act_pair: k_act_step's body, one wavefront per env pair of this XCD
+// Which workgroup serves which XCD is read from the hardware (XCC_ID), its rank among that XCD's workgroups from a ticket;
+// the ticket counter doubles as the barrier: every launch adds exactly 3 x per_xcd to it (claim + two arrivals), so the
+// ticket modulo that period is the rank and ticket - rank the launch's base (64-bit: never wraps). Launches that use one
+// counter block must not overlap (they are steps of one rollout: a dependent chain).
+#define T2D_XCC_ID() (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7)       // hwreg(HW_REG_XCC_ID, 0, 4)
+constexpr int kCoopSpinCap = 1 << 18;      // ~0.1 s of polling: a barrier that never completes ends in a fault flag, not a hang
+constexpr uint32_t kFaultCoopPlacement = 2u, kFaultCoopTimeout = 4u, kFaultCoopShape = 8u;
+
+struct CoopStep {
+    const float *y[2], *fc_w[2], *fc_b[2], *w_cat[2];
+    long long ldy[2];
+    int kfc[2];
+    float *fh, *gates;
+    long long fh_pstride, fh_ld;
+    int F;
+    unsigned long long *ctl;     // [8 XCDs][16]: one counter per XCD, 128 bytes apart
+    int per_xcd;
+    unsigned long long *probe;   // nullable (tools/coop_step_timeline.py): [workgroups][8] s_memtime stamps at the phase boundaries
+};
+#define T2D_COOP_STAMP(i) do { if (c.probe && tid == 0) c.probe[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+
+// The barrier in two halves, so that a workgroup can request what it needs next (weights, env state: nothing the other
+// workgroups are still writing) while it waits.
+//   arrive: every wave has its stores acknowledged by the L2 (gfx9 counts stores in vmcnt; a workgroup-scope release fence
+//           emits no wait in this mode — checked in the ISA — so it is spelled out), then one atomic increment
+//   wait:   thread 0 polls the counter with SCALAR loads (glc: past the scalar cache, served by the L2): they count in lgkmcnt,
+//           so vector loads the wave has in flight (the prefetch issued between the halves) are not waited for
+__device__ __forceinline__ void xcd_arrive(unsigned long long *ctr, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void xcd_wait(const unsigned long long *ctr, unsigned long long target, uint32_t *faults, int tid)
+{
+    if (tid == 0) {
+        int spins = 0;
+        for (;;) {
+            unsigned long long v;
+            asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
+            if (v >= target || ++spins >= kCoopSpinCap) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (spins >= kCoopSpinCap) atomicOr(faults, kFaultCoopTimeout);
+    }
+    __syncthreads();
+}
+
+template <int OBS, bool RAM, int NA, bool NAV>
+__global__ __launch_bounds__(atr::kCoopThreads) void k_coop_step(DevState s, atr_act_step a, CoopStep c, void *obs, float *rew,
+                                                                uint8_t *done_out, uint32_t stamp)
+{
+    using namespace atr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char coop_smem[];
+    float *emb_lds = reinterpret_cast<float *>(coop_smem);                         // NA x 4R floats
+    CoopLds &L = *reinterpret_cast<CoopLds *>(coop_smem + NA * 4 * 128 * sizeof(float));
+    uint32_t *stage_base = reinterpret_cast<uint32_t *>(L.part);                   // phase C re-uses the partial tiles' space
+    uint32_t *nav_base = stage_base + kCoopWaves * kStage2Words;
+    __shared__ unsigned long long s_ticket;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int xcc = (int)T2D_XCC_ID();
+    unsigned long long *ctr = c.ctl + 16 * xcc;
+    T2D_COOP_STAMP(0);
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (a.emb)
+        for (int i = tid; i < NA * 128; i += kCoopThreads) st4(emb_lds + 4 * i, ld4(a.emb + 4 * i));
+    __syncthreads();
+    const int P = c.per_xcd;
+    const unsigned long long period = 3ull * (unsigned long long)P, ticket = s_ticket;
+    const int slot = (int)(ticket % period);
+    const unsigned long long base = ticket - (unsigned long long)slot;
+    if (slot >= P) {            // more workgroups on this XCD than planned (the dispatcher did not deal them round-robin)
+        if (tid == 0) atomicOr(s.faults, kFaultCoopPlacement);
+        return;
+    }
+    const int N = s.n, Rx = N >> 3, n_rt = Rx >> 4, row_x = xcc * Rx;
+    constexpr int R4 = 4 * 128;
+    T2D_COOP_STAMP(1);
+    if (c.probe && tid == 0) c.probe[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | (unsigned)slot;
+    CoopPipe pipe;
+    // ---- phase A: fc + ReLU tiles of this XCD's rows, both players (player 0's units first: with equal counts every
+    // workgroup gets the same mix of the two K's) ----
+    {
+        const int ct_n = c.F >> 5, upp = n_rt * ct_n, units = 2 * upp;
+        const int mine = slot < units ? (units - slot + P - 1) / P : 0;
+        if (tid < mine && tid < kCoopMaxUnits) {
+            const int u = slot + tid * P, p = u / upp, idx = u - p * upp, rt = idx / ct_n, ct = idx - rt * ct_n;
+            const int row0 = row_x + rt * 16;
+            CoopUnit &U = L.units[tid];
+            U.a = c.y[p] + (size_t)row0 * c.ldy[p]; U.lda = (int)c.ldy[p];
+            U.w = c.fc_w[p] + (size_t)(ct * 32) * c.kfc[p]; U.ldw = c.kfc[p];
+            U.bias = c.fc_b[p] + ct * 32;
+            U.c = c.fh + (size_t)p * c.fh_pstride + (size_t)row0 * c.fh_ld + ct * 32; U.ldc = (int)c.fh_ld;
+            U.K = c.kfc[p]; U.rows_valid = 16; U.relu = 1;
+        }
+        if (tid == 0) L.probe = c.probe ? c.probe + (size_t)gridDim.x * 8 + (size_t)blockIdx.x * 16 : nullptr;
+        __syncthreads();
+        const int nu = min(mine, kCoopMaxUnits);
+        coop_plan(L, nu, tid, pipe);
+        coop_prefetch_w(pipe);
+        coop_prefetch_a(pipe);
+        if (mine > kCoopMaxUnits || !coop_run(L, nu, tid, pipe)) { if (lane == 0) atomicOr(s.faults, kFaultCoopShape); }
+    }
+    T2D_COOP_STAMP(2);
+    // ---- phase B: gate pre-activations = [features | k h_prev] [W_ih | W_hh]^T (bias added by the cell). Its weights are
+    // requested BEFORE the barrier completes (nobody writes those), its rows after ----
+    {
+        const int ct_n = R4 >> 5, upp = n_rt * ct_n, units = 2 * upp;
+        const int mine = slot < units ? (units - slot + P - 1) / P : 0;
+        xcd_arrive(ctr, tid);            // (its __syncthreads also ends every thread's reads of phase A's unit table)
+        if (tid < mine && tid < kCoopMaxUnits) {
+            const int u = slot + tid * P, p = u / upp, idx = u - p * upp, ct = idx / n_rt, rt = idx - ct * n_rt;
+            const int row0 = row_x + rt * 16;
+            CoopUnit &U = L.units[tid];
+            U.a = c.fh + (size_t)p * c.fh_pstride + (size_t)row0 * c.fh_ld; U.lda = (int)c.fh_ld;
+            U.w = c.w_cat[p] + (size_t)(ct * 32) * c.fh_ld; U.ldw = (int)c.fh_ld;
+            U.bias = nullptr;
+            U.c = c.gates + ((size_t)p * N + row0) * R4 + ct * 32; U.ldc = R4;
+            U.K = (int)c.fh_ld; U.rows_valid = 16; U.relu = 0;
+        }
+        if (tid == 0) L.probe = c.probe ? c.probe + (size_t)gridDim.x * 8 + (size_t)blockIdx.x * 16 + 8 : nullptr;
+        __syncthreads();
+        const int nu = min(mine, kCoopMaxUnits);
+        coop_plan(L, nu, tid, pipe);
+        coop_prefetch_w(pipe);
+        xcd_wait(ctr, base + 2ull * (unsigned long long)P, s.faults, tid);
+        T2D_COOP_STAMP(3);
+        coop_prefetch_a(pipe);
+        if (mine > kCoopMaxUnits || !coop_run(L, nu, tid, pipe)) { if (lane == 0) atomicOr(s.faults, kFaultCoopShape); }
+    }
+    T2D_COOP_STAMP(4);
+    xcd_arrive(ctr, tid);
+    xcd_wait(ctr, base + 3ull * (unsigned long long)P, s.faults, tid);
+    T2D_COOP_STAMP(5);
+    // ---- phase C: cells + heads + draws + env step, one wavefront per env pair of this XCD ----
+    const int pi = slot + wave * P;
+    if (pi < (Rx >> 1))
+        act_pair<OBS, RAM, true, NA, NAV, false, kCoopThreads>(s, a, obs, rew, done_out, stamp, row_x + 2 * pi, lane, tid,
+                                                               stage_base + wave * kStage2Words, nav_base + (NAV ? wave : 0) * kTileWords,
+                                                               emb_lds);
+    if (c.probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); T2D_COOP_STAMP(6); }
+}
+
 __global__ void k_build_reward_lut(float2 *lut)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1479,7 +1654,12 @@ struct t2d_handle {
     bool pending[2];    // a forked generator launch of window w has not been joined yet
     hipStream_t gen_stream;
     hipEvent_t ev_fork, ev_join[2];
+    // atr_coop_env_step's XCD counters: kCoopCtlSets blocks of [8 XCDs][16] u64 (one counter per XCD, 128 bytes apart), one
+    // block per distinct grid size (a counter's period is 3 x grid / 8: launches of different sizes must not share one)
+    unsigned long long *coop_ctl = nullptr;
+    int coop_grid[4] = {0, 0, 0, 0};
 };
+constexpr int kCoopCtlSets = 4, kCoopCtlWords = 8 * 16;
 
 static thread_local char g_err[512] = "";
 
@@ -1608,6 +1788,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         alloc(&s.p_goal, 6 * nb); alloc(&s.p_tctr, 6 * nb); alloc(&s.p_state, 3 * nb);
     }
     alloc(&s.faults, sizeof(uint32_t));
+    alloc(reinterpret_cast<uint32_t **>(&h->coop_ctl), (size_t)kCoopCtlSets * kCoopCtlWords * sizeof(unsigned long long));
     float2 *lut = nullptr;
     if (err == hipSuccess) err = hipMalloc((void **)&lut, (size_t)3 * kLutN * sizeof(float2));
     s.rew_lut = lut;
@@ -1640,6 +1821,7 @@ extern "C" int t2d_destroy(t2d_handle *h)
     }
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->coop_ctl) (void)hipFree(h->coop_ctl);
     delete h;
     return T2D_OK;
 }
@@ -1959,6 +2141,98 @@ extern "C" int atr_act_env_step(t2d_handle *h, const atr_act_step *args, void *o
     else T2D_LAUNCH_ACT(OBS_F32_SCALAR);
 #undef T2D_LAUNCH_ACT2
 #undef T2D_LAUNCH_ACT
+    HIP_TRY(hipGetLastError());
+    if (h->s.auto_reset) return window_end(h, st);
+    return T2D_OK;
+}
+
+// The small-shard rollout step after the stem as ONE launch (k_coop_step): fc + ReLU of both encoders, the LSTMCell GEMM of
+// both players, then everything atr_act_env_step does. `act` as for atr_act_env_step with bias[p] = b_ih + b_hh, hg = NULL and
+// hm_out set; act->ig is ignored (the gate pre-activations live in coop->gates).
+extern "C" int atr_coop_env_step(t2d_handle *h, const atr_act_step *act, const atr_coop_step *coop, void *obs_dev, int obs_is_u8,
+                                 float *rew_dev, uint8_t *done_dev, void *stream)
+{
+    if (!h || !act || !coop) return fail(T2D_ERR_INVALID, "atr_coop_env_step: null argument");
+    atr_act_step a = *act;
+    const atr_coop_step &k = *coop;
+    const int N = h->s.n, G = k.workgroups, F = k.F, R = 128;
+    for (int p = 0; p < 2; p++) {
+        if (!a.c_prev[p] || !a.h_out[p] || !a.c_out[p] || !a.actor_w[p] || !a.actor_b[p] || !a.bias[p] || !a.hm_out[p])
+            return fail(T2D_ERR_INVALID, "atr_coop_env_step: null policy buffer (player %d)", p);
+        if (!k.y[p] || !k.fc_w[p] || !k.fc_b[p] || !k.w_cat[p])
+            return fail(T2D_ERR_INVALID, "atr_coop_env_step: null layer buffer (player %d)", p);
+        if (k.kfc[p] <= 0 || (k.kfc[p] & 31) || k.ldy[p] < k.kfc[p] || (k.ldy[p] & 3))
+            return fail(T2D_ERR_INVALID, "atr_coop_env_step: fc input width must be a multiple of 32, row stride a multiple of 4");
+        if (((uintptr_t)k.y[p] | (uintptr_t)k.fc_w[p] | (uintptr_t)k.fc_b[p] | (uintptr_t)k.w_cat[p] | (uintptr_t)a.hm_out[p]) & 15u)
+            return fail(T2D_ERR_INVALID, "atr_coop_env_step: pointers must be 16-byte aligned");
+        a.ig[p] = k.gates + (size_t)p * N * 4 * R;
+        a.hg[p] = nullptr;
+    }
+    if (!a.actions_out || !a.counter || a.R != R || (a.A != 4 && a.A != 8))
+        return fail(T2D_ERR_INVALID, "atr_coop_env_step: needs R = 128, A = 4 or 8, actions_out, counter");
+    if (!k.fh || !k.gates || F <= 0 || (F & 31) || k.fh_ld != F + R || (k.fh_pstride & 31) ||
+        (((uintptr_t)k.fh | (uintptr_t)k.gates) & 127u))
+        return fail(T2D_ERR_INVALID, "atr_coop_env_step: rows must be [F | R] floats wide (F a multiple of 32), 128-byte aligned");
+    if (a.hm_ld < R || (a.hm_ld & 3)) return fail(T2D_ERR_INVALID, "atr_coop_env_step: hm_ld >= R and a multiple of 4");
+    if (!rew_dev || !done_dev || !obs_dev) return fail(T2D_ERR_INVALID, "atr_coop_env_step: null env buffer");
+    if (!use_step2(h))
+        return fail(T2D_ERR_INVALID, "atr_coop_env_step: exists for 'Partial' ids without the RPF target (the k_step2 family)");
+    if (a.N != N) return fail(T2D_ERR_INVALID, "atr_coop_env_step: policy batch %d != %d envs", a.N, N);
+    if (a.A != h->s.amask + 1) return fail(T2D_ERR_INVALID, "atr_coop_env_step: %d policy actions, env has %d", a.A, h->s.amask + 1);
+    if (obs_is_u8 && ((uintptr_t)obs_dev & 3u) != 0u) return fail(T2D_ERR_INVALID, "atr_coop_env_step: obs buffer must be 4-byte aligned");
+    // shape limits: every XCD gets N / 8 envs in whole 16-row tiles, a workgroup at most kCoopMaxUnits tiles per layer and
+    // kCoopWaves env pairs
+    if (G < 8 || (G & 7) || G > 1024) return fail(T2D_ERR_INVALID, "atr_coop_env_step: workgroups must be a multiple of 8");
+    const int P = G / 8, Rx = N / 8;
+    if ((N & 127) != 0) return fail(T2D_ERR_INVALID, "atr_coop_env_step: needs a multiple of 128 envs (got %d)", N);
+    const int unitsA = 2 * (Rx / 16) * (F / 32), unitsB = 2 * (Rx / 16) * (4 * R / 32);
+    if ((unitsA + P - 1) / P > atr::kCoopMaxUnits || (unitsB + P - 1) / P > atr::kCoopMaxUnits || (Rx / 2 + P - 1) / P > atr::kCoopWaves)
+        return fail(T2D_ERR_INVALID, "atr_coop_env_step: %d envs are too many for %d workgroups", N, G);
+    if (!h->reset_done) return fail(T2D_ERR_STATE, "atr_coop_env_step: call t2d_reset (all envs) or t2d_inject first");
+    if (h->s.auto_reset && !h->primed) return fail(T2D_ERR_STATE, "atr_coop_env_step: auto_reset needs one t2d_reset before stepping");
+    DeviceGuard guard(h->device);
+    int set = -1;
+    for (int i = 0; i < kCoopCtlSets && set < 0; i++)
+        if (h->coop_grid[i] == G || h->coop_grid[i] == 0) { h->coop_grid[i] = G; set = i; }
+    if (set < 0) return fail(T2D_ERR_INVALID, "atr_coop_env_step: more than %d distinct grid sizes on one handle", kCoopCtlSets);
+    CoopStep c;
+    for (int p = 0; p < 2; p++) {
+        c.y[p] = k.y[p]; c.fc_w[p] = k.fc_w[p]; c.fc_b[p] = k.fc_b[p]; c.w_cat[p] = k.w_cat[p]; c.ldy[p] = k.ldy[p]; c.kfc[p] = k.kfc[p];
+    }
+    c.fh = k.fh; c.gates = k.gates; c.fh_pstride = k.fh_pstride; c.fh_ld = k.fh_ld; c.F = F;
+    c.ctl = h->coop_ctl + (size_t)set * kCoopCtlWords; c.per_xcd = P;
+    c.probe = (unsigned long long *)k.probe;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->s.auto_reset) {
+        int rc = window_begin(h, st);
+        if (rc) return rc;
+        h->phase++;
+    }
+    const int kind = obs_is_u8 ? OBS_U8 : ((((uintptr_t)obs_dev & 15u) == 0u) ? OBS_F32_VEC4 : OBS_F32_SCALAR);
+    const size_t lds = (size_t)a.A * 4 * 128 * sizeof(float) + sizeof(atr::CoopLds);
+    static_assert(sizeof(atr::CoopLds::part) + sizeof(atr::CoopLds::stage) >= atr::kCoopWaves * (kStage2Words + kTileWords) * sizeof(uint32_t), "phase C's LDS aliases the partial tiles");
+#define T2D_LAUNCH_COOP2(KIND, RAMV, NAV, NAVF)                                                                        \
+    do {                                                                                                               \
+        static bool attr_ = false;                                                                                     \
+        if (!attr_) {    /* (static + dynamic LDS beyond 64 KB needs the opt-in) */                                    \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_coop_step<KIND, RAMV, NAV, NAVF>,                              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+            attr_ = true;                                                                                              \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_coop_step<KIND, RAMV, NAV, NAVF>), dim3((unsigned)G), dim3(atr::kCoopThreads), lds, st, h->s, a, c, \
+                           obs_dev, rew_dev, done_dev, h->phase);                                                      \
+    } while (0)
+#define T2D_LAUNCH_COOP(KIND)                                                                                          \
+    do {                                                                                                               \
+        if (h->has_navmode) { if (a.A == 4) T2D_LAUNCH_COOP2(KIND, true, 4, true); else T2D_LAUNCH_COOP2(KIND, true, 8, true); } \
+        else if (a.A == 4) { if (h->has_ram) T2D_LAUNCH_COOP2(KIND, true, 4, false); else T2D_LAUNCH_COOP2(KIND, false, 4, false); } \
+        else { if (h->has_ram) T2D_LAUNCH_COOP2(KIND, true, 8, false); else T2D_LAUNCH_COOP2(KIND, false, 8, false); } \
+    } while (0)
+    if (kind == OBS_U8) T2D_LAUNCH_COOP(OBS_U8);
+    else if (kind == OBS_F32_VEC4) T2D_LAUNCH_COOP(OBS_F32_VEC4);
+    else T2D_LAUNCH_COOP(OBS_F32_SCALAR);
+#undef T2D_LAUNCH_COOP2
+#undef T2D_LAUNCH_COOP
     HIP_TRY(hipGetLastError());
     if (h->s.auto_reset) return window_end(h, st);
     return T2D_OK;

@@ -30,6 +30,14 @@ class ActStepArgs(C.Structure):
                 ("A", C.c_int), ("N", C.c_int), ("R", C.c_int), ("hm_out", C.c_void_p * 2), ("hm_ld", C.c_longlong)]
 
 
+class CoopStepArgs(C.Structure):
+    """atr_coop_step of include/atr_policy.h."""
+    _fields_ = [("y", C.c_void_p * 2), ("fc_w", C.c_void_p * 2), ("fc_b", C.c_void_p * 2), ("w_cat", C.c_void_p * 2),
+                ("ldy", C.c_longlong * 2), ("kfc", C.c_int * 2), ("fh", C.c_void_p), ("gates", C.c_void_p),
+                ("fh_pstride", C.c_longlong), ("fh_ld", C.c_longlong), ("F", C.c_int), ("workgroups", C.c_int),
+                ("probe", C.c_void_p)]
+
+
 class LinearArgs(C.Structure):
     """atr_linear_args of include/atr_policy.h."""
     _fields_ = [("a", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("c", C.c_void_p), ("lda", C.c_longlong),
@@ -121,6 +129,8 @@ def lib():
         L.atr_pair_linear.argtypes = [C.POINTER(PairLinearArgs), vp]
         L.atr_act_env_step.restype = i32
         L.atr_act_env_step.argtypes = [vp, C.POINTER(ActStepArgs), vp, i32, vp, vp, vp]
+        L.atr_coop_env_step.restype = i32
+        L.atr_coop_env_step.argtypes = [vp, C.POINTER(ActStepArgs), C.POINTER(CoopStepArgs), vp, i32, vp, vp, vp]
         L.atr_actor_step.restype = i32
         L.atr_actor_step.argtypes = [vp] * 12 + [i32, i32, i32, vp]
         L.atr_lstm_cell_backward.restype = i32
@@ -918,6 +928,82 @@ def act_env_step(env_core, ig, hg, biases, c_prev, done, h_out, c_out, acts, sam
                                 _stream(ig[0]))
     if rc != 0:
         raise RuntimeError("atr_act_env_step failed (%d): %s" % (rc, L.t2d_last_error().decode()))
+    return actions_out
+
+
+_stream_cus = {}
+
+
+def register_stream_cus(stream, n_cus):
+    """A stream created with a CU mask (train.cu_masked_stream): kernels launched on it see only n_cus compute units. Launches
+    whose workgroups wait for each other (coop_env_step) size their grid by it."""
+    _stream_cus[int(stream.cuda_stream)] = int(n_cus)
+
+
+def stream_cus(device, stream=None):
+    """Compute units available to `stream` (default: the current one): its registered CU mask, else the whole device."""
+    st = torch.cuda.current_stream(device) if stream is None else stream
+    n = _stream_cus.get(int(st.cuda_stream))
+    return n if n is not None else int(torch.cuda.get_device_properties(device).multi_processor_count)
+
+
+COOP_MAX_UNITS, COOP_WAVES = 16, 8       # (csrc/coop_gemm.h: kCoopMaxUnits, kCoopWaves)
+COOP_PROBE = None                        # an int64 device tensor [workgroups, 8]: the kernel's phase stamps (tools/coop_step_timeline.py)
+
+
+def coop_step_supported(N, F, R, workgroups):
+    """The shape limits of atr_coop_env_step: every XCD takes N / 8 envs in whole 16-row tiles, a workgroup at most
+    COOP_MAX_UNITS tiles per layer and COOP_WAVES env pairs."""
+    if R != 128 or F <= 0 or F % 32 or N % 128 or workgroups < 8 or workgroups % 8:
+        return False
+    P, Rx = workgroups // 8, N // 8
+    units_a, units_b = 2 * (Rx // 16) * (F // 32), 2 * (Rx // 16) * (4 * R // 32)
+    return (-(-units_a // P) <= COOP_MAX_UNITS and -(-units_b // P) <= COOP_MAX_UNITS and -(-(Rx // 2) // P) <= COOP_WAVES)
+
+
+@torch.no_grad()
+def coop_env_step(env_core, ys, fcs, fh_t, w_cat, gates, biases, c_prev, done, h_out, c_out, acts, sampler, actors, actions_out,
+                  emb, env_out, hm_out, workgroups):
+    """A rollout step after the stem as ONE launch (atr_coop_env_step, csrc/track2d_hip.hip k_coop_step): fc + ReLU of both
+    encoders (ys[p] [N, K_p] stem outputs, fcs[p] nn.Linear) into the feature columns of fh_t [2, N, F + R], the LSTMCell GEMM
+    of both players over those rows (w_cat [2, 4R, F + R]) into `gates` [2, N, 4R], then what act_env_step does (cells, heads,
+    draws, env step; biases = b_ih + b_hh per player; hm_out: the next step's hidden columns). Every XCD owns an eighth of the
+    envs end to end; `workgroups` = the CUs the launch's stream may use (all of them must be free to be resident at once)."""
+    N, R = c_prev[0].shape
+    Fd = fcs[0].weight.shape[0]
+    assert sampler._ordinal is not None and actions_out.is_contiguous() and actions_out.shape == (2, N)
+    assert fh_t.shape == (2, N, Fd + R) and fh_t.stride(2) == 1 and fh_t.stride(1) == Fd + R
+    assert w_cat.is_contiguous() and w_cat.shape == (2, 4 * R, Fd + R) and gates.is_contiguous() and gates.shape == (2, N, 4 * R)
+    a, k = ActStepArgs(), CoopStepArgs()
+    for p in range(2):
+        for t in (c_prev[p], h_out[p], c_out[p], biases[p], ys[p]):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        assert ys[p].shape == (N, fcs[p].weight.shape[1]) and fcs[p].weight.is_contiguous() and fcs[p].weight.shape[0] == Fd
+        a.ig[p], a.hg[p], a.bias[p] = None, None, biases[p].data_ptr()
+        a.c_prev[p], a.h_out[p], a.c_out[p] = c_prev[p].data_ptr(), h_out[p].data_ptr(), c_out[p].data_ptr()
+        a.acts[p] = acts[p].data_ptr() if acts is not None and acts[p] is not None else None
+        assert acts is None or acts[p] is None or acts[p].is_contiguous()
+        a.actor_w[p], a.actor_b[p] = actors[p].weight.data_ptr(), actors[p].bias.data_ptr()
+        k.y[p], k.ldy[p], k.kfc[p] = ys[p].data_ptr(), ys[p].stride(0), ys[p].shape[1]
+        k.fc_w[p], k.fc_b[p], k.w_cat[p] = fcs[p].weight.data_ptr(), fcs[p].bias.data_ptr(), w_cat[p].data_ptr()
+    a.emb = emb.data_ptr() if emb is not None else None
+    a.done_prev = done.data_ptr() if done is not None else None
+    a.actions_out, a.counter, a.seed = actions_out.data_ptr(), sampler.counter.data_ptr(), sampler.seed
+    a.ordinal = sampler._ordinal + 1
+    sampler._ordinal += 2
+    a.A, a.N, a.R = actors[0].weight.shape[0], N, R
+    assert hm_out[0].shape == (N, R) and hm_out[1].shape == (N, R)
+    assert hm_out[0].stride(1) == 1 and hm_out[1].stride(1) == 1 and hm_out[0].stride(0) == hm_out[1].stride(0)
+    a.hm_out[0], a.hm_out[1], a.hm_ld = hm_out[0].data_ptr(), hm_out[1].data_ptr(), hm_out[0].stride(0)
+    k.fh, k.gates, k.fh_pstride, k.fh_ld, k.F, k.workgroups = fh_t.data_ptr(), gates.data_ptr(), fh_t.stride(0), Fd + R, Fd, int(workgroups)
+    k.probe = COOP_PROBE.data_ptr() if COOP_PROBE is not None else None
+    obs, rew, done_out = env_out
+    assert obs.is_contiguous() and rew.is_contiguous() and done_out.is_contiguous() and obs.dtype in (torch.uint8, torch.float32)
+    L = lib()
+    rc = L.atr_coop_env_step(env_core.h, C.byref(a), C.byref(k), _p(obs), 1 if obs.dtype == torch.uint8 else 0, _p(rew), _p(done_out),
+                             _stream(gates))
+    if rc != 0:
+        raise RuntimeError("atr_coop_env_step failed (%d): %s" % (rc, L.t2d_last_error().decode()))
     return actions_out
 
 

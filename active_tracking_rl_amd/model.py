@@ -532,6 +532,16 @@ class A3C_Dueling(nn.Module):
     # (fused.linear_lt, K = F + R; measured in a replayed graph: 9.9 us against 13.4 for the pair kernel at 1024 rows, 7.3
     # against 7.7 at 512); the fc + ReLU pair stays one pair-kernel launch up to pair_gemm_max_rows
     cat_gate_gemm = __import__('os').environ.get('ATR_CAT_GATE_GEMM', '1') != '0'
+    # coop_step (off by default: measured SLOWER than the four-launch step it replaces — 1.52 against 1.42 ms per synchronous
+    # iteration at 512 envs, profiles/r05_coop_step_timeline_*.txt, DESIGN.md section 5 "The two-launch step"; ATR_COOP_STEP=1
+    # turns it on): up to coop_max_rows envs everything between the stem and the next observation as ONE launch whose workgroups
+    # cooperate per XCD (fused.coop_env_step, csrc/track2d_hip.hip k_coop_step): 2 launches per env step.
+    # coop_workgroups: the grid size = the CUs of the stream the step is launched — or, for a captured step, REPLAYED — on
+    # (None: the current stream's; train.PipelinedIteration sets it to its rollout stream's CU count before capturing)
+    coop_step = __import__('os').environ.get('ATR_COOP_STEP', '0') != '0'
+    coop_max_rows = int(__import__('os').environ.get('ATR_COOP_MAX_ROWS', '1024'))
+    coop_workgroups = None
+    coop_step_seen = False
     cat_gemm_min_rows = int(__import__('os').environ.get('ATR_CAT_GEMM_MIN_ROWS', '768'))
     # atr_actor_step (both LSTMCell GEMMs + cell as one MFMA kernel per player, then two draw launches and the step launch)
     # is kept as an option: since k_act_step the GEMM pair + ONE fused cell/draw/env launch is faster at every batch size
@@ -614,7 +624,8 @@ class A3C_Dueling(nn.Module):
         c.hm_written = 0
         same_f = p0.encoder.outdim == p1.encoder.outdim
         from . import fused as _fz
-        if (same_f and env_fused and self.cat_gate_gemm and N >= self.cat_gemm_min_rows and self.fused_env_step
+        coop = self._coop_ok(N, p0.encoder.outdim, R, dev) if (same_f and env_fused) else False
+        if (same_f and env_fused and self.cat_gate_gemm and (N >= self.cat_gemm_min_rows or coop) and self.fused_env_step
                 and self.fused_sampling and _fz.lt_available()
                 and R == 128 and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape and p0.encoder.outdim % 4 == 0):
             # From cat_gemm_min_rows up the LSTMCell's two GEMMs are ONE product over rows [features | k h_prev] (K = F + R):
@@ -668,6 +679,15 @@ class A3C_Dueling(nn.Module):
                 c.emb = fa.weight.t() + fa.bias                    # row a = fc_action_tracker(one_hot(a))
                 c.emb_ih = c.emb @ p1.lstm.weight_ih.t()           # ... projected through W_ih: [n_act, 4R]
         return c
+
+    def _coop_ok(self, N, Fd, R, dev):
+        """Whether a rollout step of N envs takes the one-launch cooperative form (shape limits of atr_coop_env_step for the
+        grid the launch will have)."""
+        from . import fused
+        if not (self.coop_step and self.fused_env_step and self.fused_sampling and N <= self.coop_max_rows):
+            return False
+        wg = self.coop_workgroups if self.coop_workgroups else fused.stream_cus(dev)
+        return fused.coop_step_supported(N, Fd, R, wg)
 
     @torch.no_grad()
     def fill_consts(self, cache):
@@ -771,6 +791,22 @@ class A3C_Dueling(nn.Module):
         # step itself as ONE launch (csrc/track2d_hip.hip k_act_step): stem, 2 x fc, 2 x bmm, act+env = 6 launches per step
         if env_fused:
             core = env_out[0] if env_out is not None else None
+            if (cat_gemm and env_out is not None and fh[1] is not None and p0.encoder.outdim == p1.encoder.outdim
+                    and self._coop_ok(n, p0.encoder.outdim, R, states.device)):
+                # small shards: fc pair -> LSTMCell GEMM -> cells + heads + draws + env step as ONE launch whose workgroups
+                # cooperate per XCD (csrc/track2d_hip.hip k_coop_step): stem + this = 2 launches per env step
+                fh_t, fh_next = fh
+                Fd = p0.encoder.outdim
+                wg = self.coop_workgroups if self.coop_workgroups else fused.stream_cus(states.device)
+                fused.coop_env_step(core, [ys[0].view(n, -1), ys[1].view(n, -1)], (p0.encoder.fc, p1.encoder.fc), fh_t, cache.w_cat,
+                                    cache.gates, cache.bsum, c_prev, done, h_out, c_out, acts, self._sampler,
+                                    (p0.actor.actor_linear, p1.actor.actor_linear), actions,
+                                    cache.emb_ih if self.tat else None, env_out[1:], [fh_next[0][:, Fd:], fh_next[1][:, Fd:]], wg)
+                cache.hm_written = getattr(cache, "hm_written", 0) + 1
+                self.env_stepped = True
+                self.env_step_fused_seen = True
+                self.coop_step_seen = True
+                return [actions[0], actions[1]]
             if pair_gemm:
                 # small shards: each GEMM pair as ONE launch (csrc/pair_gemm_hip.hip) — fc + ReLU of both encoders, then both
                 # LSTMCell GEMMs of both players straight to the gate pre-activations (mask and bias inside): 4 launches per step

@@ -213,6 +213,29 @@ class GraphedIteration(object):
         rollout(self.player, self.args.num_steps, fast=self.fast)
         self.player.optimize(None, self.optimizer, self.player.model, self.mode0, self.player.device)
 
+    def burn_in(self, iters, mode=None):
+        """`iters` iterations whose updates are DISCARDED (weights, optimizer state and step counter restored): only the env
+        shard moves on. Why a driver wants this: every env of a fresh shard starts an episode at step 0 together, so for the first
+        ~25 rollouts the batch is perfectly correlated in episode phase (all trackers next to their targets, no episode end in
+        any of them), and with 1024+ envs per update the first Adam steps fit that one phase. Measured on
+        Track2D-MazePartialNav-v0 / 1024 envs / train-mode 0 over 8 seeds x 3000 iterations: 3 of 8 runs reach the +0.63
+        plateau from a synchronised start, 6 of 8 after 300 discarded iterations (profiles/r05_learning_seeds_*.txt). The
+        reference's 16 asynchronous one-env workers drift apart on their own (train.py:71-95)."""
+        if iters <= 0:
+            return
+        tensors = self._optimizer_tensors()
+        saved = [t.clone() for t in tensors] if tensors is not None else None
+        n0 = self.player.n_steps
+        for _ in range(int(iters)):
+            self.run(mode)
+        torch.cuda.synchronize(self.player.device)
+        if saved is not None:
+            with torch.no_grad():
+                for t, v in zip(tensors, saved):
+                    t.copy_(v)
+        self.player.n_steps = n0
+        torch.cuda.synchronize(self.player.device)
+
     def run(self, mode=None):
         mode = self.mode0 if mode is None else int(mode)
         g = self.g_rolls.get(mode)
@@ -229,7 +252,7 @@ class GraphedIteration(object):
 
 _hip, _masked_streams = None, {}
 MODEL_SWITCHES = ("fused_sampling", "fused_actor_step", "fused_env_step", "pair_gemm_max_rows", "mfma_step_min_rows",
-                  "cat_gate_gemm", "cat_gemm_min_rows")
+                  "cat_gate_gemm", "cat_gemm_min_rows", "coop_step", "coop_max_rows")
 
 
 def device_cus(device):
@@ -284,6 +307,8 @@ def cu_masked_stream(device, first_cu, n_cus, total_cus=None):
     if rc != 0 or not st.value:
         raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
     _masked_streams[key] = torch.cuda.ExternalStream(st.value, device=device)
+    from . import fused
+    fused.register_stream_cus(_masked_streams[key], n_cus)       # (launches whose workgroups wait for each other size their grid by it)
     return _masked_streams[key]
 
 
@@ -410,9 +435,40 @@ class PipelinedIteration(object):
             for b in self.buckets:
                 b.flat.copy_(optimizer.bucket.flat)
         self.i = 0
+        self._coop_wg = None
+        self._coop_master = bool(getattr(player.model, "coop_step", False))     # (the master's switch: ATR_COOP_STEP / A-B runs)
+        self._set_coop_grid()
         for k in range(2):
             self._capture(self.mode0, k)
         torch.cuda.synchronize(dev)
+
+    def _set_coop_grid(self):
+        """The cooperative rollout step (model._act_step -> fused.coop_env_step) launches one workgroup per CU of the stream it
+        RUNS on, and its workgroups wait for each other at barriers: every one of them must be resident at the same time. That
+        holds when the rollout has its CUs to itself — a CU-masked rollout stream (the partition tune_streams tries), or the
+        one-stream (serial) form — and NOT on a chip shared with the learner's stream, whose long-lived workgroups hold CUs the
+        step's last workgroups are waiting for (measured: barrier time-outs). So: on a masked rollout stream the replicas are
+        told its CU count (a rollout graph captured for the whole chip must not be replayed on half of it), on a shared pair
+        they keep the four-launch step. Returns True when the setting changed (graphs captured earlier are then stale)."""
+        from . import fused
+        masked = int(self.sR.cuda_stream) in fused._stream_cus
+        wg = fused.stream_cus(self.dev, self.sR) if (masked or self.serial) else 0
+        changed = wg != self._coop_wg
+        self._coop_wg = wg
+        for a in self.players:
+            a.model.coop_workgroups = wg if wg else None
+            a.model.coop_step = bool(wg) and self._coop_master
+        return changed
+
+    def _use_streams(self, sR, sL):
+        """Switch the stream pair; rollout graphs whose cooperative step was sized for another CU count are captured again."""
+        self.finish()
+        torch.cuda.synchronize(self.dev)
+        self.sR, self.sL = sR, sL
+        if self._set_coop_grid() and self._coop_master:
+            for (mode, k) in list(self.graphs.keys()):
+                self._capture(mode, k)
+            torch.cuda.synchronize(self.dev)
 
     def _bind_carry(self, p):
         p.state, p.hxs, p.cxs = self.carry["state"], self.carry["hxs"], self.carry["cxs"]
@@ -527,6 +583,29 @@ class PipelinedIteration(object):
                 out.append(t)
         return out
 
+    def burn_in(self, iters, mode=None):
+        """GraphedIteration.burn_in for this schedule: `iters` (rounded up to whole phase pairs) iterations whose updates are
+        discarded — master weights, optimizer state, both replicas' weight copies, the phase counter and the step count are
+        restored; the env shard and the carried LSTM state move on. tune_streams() has this effect as well (its trial
+        iterations are rolled back the same way), which is why the two-stream schedule looked like the better LEARNER in
+        round 4's seed table: it was the only one whose envs had drifted apart before training began."""
+        if iters <= 0:
+            return
+        self.finish()
+        torch.cuda.synchronize(self.dev)
+        tensors = self._schedule_tensors()
+        saved = [t.clone() for t in tensors]
+        i0, n0 = self.i, self.master.n_steps
+        for _ in range(int(iters) + (int(iters) & 1)):
+            self.run(mode)
+        self.finish()
+        torch.cuda.synchronize(self.dev)
+        with torch.no_grad():
+            for t, v in zip(tensors, saved):
+                t.copy_(v)
+        self.i, self.master.n_steps = i0, n0
+        torch.cuda.synchronize(self.dev)
+
     def tune_streams(self, candidates=4, iters=8, partitions=("half",), keep_updates=False):
         """Pick the stream pair the two chains overlap best on. Two things are not in the application's hands and are settled
         by trial — `iters` iterations of the schedule per candidate, timed on the host clock, the fastest kept:
@@ -550,11 +629,24 @@ class PipelinedIteration(object):
         candidates are kept only if every rank has them, all-reduce MIN) and must KEEP the same pair (the per-candidate times
         are all-reduced MAX — an iteration is as slow as its slowest rank — before the argmin).
         Returns [(ms per iteration, chosen, label)] per candidate."""
-        if self.serial:
-            return []
         import time as _time
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi:
+            # Every trial below holds collectives, so the ranks must agree on what they are about to do BEFORE any of them
+            # leaves: a rank with serial=True (or another forced CU split, another candidate count — per-rank environment
+            # variables) would return here while the others wait in an all-reduce for ever.
+            cfg = torch.tensor([1 if self.serial else 0, int(self.cu_split), int(candidates), int(iters), len(partitions)],
+                               dtype=torch.int64, device=self.dev)
+            lo, hi = cfg.clone(), cfg.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                raise RuntimeError("PipelinedIteration.tune_streams: ranks disagree on (serial, cu_split, candidates, iters, "
+                                   "partitions): min %s max %s — set ATR_PIPE_CU_SPLIT / the schedule identically on every rank"
+                                   % (lo.tolist(), hi.tolist()))
+        if self.serial:
+            return []
         pairs = [(self.sR, self.sL, "as constructed")]
         if not self.cu_split:
             pairs += [(self.sR, torch.cuda.Stream(device=self.dev), "learner stream %d" % (c + 1)) for c in range(candidates)]
@@ -592,9 +684,7 @@ class PipelinedIteration(object):
         times = [float("inf")] * len(pairs)
         for _pass in range(2):
             for j, (sR, sL, label) in enumerate(pairs):
-                self.finish()
-                torch.cuda.synchronize(self.dev)
-                self.sR, self.sL = sR, sL
+                self._use_streams(sR, sL)
                 for _ in range(2):
                     self.run()
                 self.finish()
@@ -612,7 +702,8 @@ class PipelinedIteration(object):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             times = tt.tolist()
         best = min(range(len(pairs)), key=lambda j: times[j])
-        self.sR, self.sL, self.stream_choice = pairs[best][0], pairs[best][1], pairs[best][2]
+        self._use_streams(pairs[best][0], pairs[best][1])
+        self.stream_choice = pairs[best][2]
         if saved is not None:
             with torch.no_grad():
                 for t, v in zip(tensors, saved):

@@ -125,6 +125,13 @@ def init_ranks(a):
     return world, rank, local_rank, info
 
 
+def _lt_status():
+    """Where the kernel choices of the direct hipBLASLt calls (csrc/lt_gemm.cpp) come from in THIS process: the validated record
+    (lt_tuning_gfx950.json made with the loaded library build) or timing at first use."""
+    from active_tracking_rl_amd import fused
+    return fused.lt_tuning_status()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -658,7 +665,8 @@ def main():
                                % (a.env, n, world, a.network),
                    "global_envs": n_total, "rollout": T, "hipgraph": graphed,
                    "obs": "u8 (t2d_step_u8 -> atr_stem_*_u8)" if getattr(player.env, "obs_u8", False) else "f32",
-                   "gemm_algos": "TunableOp picks from tunableop_gfx950.csv" if tuned else "library default", "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},
+                   "gemm_algos": {"torch": "TunableOp picks from tunableop_gfx950.csv" if tuned else "library default",
+                                  "hipblaslt_direct": _lt_status()}, "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},
         "roofline": roofline,
         "env_only": {"value": n * world / (eo_us * 1e-6), "unit": "env steps/s", "us_per_launch": eo_us,
                      "note": "same kernel, on-device random actions, one launch per batched step, per-rank x ranks",

@@ -136,6 +136,38 @@ struct t2d_handle;
 int atr_act_env_step(struct t2d_handle *env, const atr_act_step *args, void *obs, int obs_is_u8, float *rew,
                      unsigned char *done, void *stream);
 
+/* The small-shard rollout step after the stem as ONE launch (csrc/track2d_hip.hip: k_coop_step; csrc/coop_gemm.h) — what
+ * train.py:81-88 -> player_util.py:44-67 -> model.py:238-265 of the reference do between the conv stem and the next
+ * observation: CNN_maze's fc + ReLU for both players (perception.py:81,90), both GEMMs of nn.LSTMCell for both players
+ * (model.py:110,137,172,203) as one product over [features | k h_prev] rows, then atr_act_env_step's cells + heads + draws +
+ * env step (Track1v1Env.step, track_1v1.py:71-127). Every XCD of the chip owns one eighth of the envs end to end; its
+ * workgroups exchange the layers' activations through the L2 they share and meet at two barriers that live in that L2
+ * (no chip-wide fence): 2 launches per env step (stem, this) instead of 4.
+ *   y[p] [N, kfc[p]] (row stride ldy[p]): player p's stem output; fc_w[p] [F, kfc[p]], fc_b[p] [F];
+ *   fh: this step's rows — player p at fh + p * fh_pstride, row stride fh_ld = F + R: the fc features are written into
+ *       columns [0, F), columns [F, F + R) already hold k h_prev (written by the previous step through act->hm_out);
+ *   w_cat[p] [4R, F + R] = [W_ih | W_hh]; gates [2, N, 4R] scratch; workgroups: the grid size = the number of CUs the
+ *   stream may use (a multiple of 8; ALL of them must be able to be resident at once — the barriers spin).
+ * `act`: as for atr_act_env_step with bias[p] = b_ih + b_hh and hm_out set; act->ig / hg are ignored. N must be a multiple
+ * of 128 and small enough for the grid (N <= 2048 with 256 workgroups). Returns 0 or a T2D_ERR_* code (t2d_last_error);
+ * a placement or barrier failure on the device raises bits 1-3 of the handle's fault word (t2d_get_faults). */
+typedef struct atr_coop_step {
+    const float *y[2];
+    const float *fc_w[2];
+    const float *fc_b[2];
+    const float *w_cat[2];
+    long long ldy[2];
+    int kfc[2];
+    float *fh;
+    float *gates;
+    long long fh_pstride, fh_ld;
+    int F;
+    int workgroups;
+    void *probe;              /* NULL, or u64 [workgroups][8]: clock stamps at the kernel's phase boundaries (tools/coop_step_timeline.py) */
+} atr_coop_step;
+int atr_coop_env_step(struct t2d_handle *env, const atr_act_step *act, const atr_coop_step *coop, void *obs, int obs_is_u8,
+                      float *rew, unsigned char *done, void *stream);
+
 /* The rollout step's two small GEMM pairs as ONE launch each, for small row counts (csrc/pair_gemm_hip.hip; f32 MFMA):
  *     C[p] = act( A1[p] W1[p]^T [+ (k A2[p]) W2[p]^T] + bias[p] ),  p = 0, 1 (the two players), k[m] = (done[m] == 0)
  * A1[p] [M, k1[p]] (row stride lda1[p] floats), W1[p] [N, k1[p]] (nn.Linear layout), optional second term A2[p] [M, k2[p]],
@@ -322,11 +354,11 @@ typedef struct atr_gemm_tn_problem {
     long long ld1, ld2;      /* row strides of x1 / x2 in floats (0 = dense: M / N); multiples of 4 */
 } atr_gemm_tn_problem;
 long long atr_gemm_tn_grouped_workspace_floats(const atr_gemm_tn_problem *problems, int count, long long K);
-/* Co-run mode of the weight-gradient kernel, process-wide, returns the previous setting: while on, launches (and the workspace
+/* Co-run mode of the weight-gradient kernel, a setting of the CALLING THREAD, returns the previous setting: while on, launches (and the workspace
  * sizes that go with them) are planned for ONE workgroup per CU, so that a chain of short kernels on another stream keeps
  * running beside them (the pipelined schedule captures its learner graphs in this mode; results stay a fixed-order sum, the
  * K split differs from the default mode's). Not a per-stream setting: set it around the launches (or the graph capture) that
- * want it, from the thread that issues them. */
+ * want it, from the thread that issues them; launches and workspace-size queries of other threads are not affected. */
 int atr_gemm_tn_set_corun(int on);
 int atr_gemm_tn_grouped(const atr_gemm_tn_problem *problems, int count, long long K, float *workspace, void *stream);
 

@@ -15,8 +15,28 @@ from __future__ import print_function, division
 import os
 os.environ["OMP_NUM_THREADS"] = "1"
 import argparse
+import sys
 import time
 from datetime import datetime
+
+
+def _wants_two_hw_queues(argv):
+    """The pipelined schedule's CU partition (train.PipelinedIteration.tune_streams) gives each chain a CU-masked stream with a
+    hardware queue of its own; iterations slow down 2-3x once a process owns more than four hardware queues (measured), so the
+    ordinary streams share two. The HIP runtime reads GPU_MAX_HW_QUEUES when it initialises: the decision is taken from the raw
+    command line HERE, before torch (or anything else that may touch the runtime at import time) is imported — and only for
+    the one configuration that builds a PipelinedIteration on a single GPU. (N > 1 keeps the runtime default: measured with
+    a 1-rank RCCL group, profiles/r04_multirank_*.)"""
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument('--schedule', default='pipelined')
+    pre.add_argument('--no-graph', action='store_true')
+    known, _ = pre.parse_known_args(argv)
+    return (known.schedule == 'pipelined' and not known.no_graph and int(os.environ.get("WORLD_SIZE", "1")) == 1
+            and "GPU_MAX_HW_QUEUES" not in os.environ)
+
+
+if __name__ == '__main__' and _wants_two_hw_queues(sys.argv[1:]):
+    os.environ["GPU_MAX_HW_QUEUES"] = "2"
 
 import torch
 import torch.distributed as dist
@@ -73,6 +93,10 @@ parser.add_argument('--schedule', choices=('pipelined', 'synchronous'), default=
 parser.add_argument('--log-every', type=int, default=100, metavar='LE',
                     help='training iterations between train/* scalar records (each record joins both streams of the pipelined '
                          'schedule and reads ~10 scalars back: keep it well above 1)')
+parser.add_argument('--burn-in', type=int, default=150, metavar='BI',
+                    help='iterations before training whose updates are discarded: the envs of a fresh shard all start an episode '
+                         'at step 0 together, and the first updates would fit that one phase (0: start synchronised, as a single '
+                         'reference worker does)')
 parser.add_argument('--adv-step', type=int, default=None, metavar='AS',
                     help="--train-mode 2 only: iterations the TARGET trains before the evaluator hands back to the tracker "
                          "(test.py:88-91 of the reference reads args.adv_step, which its own main.py never defines)")
@@ -85,12 +109,7 @@ if __name__ == '__main__':
     if args.max_grad_norm is not None and args.max_grad_norm <= 0:
         parser.error("--max-grad-norm must be positive")
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # The pipelined schedule's CU partition (train.PipelinedIteration.tune_streams) gives each chain a CU-masked stream with a
-    # hardware queue of its own; iterations slow down 2-3x once a process owns more than four hardware queues (measured), so
-    # the ordinary streams share two. Read by the HIP runtime at initialisation, i.e. set here, before anything touches the
-    # GPU — and only for the schedule that needs it. (N > 1: measured with a 1-rank RCCL group, profiles/r04_multirank_*.)
-    if args.schedule == 'pipelined' and not args.no_graph and world == 1 and "GPU_MAX_HW_QUEUES" not in os.environ:
-        os.environ["GPU_MAX_HW_QUEUES"] = "2"
+    # (GPU_MAX_HW_QUEUES for the single-GPU pipelined schedule was decided before torch was imported: _wants_two_hw_queues)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(args.gpu_ids[0])))
     if world > 1:
@@ -121,6 +140,7 @@ if __name__ == '__main__':
             sched.tune_streams()
         else:
             sched = GraphedIteration(player, optimizer, args, mode=first_mode)
+        sched.burn_in(args.burn_in, first_mode)
     step = sched.run if sched is not None else None
     drain = getattr(sched, "finish", lambda: None)          # pipelined: both streams joined before the host reads anything
     it = 0

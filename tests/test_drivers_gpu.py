@@ -157,26 +157,34 @@ def test_full_observation_env_trains():
     player.env.close()
 
 
-@pytest.mark.parametrize("train_mode,cat_gemm", [(-1, False), (0, False), (1, False), (-1, True), (1, True)])
-def test_cached_rollout_learner_matches_the_recompute_learner(train_mode, cat_gemm):
+@pytest.mark.parametrize("train_mode,path", [(-1, "pair"), (0, "pair"), (1, "pair"), (-1, "cat"), (1, "cat"), (-1, "coop"),
+                                             (0, "coop"), (-1, "coop512")])
+def test_cached_rollout_learner_matches_the_recompute_learner(train_mode, path):
     """Actor/learner with the rollout cache (forward evaluated once, in the rollout: model.act_cached +
     forward_sequence_cached) against the recompute learner (forward_sequence) on the SAME rollout: loss terms and
     every parameter gradient agree to fp32 round-off (different GEMM shapes -> different summation orders). Train-mode
     0 / 1: the cached learner does not back-propagate the untrained player's recurrence — its parameters get no (or an
-    all-zero) gradient from either learner. cat_gemm: the large-batch form of the rollout step (fc + ReLU written into
-    [features | k h_prev] rows by atr_linear, both LSTMCell GEMMs as one K = 384 product, the masked hidden rows written by
-    k_act_step) forced at a small batch — the learner then reads the features in place, strided (atr_relu_backward_ld,
-    atr_embed_add_ld, the grouped weight-gradient launch with a row stride)."""
+    all-zero) gradient from either learner. The rollout step's three forms: "pair" (small batch: fc pair + gate pair kernels),
+    "cat" (the large-batch form forced at a small batch: fc + ReLU written into [features | k h_prev] rows by atr_linear, both
+    LSTMCell GEMMs as one K = 384 product, the masked hidden rows written by k_act_step; the learner then reads the features
+    in place, strided: atr_relu_backward_ld, atr_embed_add_ld, the grouped weight-gradient launch with a row stride) and
+    "coop" (the strong-scaling shards' ONE launch after the stem, k_coop_step: its fc and gate tiles come from
+    csrc/coop_gemm.h — this comparison against plain PyTorch fp32 layers is that kernel's policy-half check)."""
     from active_tracking_rl_amd.train import default_args, make_player, rollout
-    args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=1024 if cat_gemm else 256, num_steps=6,
+    cat_gemm = path != "pair"
+    n_envs = {"pair": 256, "cat": 1024, "coop": 1024, "coop512": 512}[path]
+    args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=n_envs, num_steps=6,
                         network="tat-maze-lstm", seed=11, train_mode=train_mode)
     args.gpu_ids = [0]
     player, optimizer = make_player(args, torch.device("cuda:0"), 0, 1)
     assert player.cache_rollout
-    if cat_gemm:
+    player.model.coop_step = path.startswith("coop")        # (off by default: the four-launch step won the measurement)
+    if path == "cat":
         player.model.pair_gemm_max_rows = 0
     rollout(player, args.num_steps, fast=True)
     assert player._cache is not None and (player._cache.fh_all is not None) == cat_gemm
+    assert bool(player.model.coop_step_seen) == path.startswith("coop")
+    assert player.env.core.faults() == 0
     if cat_gemm:      # the rows the one-GEMM path reads: features next to the PREVIOUS step's hidden row, masked by its done flag
         cch, T_ = player._cache, args.num_steps
         keep = (player._buf[2] == 0).float()                                          # [T, N]
@@ -261,6 +269,36 @@ def test_one_gemm_cell_refuses_a_step_without_the_fused_env_step():
     with pytest.raises(RuntimeError, match="env step inside k_act_step"):
         player.model.act_cached(player.state, cache, 0, None, env_out=None)
     player.model._sampler.end_block()
+    player.env.close()
+
+
+@pytest.mark.parametrize("schedule", ["synchronous", "pipelined"])
+def test_burn_in_moves_the_envs_and_nothing_else(schedule):
+    """burn_in(k): k iterations whose updates are discarded (what decorrelates the episode phases of a fresh shard before
+    training starts — profiles/r05_learning_seeds_*.txt): weights, optimizer state, replica copies, phase and step counters as
+    before; the env shard (episode clocks) has moved on; the next real iteration trains."""
+    from active_tracking_rl_amd.train import GraphedIteration, PipelinedIteration, default_args, make_player
+    dev = torch.device("cuda:0")
+    args = default_args(env="Track2D-BlockPartialRam-v0", network="maze-lstm", aux="none", train_mode=0, num_envs=256, seed=5)
+    player, opt = make_player(args, dev)
+    it = PipelinedIteration(player, opt, args, serial=True) if schedule == "pipelined" else GraphedIteration(player, opt, args)
+    tensors = it._schedule_tensors() if schedule == "pipelined" else it._optimizer_tensors()
+    before = [t.clone() for t in tensors]
+    n0, i0 = player.n_steps, getattr(it, "i", 0)
+    t0 = player.env.core.get_state()["t"].copy() if hasattr(player.env.core, "get_state") else None
+    it.burn_in(7)
+    torch.cuda.synchronize()
+    for t, v in zip(tensors, before):
+        assert torch.equal(t, v)
+    assert player.n_steps == n0 and getattr(it, "i", 0) == i0
+    if t0 is not None:
+        assert not np.array_equal(player.env.core.get_state()["t"], t0)       # the episode clocks have moved
+    it.run()
+    if schedule == "pipelined":
+        it.run()
+        it.finish()
+    torch.cuda.synchronize()
+    assert not torch.equal(opt.bucket.flat, before[0])
     player.env.close()
 
 

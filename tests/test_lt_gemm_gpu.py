@@ -213,7 +213,7 @@ def test_recorded_choice_is_checked_against_the_loaded_library():
     from active_tracking_rl_amd import fused
     # (shapes no other test or the tuning file uses: the plans below start from nothing)
     a, w, b, rows, ws = _problem(m=608)
-    want = F.relu(a @ w.t() + b)
+    want = torch.relu(torch.nn.functional.linear(a.double(), w.double(), b.double())).float()
     fused.linear_lt_set_choice(a, w, rows[:, :256], index=100000, bias=b, relu=True, workspace=ws)
     fused.linear_lt(a, w, rows[:, :256], bias=b, relu=True, workspace=ws)
     info = fused.linear_lt_info(a, w, rows[:, :256], bias=b, relu=True, workspace=ws)

@@ -172,6 +172,49 @@ def test_pipelined_two_stream_replays_match_the_oracle(name):
         case.close()
 
 
+@pytest.mark.parametrize("name", ["pzr512_rank7", "ram1024", "mazenav1024_rank7", "pzr1024_timelimit37"])
+def test_cooperative_two_launch_step_matches_the_oracle(name):
+    """The strong-scaling shards with the rollout step as TWO launches (stem + k_coop_step: fc pair, LSTMCell GEMM, cells, heads,
+    draws and env step in one launch whose workgroups cooperate per XCD — off by default, ATR_COOP_STEP=1): replayed synchronous
+    iterations against the oracle, and no placement / barrier / shape fault raised on the device."""
+    case, min_done = _case(name)
+    try:
+        case.player.model.coop_step = True
+        _synchronous(case)
+        assert case.player.model.coop_step_seen
+        assert case.env.core.faults() == 0
+        case.final(min_done)
+    finally:
+        case.close()
+
+
+def test_cooperative_step_on_its_own_half_of_the_cus_matches_the_oracle_512():
+    """... and under the pipelined schedule on the CU-partitioned stream pair (the rollout's 128 CUs to itself: the only form of
+    that schedule in which the cooperative step may run — train.PipelinedIteration._set_coop_grid)."""
+    from active_tracking_rl_amd.train import PipelinedIteration, cu_masked_stream
+    case, min_done = _case("pzr512_rank7")
+    try:
+        case.player.model.coop_step = True
+        case.eager()
+        it = PipelinedIteration(case.player, case.opt, case.args, warmup=0)
+        case.replicas = it.players
+        try:
+            it._use_streams(cu_masked_stream(case.dev, 128, 128), cu_masked_stream(case.dev, 0, 128))
+        except Exception as ex:
+            pytest.skip("CU-masked streams unavailable: %r" % (ex,))
+        assert all(p.model.coop_step and p.model.coop_workgroups == 128 for p in it.players)
+        for j in range(4):
+            it.run()
+            it.run()
+            it.finish()
+            case.check(it.players[0], "pipelined rollout %d" % (2 * j))
+            case.check(it.players[1], "pipelined rollout %d" % (2 * j + 1))
+        assert all(p.model.coop_step_seen for p in it.players) and case.env.core.faults() == 0
+        case.final(min_done)
+    finally:
+        case.close()
+
+
 def test_pipelined_cu_partitioned_streams_match_the_oracle_512():
     """The strong-scaling shard on the stream pair tune_streams() picks there: each chain on its own half of the CUs."""
     case, min_done = _case("pzr512_rank7")

@@ -2,7 +2,7 @@
 Library built with -DT2D_EXP=9 (T2D_LIB_PATH=scratch_exp/libexp9.so): s_memtime stamps of wave 0 of every generating
 workgroup, left in the slot's spare tile words: 6 entry | 0 start | 1 map generated | 2 free-cell index | 3 spawns / goals |
 4 front done | 7 the two queued goals drawn | 8 own flood done (Navigator.reset's plan) | 9 all three floods done (barrier) |
-5 end (validated, scalars stored). 100 ticks = 1 us."""
+5 end (validated, scalars stored). Ticks are s_memtime counts = SHADER-CLOCK cycles on this part (348 k ticks inside a 206 us kernel: ~1.7 GHz under this load), not the 100 MHz reference clock."""
 import ctypes as C
 import sys
 
@@ -18,7 +18,7 @@ out = (env.reset(), torch.empty((n, 2), device="cuda"), torch.empty((n,), dtype=
 env.L.t2d_debug_tile_words.argtypes = [C.c_void_p, C.c_void_p]
 order = [6, 0, 1, 2, 3, 4, 7, 8, 9, 5]
 names = ["entry->start", "map", "free index", "spawns/goals", "front end", "2 goal draws", "own flood", "wait floods", "finish"]
-print("%s N=%d: per generator pass, wave 0 of the generating workgroups, in s_memtime ticks (100 / us)" % (env_id, n))
+print("%s N=%d: per generator pass, wave 0 of the generating workgroups, in s_memtime ticks (shader-clock cycles, ~1.7-2.1 per ns)" % (env_id, n))
 for rep in range(10):
     env.step_random(20, 1, out)                      # one generator cycle
     torch.cuda.synchronize()

@@ -25,11 +25,17 @@ ap.add_argument("--network", default="maze-lstm")
 ap.add_argument("--train-mode", type=int, default=0)
 ap.add_argument("--seeds", type=int, nargs="+", default=[1, 2, 3, 4, 5, 6, 7, 8])
 ap.add_argument("--schedules", nargs="+", default=["synchronous", "pipelined", "pipelined-serial"])
+ap.add_argument("--burn-in", type=int, default=0,
+                help="iterations of the schedule run BEFORE training whose updates are rolled back (weights, optimizer state, counters "
+                     "restored): the env shard keeps advancing under the initial policy, so the envs' episode phases drift apart — "
+                     "what PipelinedIteration.tune_streams() does as a side effect (2 passes x ~7 stream pairs x 10 iterations)")
+ap.add_argument("--no-tune", action="store_true", help="pipelined: skip tune_streams() (and with it its ~140 untrained iterations)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 print("# %s  %d envs  %s  train-mode %d  %d iterations; mean tracker (target) reward per env step over the 100 iterations before "
       "each checkpoint" % (a.env, a.num_envs, a.network, a.train_mode, a.iters), flush=True)
 marks = list(range(a.every, a.iters + 1, a.every))
+print("# burn-in %d untrained iterations%s" % (a.burn_in, "; pipelined without tune_streams()" if a.no_tune else ""), flush=True)
 print("# schedule seed " + " ".join("@%d" % m for m in marks), flush=True)
 final = {}
 for sched in a.schedules:
@@ -40,10 +46,28 @@ for sched in a.schedules:
         pipelined = sched != "synchronous"
         if pipelined:
             it = PipelinedIteration(player, opt, args, serial=(sched == "pipelined-serial"))
-            if not it.serial:
+            if not it.serial and not a.no_tune:
                 it.tune_streams()
         else:
             it = GraphedIteration(player, opt, args)
+        if a.burn_in > 0:
+            tensors = it._schedule_tensors() if pipelined else it._optimizer_tensors()
+            saved = [t.clone() for t in tensors]
+            i0 = getattr(it, "i", 0)
+            n0 = (it.master if pipelined else player).n_steps
+            for _ in range(a.burn_in + (a.burn_in & 1)):
+                it.run()
+            if pipelined:
+                it.finish()
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for t, v in zip(tensors, saved):
+                    t.copy_(v)
+            if pipelined:
+                it.i, it.master.n_steps = i0, n0
+            else:
+                player.n_steps = n0
+            torch.cuda.synchronize()
         rew_acc = torch.zeros(2, device=dev)
         row, t0 = [], time.time()
         for i in range(1, a.iters + 1):
