@@ -259,39 +259,44 @@ __device__ __forceinline__ bool coop_run(CoopLds &L, int n_units, int tid, CoopP
 #undef COOP_WAVE_SYNC
 #undef COOP_DUMP
 #undef COOP_TRIP
-    // who contributes to which unit's tile: wave w's segment sg belongs to unit first[w] + sg. One thread per unit lists the
-    // partial-tile slots in wave order (= ascending K); every thread then sums its element with unconditional, batched LDS reads
+    // wave w's segment sg holds a piece of unit first[w] + sg. A quarter of the workgroup per unit, four columns per thread:
+    // the pieces are summed in wave order (= ascending K) with unconditional 16-byte LDS reads (a wave that holds no piece of
+    // the unit reads its slot 0 and the value is dropped), then bias, activation and one 16-byte store per thread
     if (l == 0) { L.first_unit[wave] = P.first; L.n_seg[wave] = (lo < hi && P.ok) ? P.n_seg : 0; }
     L.bias[tid] = P.bias;
     if (probe && tid == 0) probe[2] = wall_clock64();
     __syncthreads();
     if (probe && tid == 0) probe[3] = wall_clock64();
-    if (tid < n_units) {
-        int cnt = 0;
-        for (int w = 0; w < kCoopWaves; w++) {
-            const int sg = tid - L.first_unit[w];
-            if (sg >= 0 && sg < L.n_seg[w]) L.contrib[tid * kCoopWaves + cnt++] = w * kCoopMaxSeg + sg;
-        }
-        L.n_contrib[tid] = cnt;
-    }
-    __syncthreads();
-    const int orow = tid >> 5, ocol = tid & 31;
+    int fu[kCoopWaves], ns[kCoopWaves];
+#pragma unroll
+    for (int w = 0; w < kCoopWaves; w++) { fu[w] = L.first_unit[w]; ns[w] = L.n_seg[w]; }
+    const int e = tid & 127, orow = e >> 3, oc4 = (e & 7) * 4;
 #pragma unroll 1
-    for (int u = 0; u < n_units; u++) {
-        const int cnt = L.n_contrib[u];
-        int sl[kCoopWaves];
+    for (int u = tid >> 7; u < n_units; u += 4) {
+        float4 pv[kCoopWaves];
+        bool has[kCoopWaves];
 #pragma unroll
-        for (int c = 0; c < kCoopWaves; c++) sl[c] = L.contrib[u * kCoopWaves + min(c, max(cnt - 1, 0))];
-        float pv[kCoopWaves];
+        for (int w = 0; w < kCoopWaves; w++) {
+            const int sg = u - fu[w];
+            has[w] = sg >= 0 && sg < ns[w];
+            pv[w] = coop_ld4(L.part + (size_t)(w * kCoopMaxSeg + (has[w] ? sg : 0)) * kCoopTile + orow * 32 + oc4);
+        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool any = false;
 #pragma unroll
-        for (int c = 0; c < kCoopWaves; c++) pv[c] = L.part[(size_t)sl[c] * kCoopTile + tid];
-        float v = 0.f;
-#pragma unroll
-        for (int c = 0; c < kCoopWaves; c++) v += c < cnt ? pv[c] : 0.f;
-        v += L.bias[u * 32 + ocol];
+        for (int w = 0; w < kCoopWaves; w++) {
+            v.x += has[w] ? pv[w].x : 0.f; v.y += has[w] ? pv[w].y : 0.f; v.z += has[w] ? pv[w].z : 0.f; v.w += has[w] ? pv[w].w : 0.f;
+            any = any || has[w];
+        }
+        const float4 b = coop_ld4(L.bias + u * 32 + oc4);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         const CoopUnit &U = L.units[u];
-        if (U.relu) v = fmaxf(v, 0.f);
-        if (orow < U.rows_valid && cnt > 0) U.c[(size_t)orow * U.ldc + ocol] = v;
+        if (U.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (orow < U.rows_valid && any) {
+            typedef float __attribute__((address_space(1))) *gout;
+            coop_v4f o = {v.x, v.y, v.z, v.w};
+            *reinterpret_cast<coop_v4f __attribute__((address_space(1))) *>((gout)(U.c + (size_t)orow * U.ldc + oc4)) = o;
+        }
     }
     if (probe && tid == 0) probe[4] = wall_clock64();
     return P.ok;

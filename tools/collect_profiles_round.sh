@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round 4 evidence, regenerated under gpurun_out/r04/ on the GPU box (tools/publish_profiles_r04.sh copies what is to be judged
-# to profiles/):   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/collect_profiles_r04.sh'
+# A round's evidence, regenerated under gpurun_out/<tag>/ on the GPU box (tools/publish_profiles_round.sh <tag> copies what is to
+# be judged to profiles/):   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/collect_profiles_round.sh r05'
 # PMC passes are separate runs with no trace domains besides the counter collection (pool rule).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O
+TAG=${1:-r05}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 export PYTHONPATH=$R GPU_MAX_HW_QUEUES=2; cd /tmp; export TMPDIR=/tmp
 # --- the bench line (driver flags and defaults), and the same command under the profiler
 timeout 1200 python $R/bench.py > $O/bench.json 2> $O/bench.err
@@ -30,7 +30,7 @@ mkdir -p $R/scratch_exp; (cd $R/active_tracking_rl_amd/csrc && /opt/rocm/bin/hip
     -o $R/scratch_exp/libtnprobe.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
 [ -f $R/scratch_exp/libtnprobe.so ] && (cd $R && T2D_LIB_PATH=scratch_exp/libtnprobe.so timeout 300 python tools/gemm_tn_timeline.py 4096 1536 > $O/gemm_tn_timeline.txt 2>&1)
 # --- multi-rank settings under a 1-rank RCCL group
-(cd $R && bash tools/multirank_probe.sh > /dev/null 2>&1; cp gpurun_out/r04_multirank_1gpu.txt $O/multirank_1gpu.txt)
+(cd $R && bash tools/multirank_probe.sh > /dev/null 2>&1; cp gpurun_out/r04_multirank_1gpu.txt $O/multirank_1gpu.txt 2>/dev/null)
 # --- Nav / Maze: generator pass (kernel stats at 1024 / 8192 random-policy envs), its timeline (probe build, if present)
 for n in 1024 8192; do
   rm -rf /tmp/p_nav; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_nav -- python $R/tools/env_only_bench.py --env Track2D-MazePartialNav-v0 --n $n --steps 600 --warmup 100 > $O/nav_env_only_$n.txt 2>/dev/null
@@ -53,12 +53,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_pmc; (cd $R && ACT_BENCH_MODE=one timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_pmc -- python tools/act_step_bench.py 4096 > /dev/null 2>&1)
   python $R/tools/summarize_prof.py pmc /tmp/p_pmc k_act_step > $O/act_step_pmc_${c}_4096.txt
 done
+# --- round 5: the two-launch (cooperative) rollout step — its phase timeline and the shard sizes with it on / off
+for n in 512 1024; do (cd $R && timeout 300 python tools/coop_step_timeline.py $n > $O/coop_step_timeline_$n.txt 2>&1); done
+(cd $R && timeout 600 python tools/shard_sweep.py 512 1024 2048 4096 > $O/shard_sweep.txt 2>&1)
+(cd $R && ATR_COOP_STEP=1 timeout 600 python tools/shard_sweep.py 512 1024 > $O/shard_sweep_coop_step.txt 2>&1)
+(cd $R && timeout 120 scratch_exp/xcd_barrier > $O/xcd_barrier_microbench.txt 2>&1)
 # --- learning checks under the default (pipelined) schedule, and a main.py run with the evaluator's scalars
 (cd $R && timeout 600 python tools/learning_check.py --iters 1500 > $O/learning_check_ram_tracker.txt 2>&1)
 (cd $R && timeout 600 python tools/learning_check.py --env Track2D-BlockPartialPZR-v0 --network tat-maze-lstm --train-mode -1 --iters 1500 > $O/learning_check_pzr_dueling.txt 2>&1)
 (cd $R && timeout 600 python tools/learning_check.py --env Track2D-MazePartialNav-v0 --num-envs 1024 --iters 1500 > $O/learning_check_nav_tracker.txt 2>&1)
 rm -rf $O/main_logs; (cd $R && timeout 900 python main.py --shared-optimizer --split --train-mode -1 --env Track2D-BlockPartialPZR-v0 --num-envs 4096 \
-    --max-step 1000 --test-every 250 --log-dir gpurun_out/r04/main_logs/ > $O/main_py_run.txt 2>&1)
+    --max-step 1000 --test-every 250 --log-dir gpurun_out/$TAG/main_logs/ > $O/main_py_run.txt 2>&1)
 cp $(ls -d $O/main_logs/*/*/ | head -1)logger $O/main_py_logger.txt 2>/dev/null
 tail -30 $(ls $O/main_logs/*/*/Agent:0/scalars.jsonl | head -1) > $O/main_py_scalars_tail.txt 2>/dev/null
 tail -12 $(ls $O/main_logs/*/*/Test/scalars.jsonl | head -1) > $O/main_py_test_scalars_tail.txt 2>/dev/null

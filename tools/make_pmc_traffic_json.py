@@ -1,6 +1,6 @@
-"""profiles/r0N_pmc_traffic.json from the per-counter PMC summaries in profiles/ (tools/publish_profiles_r0N.sh runs this):
+"""profiles/r0N_pmc_traffic.json from the per-counter PMC summaries in profiles/ (tools/publish_profiles_round.sh runs this):
 traffic per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024 — FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies
-128-B read requests at 64 B).   python tools/make_pmc_traffic_json.py [r03 | r04]"""
+128-B read requests at 64 B).   python tools/make_pmc_traffic_json.py [r03 | r04 | r05]"""
 import json
 import os
 import re
@@ -11,10 +11,13 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 B_STEP = 1723            # algorithmic bytes per env-step of k_step2 with f32 observations
 # everything k_act_step<OBS_U8> moves per env-step: r03 = ig + hg given separately; r04 = one gate tensor + the masked hidden
 # rows for the next step's GEMM (bench.py: policy_state_included)
-B_ACT = {"r03": 16086, "r04": 13014}[RND]
-ACT_KERNEL = {"r03": "t2d::k_act_step<OBS_U8> (ig + hg given separately: the 4096-env timed region of round 3)",
+B_ACT = {"r03": 16086}.get(RND, 13014)
+_ACT_KERNEL = {"r03": "t2d::k_act_step<OBS_U8> (ig + hg given separately: the 4096-env timed region of round 3)",
               "r04": "t2d::k_act_step<OBS_U8> (one gate tensor, bias added in the kernel, masked hidden rows written: the timed "
-                     "region from 768 envs up since round 4)"}[RND]
+                     "region from 768 envs up since round 4)"}
+
+
+ACT_KERNEL = _ACT_KERNEL.get(RND, _ACT_KERNEL["r04"])
 
 
 def mean(name):
@@ -30,7 +33,7 @@ f, w, t, a = entry(4096, "env_only", B_STEP)
 out = {"formula": "(2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024 — FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
                   "read requests at 64 B)",
        "source": "profiles/%s_env_only_pmc_{FETCH,WRITE}_SIZE_<N>.txt, profiles/%s_act_step_pmc_{FETCH,WRITE}_SIZE_4096.txt "
-                 "(separate rocprofv3 --pmc passes, tools/collect_profiles_%s.sh)" % (RND, RND, RND),
+                 "(separate rocprofv3 --pmc passes, tools/collect_profiles_round.sh %s)" % (RND, RND, RND),
        "n_envs": 4096, "kernel": "t2d::k_step2 (f32 observations)", "fetch_size_kib_per_launch": f,
        "write_size_kib_per_launch": w, "traffic_bytes_per_launch": t, "algorithmic_bytes_per_launch": a}
 f, w, t, a = entry(4096, "act_step", B_ACT)
