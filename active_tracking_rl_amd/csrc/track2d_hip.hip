@@ -60,6 +60,16 @@ struct DevState {
     uint32_t *p_tctr;   // [3][2][N] TARGET stream word counter after drawing p_goal
     uint32_t *p_state;  // [3][N] bits 0-1: prepared plans (0..2), bit 2: queue head slot, bit 3: the last prepared plan does
                         //     not reach its start cell (it will be re-made inline, with more draws: nothing can follow it)
+    // ---- Maze maps grown AHEAD of the generator pass (k_pregrow; handles with Maze envs only, else null) ----
+    // A maze is a pure function of (seed, global env id, episode number, level): its growth — the one long serial chain of a
+    // generated Maze episode — need not wait for the pass that builds the rest of the episode around it. Ring of four per env,
+    // entry episode % 4; g_ep = the episode number whose maze the entry holds (kPoolEmpty: none / being written). An entry is
+    // only ever overwritten once its episode number is <= the env's current one (dead: started long ago), and the entries
+    // wanted next (current + 3, current + 4) then always fall on dead ones — so the pass and k_pregrow need no ordering
+    // between them beyond the tag's release / acquire: a pass that finds another tag grows the maze itself, as before.
+    uint32_t *g_maps;   // [4][N][256]
+    uint32_t *g_ep;     // [4][N]
+    uint32_t *pg_stats; // [4] pass: mazes taken from the pool, mazes grown inline; k_pregrow: mazes grown, entries left alone
     uint32_t *faults;   // [1]
     const float2 *rew_lut;    // [3][kLutN] (r_track, r_target) as float32(float64 formula), by w_p class and d^2
     int n;
@@ -71,6 +81,7 @@ struct DevState {
 };
 
 enum : int { OP_STEP = 0, OP_RESET = 1, OP_OBSERVE = 2 };
+constexpr uint32_t kPoolEmpty = 0xffffffffu;
 // The reward is a pure function of the integer squared distance (<= 2 * 81^2) and the mode's w_p in {0, 1, -0.5}
 // (track_1v1.py:96-104,147-152): the float64 formula is evaluated once per handle into a table by the same
 // reward_f64 device code the exhaustive parity test checks against the oracle; the step kernel then replaces a
@@ -198,6 +209,17 @@ __device__ __forceinline__ void nav_prefetch(const DevState &s, int e, uint32_t 
     wave_lds_sync();
 }
 
+// The maze of (global env id, episode): the MAP stream's first draw is the density (init_maze, track_1v1.py:219-224), the rest
+// is the growth — a pure function of its arguments, shared by the generator pass and k_pregrow.
+__device__ __forceinline__ void grow_maze(const DevState &s, uint32_t genv, uint32_t episode, int level, uint32_t *tile,
+                                          uint32_t *mlog, int lane)
+{
+    VStream ms;
+    ms.init(s.k0, s.k1, episode, genv, STREAM_MAP, 0, lane);
+    const double r = level > 0 ? (double)level * 0.02 : .03 * ms.next_double();
+    gen_maze(tile, lane, ms, r, mlog);
+}
+
 // Track1v1Env.reset -> init_maze (track_1v1.py:134-168,218-240) for one env and one episode number, executed by
 // one wave on an LDS tile. All arguments are wave-uniform. `gdir` receives the Nav direction planes.
 // DEFER_NAV: stop before the Nav target's plans (the caller makes them: k_gen_nav spreads the three floods over three waves);
@@ -218,8 +240,17 @@ __device__ __forceinline__ void generate_episode(const DevState &s, int e, uint3
     ms.init(s.k0, s.k1, episode, genv, STREAM_MAP, 0, lane);
     const int side = side_of_cfg(cfg);
     if (map_type == MAP_MAZE) {
-        double r = level > 0 ? (double)level * 0.02 : .03 * ms.next_double();
-        gen_maze(tile, lane, ms, r, mlog);
+        bool pooled = false;
+        if (s.g_maps) {      // grown ahead of time by k_pregrow? (the tag is published after the tile: acquire it)
+            const size_t po = (size_t)(episode & 3u) * s.n + e;
+            pooled = __hip_atomic_load(s.g_ep + po, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == episode;
+            if (pooled) {
+                reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(s.g_maps + po * kTileWords)[lane];
+                wave_lds_sync();
+            }
+            if (lane == 0) atomicAdd(s.pg_stats + (pooled ? 0 : 1), 1u);
+        }
+        if (!pooled) grow_maze(s, genv, episode, level, tile, mlog, lane);
     } else if (map_type == MAP_BLOCK) {
         double r = level > 0 ? (double)level * 0.05 : 0.15 * ms.next_double();
         gen_block(tile, lane, ms, r);
@@ -502,6 +533,39 @@ __global__ __launch_bounds__(256) void k_gen_nav(DevState s, uint32_t lo, uint32
     }
 #endif
 #undef T2D_NSTAMP
+}
+
+// Grow the mazes the coming generator passes will ask for: for every Maze env the episodes current + 3 and current + 4 (the two
+// pre-generated slots hold current + 1 and + 2; the pass that refills a consumed slot builds current + 3, then + 4). One wave
+// per (which, env); almost all of them find their entry already there and leave. Runs beside anything: see DevState::g_maps.
+__global__ __launch_bounds__(256) void k_pregrow(DevState s)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kWavesPerBlock][kTileWords];
+    __shared__ uint32_t mlogs[kWavesPerBlock][kMazeLogMax];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int idx = (int)blockIdx.x * kWavesPerBlock + wave;
+    if (idx >= 2 * s.n) return;
+    const int which = idx >= s.n ? 1 : 0, e = idx - which * s.n;
+    const uint32_t cfg = s.cfg[e];
+    if ((int)(cfg & 3u) != MAP_MAZE) return;
+    const uint32_t cur = __hip_atomic_load(s.episode + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t want = cur + 3u + (uint32_t)which;
+    const size_t po = (size_t)(want & 3u) * s.n + e;
+    const uint32_t tag = __hip_atomic_load(s.g_ep + po, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (an entry is re-used only when its episode has started — nobody will ask for it again — or when it holds nothing)
+    if (tag == want || (tag != kPoolEmpty && tag > cur)) { if (lane == 0) atomicAdd(s.pg_stats + 3, 1u); return; }
+    if (lane == 0) __hip_atomic_store(s.g_ep + po, kPoolEmpty, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t *tile = tiles[wave];
+    grow_maze(s, s.env_base + (uint32_t)e, want, (int)((cfg >> 5) & 15u), tile, mlogs[wave], lane);
+    wave_lds_sync();
+    reinterpret_cast<uint4 *>(s.g_maps + po * kTileWords)[lane] = reinterpret_cast<const uint4 *>(tile)[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // every lane's part of the tile before the tag
+    wave_lds_sync();
+    if (lane == 0) {
+        __hip_atomic_store(s.g_ep + po, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(s.pg_stats + 2, 1u);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_nav_prefetch(DevState s)
@@ -1656,6 +1720,11 @@ struct t2d_handle {
     // block per distinct grid size (a counter's period is 3 x grid / 8: launches of different sizes must not share one)
     unsigned long long *coop_ctl = nullptr;
     int coop_grid[4] = {0, 0, 0, 0};
+    // k_pregrow (Maze handles): forked launches run on pg_stream between a fork event on the caller's stream and a join the
+    // next generator pass (or t2d_generator_join / t2d_flush) waits for; pg_auto: every generator pass forks one behind itself
+    bool has_maze = false, pg_auto = false, pg_pending = false;
+    hipStream_t pg_stream = nullptr;
+    hipEvent_t ev_pg_fork = nullptr, ev_pg_join = nullptr;
 };
 constexpr int kCoopCtlSets = 4, kCoopCtlWords = 8 * 16;
 
@@ -1741,7 +1810,7 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
     std::memset(&h->s, 0, sizeof(h->s));
     h->device = cfg->device;
     h->reset_done = false; h->primed = false; h->has_nav = has_nav; h->has_rpf = has_rpf; h->has_ram = has_ram;
-    h->has_navmode = has_navmode; h->has_rpfmode = has_rpfmode;
+    h->has_navmode = has_navmode; h->has_rpfmode = has_rpfmode; h->has_maze = n_maze > 0;
     h->random_step = 0; h->phase = 0;
     h->gen_async = false; h->pending[0] = h->pending[1] = false;
     h->gen_stream = nullptr; h->ev_fork = nullptr; h->ev_join[0] = h->ev_join[1] = nullptr;
@@ -1785,6 +1854,12 @@ extern "C" int t2d_create(const t2d_config *cfg, t2d_handle **out)
         alloc(&s.p_field, (size_t)6 * n * kPlanWords * sizeof(uint32_t));      // three episode sets x two queued plans per env
         alloc(&s.p_goal, 6 * nb); alloc(&s.p_tctr, 6 * nb); alloc(&s.p_state, 3 * nb);
     }
+    if (n_maze > 0 && cfg->obs_type != T2D_OBS_FULL) {
+        alloc(&s.g_maps, (size_t)4 * tb);
+        alloc(&s.g_ep, 4 * nb);
+        if (err == hipSuccess) err = hipMemset(s.g_ep, 0xff, 4 * nb);      // kPoolEmpty
+        alloc(&s.pg_stats, 4 * sizeof(uint32_t));
+    }
     alloc(&s.faults, sizeof(uint32_t));
     alloc(reinterpret_cast<uint32_t **>(&h->coop_ctl), (size_t)kCoopCtlSets * kCoopCtlWords * sizeof(unsigned long long));
     float2 *lut = nullptr;
@@ -1820,6 +1895,13 @@ extern "C" int t2d_destroy(t2d_handle *h)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->coop_ctl) (void)hipFree(h->coop_ctl);
+    for (void *p : {(void *)s.g_maps, (void *)s.g_ep, (void *)s.pg_stats})
+        if (p) (void)hipFree(p);
+    if (h->pg_stream) {
+        (void)hipStreamSynchronize(h->pg_stream);
+        (void)hipStreamDestroy(h->pg_stream);
+        (void)hipEventDestroy(h->ev_pg_fork); (void)hipEventDestroy(h->ev_pg_join);
+    }
     delete h;
     return T2D_OK;
 }
@@ -1848,11 +1930,44 @@ static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t lo, uint32_t hi, 
 // Make `st` wait for every forked generator launch.
 static int join_generator(t2d_handle *h, hipStream_t st)
 {
+    if (h->pg_pending) {                       // a forked k_pregrow
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_pg_join, 0));
+        h->pg_pending = false;
+    }
     for (int w = 0; w < 2; w++)
         if (h->pending[w]) {
             HIP_TRY(hipStreamWaitEvent(st, h->ev_join[w], 0));
             h->pending[w] = false;
         }
+    return T2D_OK;
+}
+
+// k_pregrow on `st` itself (fork == 0: in order, e.g. the learner's stream of the pipelined schedule, beside the next rollout)
+// or forked onto the handle's own stream, to be joined by the next generator pass / t2d_generator_join / t2d_flush.
+static int launch_pregrow(t2d_handle *h, hipStream_t st, int fork)
+{
+    if (!h->s.g_maps) return T2D_OK;
+    const dim3 grid = env_grid(2 * h->s.n);
+    if (!fork) {
+        hipLaunchKernelGGL(k_pregrow, grid, dim3(256), 0, st, h->s);
+        HIP_TRY(hipGetLastError());
+        return T2D_OK;
+    }
+    if (!h->pg_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->pg_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_pg_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_pg_join, hipEventDisableTiming));
+    }
+    if (h->pg_pending) {                       // one in flight at a time
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_pg_join, 0));
+        h->pg_pending = false;
+    }
+    HIP_TRY(hipEventRecord(h->ev_pg_fork, st));
+    HIP_TRY(hipStreamWaitEvent(h->pg_stream, h->ev_pg_fork, 0));
+    hipLaunchKernelGGL(k_pregrow, grid, dim3(256), 0, h->pg_stream, h->s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_pg_join, h->pg_stream));
+    h->pg_pending = true;
     return T2D_OK;
 }
 
@@ -1874,7 +1989,12 @@ static int window_end(t2d_handle *h, hipStream_t st)
     if (h->phase == 0u || h->phase % h->win != 0u) return T2D_OK;
     const uint32_t w = h->phase / h->win - 1u, lo = w * h->win + 1u, hi = (w + 1u) * h->win;
     if (!h->gen_async) {
+        if (h->pg_pending) {                            // (a forked k_pregrow: its mazes are what this pass is about to take)
+            HIP_TRY(hipStreamWaitEvent(st, h->ev_pg_join, 0));
+            h->pg_pending = false;
+        }
         launch_gen(h, st, lo, hi, 0, h->has_navmode);   // the Nav plan prefetch rides in the same launch (other waves)
+        if (h->pg_auto) { int rc = launch_pregrow(h, st, 1); if (rc) return rc; }
     } else {
         if (h->has_navmode) hipLaunchKernelGGL(k_nav_prefetch, env_grid(h->s.n), dim3(256), 0, st, h->s);
         HIP_TRY(hipEventRecord(h->ev_fork, st));
@@ -2005,6 +2125,26 @@ extern "C" int t2d_generator_join(t2d_handle *h, void *stream)
 }
 
 extern "C" int t2d_generator_cycle(const t2d_handle *h) { return h ? (int)h->cycle : T2D_ERR_INVALID; }
+
+extern "C" int t2d_pregrow(t2d_handle *h, int mode, void *stream)
+{
+    if (!h) return fail(T2D_ERR_INVALID, "t2d_pregrow: null handle");
+    if (mode < 0 || mode > 3) return fail(T2D_ERR_INVALID, "t2d_pregrow: mode %d", mode);
+    DeviceGuard guard(h->device);
+    if (mode == T2D_PREGROW_AUTO_ON || mode == T2D_PREGROW_AUTO_OFF) { h->pg_auto = mode == T2D_PREGROW_AUTO_ON; return T2D_OK; }
+    return launch_pregrow(h, (hipStream_t)stream, mode == T2D_PREGROW_FORK ? 1 : 0);
+}
+
+extern "C" int t2d_pregrow_stats(t2d_handle *h, uint32_t stats_host[4], void *stream)
+{
+    if (!h || !stats_host) return fail(T2D_ERR_INVALID, "t2d_pregrow_stats: null argument");
+    DeviceGuard guard(h->device);
+    std::memset(stats_host, 0, 4 * sizeof(uint32_t));
+    if (!h->s.pg_stats) return T2D_OK;
+    HIP_TRY(hipMemcpyAsync(stats_host, h->s.pg_stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return T2D_OK;
+}
 
 template <bool RANDOM>
 static int step_impl(t2d_handle *h, hipStream_t st, const void *a0, const void *a1, int adt, float *obs, float *rew,

@@ -162,6 +162,10 @@ class VecEnv(object):
     def generator_join(self):
         self.core.generator_join()
 
+    def pregrow(self, fork=True):
+        """Maze maps of the coming episodes grown ahead of the generator pass (VecTrack2D.pregrow); no-op without Maze envs."""
+        self.core.pregrow(fork)
+
     @property
     def generator_cycle(self):
         return self.core.generator_cycle

@@ -99,6 +99,7 @@ def capture_allreduce_default():
 
 
 CAPTURE_ALLREDUCE_DEFAULT = False
+PREGROW_MODE = os.environ.get("ATR_PREGROW_MODE", "inline")    # pipelined schedule: "inline" on the learner's stream | "fork" | "off"
 CORUN_MIN_ENVS = 1024      # PipelinedIteration: the learner's dW kernel in its one-workgroup-per-CU form from this shard size up
 
 
@@ -194,6 +195,11 @@ class GraphedIteration(object):
             self._bind_carry()
             player.carry_out, player.carry_written = self.carry, ()   # the rollout's epilogue kernel publishes the carry
             rollout(player, args.num_steps, fast=self.fast)
+            # (growing the next passes' Maze maps on a forked stream under the learner — env.pregrow(fork=True) here — was
+            # measured: -2 % on configs[3] / [4]: on one stream the growth only moves from the pass to the fork, and the fork /
+            # join inside the graph costs more than the overlap returns. The pipelined schedule has a second stream to put it on.)
+            if PREGROW_MODE == "fork" and hasattr(player.env, "pregrow"):
+                player.env.pregrow(fork=True)
             stats = player.compute_grads(self.optimizer, mode)
             if hasattr(player.env, "generator_join"):
                 player.env.generator_join()   # the env's forked generator launches end inside the captured region
@@ -499,7 +505,14 @@ class PipelinedIteration(object):
         g_l = torch.cuda.CUDAGraph()
         from . import fused
         with fused.gemm_tn_corun(self.corun), torch.cuda.graph(g_l, capture_error_mode="thread_local"):
+            if PREGROW_MODE != "off" and hasattr(p.env, "pregrow"):
+                # the Maze maps the NEXT rollouts' generator passes will ask for, grown on the learner's stream beside the
+                # rollout that is running now: off the rollout chain, which bounds this schedule (no ordering needed between
+                # the two: vec_env.VecTrack2D.pregrow). The pass itself: 206 -> 104 us at 1024 Maze + Nav envs.
+                p.env.pregrow(fork=PREGROW_MODE == "fork")
             stats = p.compute_grads(_BucketOnly(self.buckets[k]), mode)
+            if PREGROW_MODE == "fork" and hasattr(p.env, "generator_join"):
+                p.env.generator_join()
             self.optimizer.bucket.grad.copy_(self.buckets[k].grad)
         self.graphs[(mode, k)] = (g_r, g_l, stats)
         return self.graphs[(mode, k)]

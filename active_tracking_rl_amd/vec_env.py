@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
     "t2d_last_error", "t2d_abi_version", "t2d_config_size", "t2d_create", "t2d_destroy", "t2d_num_envs", "t2d_reset", "t2d_step",
     "t2d_observe", "t2d_inject", "t2d_inject_plan", "t2d_inject_nav_goal", "t2d_get_state", "t2d_get_maps", "t2d_get_target",
     "t2d_get_faults", "t2d_step_u8", "t2d_step_random", "t2d_rollout_random", "t2d_reward_table", "t2d_flush",
-    "t2d_generator_async", "t2d_generator_join", "t2d_generator_cycle",
+    "t2d_generator_async", "t2d_generator_join", "t2d_generator_cycle", "t2d_pregrow", "t2d_pregrow_stats",
 )
 
 
@@ -98,6 +98,10 @@ def load_library():
     L.t2d_get_target.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     L.t2d_get_faults.restype = i32
     L.t2d_get_faults.argtypes = [vp, vp, vp]
+    L.t2d_pregrow.restype = i32
+    L.t2d_pregrow.argtypes = [vp, i32, vp]
+    L.t2d_pregrow_stats.restype = i32
+    L.t2d_pregrow_stats.argtypes = [vp, vp, vp]
     L.t2d_step_random.restype = i32
     L.t2d_step_random.argtypes = [vp, i32, u64, vp, vp, vp, vp]
     L.t2d_rollout_random.restype = i32
@@ -357,6 +361,29 @@ class VecTrack2D(object):
         _check(self.L.t2d_get_target(self.h, first, count, _np_ptr(plan), _np_ptr(ln), _np_ptr(cur), _np_ptr(ng),
                                      self._stream()))
         return dict(plan=plan, len=ln, cursor=cur, navgoal=ng)
+
+    PREGROW_INLINE, PREGROW_FORK, PREGROW_AUTO_ON, PREGROW_AUTO_OFF = 0, 1, 2, 3
+
+    def pregrow(self, fork=True):
+        """Grow the Maze maps the coming generator passes will need ahead of them (t2d_pregrow, csrc k_pregrow: a maze is a pure
+        function of seed, env id and episode number, and its growth is the long serial chain of a generated episode). fork: on
+        the handle's own stream, joined by the next pass / generator_join(); else in order on the current stream (meant for a
+        stream that runs BESIDE the one stepping the envs). No-op without Maze envs; same episodes bit for bit either way.
+        (T2D_PREGROW=0 in the environment turns the call into a no-op: A/B runs.)"""
+        if os.environ.get("T2D_PREGROW", "1") == "0":
+            return
+        _check(self.L.t2d_pregrow(self.h, self.PREGROW_FORK if fork else self.PREGROW_INLINE, self._stream()))
+
+    def pregrow_auto(self, enable=True):
+        """Every generator pass forks a pregrow() behind itself (plain stepping loops: the growth runs under the next steps)."""
+        _check(self.L.t2d_pregrow(self.h, self.PREGROW_AUTO_ON if enable else self.PREGROW_AUTO_OFF, self._stream()))
+
+    def pregrow_stats(self):
+        """dict(taken, grown_in_pass, pregrown, left): mazes the passes copied from the ring / grew themselves, mazes k_pregrow
+        grew, ring entries it found in order."""
+        f = np.zeros(4, np.uint32)
+        _check(self.L.t2d_pregrow_stats(self.h, _np_ptr(f), self._stream()))
+        return dict(taken=int(f[0]), grown_in_pass=int(f[1]), pregrown=int(f[2]), left=int(f[3]))
 
     def faults(self):
         f = np.zeros(1, np.uint32)

@@ -161,6 +161,26 @@ int t2d_get_maps(t2d_handle *h, int first, int count, uint8_t *maps_host, void *
 int t2d_get_target(t2d_handle *h, int first, int count, int32_t *plan_host, int32_t *len_host,
                    int32_t *cursor_host, int32_t *navgoal_host, void *stream);
 
+/* Maze maps grown ahead of the generator pass (csrc/track2d_hip.hip: k_pregrow). RandomMazeGenerator._generate_maze
+ * (generators.py:115-145) is one long serial chain per map and, in this library, a pure function of (seed, global env id,
+ * episode number, level): it need not run inside the pass that builds a new episode (reset(), track_1v1.py:134-168) around
+ * it. t2d_pregrow grows, for every Maze env, the mazes of the episodes the coming passes will build (current + 3, + 4) into a
+ * per-env ring the pass then copies from; a pass that does not find its maze there grows it itself: results are the same
+ * bit for bit either way. No-op for handles without Maze envs.
+ *   T2D_PREGROW_INLINE    launch on `stream`, in order (e.g. a stream that runs beside the one that steps the envs: safe
+ *                         without any ordering between the two — a ring entry is only re-used once its episode has started)
+ *   T2D_PREGROW_FORK      launch on the handle's own stream, forked from `stream` here and joined into the caller's
+ *                         stream by the next generator pass, t2d_generator_join or t2d_flush (capturable: join before the
+ *                         capture ends)
+ *   T2D_PREGROW_AUTO_ON / _OFF   every generator pass forks one behind itself (plain stepping loops) */
+#define T2D_PREGROW_INLINE 0
+#define T2D_PREGROW_FORK 1
+#define T2D_PREGROW_AUTO_ON 2
+#define T2D_PREGROW_AUTO_OFF 3
+int t2d_pregrow(t2d_handle *h, int mode, void *stream);
+/* {mazes the passes took from the ring, mazes the passes grew themselves, mazes k_pregrow grew, entries it left}. Synchronises. */
+int t2d_pregrow_stats(t2d_handle *h, uint32_t stats_host[4], void *stream);
+
 /* Sticky device-side fault word (bit 0: an action outside 0..3 was seen and masked). Synchronises. */
 int t2d_get_faults(t2d_handle *h, uint32_t *faults_host, void *stream);
 

@@ -675,3 +675,46 @@ def test_device_ram_and_nav_targets_follow_reference_plans(vec, golden_episodes)
             assert env.faults() == 0
             env.close()
     assert checked_ram >= 40 and checked_nav >= 200
+
+
+@pytest.mark.parametrize("env_id,mixed", [("Track2D-MazePartialNav-v0", False), ("Track2D-MazePartialPZR-v1", False),
+                                          ("Track2D-BlockPartialAdv-v0", True)])
+def test_pregrown_mazes_give_the_same_episodes(env_id, mixed):
+    """t2d_pregrow (k_pregrow): Maze maps grown AHEAD of the generator pass, on another stream, into a per-env ring the pass
+    copies from. Two handles with the same seed — one that grows every maze inside the pass, one with pregrow after every pass
+    (auto mode: forked behind the pass, under the following steps) — stepped with the same actions through many short episodes:
+    every observation, reward and done flag equal, final states equal, and the ring is really used (most mazes taken from it).
+    RandomMazeGenerator._generate_maze, generators.py:115-145; reset(), track_1v1.py:134-168."""
+    from active_tracking_rl_amd.vec_env import VecTrack2D
+    n, steps = 192, 260
+    kw = dict(num_envs=n, seed=21, env_id_base=640, max_episode_steps=13)
+    if mixed:
+        kw["map_type_per_env"] = np.array([i % 2 for i in range(n)], np.uint8)      # Block / Maze alternating
+    a, b = VecTrack2D(env_id, **kw), VecTrack2D(env_id, **kw)
+    b.pregrow_auto(True)
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    rs = np.random.RandomState(5)
+    dones = 0
+    for t in range(steps):
+        acts = torch.from_numpy(rs.randint(0, 4, size=(2, n))).cuda()
+        ra = a.step(acts[0], acts[1])
+        rb = b.step(acts[0], acts[1])
+        if t % 37 == 5:
+            b.pregrow(fork=False)                                   # (and the in-order form now and then: same ring)
+        for x, y, what in zip(ra, rb, ("obs", "rew", "done")):
+            assert torch.equal(x, y), (what, t)
+        dones += int(ra[2].sum())
+        if t == 59:
+            st0 = b.pregrow_stats()                                 # (the first passes found an empty ring)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(a.get_maps(), b.get_maps())
+    st = b.pregrow_stats()
+    assert dones > 10 * n
+    taken, inline = st["taken"] - st0["taken"], st["grown_in_pass"] - st0["grown_in_pass"]
+    assert st["pregrown"] > 0 and taken > 100 and taken >= 9 * inline, (st0, st)
+    assert a.pregrow_stats()["taken"] == 0
+    assert a.faults() == 0 and b.faults() == 0
+    a.close(); b.close()

@@ -15,8 +15,11 @@ ap.add_argument("--warmup", type=int, default=200)
 ap.add_argument("--no-auto-reset", action="store_true")
 ap.add_argument("--no-obs", action="store_true")
 ap.add_argument("--fused", action="store_true", help="t2d_rollout_random: up to 10 steps per launch, all outputs kept")
+ap.add_argument("--pregrow", action="store_true", help="Maze maps grown ahead of the generator pass, forked behind it (t2d_pregrow auto mode)")
 args = ap.parse_args()
 env = VecTrack2D(args.env, num_envs=args.n, seed=1, auto_reset=not args.no_auto_reset)
+if args.pregrow:
+    env.pregrow_auto(True)
 out = (env.reset(), torch.empty((args.n, 2), device="cuda"), torch.empty((args.n,), dtype=torch.uint8, device="cuda"))
 if args.no_obs:
     import ctypes as C
