@@ -480,6 +480,18 @@ extern "C" int t2d_np_target_action(t2d_np *e, int32_t *action)
     return 0;
 }
 
+// The MT19937 state RandomState.seed(seed) leaves behind: 624 words + the read position (624 = "regenerate before the next
+// word"). What t2d_np_attach (csrc/track2d_hip.hip) uploads per env for the DEVICE-side numpy-exact generators.
+extern "C" int t2d_np_mt_state(uint32_t seed, uint32_t out[625])
+{
+    if (!out) return fail(-1, "t2d_np_mt_state: null argument");
+    Stream rs;
+    rs.seed(seed);
+    std::memcpy(out, rs.mt, sizeof(rs.mt));
+    out[624] = (uint32_t)rs.pos;
+    return 0;
+}
+
 // ---- many envs at once: the per-env calls above spread over host threads (each env owns its stream: no shared state) ----
 #include <atomic>
 #include <thread>

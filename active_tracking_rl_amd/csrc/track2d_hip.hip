@@ -20,6 +20,7 @@
 
 #include "../../include/atr_policy.h"
 #include "../../include/track2d.h"
+#include "../../include/track2d_np.h"
 #include "atr_cell.h"
 #include "coop_gemm.h"
 #include "t2d_device.h"
@@ -67,6 +68,7 @@ struct DevState {
     // only ever overwritten once its episode number is <= the env's current one (dead: started long ago), and the entries
     // wanted next (current + 3, current + 4) then always fall on dead ones — so the pass and k_pregrow need no ordering
     // between them beyond the tag's release / acquire: a pass that finds another tag grows the maze itself, as before.
+    uint32_t *np_mt;    // [N][kNpStateWords] per-env MT19937 state (t2d_np_attach: the generator draws from numpy-legacy streams), else null
     uint32_t *g_maps;   // [4][N][256]
     uint32_t *g_ep;     // [4][N]
     uint32_t *pg_stats; // [4] pass: mazes taken from the pool, mazes grown inline; k_pregrow: mazes grown, entries left alone
@@ -82,6 +84,7 @@ struct DevState {
 
 enum : int { OP_STEP = 0, OP_RESET = 1, OP_OBSERVE = 2 };
 constexpr uint32_t kPoolEmpty = 0xffffffffu;
+constexpr int kNpStateWords = 640;           // 624 words of MT19937 state, the read position at [624], padding
 // The reward is a pure function of the integer squared distance (<= 2 * 81^2) and the mode's w_p in {0, 1, -0.5}
 // (track_1v1.py:96-104,147-152): the float64 formula is evaluated once per handle into a table by the same
 // reward_f64 device code the exhaustive parity test checks against the oracle; the step kernel then replaces a
@@ -533,6 +536,214 @@ __global__ __launch_bounds__(256) void k_gen_nav(DevState s, uint32_t lo, uint32
     }
 #endif
 #undef T2D_NSTAMP
+}
+
+// ---- numpy-exact episodes on the device (t2d_np_attach) ------------------------------------------------------------------
+// The reference draws everything from numpy's legacy global stream (generators.py:28,44,61,90,131,140,166; track_1v1.py:
+// 223,229): MT19937 words turned into doubles (random_sample: two words), bounded integers (masked rejection: one word per
+// attempt) and, for every choice(n, k, replace=False), a WHOLE Fisher-Yates permutation(n) of which the first k entries are
+// used — four permutations of ~6000 per Block reset. One wavefront per env restates that draw for draw: the MT state (624
+// words) and the permutation (u16[6400]) live in LDS, the twist is done 64 words at a time, the shuffles are the serial loops
+// they are (~0.7 ms each: this is the parity mode, environment.NumpyVecEnv(device_generators=True), not the throughput path).
+struct NpStream {
+    uint32_t *mt;      // LDS [624]
+    int pos, lane;
+    // the twist, in ten passes of 64: word k needs the OLD k + 1 (its neighbour in the same pass: everybody reads before anybody
+    // writes) and word (k + 397) % 624 — old for k < 227, and for k >= 227 the new k - 227, written at least two passes earlier
+    __device__ __forceinline__ void refill()
+    {
+#pragma unroll 1
+        for (int p = 0; p < 10; p++) {
+            const int k = p * 64 + lane;
+            uint32_t nv = 0u;
+            if (k < 624) {
+                const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                nv = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            wave_lds_sync();
+            if (k < 624) mt[k] = nv;
+            wave_lds_sync();
+        }
+        pos = 0;
+    }
+    __device__ __forceinline__ uint32_t word()
+    {
+        if (pos >= 624) refill();
+        uint32_t y = mt[pos++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return uni(y);
+    }
+    __device__ __forceinline__ double uniform()          // random_sample(): 53 bits out of two words
+    {
+        const uint32_t a = word() >> 5, b = word() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    __device__ __forceinline__ uint32_t upto(uint32_t top)   // uniform in [0, top]; top == 0 draws nothing
+    {
+        if (top == 0u) return 0u;
+        uint32_t mask = top;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t v;
+        do { v = word() & mask; } while (v > top);
+        return v;
+    }
+    __device__ __forceinline__ int randint(int low, int high) { return low + (int)upto((uint32_t)(high - 1 - low)); }
+    // permutation(n): arange(n) shuffled from the top (i = n - 1 .. 1: swap with a uniform j in [0, i])
+    __device__ __forceinline__ void permutation(int n, uint16_t *perm)
+    {
+        for (int i = lane; i < n; i += 64) perm[i] = (uint16_t)i;
+        wave_lds_sync();
+#pragma unroll 1
+        for (int i = n - 1; i >= 1; i--) {
+            const uint16_t a = perm[i];
+            const int j = (int)upto((uint32_t)i);
+            const uint16_t b = perm[j];
+            wave_lds_sync();
+            if (lane == 0) { perm[i] = b; perm[j] = a; }
+            wave_lds_sync();
+        }
+    }
+};
+
+__device__ __forceinline__ void tile_set(uint32_t *tile, int r, int c, int lane)
+{
+    if (lane == 0) tile[r * kRowWords + (c >> 5)] |= 1u << (c & 31);
+}
+
+// One reset() of the reference env (track_1v1.py:134-168 -> init_maze :218-240) from the env's numpy stream.
+__device__ __forceinline__ void generate_episode_np(NpStream &rs, uint16_t *perm, uint32_t *tile, int lane, uint32_t cfg,
+                                                    uint32_t &pos, uint32_t &goals, uint32_t &d2)
+{
+    const int map_type = cfg & 3, level = (cfg >> 5) & 15;
+    const int side = side_of_cfg(cfg);
+    tile_clear(tile, lane);
+    wave_lds_sync();
+    if (map_type == MAP_MAZE) {     // RandomMazeGenerator._generate_maze (generators.py:115-145), width = height = 80 -> 81 x 81
+        const double r = level > 0 ? (double)level * 0.02 : .03 * rs.uniform();
+        const int S = 81;
+        const int complexity = (int)(r * (5.0 * (S + S))), density = (int)(r * (double)((S / 2) * (S / 2)));
+        tile_border(tile, S, lane);
+        wave_lds_sync();
+#pragma unroll 1
+        for (int i = 0; i < density; i++) {
+            int x = rs.randint(0, S / 2 + 1) * 2;            // the tuple on generators.py:131 evaluates x's draw first
+            int y = rs.randint(0, S / 2 + 1) * 2;
+            tile_set(tile, y, x, lane);
+            wave_lds_sync();
+#pragma unroll 1
+            for (int j = 0; j < complexity; j++) {
+                int nr[4], nc[4], n = 0;
+                if (x > 1) { nr[n] = y; nc[n] = x - 2; n++; }
+                if (x < S - 2) { nr[n] = y; nc[n] = x + 2; n++; }
+                if (y > 1) { nr[n] = y - 2; nc[n] = x; n++; }
+                if (y < S - 2) { nr[n] = y + 2; nc[n] = x; n++; }
+                if (n == 0) continue;
+                const int k = rs.randint(0, n);
+                int pr = nr[0], pc = nc[0];
+#pragma unroll
+                for (int q = 1; q < 4; q++) if (q == k) { pr = nr[q]; pc = nc[q]; }
+                if (tile_bit(tile, pr, pc) == 0u) {
+                    tile_set(tile, pr, pc, lane);
+                    tile_set(tile, pr + (y - pr) / 2, pc + (x - pc) / 2, lane);
+                    wave_lds_sync();
+                    x = pc; y = pr;
+                }
+            }
+        }
+    } else {                        // RandomBlockMazeGenerator._generate_maze (generators.py:157-176); Empty: ratio 0
+        const double r = map_type == MAP_BLOCK ? (level > 0 ? (double)level * 0.05 : 0.15 * rs.uniform()) : 0.0;
+        const int K = (int)(r * 6400.0);
+        rs.permutation(6400, perm);                          // (the whole shuffle is drawn even for K = 0)
+        for (int i = lane; i < K; i += 64) {
+            const uint32_t c = perm[i];
+            const uint32_t row = c / 80u + 1u, col = c - (c / 80u) * 80u + 1u;
+            atomicOr(&tile[row * kRowWords + (col >> 5)], 1u << (col & 31u));
+        }
+        wave_lds_sync();
+        tile_border(tile, 82, lane);
+        wave_lds_sync();
+    }
+    const FreeIndex fi = build_free_index(tile, side, lane);
+    const int n = fi.total;
+    uint32_t g0, g1;
+    auto sample_goal2 = [&]() {     // sample_goal(2): choice(len, 2, replace=False) = permutation(len)[:2]
+        rs.permutation(n, perm);
+        const int i0 = uni((int)perm[0]), i1 = uni((int)perm[1]);
+        g0 = select_free(tile, side, fi, i0, lane);
+        g1 = select_free(tile, side, fi, i1, lane);
+    };
+    sample_goal2();
+    // sample_close_states(2, 1): choice(len, 2, replace=False) of which only the first is used, then get_around, then
+    // sample_state(0) = choice(len, 0, replace=False) — still a whole permutation
+    rs.permutation(n, perm);
+    const uint32_t tr = select_free(tile, side, fi, uni((int)perm[0]), lane);
+    const int r = (int)(tr & 0xffu), c = (int)(tr >> 8);
+    const int x0 = max(0, r - 1), x1 = min(side - 1, r + 1), y0 = max(0, c - 1), y1 = min(side - 1, c + 1);
+    int m = 0;
+    for (int rr = x0; rr < x1; rr++)
+        for (int cc = y0; cc < y1; cc++) m += (int)(tile_bit(tile, rr, cc) == 0u);
+    rs.permutation(m, perm);
+    int j = uni((int)perm[0]);
+    uint32_t tg = tr;
+    for (int rr = x0; rr < x1; rr++)
+        for (int cc = y0; cc < y1; cc++)
+            if (tile_bit(tile, rr, cc) == 0u) {
+                if (j == 0) tg = (uint32_t)rr | ((uint32_t)cc << 8);
+                j--;
+            }
+    rs.permutation(n, perm);
+    while (tr == g0 || tr == g1) sample_goal2();             // goal_test loop, track_1v1.py:239-240
+    pos = tr | (tg << 16);
+    goals = g0 | (g1 << 16);
+    const int dr = (int)(tg & 0xffu) - r, dc = (int)(tg >> 8) - c;
+    d2 = (uint32_t)(dr * dr + dc * dc);
+}
+
+// The generator pass of a numpy-stream handle: ONE wave per env, its consumed slots refilled in episode order (the stream is
+// sequential: episode k + 1's draws follow episode k's).
+constexpr int kNpWaves = 2;
+__global__ __launch_bounds__(64 * kNpWaves) void k_gen_np(DevState s, uint32_t lo, uint32_t hi, int force)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kNpWaves][kTileWords];
+    __shared__ uint32_t mts[kNpWaves][624];
+    __shared__ uint16_t perms[kNpWaves][6400];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int e = (int)blockIdx.x * kNpWaves + wave;
+    if (e >= s.n) return;
+    const uint32_t cfg = s.cfg[e];
+    const uint32_t cur = s.episode[e];
+    const uint32_t req0 = s.gen_req[e], req1 = s.gen_req[(size_t)s.n + e];
+    const bool need0 = force || (req0 >= lo && req0 <= hi && req0 != 0u), need1 = force || (req1 >= lo && req1 <= hi && req1 != 0u);
+    if (!need0 && !need1) return;
+    uint32_t *mt_g = s.np_mt + (size_t)e * kNpStateWords;
+    NpStream rs;
+    rs.mt = mts[wave]; rs.lane = lane;
+    for (int i = lane; i < 624; i += 64) rs.mt[i] = mt_g[i];
+    rs.pos = (int)mt_g[624];
+    wave_lds_sync();
+    // slot p holds the lowest episode number above the current one with parity p: the lower of the two first
+    const int first = (int)((cur + 1u) & 1u);
+#pragma unroll 1
+    for (int t = 0; t < 2; t++) {
+        const int slot = t == 0 ? first : 1 - first;
+        if (!(slot == 0 ? need0 : need1)) continue;
+        const size_t so = (size_t)slot * s.n + e;
+        uint32_t pos, goals, d2;
+        generate_episode_np(rs, perms[wave], tiles[wave], lane, cfg, pos, goals, d2);
+        wave_lds_sync();
+        store_slot_map(s, so, tiles[wave], lane, cfg, pos);
+        if (lane == 0) {
+            s.n_pos[so] = pos; s.n_goals[so] = goals; s.n_plan[so] = 0u; s.n_tctr[so] = 0u;
+            s.n_navgoal[so] = goals >> 16; s.n_d2[so] = d2; s.gen_req[so] = 0u; s.n_nav2[so] = 0u;
+        }
+        wave_lds_sync();
+    }
+    for (int i = lane; i < 624; i += 64) mt_g[i] = rs.mt[i];
+    if (lane == 0) mt_g[624] = (uint32_t)rs.pos;
 }
 
 // Grow the mazes the coming generator passes will ask for: for every Maze env the episodes current + 3 and current + 4 (the two
@@ -1895,7 +2106,7 @@ extern "C" int t2d_destroy(t2d_handle *h)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->coop_ctl) (void)hipFree(h->coop_ctl);
-    for (void *p : {(void *)s.g_maps, (void *)s.g_ep, (void *)s.pg_stats})
+    for (void *p : {(void *)s.g_maps, (void *)s.g_ep, (void *)s.pg_stats, (void *)s.np_mt})
         if (p) (void)hipFree(p);
     if (h->pg_stream) {
         (void)hipStreamSynchronize(h->pg_stream);
@@ -1911,6 +2122,10 @@ constexpr int kGenNavMaxEnvs = 2048;
 
 static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t lo, uint32_t hi, int force, bool prefetch = false)
 {
+    if (h->s.np_mt) {                               // numpy-stream handle (t2d_np_attach): one wave per env, slots in episode order
+        hipLaunchKernelGGL(k_gen_np, dim3((unsigned)((h->s.n + kNpWaves - 1) / kNpWaves)), dim3(64 * kNpWaves), 0, st, h->s, lo, hi, force);
+        return;
+    }
     const dim3 grid = env_grid(2 * h->s.n);        // one wave per (slot, env)
     // Nav targets, small shards: one WORKGROUP per (slot, env), the three floods of a generated episode on three waves
     // (k_gen_nav: the pass is as long as its slowest generation — 238 -> 206 us at 1024 Maze + Nav envs). A large batch has
@@ -1946,7 +2161,7 @@ static int join_generator(t2d_handle *h, hipStream_t st)
 // or forked onto the handle's own stream, to be joined by the next generator pass / t2d_generator_join / t2d_flush.
 static int launch_pregrow(t2d_handle *h, hipStream_t st, int fork)
 {
-    if (!h->s.g_maps) return T2D_OK;
+    if (!h->s.g_maps || h->s.np_mt) return T2D_OK;      // (numpy-stream handles build their maps from the stream, in the pass)
     const dim3 grid = env_grid(2 * h->s.n);
     if (!fork) {
         hipLaunchKernelGGL(k_pregrow, grid, dim3(256), 0, st, h->s);
@@ -2133,6 +2348,25 @@ extern "C" int t2d_pregrow(t2d_handle *h, int mode, void *stream)
     DeviceGuard guard(h->device);
     if (mode == T2D_PREGROW_AUTO_ON || mode == T2D_PREGROW_AUTO_OFF) { h->pg_auto = mode == T2D_PREGROW_AUTO_ON; return T2D_OK; }
     return launch_pregrow(h, (hipStream_t)stream, mode == T2D_PREGROW_FORK ? 1 : 0);
+}
+
+extern "C" int t2d_np_attach(t2d_handle *h, const uint32_t *states_host)
+{
+    if (!h || !states_host) return fail(T2D_ERR_INVALID, "t2d_np_attach: null argument");
+    if (h->primed || h->reset_done) return fail(T2D_ERR_STATE, "t2d_np_attach: attach the streams before the first t2d_reset");
+    if (h->has_ram || h->has_navmode || h->has_rpfmode)
+        return fail(T2D_ERR_INVALID, "t2d_np_attach: scripted Ram / Nav / RPF targets draw from the stream between resets: those "
+                                     "stay on the host streams (environment.NumpyVecEnv); Adv / PZR / Far / Ext only");
+    DeviceGuard guard(h->device);
+    const int n = h->s.n;
+    std::vector<uint32_t> padded((size_t)n * kNpStateWords, 0u);
+    for (int i = 0; i < n; i++) {
+        if (states_host[(size_t)i * 625 + 624] > 624u) return fail(T2D_ERR_INVALID, "t2d_np_attach: env %d: read position > 624", i);
+        std::memcpy(&padded[(size_t)i * kNpStateWords], states_host + (size_t)i * 625, 625 * sizeof(uint32_t));
+    }
+    if (!h->s.np_mt) HIP_TRY(hipMalloc((void **)&h->s.np_mt, padded.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(h->s.np_mt, padded.data(), padded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return T2D_OK;
 }
 
 extern "C" int t2d_pregrow_stats(t2d_handle *h, uint32_t stats_host[4], void *stream)

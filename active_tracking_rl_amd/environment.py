@@ -192,7 +192,12 @@ class NumpyVecEnv(object):
     Costs a host round trip per step (done flags down, target actions / new episodes up): a parity tool, not the
     throughput path."""
 
-    def __init__(self, env_ids, seeds, device="cuda:0", threads=0):
+    def __init__(self, env_ids, seeds, device="cuda:0", threads=0, device_generators=False):
+        """device_generators: the numpy-legacy streams live ON THE DEVICE (np_mode.attach_device_streams -> csrc k_gen_np: MT19937,
+        numpy's doubles / bounded integers / whole Fisher-Yates permutations, the reference's map generators and samplers, one
+        wavefront per env) and finished envs restart inside the step launch from episodes pre-generated out of their own stream:
+        no host round trip, same episodes. For ids whose target draws nothing itself (Adv, PZR, Far); scripted Ram / Nav / RPF
+        targets interleave their draws with the resets and stay on the host streams (device_generators=False)."""
         from .np_mode import NpBatchSource
         n = len(seeds)
         ids = [env_ids] * n if isinstance(env_ids, str) else list(env_ids)
@@ -200,6 +205,23 @@ class NumpyVecEnv(object):
         sp = [registry.spec(i) for i in ids]
         assert len(set(x["obs_type"] for x in sp)) == 1, "one observation type per handle"
         self.num_envs, self.env_ids = n, ids
+        self.device_generators = bool(device_generators)
+        if self.device_generators:
+            from .np_mode import attach_device_streams
+            bad = sorted(set(x["target_mode"] for x in sp) - {"Adv", "PZR", "Far"})
+            if bad:
+                raise ValueError("NumpyVecEnv(device_generators=True): target mode(s) %s draw from the stream between resets; "
+                                 "use the host streams (device_generators=False)" % ", ".join(bad))
+            self.src = None
+            self.core = VecTrack2D(ids[0], num_envs=n, device=device, seed=int(seeds[0]), auto_reset=True,
+                                   map_type_per_env=np.array([registry.MAP_CODE[x["map_type"]] for x in sp], np.uint8),
+                                   target_mode_per_env=np.array([registry.TARGET_CODE[x["target_mode"]] for x in sp], np.uint8),
+                                   level_per_env=np.array([x["level"] for x in sp], np.uint8), obs_type=sp[0]["obs_type"])
+            attach_device_streams(self.core, seeds)
+            self.device = self.core.device
+            self.observation_space, self.action_space = _spaces(self.core.obs_hw, self.core.num_actions)
+            self._scripted_idx = np.zeros(0, np.int64)
+            return
         self.src = NpBatchSource([x["map_type"] for x in sp], [x["target_mode"] for x in sp], [x["level"] for x in sp], seeds,
                                  threads)
         modes = np.array([registry.TARGET_CODE["Ext"] if self.src.scripted[i] else registry.TARGET_CODE[sp[i]["target_mode"]]
@@ -219,6 +241,9 @@ class NumpyVecEnv(object):
 
     def reset(self, mask=None):
         """New episodes for every env (or those where mask is set) from their streams; returns all observations."""
+        if self.device_generators:             # the next episode of every (masked) env's own stream, generated on the device
+            m = None if mask is None else torch.as_tensor(np.asarray(mask), dtype=torch.uint8, device=self.device)
+            return self.core.reset(m)
         idx = np.arange(self.num_envs) if mask is None else np.nonzero(np.asarray(mask))[0]
         self._inject(idx, *self.src.reset(idx))
         return self.core.observe()
@@ -233,6 +258,9 @@ class NumpyVecEnv(object):
             ta = self.src.target_actions(self._scripted_idx)
             a1[torch.as_tensor(self._scripted_idx, device=dev)] = torch.as_tensor(ta, dtype=torch.int64, device=dev)
         obs, rew, done = self.core.step(a0, a1.contiguous())
+        if self.device_generators:             # (finished envs restarted inside the launch; info['distance'] of the step itself)
+            # (for an env that finished, d2 already belongs to its next episode: info['distance'] is the step's only while running)
+            return obs, rew, done, {"distance": np.sqrt(self.core.get_state()["d2"].astype(np.float64))}
         d2 = self.core.get_state()["d2"].astype(np.float64)
         fin = np.nonzero(done.cpu().numpy())[0]
         if len(fin):
@@ -244,7 +272,8 @@ class NumpyVecEnv(object):
 
     def close(self):
         self.core.close()
-        self.src.close()
+        if self.src is not None:
+            self.src.close()
 
 
 class Track2DEnv(object):

@@ -9,7 +9,7 @@ from . import registry, vec_env
 
 NP_SYMBOLS = ("t2d_np_create", "t2d_np_destroy", "t2d_np_last_error", "t2d_np_seed", "t2d_np_reset",
               "t2d_np_target_action", "t2d_np_get_plan", "t2d_np_astar", "t2d_np_draw", "t2d_np_reset_many",
-              "t2d_np_target_actions")
+              "t2d_np_target_actions", "t2d_np_mt_state", "t2d_np_attach")
 _ready = False
 
 
@@ -35,6 +35,10 @@ def _lib():
         L.t2d_np_astar.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp]
         L.t2d_np_draw.restype = i32
         L.t2d_np_draw.argtypes = [vp, i32, u32, u32, vp]
+        L.t2d_np_mt_state.restype = i32
+        L.t2d_np_mt_state.argtypes = [u32, vp]
+        L.t2d_np_attach.restype = i32
+        L.t2d_np_attach.argtypes = [vp, vp]
         L.t2d_np_reset_many.restype = i32
         L.t2d_np_reset_many.argtypes = [vp, i32, vp, vp, vp, vp, i32]
         L.t2d_np_target_actions.restype = i32
@@ -145,6 +149,26 @@ class NpBatchSource(object):
         if idx:
             _check(self.L.t2d_np_target_actions(self._handles(idx), len(idx), _ptr(a), self.threads))
         return a
+
+
+def mt_states(seeds):
+    """uint32 [len(seeds), 625]: the MT19937 state np.random.seed(seed) leaves behind, per seed (624 words + the read position)."""
+    L = _lib()
+    out = np.zeros((len(seeds), 625), np.uint32)
+    for i, sd in enumerate(seeds):
+        _check(L.t2d_np_mt_state(int(sd) & 0xFFFFFFFF, _ptr(out[i])))
+    return out
+
+
+def attach_device_streams(core, seeds):
+    """Hand a vec_env.VecTrack2D one numpy-legacy stream per env (np.random.seed(seeds[i])): from now on its generator — reset()
+    and the pre-generated episodes of the in-launch auto-reset — restates the reference's draws on the device (t2d_np_attach,
+    csrc/track2d_hip.hip k_gen_np). Before the first reset; Adv / PZR / Far (and host-driven Ext) targets only."""
+    assert len(seeds) == core.num_envs
+    st = np.ascontiguousarray(mt_states(seeds))
+    rc = _lib().t2d_np_attach(core.h, _ptr(st))
+    if rc != 0:
+        raise NpError("t2d_np_attach failed (%d): %s" % (rc, core.L.t2d_last_error().decode()))
 
 
 def astar(maze, start, goal, max_len=8192):

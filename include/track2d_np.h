@@ -47,6 +47,20 @@ int t2d_np_reset(t2d_np *e, uint8_t *maze, int32_t *side, int32_t pos[4], int32_
  * does not depend on the tracker). Error for the policy-driven modes (Adv / PZR / Far). */
 int t2d_np_target_action(t2d_np *e, int32_t *action);
 
+/* The MT19937 state np.random.seed(seed) leaves behind (624 words, then the read position), for t2d_np_attach. */
+int t2d_np_mt_state(uint32_t seed, uint32_t out[625]);
+/* DEVICE-side reference-exact episodes (csrc/track2d_hip.hip: k_gen_np). After this call the handle's generator — t2d_reset,
+ * the in-launch auto-reset's pre-generated episodes — draws env i's maps, goals and spawns from ITS OWN numpy-legacy stream
+ * (states_host [N][625]: t2d_np_mt_state(seed_i)), restating init_maze / RandomBlockMazeGenerator / RandomMazeGenerator /
+ * sample_goal / sample_close_states / get_around (track_1v1.py:218-240; generators.py:38-94,115-176) draw for draw — whole
+ * Fisher-Yates permutations included — on one wavefront per env: episode k of env i is the k-th reset() of the reference
+ * env after np.random.seed(seed_i), at batch scale, with no host in the loop. For target modes that draw nothing themselves
+ * (Adv, PZR, Far; Ext = host-driven), any map type, 'Partial' or 'Full' observations; call it before the first t2d_reset.
+ * Returns 0 or a T2D_ERR_* code (t2d_last_error). (Scripted Ram / Nav targets interleave their own draws with the resets:
+ * they stay on the host streams, environment.NumpyVecEnv.) */
+struct t2d_handle;
+int t2d_np_attach(struct t2d_handle *h, const uint32_t *states_host);
+
 /* The two per-step / per-episode calls for MANY envs (a batch replayed against the reference: each env keeps its own stream,
  * so the calls are independent and are spread over `threads` host threads; 0 = one per hardware thread). envs[i] -> entry i of
  * every output: mazes [count][82*82], sides [count], pos / goals [count][4]; actions [count]. Returns 0 or the first failing

@@ -809,6 +809,72 @@ def test_numpy_rng_batch_replays_all_reference_episodes_concurrently_in_one_hand
           % (steps, dt, steps / dt))
 
 
+def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_alone():
+    """NumpyVecEnv(device_generators=True): the numpy-legacy streams live on the DEVICE (t2d_np_attach -> k_gen_np: MT19937, numpy's
+    doubles / bounded integers / whole Fisher-Yates permutations, init_maze, both map generators, sample_goal,
+    sample_close_states, get_around restated draw for draw, one wavefront per env) and a finished env restarts inside the step
+    launch from an episode pre-generated out of its own stream. Every multi-episode capture of episodes.npz whose target draws
+    nothing itself (PZR / Adv / Far on Block / Maze / Empty maps, levels 0 / 1), four copies each, advanced in lock step from
+    (env id, seed, recorded policy actions) ALONE — no host stream, no injection: every observation, reward and done flag of
+    every episode equals the reference's, the first observation of every following episode included."""
+    from conftest import GOLDEN
+    from active_tracking_rl_amd.environment import NumpyVecEnv
+    g = np.load(os.path.join(GOLDEN, "episodes.npz"))
+    names = [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) in ("PZR", "Adv", "Far")] * 4
+    ids, seeds, eps = [], [], []
+    for name in names:
+        mp, mode, lvl, seed, _ = [str(x) for x in g[name + "/meta"]]
+        ids.append("Track2D-%sPartial%s-v%s" % (mp, mode, lvl))
+        seeds.append(int(seed))
+        eps.append([{k: g["%s/ep%d_%s" % (name, e, k)] for k in ("obs0", "act_in", "obs", "rew", "done", "pos")}
+                    for e in range(int(g[name + "/n_eps"]))])
+    n = len(names)
+    assert n >= 24 and len(set(i.split("Partial")[0] for i in ids)) == 3          # Block, Maze and Empty maps among them
+    with pytest.raises(ValueError, match="draw from the stream between resets"):
+        NumpyVecEnv(["Track2D-BlockPartialRam-v0"], [1], device_generators=True)
+    env = NumpyVecEnv(ids, seeds, device_generators=True)
+    obs = env.reset().cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(obs[i], eps[i][0]["obs0"].astype(np.float32)), (names[i], "first reset")
+    cur = [[0, 0] for _ in range(n)]
+    steps = 0
+    while any(c[0] < len(eps[i]) for i, c in enumerate(cur)):
+        act = np.zeros((2, n), np.int64)
+        for i, (e, t) in enumerate(cur):
+            if e < len(eps[i]):
+                act[:, i] = eps[i][e]["act_in"][t]
+        obs, rew, done, info = env.step([act[0], act[1]])
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        cut = np.zeros(n, bool)
+        for i, (e, t) in enumerate(cur):
+            if e >= len(eps[i]):
+                continue
+            E = eps[i][e]
+            last = t == len(E["act_in"]) - 1
+            assert bool(done[i]) == bool(E["done"][t]), (names[i], e, t, "done")
+            assert np.array_equal(rew[i].astype(np.float64), E["rew"][t].astype(np.float32).astype(np.float64)), (names[i], e, t)
+            if not done[i]:
+                dr = E["pos"][t, 1] - E["pos"][t, 0]
+                assert abs(info["distance"][i] - float(np.sqrt(float((dr * dr).sum())))) < 1e-12
+                assert np.array_equal(obs[i], E["obs"][t].astype(np.float32)), (names[i], e, t, "obs")
+            elif e + 1 < len(eps[i]):             # finished: restarted inside the launch, from the env's own stream
+                assert last
+                assert np.array_equal(obs[i], eps[i][e + 1]["obs0"].astype(np.float32)), (names[i], e + 1, "obs0 after done")
+            steps += 1
+            if last:
+                cur[i] = [e + 1, 0]
+                cut[i] = not done[i] and e + 1 < len(eps[i])       # the capture stopped this episode early: reset() as it did
+            else:
+                cur[i][1] = t + 1
+        if cut.any():
+            fresh = env.reset(cut).cpu().numpy()
+            for i in np.nonzero(cut)[0]:
+                assert np.array_equal(fresh[i], eps[i][cur[i][0]]["obs0"].astype(np.float32)), (names[i], cur[i][0], "obs0")
+    assert env.core.faults() == 0
+    env.close()
+    assert steps > 2000
+
+
 def test_create_env_numpy_rng_batch_equals_single_numpy_envs():
     """create_env(..., num_envs=4, rng="numpy") is the batch form of the reference-exact mode: env i runs np.random.seed(seed + i),
     i.e. what four single create_env(..., rng="numpy") envs seeded seed + i do (the reference worker's env.seed(seed + rank),
