@@ -78,3 +78,15 @@ def test_policy_driven_modes_have_no_scripted_action(npm):
     with pytest.raises(npm.NpError):
         src.target_action()
     src.close()
+
+
+def test_mt_state_export_equals_numpys_seeded_state():
+    """t2d_np_mt_state(seed): the 624 words + read position np.random.seed(seed) leaves behind — what t2d_np_attach uploads per
+    env for the device-side generators (k_gen_np) — against numpy's own RandomState."""
+    from active_tracking_rl_amd import np_mode
+    seeds = [0, 1, 11, 12345, 2 ** 32 - 1]
+    st = np_mode.mt_states(seeds)
+    assert st.shape == (len(seeds), 625) and st.dtype == np.uint32
+    for i, sd in enumerate(seeds):
+        kind, key, pos = np.random.RandomState(sd).get_state()[:3]
+        assert kind == "MT19937" and np.array_equal(st[i, :624], key) and int(st[i, 624]) == pos == 624
