@@ -365,10 +365,13 @@ def create_env(env_id, args, num_envs=None, device=None, env_id_base=0, obs_u8=N
     if obs_u8 is None:
         obs_u8 = bool(getattr(args, "obs_u8", False))
     rng = rng if rng is not None else getattr(args, "rng", "philox")
-    if n > 1 and rng == "numpy":      # the reference-exact mode for a batch: env i on np.random.seed(seed + env_id_base + i)
+    if n > 1 and rng in ("numpy", "numpy-device"):      # the reference-exact mode for a batch: env i on np.random.seed(seed + env_id_base + i)
         if stack != 1 or rescale:
             raise NotImplementedError("rng='numpy' with num_envs > 1 returns raw float32 observations (no frame stack / rescale)")
-        return NumpyVecEnv(env_id, [int(seed) + int(env_id_base) + i for i in range(n)], device=device)
+        # rng="numpy-device" / args.np_device: the streams on the device (t2d_np_attach) where the target mode allows it
+        on_dev = rng == "numpy-device" or bool(getattr(args, "np_device", False))
+        return NumpyVecEnv(env_id, [int(seed) + int(env_id_base) + i for i in range(n)], device=device,
+                           device_generators=on_dev and registry.spec(env_id)["target_mode"] in ("Adv", "PZR", "Far"))
     if n > 1:
         return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base, rescale=rescale,
                       obs_u8=obs_u8, inv=inv)

@@ -691,6 +691,27 @@ class PipelinedIteration(object):
         tensors = None if keep_updates else self._schedule_tensors()
         saved = [t.clone() for t in tensors] if tensors is not None else None
         i0, n0 = self.i, self.master.n_steps
+        # A trial must be long enough for the steady state to show: one call of run() is one PHASE, a trial starts with an empty
+        # pipeline and ends with finish(), and at 512 envs eight iterations are 10 ms of which the fill / drain is a fifth — the
+        # CU partition (1.13 ms per iteration in steady state against 1.24 on shared streams) then only TIES its trial and loses
+        # it every other run (profiles/r05_bench.json: 8.3 M instead of 9.1). So the trial length is set from a pilot: ~50 ms per
+        # candidate, at least `iters`, at most 64 iterations (the same on every rank: the pilot time is all-reduced MAX).
+        self._use_streams(pairs[0][0], pairs[0][1])
+        for _ in range(2):
+            self.run()
+        self.finish()
+        torch.cuda.synchronize(self.dev)
+        t0 = _time.perf_counter()
+        for _ in range(4):
+            self.run()
+        self.finish()
+        torch.cuda.synchronize(self.dev)
+        pilot_ms = (_time.perf_counter() - t0) / 4 * 1e3
+        if multi:
+            pm = torch.tensor([pilot_ms], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(pm, op=dist.ReduceOp.MAX)
+            pilot_ms = float(pm.item())
+        iters = max(int(iters), min(64, int(50.0 / max(pilot_ms, 1e-3))))
         iters += iters & 1              # whole pairs of phases per candidate: the replica parity is the same afterwards
         # two passes over the list, the better of a candidate's two times counts: one 8-iteration sample is noisy enough to
         # lose the CU partition its trial at 512 envs in two runs of six (8.2 M env steps/s instead of 8.9)
@@ -721,7 +742,7 @@ class PipelinedIteration(object):
             with torch.no_grad():
                 for t, v in zip(tensors, saved):
                     t.copy_(v)
-            assert (self.i - i0) % 2 == 0      # (each candidate ran 2 x (2 + iters) phases: replica i0 & 1 is next, as before)
+            assert (self.i - i0) % 2 == 0      # (pilot 2 + 4, each candidate 2 x (2 + iters) phases: replica i0 & 1 is next, as before)
             self.i, self.master.n_steps = i0, n0
             torch.cuda.synchronize(self.dev)
         return [(times[j], j == best, pairs[j][2]) for j in range(len(pairs))]

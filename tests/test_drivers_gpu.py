@@ -910,6 +910,35 @@ def test_create_env_numpy_rng_batch_equals_single_numpy_envs():
         e.close()
 
 
+def test_create_env_numpy_device_streams_equal_the_host_streams():
+    """create_env(..., num_envs=n, rng="numpy-device"): the numpy-legacy streams on the device (t2d_np_attach, k_gen_np) against the
+    host-stream batch (rng="numpy": csrc/np_mode.cpp + t2d_inject) on the same seeds — two independent restatements of the
+    reference's draws, one in HIP and one in C++ — over many short episodes with in-launch restarts on the device side: every
+    observation, reward and done flag equal."""
+    import argparse
+    from active_tracking_rl_amd.environment import NumpyVecEnv, create_env
+    mk = lambda seed: argparse.Namespace(stack_frames=1, seed=seed, rescale=False, gpu_ids=[0])
+    for env_id in ("Track2D-BlockPartialPZR-v0", "Track2D-MazePartialAdv-v0", "Track2D-EmptyPartialFar-v1"):
+        dev_env = create_env(env_id, mk(77), num_envs=24, rng="numpy-device")
+        host_env = create_env(env_id, mk(77), num_envs=24, rng="numpy")
+        assert isinstance(dev_env, NumpyVecEnv) and dev_env.device_generators and not host_env.device_generators
+        assert torch.equal(dev_env.reset(), host_env.reset())
+        rs = np.random.RandomState(9)
+        ends = 0
+        for t in range(150):
+            a = rs.randint(0, 4, size=(2, 24))
+            od, rd, dd, _ = dev_env.step([a[0], a[1]])
+            oh, rh, dh, _ = host_env.step([a[0], a[1]])
+            assert torch.equal(dd, dh) and torch.equal(rd, rh) and torch.equal(od, oh), (env_id, t)
+            ends += int(dd.sum())
+        assert ends > 24
+        dev_env.close(); host_env.close()
+    # a scripted target falls back to the host streams
+    e = create_env("Track2D-BlockPartialRam-v0", mk(5), num_envs=4, rng="numpy-device")
+    assert not e.device_generators
+    e.close()
+
+
 def test_max_grad_norm_is_applied_inside_the_captured_update_graphs():
     """--max-grad-norm under the graphed drivers: the clip (clip_grad_norm_ on the flat bucket, player_util.py:157's intent) is
     captured in the update graph of GraphedIteration and PipelinedIteration — the gradient the last update consumed has at most

@@ -36,6 +36,12 @@ for n in 1024 8192; do
   rm -rf /tmp/p_nav; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_nav -- python $R/tools/env_only_bench.py --env Track2D-MazePartialNav-v0 --n $n --steps 600 --warmup 100 > $O/nav_env_only_$n.txt 2>/dev/null
   python $R/tools/summarize_prof.py stats /tmp/p_nav > $O/nav_kernel_stats_$n.txt
 done
+# (round 5) the same loop with the Maze maps grown ahead of the pass (t2d_pregrow, forked behind every pass), and the pipelined
+# iteration of configs[3], where k_pregrow runs on the learner's stream
+rm -rf /tmp/p_nav; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_nav -- python $R/tools/env_only_bench.py --env Track2D-MazePartialNav-v0 --n 1024 --steps 600 --warmup 100 --pregrow > $O/nav_env_only_1024_pregrow.txt 2>/dev/null
+python $R/tools/summarize_prof.py stats /tmp/p_nav > $O/nav_kernel_stats_1024_pregrow.txt
+rm -rf /tmp/p_it; ITER_PROFILE_SCHEDULE=pipelined timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_it -- python $R/tools/iter_profile.py 200 Track2D-MazePartialNav-v0 1024 maze-lstm none 0 > /dev/null 2>&1
+python $R/tools/summarize_prof.py stats /tmp/p_it 200 > $O/iteration_kernel_stats_config3_pipelined.txt
 # (the probe build of the library, -DT2D_EXP=9, compiled here from the sources of this very tree)
 mkdir -p $R/scratch_exp; (cd $R/active_tracking_rl_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -ldl -Wno-unused-result -DT2D_EXP=9 \
     -o $R/scratch_exp/libexp9.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
@@ -68,4 +74,5 @@ cp $(ls -d $O/main_logs/*/*/ | head -1)logger $O/main_py_logger.txt 2>/dev/null
 tail -30 $(ls $O/main_logs/*/*/Agent:0/scalars.jsonl | head -1) > $O/main_py_scalars_tail.txt 2>/dev/null
 tail -12 $(ls $O/main_logs/*/*/Test/scalars.jsonl | head -1) > $O/main_py_test_scalars_tail.txt 2>/dev/null
 find $O/main_logs -name "*.dat" -delete
+(cd $R && timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1)
 ls -la $O
