@@ -619,9 +619,10 @@ class PipelinedIteration(object):
         self.i, self.master.n_steps = i0, n0
         torch.cuda.synchronize(self.dev)
 
-    def tune_streams(self, candidates=4, iters=8, partitions=("half",), keep_updates=False):
+    def tune_streams(self, candidates=4, iters=None, partitions=("half",), keep_updates=False):
         """Pick the stream pair the two chains overlap best on. Two things are not in the application's hands and are settled
-        by trial — `iters` iterations of the schedule per candidate, timed on the host clock, the fastest kept:
+        by trial — `iters` iterations of the schedule per candidate (None: as many as fill ~50 ms, 8 to 64, from a pilot), timed on
+        the host clock, the fastest kept:
           * HIP multiplexes its streams onto a few hardware queues (4 by default) in an order the application does not
             control: two streams that land on one queue run the two chains back to back (measured at 512 envs: 1.73 ms per
             iteration against 1.33 ms on distinct queues, 1.62 ms synchronous), and the mapping depends on how many streams
@@ -649,7 +650,8 @@ class PipelinedIteration(object):
             # Every trial below holds collectives, so the ranks must agree on what they are about to do BEFORE any of them
             # leaves: a rank with serial=True (or another forced CU split, another candidate count — per-rank environment
             # variables) would return here while the others wait in an all-reduce for ever.
-            cfg = torch.tensor([1 if self.serial else 0, int(self.cu_split), int(candidates), int(iters), len(partitions)],
+            cfg = torch.tensor([1 if self.serial else 0, int(self.cu_split), int(candidates), -1 if iters is None else int(iters),
+                                len(partitions)],
                                dtype=torch.int64, device=self.dev)
             lo, hi = cfg.clone(), cfg.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -694,24 +696,25 @@ class PipelinedIteration(object):
         # A trial must be long enough for the steady state to show: one call of run() is one PHASE, a trial starts with an empty
         # pipeline and ends with finish(), and at 512 envs eight iterations are 10 ms of which the fill / drain is a fifth — the
         # CU partition (1.13 ms per iteration in steady state against 1.24 on shared streams) then only TIES its trial and loses
-        # it every other run (profiles/r05_bench.json: 8.3 M instead of 9.1). So the trial length is set from a pilot: ~50 ms per
-        # candidate, at least `iters`, at most 64 iterations (the same on every rank: the pilot time is all-reduced MAX).
-        self._use_streams(pairs[0][0], pairs[0][1])
-        for _ in range(2):
-            self.run()
-        self.finish()
-        torch.cuda.synchronize(self.dev)
-        t0 = _time.perf_counter()
-        for _ in range(4):
-            self.run()
-        self.finish()
-        torch.cuda.synchronize(self.dev)
-        pilot_ms = (_time.perf_counter() - t0) / 4 * 1e3
-        if multi:
-            pm = torch.tensor([pilot_ms], dtype=torch.float64, device=self.dev)
-            dist.all_reduce(pm, op=dist.ReduceOp.MAX)
-            pilot_ms = float(pm.item())
-        iters = max(int(iters), min(64, int(50.0 / max(pilot_ms, 1e-3))))
+        # it every other run (one collection pass of round 5: 8.3 M instead of 9.1). So the trial length is set from a pilot: ~50 ms per
+        # candidate, 8 to 64 iterations (the same on every rank: the pilot time is all-reduced MAX), unless the caller fixes `iters`.
+        if iters is None:
+            self._use_streams(pairs[0][0], pairs[0][1])
+            for _ in range(2):
+                self.run()
+            self.finish()
+            torch.cuda.synchronize(self.dev)
+            t0 = _time.perf_counter()
+            for _ in range(4):
+                self.run()
+            self.finish()
+            torch.cuda.synchronize(self.dev)
+            pilot_ms = (_time.perf_counter() - t0) / 4 * 1e3
+            if multi:
+                pm = torch.tensor([pilot_ms], dtype=torch.float64, device=self.dev)
+                dist.all_reduce(pm, op=dist.ReduceOp.MAX)
+                pilot_ms = float(pm.item())
+            iters = max(8, min(64, int(50.0 / max(pilot_ms, 1e-3))))
         iters += iters & 1              # whole pairs of phases per candidate: the replica parity is the same afterwards
         # two passes over the list, the better of a candidate's two times counts: one 8-iteration sample is noisy enough to
         # lose the CU partition its trial at 512 envs in two runs of six (8.2 M env steps/s instead of 8.9)
