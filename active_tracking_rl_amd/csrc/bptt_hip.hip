@@ -36,8 +36,15 @@ constexpr int kBLd = kBK + 4;               // LDS row stride (floats): 16-B rea
 struct Bptt {
     const float *dh[2];        // per player: dL/dh_t from the heads [T, N, R] (nullable: zero)
     const float *keep;         // [T, N] float episode masks
-    const float *acts;         // + p * acts_ps + (t * N + n) * 4R : activated gates (i, f, g, o)
-    long long acts_ps;
+    const float *acts;         // + p * acts_ps + (t * N + n) * 4R : activated gates (i, f, g, o) — or, PRE, what the rollout's
+    long long acts_ps;         //   gate GEMM wrote: the pre-activations without bias (activated here: same expressions)
+    // PRE only: per player b_ih + b_hh [4R]; the tracker-action embedding projected through W_ih [n_act, 4R] added to player
+    // emb_player's pre-activations, row = the tracker's action of that step (int64, act + t * act_ts + n)
+    const float *bias[2];
+    const float *emb;
+    const long long *act;
+    long long act_ts;
+    int emb_player, n_act;
     const float *c_all;        // + p * c_ps + (t * N + n) * R : cell states, slot t = before step t, slot t + 1 = after
     long long c_ps;
     const float *whh[2];       // per player: weight_hh [4R, R] (nn.LSTMCell layout)
@@ -47,9 +54,10 @@ struct Bptt {
     int P, T, N;
 };
 
+template <bool PRE>
 __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
 {
-    extern __shared__ __attribute__((aligned(16))) float tileA[];      // [2][kBRows][kBLd]
+    extern __shared__ __attribute__((aligned(16))) float tileA[];      // [2][kBRows][kBLd] (+ PRE: the embedding table)
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int col = l & 15, q = l >> 4;
     const int tiles = (a.N + kBRows - 1) / kBRows;
@@ -72,6 +80,20 @@ __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
     const float *call = a.c_all + (size_t)p * a.c_ps;
     const float *dhp = a.dh[p];
     float *dg = a.dg + (size_t)p * a.dg_ps;
+    // PRE: the rollout kept the gate GEMM's output instead of the activated gates (k_act_step then writes 4R floats per row and
+    // step less); the activations are recomputed here exactly as k_act_step computed them: ((pre + bias) + emb[a_tracker]),
+    // sigmoidf_ / tanhf_ of atr_cell.h
+    float bi = 0.f, bf = 0.f, bg = 0.f, bo = 0.f;
+    float *embL = tileA + (size_t)2 * kBRows * kBLd;
+    const bool with_emb = PRE && a.emb != nullptr && p == a.emb_player;
+    if (PRE) {
+        const float *b = a.bias[p];
+        bi = b[u]; bf = b[kBR + u]; bg = b[2 * kBR + u]; bo = b[3 * kBR + u];
+        if (with_emb)
+            for (int i = tid; i < a.n_act * kBK; i += 512) embL[i] = a.emb[i];
+        __syncthreads();
+    }
+    int ai[4] = {0, 0, 0, 0};
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};          // dG_{t+1} W_hh for this thread's pairs (gradient arriving through h_t)
     float dcc[4] = {0.f, 0.f, 0.f, 0.f};       // dc_{t+1} f_{t+1}
     // staged inputs of one step (fetched one step ahead, under the MFMAs)
@@ -86,6 +108,7 @@ __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
             cv[i] = call[(r_ + a.N) * kBR + u];                  /* c after step t: slot t + 1 */                      \
             cpv[i] = call[r_ * kBR + u];                         /* c before step t */                                 \
             dhh[i] = dhp ? dhp[r_ * kBR + u] : 0.0f;                                                                   \
+            if (with_emb) ai[i] = (int)a.act[(size_t)tt_ * a.act_ts + rows[i]];                                        \
             ko[i] = a.keep[r_];                                                                                        \
             ki[i] = tt_ > 0 ? a.keep[r_ - a.N] : 1.0f;                                                                 \
         }                                                                                                              \
@@ -98,6 +121,14 @@ __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
         // ---- cell backward of this thread's 4 pairs (k_lstm_cell_bwd's expressions)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
+            if (PRE) {
+                float xi = gi[i] + bi, xf = gf[i] + bf, xg = gg[i] + bg, xo = go[i] + bo;
+                if (with_emb) {
+                    const float *e_ = embL + ai[i] * kBK + u;
+                    xi = e_[0] + xi; xf = e_[kBR] + xf; xg = e_[2 * kBR] + xg; xo = e_[3 * kBR] + xo;
+                }
+                gi[i] = sigmoidf_(xi); gf[i] = sigmoidf_(xf); gg[i] = tanhf_(xg); go[i] = sigmoidf_(xo);
+            }
             float dh = dhh[i], dcn = 0.0f;
             if (has_next) { dh = fmaf(ko[i], acc[i], dh); dcn = ko[i] * dcc[i]; }
             const float tc = tanhf_(cv[i]);
@@ -163,6 +194,21 @@ __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
 
 using namespace atr;
 
+static int bptt_launch(const Bptt &a, bool pre, void *stream)
+{
+    const size_t lds = (size_t)2 * kBRows * kBLd * sizeof(float) + (pre ? (size_t)kMaxActions * kBK * sizeof(float) : 0);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[pre ? 1 : 0]) {
+        const void *fn = pre ? (const void *)k_lstm_bptt<true> : (const void *)k_lstm_bptt<false>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        attr_set[pre ? 1 : 0] = true;
+    }
+    const unsigned grid = (unsigned)(a.P * ((a.N + kBRows - 1) / kBRows));
+    if (pre) hipLaunchKernelGGL(k_lstm_bptt<true>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_lstm_bptt<false>, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int atr_lstm_bptt(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *acts,
                              long long acts_pstride, const float *c_all, long long c_pstride, const float *whh0,
                              const float *whh1, float *dg, long long dg_pstride, float *dh_init, float *dc_init, int P, int T,
@@ -175,14 +221,26 @@ extern "C" int atr_lstm_bptt(const float *dh0_heads, const float *dh1_heads, con
     a.dh[0] = dh0_heads; a.dh[1] = dh1_heads; a.keep = keep; a.acts = acts; a.acts_ps = acts_pstride; a.c_all = c_all;
     a.c_ps = c_pstride; a.whh[0] = whh0; a.whh[1] = whh1; a.dg = dg; a.dg_ps = dg_pstride; a.dh0 = dh_init; a.dc0 = dc_init;
     a.P = P; a.T = T; a.N = N;
-    const size_t lds = (size_t)2 * kBRows * kBLd * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_lstm_bptt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -2;
-        attr_set = true;
-    }
-    const unsigned grid = (unsigned)(P * ((N + kBRows - 1) / kBRows));
-    hipLaunchKernelGGL(k_lstm_bptt, dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    a.bias[0] = a.bias[1] = nullptr; a.emb = nullptr; a.act = nullptr; a.act_ts = 0; a.emb_player = -1; a.n_act = 0;
+    return bptt_launch(a, false, stream);
+}
+
+// atr_lstm_bptt over a rollout that stored the gate GEMM's OUTPUT (pre-activations without bias) instead of the activated gates.
+extern "C" int atr_lstm_bptt_pre(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *pre,
+                                 long long pre_pstride, const float *bias0, const float *bias1, const float *emb, int emb_player,
+                                 int n_act, const long long *act_tracker, long long act_tstride, const float *c_all,
+                                 long long c_pstride, const float *whh0, const float *whh1, float *dg, long long dg_pstride,
+                                 float *dh_init, float *dc_init, int P, int T, int N, int R, void *stream)
+{
+    if (!keep || !pre || !bias0 || !c_all || !whh0 || !dg || !dh_init || !dc_init || P < 1 || P > 2 || (P == 2 && (!whh1 || !bias1)) ||
+        T < 1 || N < 1 || R != kBR)
+        return -1;
+    if (emb && (!act_tracker || n_act < 1 || n_act > kMaxActions || emb_player < 0 || emb_player >= P)) return -1;
+    Bptt a;
+    a.dh[0] = dh0_heads; a.dh[1] = dh1_heads; a.keep = keep; a.acts = pre; a.acts_ps = pre_pstride; a.c_all = c_all;
+    a.c_ps = c_pstride; a.whh[0] = whh0; a.whh[1] = whh1; a.dg = dg; a.dg_ps = dg_pstride; a.dh0 = dh_init; a.dc0 = dc_init;
+    a.P = P; a.T = T; a.N = N;
+    a.bias[0] = bias0; a.bias[1] = bias1; a.emb = emb; a.act = act_tracker; a.act_ts = act_tstride;
+    a.emb_player = emb ? emb_player : -1; a.n_act = emb ? n_act : 0;
+    return bptt_launch(a, true, stream);
 }

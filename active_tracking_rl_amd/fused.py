@@ -125,6 +125,9 @@ def lib():
         L.atr_embed_grad.argtypes = [vp, vp, ll, ll, ll, vp, vp, vp, ll, i32, i32, vp]
         L.atr_lstm_bptt.restype = i32
         L.atr_lstm_bptt.argtypes = [vp, vp, vp, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, i32, i32, i32, i32, vp]
+        L.atr_lstm_bptt_pre.restype = i32
+        L.atr_lstm_bptt_pre.argtypes = [vp, vp, vp, vp, ll, vp, vp, vp, i32, i32, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp,
+                                        i32, i32, i32, i32, vp]
         L.atr_pair_linear.restype = i32
         L.atr_pair_linear.argtypes = [C.POINTER(PairLinearArgs), vp]
         L.atr_act_env_step.restype = i32
@@ -663,27 +666,62 @@ class _LstmSeq(torch.autograd.Function):
 use_fused_bptt = True   # the whole recurrence backward as ONE launch (csrc/bptt_hip.hip) instead of 2 launches per step
 
 
-def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs, whh_nn=None, want_dwhh=True):
+def activate_preacts(pre, info):
+    """The activated gates (i, f, g, o) [P, T, N, 4R] from stored pre-activations (`info`: see _lstm_bptt) with tensor ops — what
+    the fused BPTT kernel recomputes in registers; only the per-step fallback recurrence needs them materialised."""
+    P, T, N, R4 = pre.shape
+    R = R4 // 4
+    x = pre + torch.stack(list(info["bias"]), 0).view(P, 1, 1, R4)
+    if info.get("emb") is not None and 0 <= info["emb_player"] < P:
+        x[info["emb_player"]] = info["emb"][info["act"]] + x[info["emb_player"]]
+    x = x.view(P, T, N, 4, R)
+    return torch.stack([torch.sigmoid(x[..., 0, :]), torch.sigmoid(x[..., 1, :]), torch.tanh(x[..., 2, :]),
+                        torch.sigmoid(x[..., 3, :])], -2).reshape(P, T, N, R4).contiguous()
+
+
+def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs, whh_nn=None, want_dwhh=True, pre=None):
     """Back-propagation through time over stored activations: dhs = per-player dL/dh_seq [T,N,R] (None = zero).
     Returns dG [P, T*N, 4R] (= dL/d ig), dL/dh0, dL/dc0 [P,N,R] and dL/dW_hh^T [P,R,4R]. whh_nn: per-player weight_hh [4R,R]
-    (nn layout; made from whh [P,R,4R] when absent)."""
+    (nn layout; made from whh [P,R,4R] when absent).
+    pre: None, or dict(bias=[per-player b_ih + b_hh [4R]], emb=[n_act, 4R] or None, emb_player, act=[T, N] int64 view of the
+    tracker's actions) — `acts` then holds the rollout's gate PRE-activations without bias (model._act_step's one-GEMM path keeps
+    the GEMM's output instead of the activated gates) and the activations are recomputed inside the kernel."""
     L = lib()
     P, T1, N, R = h_all.shape
     T = T1 - 1
     dev = h_all.device
+    fused_ok = (use_fused_bptt and R == 128 and h_all.is_cuda and acts.is_contiguous() and c_all.is_contiguous()
+                and keep.is_contiguous())
+    if pre is not None and not fused_ok:
+        acts, pre = activate_preacts(acts, pre), None
     dG = torch.empty((P, T, N, 4 * R), dtype=torch.float32, device=dev)
     dhn = torch.empty((P, N, R), dtype=torch.float32, device=dev)
     dcc = torch.empty((P, N, R), dtype=torch.float32, device=dev)
     st = _stream(h_all)
     ps, pa, step, astep = (T + 1) * N * R, T * N * 4 * R, N * R * 4, N * 4 * R * 4
-    if use_fused_bptt and R == 128 and h_all.is_cuda and acts.is_contiguous() and c_all.is_contiguous() and keep.is_contiguous():
+    if fused_ok:
         if whh_nn is None:
             wt = whh.transpose(1, 2).contiguous()
             whh_nn = [wt[p] for p in range(P)]
         whh_nn = [w if w.is_contiguous() else w.contiguous() for w in whh_nn]
         dh_c = [d.contiguous() if d is not None else None for d in dhs]
-        rc = L.atr_lstm_bptt(_pn(dh_c[0]), _pn(dh_c[1]) if P > 1 else None, _p(keep), _p(acts), pa, _p(c_all), ps,
-                             _p(whh_nn[0]), _p(whh_nn[1]) if P > 1 else None, _p(dG), pa, _p(dhn), _p(dcc), P, T, N, R, st)
+        if pre is not None:
+            bias = [b.contiguous() for b in pre["bias"]]
+            emb = pre.get("emb")
+            ep = int(pre.get("emb_player", -1))
+            if emb is None or not (0 <= ep < P):
+                emb, ep, act, n_act, act_ts = None, -1, None, 0, 0
+            else:
+                emb, act = emb.contiguous(), pre["act"]
+                assert act.dtype == torch.int64 and act.shape == (T, N) and act.stride(1) == 1
+                n_act, act_ts = emb.shape[0], act.stride(0)
+            rc = L.atr_lstm_bptt_pre(_pn(dh_c[0]), _pn(dh_c[1]) if P > 1 else None, _p(keep), _p(acts), acts.stride(0),
+                                     _p(bias[0]), _p(bias[1]) if P > 1 else None, _pn(emb), ep, n_act, _pn(act), act_ts,
+                                     _p(c_all), ps, _p(whh_nn[0]), _p(whh_nn[1]) if P > 1 else None, _p(dG), pa, _p(dhn),
+                                     _p(dcc), P, T, N, R, st)
+        else:
+            rc = L.atr_lstm_bptt(_pn(dh_c[0]), _pn(dh_c[1]) if P > 1 else None, _p(keep), _p(acts), pa, _p(c_all), ps,
+                                 _p(whh_nn[0]), _p(whh_nn[1]) if P > 1 else None, _p(dG), pa, _p(dhn), _p(dcc), P, T, N, R, st)
         if rc != 0:
             raise RuntimeError("atr_lstm_bptt failed (%d)" % rc)
     else:
@@ -728,7 +766,7 @@ class _LstmSeqCached(torch.autograd.Function):
         whh = h_all.new_empty(0) if fused_path else torch.stack([w.t() for w in whh_l], 0).contiguous()
         ctx.save_for_backward(keep.contiguous(), h_all, c_all, acts, whh, *feats, *wih, *whh_l, *fw[3 * P:5 * P])
         ctx.P = P
-        need, ctx.hm = need                       # (lstm_sequence_cached packs the two non-tensor arguments together)
+        need, ctx.hm, ctx.pre = need              # (lstm_sequence_cached packs the non-tensor arguments together)
         ctx.need = tuple(bool(x) for x in need) if need is not None else (True,) * P
         return tuple(h_all[p, 1:] for p in range(P))
 
@@ -743,7 +781,8 @@ class _LstmSeqCached(torch.autograd.Function):
         db2 = None
         q = _deferred
         T, N, R = h_all.shape[1] - 1, h_all.shape[2], h_all.shape[3]
-        if whh.numel() == 0 and not (use_fused_bptt and R == 128 and acts.is_contiguous() and c_all.is_contiguous()):
+        if whh.numel() == 0 and not (use_fused_bptt and R == 128 and acts.is_contiguous() and c_all.is_contiguous()
+                                     and keep.is_contiguous()):
             whh = torch.stack([w.t() for w in whh_nn], 0).contiguous()
         if all(ctx.need):
             groups = [list(range(P))]
@@ -752,8 +791,11 @@ class _LstmSeqCached(torch.autograd.Function):
         for grp in groups:
             a, b = grp[0], grp[-1] + 1
             defer = q is not None and use_fused_bptt and R == 128 and T * N >= 4096
+            pre = None
+            if ctx.pre is not None:          # (this group's slice of the stored pre-activations' side information)
+                pre = dict(ctx.pre, bias=list(ctx.pre["bias"][a:b]), emb_player=ctx.pre.get("emb_player", -1) - a)
             dG, _, _, dwhh = _lstm_bptt(whh[a:b], keep, h_all[a:b], c_all[a:b], acts[a:b], dhs[a:b], whh_nn=list(whh_nn[a:b]),
-                                        want_dwhh=not defer)
+                                        want_dwhh=not defer, pre=pre)
             for i, p in enumerate(grp):
                 dfeat[p] = dG[i] @ wih[p]
                 if defer:
@@ -785,15 +827,16 @@ class _LstmSeqCached(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + db_hh
 
 
-def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts, need=None, hm=None):
+def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts, need=None, hm=None, pre=None):
     """feats: per-player [T*N, F] (with grad); lstms: the nn.LSTMCells; stored activations from the rollout.
     need: per player, whether anything upstream of its hidden sequence is trained (None = all).
     hm: per player the MASKED previous hidden rows k_{t-1} h_{t-1} as [T*N, R] (row-strided views are fine) when the rollout
-    stored them (model._act_step's one-GEMM path) — dW_hh then needs no row factors."""
+    stored them (model._act_step's one-GEMM path) — dW_hh then needs no row factors.
+    pre: `acts` holds gate pre-activations without bias instead of activated gates (see _lstm_bptt)."""
     P = len(lstms)
     args = list(feats) + [l.weight_ih for l in lstms] + [l.weight_hh for l in lstms] + \
         [l.bias_ih for l in lstms] + [l.bias_hh for l in lstms]
-    return _LstmSeqCached.apply(keep, h_all, c_all, acts, (need, hm), *args)
+    return _LstmSeqCached.apply(keep, h_all, c_all, acts, (need, hm, pre), *args)
 
 
 @torch.no_grad()

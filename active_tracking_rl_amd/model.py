@@ -539,6 +539,10 @@ class A3C_Dueling(nn.Module):
     # coop_workgroups: the grid size = the CUs of the stream the step is launched — or, for a captured step, REPLAYED — on
     # (None: the current stream's; train.PipelinedIteration sets it to its rollout stream's CU count before capturing)
     coop_step = __import__('os').environ.get('ATR_COOP_STEP', '0') != '0'
+    # one-GEMM path: the rollout keeps the gate GEMM's OUTPUT per step (pre-activations without bias, written straight into
+    # the rollout cache) instead of the activated gates — the step's last kernel writes 4R floats per row less (16.8 of its
+    # 54 MB per launch at 4096 envs) and the learner's BPTT kernel recomputes the activations from them (fused.lstm_bptt pre mode)
+    store_preacts = __import__('os').environ.get('ATR_STORE_PREACTS', '1') != '0'
     coop_max_rows = int(__import__('os').environ.get('ATR_COOP_MAX_ROWS', '1024'))
     coop_workgroups = None
     coop_step_seen = False
@@ -647,7 +651,12 @@ class A3C_Dueling(nn.Module):
             c.f_all = None
             c.f = [torch.empty((T, N, p.encoder.outdim), device=dev) for p in (p0, p1)]
         c.feat1 = torch.empty((T, N, p1.encoder.outdim), device=dev) if self.tat else None
-        c.acts = torch.empty((2, T, N, 4 * R), device=dev)
+        c.pre_all = None
+        if c.fh_all is not None and self.store_preacts and fused_lstm and not coop:
+            c.pre_all = torch.empty((2, T, N, 4 * R), device=dev)     # slot t = the gate GEMM's output of step t
+            c.acts = None
+        else:
+            c.acts = torch.empty((2, T, N, 4 * R), device=dev)
         c.h_all = torch.empty((2, T + 1, N, R), device=dev)
         c.c_all = torch.empty((2, T + 1, N, R), device=dev)
         c.actions = torch.empty((T, 2, N), dtype=torch.int64, device=dev) if self.fused_sampling else None
@@ -718,9 +727,11 @@ class A3C_Dueling(nn.Module):
         return self._act_step(states, cache, [cache.y[0][t], cache.y[1][t]], [cache.f[0][t], cache.f[1][t]],
                               cache.feat1[t] if cache.feat1 is not None else None,
                               cache.h_all[:, t], cache.c_all[:, t], cache.h_all[:, t + 1], cache.c_all[:, t + 1],
-                              cache.acts[:, t], cache.actions[t] if cache.actions is not None else None, done,
+                              cache.acts[:, t] if cache.acts is not None else None,
+                              cache.actions[t] if cache.actions is not None else None, done,
                               f_pair=cache.f_all[:, t] if cache.f_all is not None else None, env_out=env_out,
-                              fh=(cache.fh_all[:, t], cache.fh_all[:, t + 1]) if cache.fh_all is not None else None)
+                              fh=(cache.fh_all[:, t], cache.fh_all[:, t + 1]) if cache.fh_all is not None else None,
+                              gates=cache.pre_all[:, t] if getattr(cache, "pre_all", None) is not None else None)
 
     @torch.no_grad()
     def boot_values(self, states, cache, done, v_out):
@@ -741,7 +752,7 @@ class A3C_Dueling(nn.Module):
             b.f = [b.f_all[0], b.f_all[1]] if b.f_all is not None else [torch.empty_like(cache.f[i][0]) for i in range(2)]
             b.feat1 = torch.empty_like(cache.feat1[0]) if cache.feat1 is not None else None
             b.h, b.c = torch.empty((2, N, R), device=dev), torch.empty((2, N, R), device=dev)
-            b.acts = torch.empty((2, N, 4 * R), device=dev)
+            b.acts = torch.empty((2, N, 4 * R), device=dev) if cache.acts is not None else None
             b.actions = torch.empty((2, N), dtype=torch.int64, device=dev) if cache.actions is not None else None
         T = cache.T
         self._act_step(states, cache, b.y, b.f, b.feat1, cache.h_all[:, T], cache.c_all[:, T], b.h, b.c, b.acts, b.actions,
@@ -750,7 +761,7 @@ class A3C_Dueling(nn.Module):
         return v_out
 
     def _act_step(self, states, cache, y, f_out, feat1, h_prev, c_prev, h_out, c_out, acts, actions, done, f_pair=None,
-                  env_out=None, fh=None):
+                  env_out=None, fh=None, gates=None):
         """One actor step of both players on explicit buffers: y / f_out per-player stem and fc outputs, h_prev / c_prev
         [2,N,R] (un-masked; `done` [N] uint8 of the previous step is applied inside), h_out / c_out [2,N,R], acts
         [2,N,4R] (activated gates), actions [2,N] int64 or None."""
@@ -779,7 +790,7 @@ class A3C_Dueling(nn.Module):
                      and p0.actor.actor_linear.weight.shape == p1.actor.actor_linear.weight.shape
                      and p0.actor.actor_linear.weight.shape[0] <= 8
                      and all(t.is_contiguous() for t in (c_prev[0], c_prev[1], h_out[0], h_out[1], c_out[0], c_out[1],
-                                                         acts[0], acts[1], h_prev[0], h_prev[1])))
+                                                         h_prev[0], h_prev[1]) + ((acts[0], acts[1]) if acts is not None else ())))
         # fh = (this step's [2, N, F + R] rows of the [features | k h_prev] store, the next step's): one gate GEMM, K = F + R
         cat_gemm = env_fused and fh is not None and getattr(cache, "gates", None) is not None
         pair_gemm = env_fused and not cat_gemm and n <= self.pair_gemm_max_rows and getattr(cache, "gates", None) is not None
@@ -836,7 +847,9 @@ class A3C_Dueling(nn.Module):
                     for i, p in enumerate((p0, p1)):
                         fused.linear_lt(ys[i].view(n, -1), p.encoder.fc.weight, fh_t[i][:, :Fd], bias=p.encoder.fc.bias,
                                         relu=True, workspace=self._lt_ws)
-                g = cache.gates
+                # (gates: this step's slot of the rollout's pre-activation store — kept for the learner instead of the activated
+                # gates — else the scratch tensor)
+                g = gates if gates is not None else cache.gates
                 fused.linear_lt(fh_t, cache.w_cat, g, workspace=self._lt_ws)
                 ig, hg_, bs = g, None, cache.bsum
                 hm = [fh_next[0][:, Fd:], fh_next[1][:, Fd:]] if (fh_next is not None and env_out is not None) else None
@@ -931,7 +944,15 @@ class A3C_Dueling(nn.Module):
         if getattr(cache, "fh_all", None) is not None and getattr(cache, "hm_written", 0) >= T:
             Fd = cache.f_all.shape[-1]
             hm = [cache.fh_all[i, :T, :, Fd:].view(T * N, -1) for i in range(2)]
-        return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, cache.acts, need, hm=hm)
+        pre = None
+        acts = cache.acts
+        if getattr(cache, "pre_all", None) is not None:
+            # the rollout kept the gate GEMM's outputs: the BPTT kernel re-activates them (bias, the tracker-action embedding of
+            # the tracker-aware target, then the cell's own sigmoid / tanh: the values the rollout computed, bit for bit)
+            acts = cache.pre_all
+            pre = dict(bias=[cache.bsum[0], cache.bsum[1]], emb=cache.emb_ih if self.tat else None, emb_player=1,
+                       act=actions_seq[:, :, 0])
+        return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, acts, need, hm=hm, pre=pre)
 
     def forward_sequence_cached(self, cache, states_seq, actions_seq, keep):
         """forward_sequence over a cached rollout: only the heads are evaluated forward; the backward pass is the

@@ -30,11 +30,11 @@ Extra objects on the same JSON line:
                is measured where it runs: a whole 20-step rollout of the player is captured into a hipGraph twice — as it is,
                and with the k_act_step launches left out — and replayed alternately with HIP events on the launch stream; the
                difference / 20 is the kernel's in-situ cost (`avg_launch_us`; rocprofv3's average for the kernel in a replayed
-               iteration, profiles/r04_iteration_kernel_stats.txt, rides along as `rocprof_in_iteration_us` and must agree).
+               iteration, profiles/r05_iteration_kernel_stats.txt, rides along as `rocprof_in_iteration_us` and must agree).
                `frac` = that figure / 8 TB/s. The same duration priced with EVERYTHING the fused kernel moves (gate
                pre-activations, cell / hidden state, activated gates parked for the learner) is reported under its own name,
                `policy_state_included`, never as `frac`. `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc
-               passes (profiles/r04_pmc_traffic.json). `other_variants`: the stand-alone step kernel (k_step2; what t2d_step /
+               passes (profiles/r05_pmc_traffic.json). `other_variants`: the stand-alone step kernel (k_step2; what t2d_step /
                t2d_step_u8 launch for callers that bring their own actions), measured alone in a 9-launch graph.
   env_only     the stand-alone step kernel driven with on-device random actions (no policy): launches/s -> env steps/s, per
                launch and in the persistent mode (t2d_rollout_random: up to 10 steps per launch).
@@ -411,6 +411,8 @@ def main():
         one_gate = n <= getattr(mdl, "pair_gemm_max_rows", 0) or (getattr(mdl, "cat_gate_gemm", False)
                                                                   and n >= getattr(mdl, "cat_gemm_min_rows", 1 << 30))
         masked_h = getattr(mdl, "cat_gate_gemm", False) and n >= getattr(mdl, "cat_gemm_min_rows", 1 << 30)
+        # (round 5) on that path the rollout keeps the gate GEMM's output for the learner instead of the activated gates
+        keep_pre = bool(masked_h and getattr(mdl, "store_preacts", False) and not getattr(mdl, "coop_step", False))
         gts = torch.randn(2, n, 4 * R, device=device)
         hgt = None if one_gate else torch.randn(2, n, 4 * R, device=device)
         cprev, hout, cout = (torch.zeros(2, n, R, device=device) for _ in range(3))
@@ -425,7 +427,8 @@ def main():
 
         def act_launch():
             fz.act_env_step(core, [gts[0], gts[1]], [hgt[0], hgt[1]] if hgt is not None else None, bsum,
-                            [cprev[0], cprev[1]], out[2], [hout[0], hout[1]], [cout[0], cout[1]], [actst[0], actst[1]], smp,
+                            [cprev[0], cprev[1]], out[2], [hout[0], hout[1]], [cout[0], cout[1]],
+                            None if keep_pre else [actst[0], actst[1]], smp,
                             heads, actn, emb=embt, env_out=out8,
                             hm_out=[rows_next[0][:, 256:], rows_next[1][:, 256:]] if masked_h else None)
         core.flush()
@@ -451,8 +454,8 @@ def main():
         ka_us = tot * 1e3 / (40 * 9)
         # everything the fused kernel moves per env-step: the env's 709 B (u8 observations) + per player: gate pre-activations
         # read (4R floats; twice when ig / hg arrive separately), c_prev read, h / c written, activated gates written (the
-        # learner's cache), the masked hidden row for the next step's GEMM (one-GEMM path), + actions 16 B + previous done 1 B
-        per_player = 4 * R * 4 * (1 if one_gate else 2) + 3 * R * 4 + 4 * R * 4 + (R * 4 if masked_h else 0)
+        # learner's cache; not when the rollout keeps the GEMM's output instead: keep_pre), the masked hidden row for the next step's GEMM (one-GEMM path), + actions 16 B + previous done 1 B
+        per_player = 4 * R * 4 * (1 if one_gate else 2) + 3 * R * 4 + (0 if keep_pre else 4 * R * 4) + (R * 4 if masked_h else 0)
         ka_bytes = B_STEP_U8 + 2 * per_player + 17
         # (2) in situ: a whole T-step rollout of the player as a hipGraph, with and without the k_act_step launches; replayed
         # alternately, HIP events on the launch stream around each replay; difference / T = what the kernel costs where it runs
@@ -559,7 +562,7 @@ def main():
         stem_roof = {"error": repr(ex)}
 
     traffic, traffic_src, traffic_u8, traffic_u8_src, traffic_act, traffic_act_src = None, None, None, None, None, None
-    for fname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for fname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:   # HBM traffic of the same kernels from the committed rocprofv3 --pmc passes (cannot be taken inside this run)
             pm = json.load(open(os.path.join(ROOT, "profiles", fname)))
             if pm.get("n_envs") == n and traffic is None:
@@ -576,7 +579,7 @@ def main():
         except Exception:
             pass
     kernel_sum, rocprof_act_us = None, None
-    for fname in ("r04_iteration_kernel_stats.txt", "r03_iteration_kernel_stats.txt"):
+    for fname in ("r05_iteration_kernel_stats.txt", "r04_iteration_kernel_stats.txt", "r03_iteration_kernel_stats.txt"):
         try:   # one replayed iteration under rocprofv3 --kernel-trace --stats (tools/iter_profile.py), committed: the sum of its
             # kernel durations, and the in-iteration average of the env kernel the in-situ figure below must agree with
             tot_ms = its = None
@@ -633,8 +636,10 @@ def main():
                 "achieved": ka_bytes * n / (dur * 1e-6) / 1e9, "frac_of_peak": ka_bytes * n / (dur * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "alone": {"avg_launch_us": ka_us, "frac_of_peak": ka_bytes * n / (ka_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
                 "note": "NOT SURVEY 8(d)'s figure: the env's 709 B + per player gate pre-activations read (one tensor: the "
-                        "LSTMCell's two GEMMs are one product since round 4), c_prev read, h / c written, activated gates "
-                        "written for the learner, the masked hidden row for the next step's GEMM, + actions + previous done"}}
+                        "LSTMCell's two GEMMs are one product since round 4), c_prev read, h / c written, " +
+                        ("(no activated gates: since round 5 the rollout keeps the gate GEMM's output for the learner instead), "
+                         if keep_pre else "activated gates written for the learner, ") +
+                        "the masked hidden row for the next step's GEMM, + actions + previous done"}}
     # `roofline` = the env kernel of the TIMED REGION at this batch size; the other variants ride along, each with its flag
     variants = {"step_f32": f32_variant, "step_u8": u8_variant, "act_step": act_variant}
     pick = "act_step" if (fused_in_region and act_variant) else ("step_u8" if (u8_variant and u8_variant["in_timed_region"])

@@ -258,6 +258,17 @@ int atr_lstm_cell_backward(const float *dh_out, long long dh_pstride, const floa
 int atr_lstm_bptt(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *acts, long long acts_pstride,
                   const float *c_all, long long c_pstride, const float *whh0, const float *whh1, float *dg,
                   long long dg_pstride, float *dh_init, float *dc_init, int P, int T, int N, int R, void *stream);
+/* atr_lstm_bptt for a rollout that kept the OUTPUT of the step's gate GEMM — the pre-activations without bias, [P][T][N][4R] at
+ * `pre` + p * pre_pstride — instead of the activated gates (atr_act_env_step / atr_coop_env_step with acts == NULL: the step's
+ * last kernel then writes 4R floats per row less). The activations are recomputed inside with the expressions the step used:
+ * ((pre + bias_p) + emb[a_tracker]) then the sigmoid / tanh of csrc/atr_cell.h — bias0 / bias1 = b_ih + b_hh per player [4R];
+ * emb (nullable) [n_act, 4R] = fc_action_tracker(one_hot(.)) projected through W_ih (model.py:193-194), added for player
+ * emb_player with row act_tracker[t * act_tstride + n] (int64: the rollout's action store, read in place). */
+int atr_lstm_bptt_pre(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *pre, long long pre_pstride,
+                      const float *bias0, const float *bias1, const float *emb, int emb_player, int n_act,
+                      const long long *act_tracker, long long act_tstride, const float *c_all, long long c_pstride,
+                      const float *whh0, const float *whh1, float *dg, long long dg_pstride, float *dh_init, float *dc_init,
+                      int P, int T, int N, int R, void *stream);
 /* fc_action_tracker(one_hot(a_tracker)) added to the target's features over all stored steps (TAT.forward, model.py:193-194 of
  * the reference): out[r][c] = f[r][c] + w[c][action of row r] + b[c], w = fc_action_tracker.weight [C, A] (A <= 8, C
  * multiple of 4), actions int64; the action of row r is actions[(r / act_n) * act_tstride + (r % act_n) * act_stride] — a flat

@@ -13,7 +13,9 @@ import os
 rows = [int(x) for x in sys.argv[1:]] or [512, 1024, 2048, 4096]
 MODE = os.environ.get("ACT_BENCH_MODE", "all")      # "sep": only k_act_step with separate ig / hg (for the PMC passes);
 #                                                      "one": only the round-4 form of the timed region above 768 rows — one gate
-#                                                      tensor, bias added in the kernel, masked hidden rows written (hm_out)
+#                                                      tensor, bias added in the kernel, masked hidden rows written (hm_out);
+#                                                      "pre": that form WITHOUT the activated-gates store (round 5: the rollout
+#                                                      keeps the gate GEMM's output for the learner instead)
 R = 128
 for n in rows:
     core = VecTrack2D("Track2D-BlockPartialPZR-v0", num_envs=n, seed=1)
@@ -28,23 +30,23 @@ for n in rows:
             torch.zeros((n,), dtype=torch.uint8, device=dev))
     res = []
     rows_next = torch.empty(2, n, 384, device=dev)
-    for separate in ((True,) if MODE == "sep" else ((False,) if MODE == "one" else (True, False))):
+    for separate in ((True,) if MODE == "sep" else ((False,) if MODE in ("one", "pre") else (True, False))):
         g = torch.randn(2, n, 4 * R, device=dev)
         hg = torch.randn(2, n, 4 * R, device=dev) if separate else None
-        bs = [torch.zeros(4 * R, device=dev) for _ in range(2)] if (separate or MODE == "one") else None
-        hm = [rows_next[0][:, 256:], rows_next[1][:, 256:]] if MODE == "one" else None
+        bs = [torch.zeros(4 * R, device=dev) for _ in range(2)] if (separate or MODE in ("one", "pre")) else None
+        hm = [rows_next[0][:, 256:], rows_next[1][:, 256:]] if MODE in ("one", "pre") else None
 
         def fused_launch():
             fz.act_env_step(core, [g[0], g[1]], [hg[0], hg[1]] if hg is not None else None, bs, [cprev[0], cprev[1]], out8[2],
-                            [hout[0], hout[1]], [cout[0], cout[1]], [acts[0], acts[1]], smp, actors, actn, emb=emb, env_out=out8,
-                            hm_out=hm)
+                            [hout[0], hout[1]], [cout[0], cout[1]], None if MODE == "pre" else [acts[0], acts[1]], smp, actors, actn,
+                            emb=emb, env_out=out8, hm_out=hm)
 
         def three_launches():
             for p in range(2):
                 fz.lstm_cell_act_into(g[p], hg[p], cprev[p], out8[2], hout[p], cout[p], acts[p], smp, actors[p], actn[p],
                                       emb=emb if p == 1 else None, act_in=actn[0] if p == 1 else None, bias=bs[p])
             core.step_u8(actn[0], actn[1], out=out8)
-        for fn in ([fused_launch] if MODE in ("sep", "one") else ([fused_launch, three_launches] if separate else [fused_launch])):
+        for fn in ([fused_launch] if MODE in ("sep", "one", "pre") else ([fused_launch, three_launches] if separate else [fused_launch])):
             core.flush()
             smp.begin_block()
             s = torch.cuda.Stream()
@@ -70,7 +72,11 @@ for n in rows:
             res.append(tot * 1e3 / (40 * 9))
     per_player = lambda sep: 4 * R * 4 * (2 if sep else 1) + 3 * R * 4 + 4 * R * 4
     b_sep, b_one = 709 + 2 * per_player(True) + 17, 709 + 2 * per_player(False) + 17
-    if MODE == "one":
+    if MODE == "pre":
+        b_r5 = b_one + 2 * R * 4 - 2 * 4 * R * 4
+        print("rows %5d | k_act_step (one gate tensor + bias + masked hidden rows, NO activated-gates store) %6.2f us = %5.0f GB/s of %d B "
+              "per env-step" % (n, res[0], b_r5 * n / res[0] / 1e3, b_r5), flush=True)
+    elif MODE == "one":
         b_r4 = b_one + 2 * R * 4
         print("rows %5d | k_act_step (one gate tensor + bias + masked hidden rows) %6.2f us = %5.0f GB/s of %d B per env-step" % (
             n, res[0], b_r4 * n / res[0] / 1e3, b_r4), flush=True)
