@@ -302,6 +302,37 @@ def test_burn_in_moves_the_envs_and_nothing_else(schedule):
     player.env.close()
 
 
+@pytest.mark.parametrize("train_mode", [-1, 0, 1])
+def test_keeping_the_gate_gemm_output_instead_of_the_activated_gates_changes_no_bit(train_mode):
+    """One-GEMM rollout path, round 5: the rollout keeps the gate GEMM's OUTPUT per step (pre-activations without bias) and the
+    learner's BPTT kernel re-activates it (atr_lstm_bptt_pre: ((pre + bias) + emb[a_tracker]) then the cell's own sigmoid / tanh) —
+    against the round-4 form that stores the activated gates from k_act_step: same seeds, same rollout (observations, actions,
+    LSTM states equal bit for bit), and the SAME GRADIENT bit for bit, for every training mode (mode 1: the tracker-aware
+    target's embedding row alone in its group)."""
+    from active_tracking_rl_amd.train import default_args, make_player, rollout
+    res = []
+    for keep_pre in (True, False):
+        args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=1024, num_steps=8, network="tat-maze-lstm", seed=23,
+                            train_mode=train_mode)
+        args.gpu_ids = [0]
+        player, opt = make_player(args, torch.device("cuda:0"), 0, 1)
+        player.model.store_preacts = keep_pre
+        player.model.pair_gemm_max_rows = 0
+        rollout(player, args.num_steps, fast=True)
+        c = player._cache
+        assert (c.pre_all is not None) == keep_pre and (c.acts is None) == keep_pre and c.fh_all is not None
+        acts_buf, obs = player._actions_buf.clone(), player._buf[0].clone()
+        h_all, c_all = c.h_all.clone(), c.c_all.clone()
+        player.compute_grads(opt, train_mode)
+        torch.cuda.synchronize()
+        res.append((acts_buf, obs, h_all, c_all, opt.bucket.grad.clone()))
+        player.env.close()
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[0][4]).all() and float(res[0][4].abs().sum()) > 0
+    assert torch.equal(res[0][4], res[1][4])
+
+
 def test_bootstrap_values_and_rollout_bookkeeping_kernels():
     """The learner's bootstrap V(s_T) through the rollout's fused kernels (model.boot_values: one more actor step into
     scratch + critic heads) against the plain model pieces evaluated with the tracker action it drew; the rollout
