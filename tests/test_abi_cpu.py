@@ -98,3 +98,15 @@ def test_evaluator_train_mode_schedule_follows_the_reference():
     args = argparse.Namespace(init_step=3, train_mode=2)
     with pytest.raises(AttributeError):
         schedule_train_modes(args, [0], 7, {})
+
+
+def test_cooperative_step_shape_limits_match_the_kernel():
+    """fused.coop_step_supported (what model._act_step asks before it takes the two-launch step) restates the limits
+    atr_coop_env_step enforces (csrc/coop_gemm.h: 16 tiles per layer and 8 env pairs per workgroup, whole 16-row tiles per XCD)."""
+    from active_tracking_rl_amd import fused
+    ok = lambda n, wg: fused.coop_step_supported(n, 256, 128, wg)
+    assert ok(512, 256) and ok(1024, 256) and ok(2048, 256) and ok(128, 256)
+    assert not ok(4096, 256)            # 32 gate tiles per workgroup
+    assert ok(512, 128) and ok(1024, 128) and not ok(2048, 128)
+    assert not ok(500, 256) and not ok(512, 100) and not ok(512, 4)
+    assert not fused.coop_step_supported(512, 250, 128, 256) and not fused.coop_step_supported(512, 256, 64, 256)

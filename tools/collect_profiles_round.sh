@@ -24,6 +24,7 @@ prof_iter iteration_kernel_stats_config3 Track2D-MazePartialNav-v0 1024 maze-lst
 (cd $R && timeout 300 python tools/lt_gemm_bench.py > $O/lt_gemm_bench.txt 2>&1)
 (cd $R && timeout 300 python tools/act_step_bench.py > $O/act_step_bench.txt 2>&1)
 (cd $R && ACT_BENCH_MODE=one timeout 300 python tools/act_step_bench.py 512 1024 2048 4096 >> $O/act_step_bench.txt 2>&1)
+(cd $R && ACT_BENCH_MODE=pre timeout 300 python tools/act_step_bench.py 512 1024 2048 4096 >> $O/act_step_bench.txt 2>&1)
 # --- the learner's grouped weight-gradient GEMM alone, and its per-workgroup timeline (probe build -DATR_TN_PROBE=1, compiled here)
 (cd $R && timeout 300 python tools/gemm_group_bench.py 512 1024 2048 4096 > $O/gemm_group_bench.txt 2>&1)
 mkdir -p $R/scratch_exp; (cd $R/active_tracking_rl_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -ldl -Wno-unused-result -DATR_TN_PROBE=1 \
@@ -52,11 +53,12 @@ for n in 4096 65536 262144 1048576; do
   python $R/tools/summarize_prof.py stats /tmp/p_env > $O/env_only_kernel_stats_$n.txt
 done
 # --- HBM traffic (PMC): FETCH_SIZE and WRITE_SIZE in separate passes — the stand-alone step kernel at 4096 envs, and the fused
-# end-of-step kernel in the form the timed region runs it (one gate tensor, bias, masked hidden rows)
+# end-of-step kernel in the form the timed region runs it (one gate tensor, bias, masked hidden rows; since round 5 without the
+# activated-gates store: ACT_BENCH_MODE=pre)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_pmc; timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_pmc -- python $R/tools/env_only_bench.py --n 4096 --steps 300 --warmup 50 > /dev/null 2>&1
   python $R/tools/summarize_prof.py pmc /tmp/p_pmc k_step2 > $O/env_only_pmc_${c}_4096.txt
-  rm -rf /tmp/p_pmc; (cd $R && ACT_BENCH_MODE=one timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_pmc -- python tools/act_step_bench.py 4096 > /dev/null 2>&1)
+  rm -rf /tmp/p_pmc; (cd $R && ACT_BENCH_MODE=pre timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_pmc -- python tools/act_step_bench.py 4096 > /dev/null 2>&1)
   python $R/tools/summarize_prof.py pmc /tmp/p_pmc k_act_step > $O/act_step_pmc_${c}_4096.txt
 done
 # --- round 5: the two-launch (cooperative) rollout step — its phase timeline and the shard sizes with it on / off

@@ -10,14 +10,16 @@ P = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 B_STEP = 1723            # algorithmic bytes per env-step of k_step2 with f32 observations
 # everything k_act_step<OBS_U8> moves per env-step: r03 = ig + hg given separately; r04 = one gate tensor + the masked hidden
-# rows for the next step's GEMM (bench.py: policy_state_included)
-B_ACT = {"r03": 16086}.get(RND, 13014)
+# rows for the next step's GEMM; r05 = r04 without the activated gates (bench.py: policy_state_included)
+B_ACT = {"r03": 16086, "r04": 13014}.get(RND, 8918)
 _ACT_KERNEL = {"r03": "t2d::k_act_step<OBS_U8> (ig + hg given separately: the 4096-env timed region of round 3)",
               "r04": "t2d::k_act_step<OBS_U8> (one gate tensor, bias added in the kernel, masked hidden rows written: the timed "
-                     "region from 768 envs up since round 4)"}
+                     "region from 768 envs up since round 4)",
+              "r05": "t2d::k_act_step<OBS_U8> (round 4's form without the activated-gates store: the rollout keeps the gate GEMM's "
+                     "output for the learner instead; tools/act_step_bench.py ACT_BENCH_MODE=pre)"}
 
 
-ACT_KERNEL = _ACT_KERNEL.get(RND, _ACT_KERNEL["r04"])
+ACT_KERNEL = _ACT_KERNEL.get(RND, _ACT_KERNEL["r05"])
 
 
 def mean(name):
