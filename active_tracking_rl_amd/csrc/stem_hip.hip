@@ -61,25 +61,29 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __buil
 // back-edge and the decode happens in store_x: converting at load time would make the prefetch a blocking load.
 // Bytes are fetched as the aligned dword that holds them (never leaves the byte's own 4-byte granule): lanes l, l+64
 // and l+128 of a frame share the same byte offset within their dwords.
+// The loads are branch-free GLOBAL loads (the frame index clamped to the last frame, the third element's lane clamped to 40:
+// what a lane beyond the data fetches is never decoded): a load under a branch, or a flat one (what a pointer that travelled
+// through a kernel-argument struct becomes), makes the compiler drain vmcnt to 0 at the loop head — and with it the
+// PREVIOUS frame's output stores — instead of waiting for just these three words.
 struct XRegs { uint32_t w[3]; uint32_t sh; };
+typedef const uint32_t __attribute__((address_space(1))) *stem_gwords;
 template <typename XT>
 __device__ __forceinline__ XRegs load_x(const XT *__restrict__ x, long long m, long long M, long long xs, int l)
 {
     XRegs r;
-    r.w[0] = r.w[1] = r.w[2] = 0u;
-    r.sh = 0u;
-    if (m < M) {
-        if (sizeof(XT) == 4) {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(x + m * xs);
-            r.w[0] = p[l]; r.w[1] = p[l + 64];
-            if (l < 41) r.w[2] = p[l + 128];
-        } else {
-            const uintptr_t a = reinterpret_cast<uintptr_t>(x + m * xs) + (uintptr_t)l;
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
-            r.sh = 8u * (uint32_t)(a & 3u);
-            r.w[0] = p[0]; r.w[1] = p[16];
-            if (l < 41) r.w[2] = p[32];
-        }
+    const long long mm = m < M ? m : M - 1;
+    const int l2 = l < 41 ? l : 40;
+    if (sizeof(XT) == 4) {
+        stem_gwords p = (stem_gwords) reinterpret_cast<const uint32_t *>(x + mm * xs);
+        r.sh = 0u;
+        r.w[0] = p[l]; r.w[1] = p[l + 64]; r.w[2] = p[l2 + 128];
+    } else {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(x + mm * xs) + (uintptr_t)l;
+        stem_gwords p = (stem_gwords) reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+        const uintptr_t a2 = reinterpret_cast<uintptr_t>(x + mm * xs) + (uintptr_t)(l2 + 128);
+        stem_gwords p2 = (stem_gwords) reinterpret_cast<const uint32_t *>(a2 & ~(uintptr_t)3);
+        r.sh = 8u * (uint32_t)(a & 3u);
+        r.w[0] = p[0]; r.w[1] = p[16]; r.w[2] = p2[0];
     }
     return r;
 }
@@ -172,17 +176,28 @@ __global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
     const long long stride = (long long)nblk * kWaves;
     long long m = (long long)blk * kWaves + wave;
     XRegs xv = load_x(x, m, M, xs, l);
+    const int c = l & 15, q = l >> 4;
+    // The conv2 weights in MFMA operand order: every lane wants 72 of the 4608, its output channel's row strided by taps — fetched
+    // straight from memory that is 64 cache lines per wave instruction, 72 times per wave, 12 waves per CU through one L1: at the
+    // rollout's launch sizes (2-3 frames per wave) that gather was most of the kernel. So the workgroup copies the 18 KB once,
+    // coalesced, into the (not yet used) frame buffers — rows padded to 145 floats: (17 c + 9 q) mod 64 makes the gather at most a
+    // 2-way bank conflict — and the lanes pick their operands from there.
+    float W[2][36];
+    {
+        float *wst = reinterpret_cast<float *>(lds);            // 32 x 145 floats = 18.1 KB of the workgroup's 31.5 KB
+        for (int i = (int)threadIdx.x; i < kW2; i += kThreads) wst[(i / 144) * 145 + (i % 144)] = w2[i];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int cq = 0; cq < 4; cq++) {
+                W[0][t * 4 + cq] = wst[c * 145 + (4 * cq + q) * 9 + t];
+                W[1][t * 4 + cq] = wst[(16 + c) * 145 + (4 * cq + q) * 9 + t];
+            }
+        __syncthreads();
+    }
     zero_wave(s.x, kXSize, l);
     zero_wave(s.a1, kA1Size, l);
-    const int c = l & 15, q = l >> 4;
-    float W[2][36];
-#pragma unroll
-    for (int t = 0; t < 9; t++)
-#pragma unroll
-        for (int cq = 0; cq < 4; cq++) {
-            W[0][t * 4 + cq] = w2[c * 144 + (4 * cq + q) * 9 + t];
-            W[1][t * 4 + cq] = w2[(16 + c) * 144 + (4 * cq + q) * 9 + t];
-        }
     const float bias0 = b2[c], bias1 = b2[16 + c];
     const Conv1W cw = load_conv1_w(w1, b1, l);
     // A operand: position p = l&15 (oh = p>>2, ow = p&3), channel-in-step q
@@ -213,18 +228,22 @@ __global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
 
 // dz2 = dy * (y > 0) of one frame: lane (c, q) holds channels c and 16+c, positions 4q..4q+3.
 struct DzRegs { float4 y0, y1, d0, d1; };
+typedef float stem_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stem_ldg4(const float *p)
+{
+    const stem_v4f v = *reinterpret_cast<const stem_v4f __attribute__((address_space(1))) *>(
+        (const float __attribute__((address_space(1))) *)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+// (branch-free like load_x: a frame index past the end re-reads the last frame, and the loop never uses it)
 __device__ __forceinline__ DzRegs load_dz(const float *__restrict__ y, const float *__restrict__ dy, long long m,
                                           long long M, int c, int q)
 {
     DzRegs r;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m < M) {
-        const float4 *yy = reinterpret_cast<const float4 *>(y + m * 512), *dd = reinterpret_cast<const float4 *>(dy + m * 512);
-        r.y0 = yy[c * 4 + q]; r.y1 = yy[(16 + c) * 4 + q];
-        r.d0 = dd[c * 4 + q]; r.d1 = dd[(16 + c) * 4 + q];
-    } else {
-        r.y0 = z; r.y1 = z; r.d0 = z; r.d1 = z;
-    }
+    const long long mm = m < M ? m : M - 1;
+    const float *yy = y + mm * 512, *dd = dy + mm * 512;
+    r.y0 = stem_ldg4(yy + 4 * (c * 4 + q)); r.y1 = stem_ldg4(yy + 4 * ((16 + c) * 4 + q));
+    r.d0 = stem_ldg4(dd + 4 * (c * 4 + q)); r.d1 = stem_ldg4(dd + 4 * ((16 + c) * 4 + q));
     return r;
 }
 __device__ __forceinline__ float4 relu_mask(const float4 &yv, const float4 &dv)
@@ -292,6 +311,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_bwd(const XT *__restrict__
             const float a0 = s.dz[c * 16 + 4 * r + q], a1v = s.dz[(16 + c) * 16 + 4 * r + q];
 #pragma unroll
             for (int t = 0; t < 9; t++) {
+                // padded rows 0 and 8 of a1 are the zero border: output row 0 never sees tap row 0, output row 3 never tap
+                // row 2 — 12 of the 72 products are structurally zero and are not issued
+                if ((r == 0 && t / 3 == 0) || (r == 3 && t / 3 == 2)) continue;
                 const float b = bp[(2 * r + t / 3) * kA1Row + (t % 3)];
                 acc[0][t] = mfma(a0, b, acc[0][t]);
                 acc[1][t] = mfma(a1v, b, acc[1][t]);

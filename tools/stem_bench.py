@@ -1,32 +1,54 @@
-"""Micro-benchmark of the fused conv stem (csrc/stem_hip.hip) vs the GEMM formulation, forward and backward."""
-import time
+"""Micro-benchmark of the fused conv stem (csrc/stem_hip.hip), forward and backward, at the rollout's launch sizes (2 x shard
+frames per step) and the learner's (20 steps at once): microseconds per launch and the fraction of the dense f32 MFMA peak
+(157.3 TFLOP/s) the ALGORITHMIC flops reach (zero-border taps not counted: bench.py's policy_stem figure).
+    python tools/stem_bench.py [M ...]"""
+import sys
+
 import torch
+
 from active_tracking_rl_amd import fused
 from active_tracking_rl_amd.model import CNN_maze
 
 torch.manual_seed(0)
-enc = CNN_maze((1, 13, 13), 1).cuda()
-def timeit(fn, n=20):
-    for _ in range(3): fn()
+dev = torch.device("cuda:0")
+enc = CNN_maze((1, 13, 13), 1).to(dev)
+PEAK = 157.3
+C1, C2 = 16 * 361, 32 * 16 * 100            # real (non-border) multiply-adds per frame of conv1, conv2
+
+
+def t_us(fn, reps):
+    fn(); fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / n
-for M in (4096, 8192, 81920, 163840):
-    x = torch.randint(0, 5, (M, 169), device="cuda").float()
-    g = torch.randn(M, 512, device="cuda")
-    params = [enc.conv1.weight, enc.conv1.bias, enc.conv2.weight, enc.conv2.bias]
-    def f_fused(): return fused.stem(x, enc.conv1, enc.conv2)
-    def f_gemm(): return enc.forward_dense_stem(x)
-    y = f_fused()
-    def b_fused():
-        y = f_fused(); torch.autograd.grad(y, params, g)
-    def b_gemm():
-        y = f_gemm(); torch.autograd.grad(y, params, g)
-    tf, tg = timeit(lambda: f_fused()), timeit(lambda: f_gemm())
-    tbf, tbg = timeit(b_fused), timeit(b_gemm)
-    mac = M * (512 * 144 + 784 * 9)
-    print("M=%7d  fwd fused %8.1f us (%.1f TMAC/s)  gemm %8.1f us | fwd+bwd fused %8.1f us  gemm %8.1f us" % (
-        M, tf, mac / tf / 1e6, tg, tbf, tbg))
+    best = None
+    for _ in range(3):
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        best = us if best is None else min(best, us)
+    return best
+
+
+for M in ([int(v) for v in sys.argv[1:]] or [1024, 2048, 4096, 8192, 81920, 163840]):
+    xf = torch.randint(0, 5, (M, 169), device=dev).float()
+    xu = torch.randint(0, 5, (M, 169), device=dev).to(torch.uint8)
+    y = torch.empty((M, 512), device=dev)
+    dy = torch.randn((M, 512), device=dev)
+    prm = [enc.conv1.weight.detach().contiguous(), enc.conv1.bias.detach(), enc.conv2.weight.detach().contiguous(), enc.conv2.bias.detach()]
+    reps = 200 if M <= 8192 else 20
+    row = "M=%7d" % M
+    for name, x in (("f32", xf), ("u8", xu)):
+        g = torch.cuda.CUDAGraph()          # launches back to back inside a graph: what the rollout / learner graphs do
+        fused.stem_into(x, enc.conv1, enc.conv2, y)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            for _ in range(10):
+                fused.stem_into(x, enc.conv1, enc.conv2, y)
+        f = t_us(g.replay, max(reps // 10, 2)) / 10
+        b = t_us(lambda: fused._stem_backward(x, y, dy, prm[0], prm[1], prm[2], (prm[0].shape, prm[2].shape)), reps)
+        row += " | %s fwd %7.2f us %.3f  bwd %7.2f us %.3f" % (
+            name, f, 2.0 * (C1 + C2) * M / (f * 1e-6) / 1e12 / PEAK, b, 2.0 * (2 * C2 + 2 * C1) * M / (b * 1e-6) / 1e12 / PEAK)
+    print(row, flush=True)
