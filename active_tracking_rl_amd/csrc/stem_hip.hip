@@ -51,6 +51,14 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Workgroup barrier that orders LDS traffic only. __syncthreads() is a workgroup-scope fence over ALL memory: it drains vmcnt
+// too, i.e. every wave would sit at the barrier until the output stores it has just issued are acknowledged by the L2 and the
+// next pass's prefetched frames have arrived (measured in k_stem_fwd16: 40 % of the kernel). The tiles the waves hand each
+// other live in LDS; global memory is not shared inside the kernel.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ float xor_sum(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -223,6 +231,194 @@ __global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
                                     fmaxf(acc0[2] + bias0, 0.f), fmaxf(acc0[3] + bias0, 0.f));
         yo[(16 + c) * 4 + q] = make_float4(fmaxf(acc1[0] + bias1, 0.f), fmaxf(acc1[1] + bias1, 0.f),
                                            fmaxf(acc1[2] + bias1, 0.f), fmaxf(acc1[3] + bias1, 0.f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward, 16 frames per workgroup pass (k_stem_fwd16): the launch sizes from 4096 frames up.
+//
+// k_stem_fwd above puts the 16 output positions of ONE frame on the MFMA's 16 rows — and 44 of the 144 (position, tap)
+// pairs of a 4x4 output over a zero-bordered 7x7 input are structural zeros (output row 0 never sees tap row 0, ...): 31 % of
+// the 72 MFMAs per frame multiply zeros, and which rows are zero changes from tap to tap, so no MFMA can be dropped.
+// Here the rows are 16 FRAMES at one fixed output position: D_p[frame][co] = sum over the taps that are REAL for p, and the
+// border products are simply not issued — 100 (position, tap) pairs x 4 channel groups x 2 column halves = 800 MFMAs per 16
+// frames = 50 per frame instead of 72. The workgroup's 4 waves each own two output rows x one half of the output channels (50
+// pairs x 4 groups = 200 MFMAs each — equal work — and a lane ends up with 32 contiguous bytes of y per frame: the first
+// version split the output into 2x2 quadrants, stored 8-byte pieces, and spent 40 % of its time on them); a1 of the 16 frames
+// lies in LDS frame-innermost ([ci][ih][iw][frame]: the A operand of lane (frame = l & 15, k = l >> 4) is one conflict-free
+// ds_read_b32 at an immediate offset), un-bordered.
+// conv1 is one lane per (frame, channel) on plain f32 FMAs, border taps skipped at compile time too.
+// Every frame's arithmetic is the one of k_stem_fwd in the same order (taps ascending, channel groups inside; products with
+// border zeros left out change no sum), so the two kernels agree bit for bit — a frame's result does not depend on the launch
+// size it was part of.
+constexpr int kF = 16;                          // frames per pass
+constexpr int kXF = 212;                        // x tile: 13 rows of 16 floats per frame + 4: frame f starts at bank 20 f mod 64
+constexpr int kA1F = kC1 * 49 * kF;             // a1 tile: 12544 floats
+constexpr int kYC = 20, kYF = 32 * kYC;        // output tile (aliased on a1): 16 positions + 4 per channel: conflict-free 16-byte writes
+struct LdsF16 { float x[kF * kXF]; float a1[kA1F]; };      // 13568 + 50176 B = 62.25 KB: two workgroups per CU
+static_assert(kF * kYF <= kA1F, "the output tile must fit over a1");
+
+// One thread fetches elements j = (tid & 15) + 16 k (k = 0..10) of frame tid >> 4 of the pass: 16 lanes sweep a frame.
+struct XTile { uint32_t v[11]; };
+template <typename XT>
+__device__ __forceinline__ XTile load_xtile(const XT *__restrict__ x, long long m0, long long M, long long xs, int tid)
+{
+    XTile r;
+    long long m = m0 + (tid >> 4);
+    m = m < M ? m : M - 1;
+    const XT __attribute__((address_space(1))) *p = (const XT __attribute__((address_space(1))) *)(x + m * xs);
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        int j = (tid & 15) + 16 * k;
+        j = j < 169 ? j : 168;
+        if (sizeof(XT) == 4) r.v[k] = __float_as_uint((float)p[j]);
+        else r.v[k] = (uint32_t)p[j];
+    }
+    return r;
+}
+template <typename XT>
+__device__ __forceinline__ void store_xtile(float *xt, const XTile &r, int tid)
+{
+    float *dst = xt + (tid >> 4) * kXF;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const int j = (tid & 15) + 16 * k;
+        const int row = (j * 79) >> 10;             // j / 13 for j < 176
+        const float v = sizeof(XT) == 4 ? __uint_as_float(r.v[k]) : (float)r.v[k];
+        if (j < 169) dst[row * 16 + (j - row * 13)] = v;
+    }
+}
+
+// conv1 + ReLU of frame f (this lane's), channel ch -> a1[(ch * 49 + r * 7 + c) * 16 + f].
+__device__ __forceinline__ void conv1_lane(const float *xf, float *a1o, const float (&w)[9], float b)
+{
+    float R[3][13];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            const int ir = 2 * r - 1 + kh;
+            if (ir < 0 || ir > 12) continue;        // (the zero border: rows -1 and 13)
+            if (kh == 0) {                          // row 2r - 1 = the previous output row's last one
+#pragma unroll
+                for (int j = 0; j < 13; j++) R[0][j] = R[2][j];
+                continue;
+            }
+            const float4 *row = reinterpret_cast<const float4 *>(xf + ir * 16);
+            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+            const float r3 = xf[ir * 16 + 12];
+            const float t[13] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3};
+#pragma unroll
+            for (int j = 0; j < 13; j++) R[kh][j] = t[j];
+        }
+#pragma unroll
+        for (int c = 0; c < 7; c++) {
+            float acc = b;
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++) {
+                if (2 * r - 1 + kh < 0 || 2 * r - 1 + kh > 12) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    const int ic = 2 * c - 1 + kw;
+                    if (ic < 0 || ic > 12) continue;
+                    acc = fmaf(R[kh][ic], w[kh * 3 + kw], acc);
+                }
+            }
+            a1o[(r * 7 + c) * kF] = fmaxf(acc, 0.0f);
+        }
+    }
+}
+
+// conv2 of output rows 2 QA, 2 QA + 1 (8 positions) x one half of the output channels for the pass's 16 frames: D[frame][co]
+// per position. ap = a1 + q * 49 * 16 + frame (this lane's A-operand base); Wh = the half's weights in B-operand order.
+template <int QA>
+__device__ __forceinline__ void conv2_rows(const float *ap, const float (&Wh)[36], f32x4 (&acc)[8])
+{
+#pragma unroll
+    for (int p = 0; p < 8; p++) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int cq = 0; cq < 4; cq++)
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int oh = 2 * QA + (p >> 2), ow = p & 3;
+                const int ih = 2 * oh - 1 + t / 3, iw = 2 * ow - 1 + t % 3;
+                if (ih < 0 || ih > 6 || iw < 0 || iw > 6) continue;
+                acc[p] = mfma(ap[(cq * 4 * 49 + ih * 7 + iw) * kF], Wh[t * 4 + cq], acc[p]);
+            }
+}
+
+template <typename XT>
+__global__ __launch_bounds__(kThreads, 2) void k_stem_fwd16(StemPair pr)
+{
+    __shared__ __attribute__((aligned(16))) LdsF16 s;
+    const int tid = (int)threadIdx.x, l = tid & 63, wave = tid >> 6;
+    const bool second = (int)blockIdx.x >= pr.split;
+    const StemProblem &pb = pr.p[second ? 1 : 0];
+    const XT *__restrict__ x = reinterpret_cast<const XT *>(pb.x);
+    const float *__restrict__ w1 = pb.w1, *__restrict__ b1 = pb.b1, *__restrict__ w2 = pb.w2, *__restrict__ b2 = pb.b2;
+    float *__restrict__ y = pb.y;
+    const long long M = pb.M, xs = pb.xs;
+    const int blk = second ? (int)blockIdx.x - pr.split : (int)blockIdx.x;
+    const int nblk = second ? (int)gridDim.x - pr.split : pr.split;
+    const long long stride = (long long)nblk * kF;
+    long long m0 = (long long)blk * kF;
+    XTile xv = load_xtile(x, m0, M, xs, tid);
+    const int c = l & 15, q = l >> 4;
+    // wave = (output row pair qa, output channel half h): 50 real (position, tap) pairs x 4 channel groups = 200 MFMAs each
+    const int qa = wave >> 1, h = wave & 1;
+    float Wh[36];
+    {
+        float *wst = s.a1;                          // (see k_stem_fwd: the conv2 weights pass through LDS, rows padded to 145)
+        for (int i = tid; i < kW2; i += kThreads) wst[(i / 144) * 145 + (i % 144)] = w2[i];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int cq = 0; cq < 4; cq++) Wh[t * 4 + cq] = wst[(16 * h + c) * 145 + (4 * cq + q) * 9 + t];
+    }
+    const float bias = b2[16 * h + c];
+    const int ch = 4 * wave + q;                    // conv1: this lane's channel (q <-> ch mod 4: conflict-free a1 writes)
+    float cw[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) cw[k] = w1[ch * 9 + k];
+    const float cb = b1[ch];
+    store_xtile<XT>(s.x, xv, tid);
+    xv = load_xtile(x, m0 + stride, M, xs, tid);
+    const float *xf = s.x + c * kXF;
+    float *a1o = s.a1 + ch * 49 * kF + c;
+    const float *ap = s.a1 + q * 49 * kF + c;
+    lds_barrier();
+    for (; m0 < M; m0 += stride) {
+        conv1_lane(xf, a1o, cw, cb);
+        lds_barrier();                            // a1 complete; the x tile is free
+        store_xtile<XT>(s.x, xv, tid);
+        xv = load_xtile(x, m0 + 2 * stride, M, xs, tid);
+        f32x4 acc[8];
+        if (qa == 0) conv2_rows<0>(ap, Wh, acc);
+        else conv2_rows<1>(ap, Wh, acc);
+        // Output: lane (c, q) holds frames 4 q + r, channel 16 h + c, 8 positions — 32 bytes here, 32 there: stored from
+        // the accumulators that is 64 separate half-sector pieces per store instruction, and the L2's request rate (not its
+        // bandwidth) becomes the kernel's bound (measured: 254 us at 163840 frames, 167 us with the same bytes laid out 1 KB
+        // per instruction). So the 16 frames' outputs meet in LDS (over a1, which conv2 is done with) and leave as whole rows.
+        lds_barrier();                              // a1 is free (and the next x tile complete)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float4 *yt = reinterpret_cast<float4 *>(s.a1 + (4 * q + r) * kYF + (16 * h + c) * kYC + 8 * qa);
+            yt[0] = make_float4(fmaxf(acc[0][r] + bias, 0.f), fmaxf(acc[1][r] + bias, 0.f), fmaxf(acc[2][r] + bias, 0.f),
+                                fmaxf(acc[3][r] + bias, 0.f));
+            yt[1] = make_float4(fmaxf(acc[4][r] + bias, 0.f), fmaxf(acc[5][r] + bias, 0.f), fmaxf(acc[6][r] + bias, 0.f),
+                                fmaxf(acc[7][r] + bias, 0.f));
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = tid + kThreads * i, f = idx >> 7, co = (idx >> 2) & 31, k = idx & 3;
+            const float4 v = *reinterpret_cast<const float4 *>(s.a1 + f * kYF + co * kYC + 4 * k);
+            if (m0 + f < M) *reinterpret_cast<float4 *>(y + (m0 + f) * 512 + co * 16 + 4 * k) = v;
+        }
+        lds_barrier();                              // the output tile has left a1
     }
 }
 
@@ -489,6 +685,20 @@ static StemProblem make_problem(const void *x, long long x_stride, const float *
     return p;
 }
 
+// From kFwd16MinFrames frames up the forward runs 16 frames per workgroup pass (k_stem_fwd16: no MFMA on border zeros); below
+// that there are not enough passes to go round the CUs and a wave per frame (k_stem_fwd) is the better fit. Same results.
+constexpr int kFwd16BlocksPerCu = 2;
+static long long fwd16_min_frames()
+{
+    static const long long v = getenv("ATR_STEM_FWD16_MIN") ? atoll(getenv("ATR_STEM_FWD16_MIN")) : 4096;   // (crossover experiments)
+    return v;
+}
+static int stem_grid16(long long M)
+{
+    const long long cap = (long long)stem_grid(1LL << 40, kFwd16BlocksPerCu), need = (M + kF - 1) / kF;
+    return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
+}
+
 template <typename XT>
 static int stem_forward_impl(const XT *x, long long x_stride, const float *w1, const float *b1, const float *w2,
                              const float *b2, float *y, long long M, void *stream)
@@ -497,8 +707,13 @@ static int stem_forward_impl(const XT *x, long long x_stride, const float *w1, c
     if (M == 0) return 0;
     StemPair pr;
     pr.p[0] = pr.p[1] = make_problem(x, x_stride, w1, b1, w2, b2, y, M);
-    pr.split = stem_grid(M, kFwdBlocksPerCu);
-    hipLaunchKernelGGL((k_stem_fwd<XT>), dim3((unsigned)pr.split), dim3(kThreads), 0, (hipStream_t)stream, pr);
+    if (M >= fwd16_min_frames()) {
+        pr.split = stem_grid16(M);
+        hipLaunchKernelGGL((k_stem_fwd16<XT>), dim3((unsigned)pr.split), dim3(kThreads), 0, (hipStream_t)stream, pr);
+    } else {
+        pr.split = stem_grid(M, kFwdBlocksPerCu);
+        hipLaunchKernelGGL((k_stem_fwd<XT>), dim3((unsigned)pr.split), dim3(kThreads), 0, (hipStream_t)stream, pr);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -515,16 +730,19 @@ static int stem_forward2_impl(const XT *x0, long long x0_stride, const float *w1
     pr.p[0] = make_problem(x0, x0_stride, w1_0, b1_0, w2_0, b2_0, y0, M0);
     pr.p[1] = make_problem(x1, x1_stride, w1_1, b1_1, w2_1, b2_1, y1, M1);
     // split the resident workgroups in proportion to the frame counts (every wave gets the same number of frames)
-    const int total = stem_grid(M0 + M1, kFwdBlocksPerCu);
+    const bool f16 = M0 + M1 >= fwd16_min_frames();
+    const int per = f16 ? kF : kWaves;
+    const int total = f16 ? stem_grid16(M0 + M1) : stem_grid(M0 + M1, kFwdBlocksPerCu);
     int g0 = (int)(((long long)total * M0 + (M0 + M1) / 2) / (M0 + M1));
-    const int need0 = (int)((M0 + kWaves - 1) / kWaves), need1 = (int)((M1 + kWaves - 1) / kWaves);
+    const int need0 = (int)((M0 + per - 1) / per), need1 = (int)((M1 + per - 1) / per);
     if (g0 < 1) g0 = 1;
     if (g0 > need0) g0 = need0;
     int g1 = total - g0;
     if (g1 < 1) g1 = 1;
     if (g1 > need1) g1 = need1;
     pr.split = g0;
-    hipLaunchKernelGGL((k_stem_fwd<XT>), dim3((unsigned)(g0 + g1)), dim3(kThreads), 0, (hipStream_t)stream, pr);
+    if (f16) hipLaunchKernelGGL((k_stem_fwd16<XT>), dim3((unsigned)(g0 + g1)), dim3(kThreads), 0, (hipStream_t)stream, pr);
+    else hipLaunchKernelGGL((k_stem_fwd<XT>), dim3((unsigned)(g0 + g1)), dim3(kThreads), 0, (hipStream_t)stream, pr);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

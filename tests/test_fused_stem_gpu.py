@@ -388,6 +388,41 @@ def test_u8_frames_give_the_float_results_bit_for_bit(M):
     assert torch.equal(out_u, out_f)
 
 
+@pytest.mark.parametrize("M", [4096, 4099, 12301])
+def test_sixteen_frame_forward_equals_the_wave_per_frame_forward_bit_for_bit(M):
+    """From 4096 frames up atr_stem_forward* runs 16 frames per workgroup pass (k_stem_fwd16: frames on the MFMA rows, border
+    taps not issued); below that one wave per frame (k_stem_fwd). A frame's output must not depend on the launch it was part
+    of (the rollout evaluates 2 N frames per step, the recompute learner 20 x 2 N at once): the same frames in chunks of 1000
+    give the same bits — floats, bytes, a strided view, a ragged last pass, and the two-problem launch."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(M)
+    dev = "cuda"
+    encs = []
+    for _ in range(2):
+        conv1 = torch.nn.Conv2d(1, 16, 3, 2, 1).to(dev)
+        conv2 = torch.nn.Conv2d(16, 32, 3, 2, 1).to(dev)
+        with torch.no_grad():
+            conv1.weight.mul_(2.0); conv2.weight.mul_(3.0); conv1.bias.normal_(0, 0.2); conv2.bias.normal_(0, 0.2)
+        encs.append((conv1, conv2))
+    obs = torch.tensor(np.random.RandomState(M).choice([0, 1, 2, 4], size=(M, 2, 13, 13)).astype(np.uint8), device=dev)
+
+    def chunked(view, enc):
+        return torch.cat([fused.stem(view[i:i + 1000], enc[0], enc[1]) for i in range(0, M, 1000)])
+    for view in (obs[:, 1], obs[:, 0].contiguous(), obs[:, 0].float()):
+        big = fused.stem(view, *encs[0])
+        assert torch.equal(big, chunked(view, encs[0]))
+        yr = _ref(view.float().reshape(M, 169), encs[0][0].weight, encs[0][0].bias, encs[0][1].weight, encs[0][1].bias)
+        torch.testing.assert_close(big, yr, rtol=1e-5, atol=1e-5)
+
+    class E:
+        def __init__(self, c):
+            self.conv1, self.conv2 = c
+    oa, ob = torch.empty((M, 512), device=dev), torch.empty((M - 7, 512), device=dev)
+    fused.stem_into2(obs[:, 0], E(encs[0]), oa, obs[:M - 7, 1], E(encs[1]), ob)
+    assert torch.equal(oa, chunked(obs[:, 0], encs[0]))
+    assert torch.equal(ob, chunked(obs[:, 1], encs[1])[:M - 7])
+
+
 @pytest.mark.parametrize("N", [1, 130, 4096])
 def test_actor_step_mfma_kernel_matches_lstmcell(N):
     """atr_actor_step (both LSTMCell GEMMs + the cell as one f32-MFMA kernel) against torch.nn.LSTMCell in float64 on
