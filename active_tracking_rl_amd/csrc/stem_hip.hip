@@ -154,6 +154,22 @@ __device__ __forceinline__ void zero_wave(float *p, int n, int l)
     for (int i = l; i < n; i += 64) p[i] = 0.0f;
 }
 
+// The workgroup's copy of the conv2 weights into LDS rows of 145 floats: 18 loads per thread, all in flight before the first
+// is parked (one memory latency, not one per trip of a loop).
+__device__ __forceinline__ void stage_w2(float *wst, const float *__restrict__ w2, int tid)
+{
+    static_assert(kW2 == 18 * kThreads, "18 elements per thread");
+    const float __attribute__((address_space(1))) *g = (const float __attribute__((address_space(1))) *)w2;
+    float v[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) v[k] = g[tid + kThreads * k];
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+        const int i = tid + kThreads * k;
+        wst[(i / 144) * 145 + (i % 144)] = v[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // forward: D[pos][co] = sum_k im2col(a1)[pos][k] * W2[co][k]; step s = t*4 + cq covers tap t = kh*3+kw of the
 // input channels 4cq..4cq+3 (k within the step = ci & 3).
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
     float W[2][36];
     {
         float *wst = reinterpret_cast<float *>(lds);            // 32 x 145 floats = 18.1 KB of the workgroup's 31.5 KB
-        for (int i = (int)threadIdx.x; i < kW2; i += kThreads) wst[(i / 144) * 145 + (i % 144)] = w2[i];
+        stage_w2(wst, w2, (int)threadIdx.x);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 9; t++)
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// forward, 16 frames per workgroup pass (k_stem_fwd16): the launch sizes from 4096 frames up.
+// forward, 16 frames per workgroup pass (k_stem_fwd16): the launch sizes from 16384 frames up.
 //
 // k_stem_fwd above puts the 16 output positions of ONE frame on the MFMA's 16 rows — and 44 of the 144 (position, tap)
 // pairs of a 4x4 output over a zero-bordered 7x7 input are structural zeros (output row 0 never sees tap row 0, ...): 31 % of
@@ -289,43 +305,47 @@ __device__ __forceinline__ void store_xtile(float *xt, const XTile &r, int tid)
     }
 }
 
-// conv1 + ReLU of frame f (this lane's), channel ch -> a1[(ch * 49 + r * 7 + c) * 16 + f].
+// conv1 + ReLU of frame f (this lane's), channel ch -> a1[(ch * 49 + r * 7 + c) * 16 + f]. Output row r reads input rows
+// 2r - 1 .. 2r + 1 (row -1 and row 13 are the zero border: their taps are not issued); the two new rows of output row r + 1 are
+// requested from LDS before row r is computed.
+__device__ __forceinline__ void load_row13(const float *xf, int ir, float (&t)[13])
+{
+    const float4 *row = reinterpret_cast<const float4 *>(xf + ir * 16);
+    const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+    const float r3 = xf[ir * 16 + 12];
+    t[0] = r0.x; t[1] = r0.y; t[2] = r0.z; t[3] = r0.w; t[4] = r1.x; t[5] = r1.y; t[6] = r1.z; t[7] = r1.w;
+    t[8] = r2.x; t[9] = r2.y; t[10] = r2.z; t[11] = r2.w; t[12] = r3;
+}
 __device__ __forceinline__ void conv1_lane(const float *xf, float *a1o, const float (&w)[9], float b)
 {
-    float R[3][13];
+    float R[3][13], Nx[2][13];
+    load_row13(xf, 0, R[1]);
+    load_row13(xf, 1, R[2]);
 #pragma unroll
     for (int r = 0; r < 7; r++) {
+        if (r < 6) {
+            load_row13(xf, 2 * r + 2, Nx[0]);
+            if (2 * r + 3 <= 12) load_row13(xf, 2 * r + 3, Nx[1]);
+        }
+        float acc[7];                               // the row's 7 outputs advance together: 7 independent FMA chains
+#pragma unroll
+        for (int c = 0; c < 7; c++) acc[c] = b;
 #pragma unroll
         for (int kh = 0; kh < 3; kh++) {
-            const int ir = 2 * r - 1 + kh;
-            if (ir < 0 || ir > 12) continue;        // (the zero border: rows -1 and 13)
-            if (kh == 0) {                          // row 2r - 1 = the previous output row's last one
+            if (2 * r - 1 + kh < 0 || 2 * r - 1 + kh > 12) continue;
 #pragma unroll
-                for (int j = 0; j < 13; j++) R[0][j] = R[2][j];
-                continue;
-            }
-            const float4 *row = reinterpret_cast<const float4 *>(xf + ir * 16);
-            const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-            const float r3 = xf[ir * 16 + 12];
-            const float t[13] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3};
+            for (int kw = 0; kw < 3; kw++)
 #pragma unroll
-            for (int j = 0; j < 13; j++) R[kh][j] = t[j];
-        }
-#pragma unroll
-        for (int c = 0; c < 7; c++) {
-            float acc = b;
-#pragma unroll
-            for (int kh = 0; kh < 3; kh++) {
-                if (2 * r - 1 + kh < 0 || 2 * r - 1 + kh > 12) continue;
-#pragma unroll
-                for (int kw = 0; kw < 3; kw++) {
+                for (int c = 0; c < 7; c++) {
                     const int ic = 2 * c - 1 + kw;
                     if (ic < 0 || ic > 12) continue;
-                    acc = fmaf(R[kh][ic], w[kh * 3 + kw], acc);
+                    acc[c] = fmaf(R[kh][ic], w[kh * 3 + kw], acc[c]);
                 }
-            }
-            a1o[(r * 7 + c) * kF] = fmaxf(acc, 0.0f);
         }
+#pragma unroll
+        for (int c = 0; c < 7; c++) a1o[(r * 7 + c) * kF] = fmaxf(acc[c], 0.0f);
+#pragma unroll
+        for (int j = 0; j < 13; j++) { R[0][j] = R[2][j]; R[1][j] = Nx[0][j]; R[2][j] = Nx[1][j]; }
     }
 }
 
@@ -349,11 +369,19 @@ __device__ __forceinline__ void conv2_rows(const float *ap, const float (&Wh)[36
             }
 }
 
+#ifdef STEM_PROBE        // probe build only (tools/stem_timeline_probe.py): wall-clock stamps of wave 0 at the phase boundaries
+__device__ unsigned long long g_stem_probe[2048 * 8];
+#define STEM_STAMP(i) do { if (tid == 0 && blockIdx.x < 2048) g_stem_probe[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define STEM_STAMP(i) do { } while (0)
+#endif
+
 template <typename XT>
 __global__ __launch_bounds__(kThreads, 2) void k_stem_fwd16(StemPair pr)
 {
     __shared__ __attribute__((aligned(16))) LdsF16 s;
     const int tid = (int)threadIdx.x, l = tid & 63, wave = tid >> 6;
+    STEM_STAMP(0);
     const bool second = (int)blockIdx.x >= pr.split;
     const StemProblem &pb = pr.p[second ? 1 : 0];
     const XT *__restrict__ x = reinterpret_cast<const XT *>(pb.x);
@@ -371,7 +399,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_fwd16(StemPair pr)
     float Wh[36];
     {
         float *wst = s.a1;                          // (see k_stem_fwd: the conv2 weights pass through LDS, rows padded to 145)
-        for (int i = tid; i < kW2; i += kThreads) wst[(i / 144) * 145 + (i % 144)] = w2[i];
+        stage_w2(wst, w2, tid);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 9; t++)
@@ -390,9 +418,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_fwd16(StemPair pr)
     float *a1o = s.a1 + ch * 49 * kF + c;
     const float *ap = s.a1 + q * 49 * kF + c;
     lds_barrier();
+    STEM_STAMP(1);
     for (; m0 < M; m0 += stride) {
         conv1_lane(xf, a1o, cw, cb);
         lds_barrier();                            // a1 complete; the x tile is free
+        STEM_STAMP(2);
         store_xtile<XT>(s.x, xv, tid);
         xv = load_xtile(x, m0 + 2 * stride, M, xs, tid);
         f32x4 acc[8];
@@ -403,6 +433,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_fwd16(StemPair pr)
         // bandwidth) becomes the kernel's bound (measured: 254 us at 163840 frames, 167 us with the same bytes laid out 1 KB
         // per instruction). So the 16 frames' outputs meet in LDS (over a1, which conv2 is done with) and leave as whole rows.
         lds_barrier();                              // a1 is free (and the next x tile complete)
+        STEM_STAMP(3);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             float4 *yt = reinterpret_cast<float4 *>(s.a1 + (4 * q + r) * kYF + (16 * h + c) * kYC + 8 * qa);
@@ -416,10 +447,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_fwd16(StemPair pr)
         for (int i = 0; i < 8; i++) {
             const int idx = tid + kThreads * i, f = idx >> 7, co = (idx >> 2) & 31, k = idx & 3;
             const float4 v = *reinterpret_cast<const float4 *>(s.a1 + f * kYF + co * kYC + 4 * k);
+            // (plain stores: streamed past the L2 — nontemporal — the launch itself is 1-2 us shorter, but the GEMM that reads y
+            // next pays more than that: measured +25..65 us per 20-step iteration)
             if (m0 + f < M) *reinterpret_cast<float4 *>(y + (m0 + f) * 512 + co * 16 + 4 * k) = v;
         }
         lds_barrier();                              // the output tile has left a1
+        STEM_STAMP(4);
     }
+#ifdef STEM_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STEM_STAMP(5);
+#endif
 }
 
 // dz2 = dy * (y > 0) of one frame: lane (c, q) holds channels c and 16+c, positions 4q..4q+3.
@@ -685,17 +723,23 @@ static StemProblem make_problem(const void *x, long long x_stride, const float *
     return p;
 }
 
-// From kFwd16MinFrames frames up the forward runs 16 frames per workgroup pass (k_stem_fwd16: no MFMA on border zeros); below
-// that there are not enough passes to go round the CUs and a wave per frame (k_stem_fwd) is the better fit. Same results.
+// From 16384 frames per launch up the forward runs 16 frames per workgroup pass (k_stem_fwd16: no MFMA on border zeros; 0.66 of the
+// f32 MFMA peak at 163840 frames against 0.54 of k_stem_fwd). In isolation it wins from 3072 frames up (tools/stem_bench.py,
+// tools/stem_rollout_bench.py: 13.9 against 17.2 us for the rollout step's 2 x 4096 frames), but inside the iteration a launch
+// of that size is bounded by what surrounds its 14 us of work (tools/stem_timeline_probe.py: dispatch, and the write-back of
+// 16.8 MB of outputs at the kernel boundary: 24.5 against 24.9 us in rocprofv3's kernel trace), and beside the learner's kernels
+// under the pipelined schedule its 62 KB of LDS and 236 VGPRs are the worse neighbour (16.58 against 16.97 M env steps/s at
+// 4096 envs): the rollout's launches stay with a wave per frame. Same results bit for bit either way.
 constexpr int kFwd16BlocksPerCu = 2;
 static long long fwd16_min_frames()
 {
-    static const long long v = getenv("ATR_STEM_FWD16_MIN") ? atoll(getenv("ATR_STEM_FWD16_MIN")) : 4096;   // (crossover experiments)
+    static const long long v = getenv("ATR_STEM_FWD16_MIN") ? atoll(getenv("ATR_STEM_FWD16_MIN")) : 16384;   // (crossover experiments)
     return v;
 }
 static int stem_grid16(long long M)
 {
-    const long long cap = (long long)stem_grid(1LL << 40, kFwd16BlocksPerCu), need = (M + kF - 1) / kF;
+    static const int bpc = getenv("ATR_STEM_FWD16_BLOCKS") ? atoi(getenv("ATR_STEM_FWD16_BLOCKS")) : kFwd16BlocksPerCu;   // (co-run experiments)
+    const long long cap = (long long)stem_grid(1LL << 40, bpc >= 1 && bpc <= 2 ? bpc : kFwd16BlocksPerCu), need = (M + kF - 1) / kF;
     return (int)(need < cap ? (need < 1 ? 1 : need) : cap);
 }
 
@@ -799,3 +843,10 @@ extern "C" int atr_stem_backward_u8(const unsigned char *x, long long x_stride, 
 {
     return stem_backward_impl<uint8_t>(x, x_stride, y, dy, w1, b1, w2, dw1, db1, dw2, db2, workspace, M, stream);
 }
+
+#ifdef STEM_PROBE
+extern "C" int atr_stem_probe_read(unsigned long long *host, int n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(atr::g_stem_probe), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
