@@ -664,6 +664,281 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_bwd(const XT *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// backward, 16 frames per workgroup pass (k_stem_bwd16): the learner's launch sizes (from 16384 frames up).
+//
+// The same move as k_stem_fwd16: with 16 FRAMES on an MFMA dimension, the products with the zero border of a1 are not issued —
+// and with it the register col2im, the cross-lane shifts and the packed-FMA filter gradient of k_stem_bwd go too:
+//   (1) dW2[co][ci][t] += sum over frames and the positions that are REAL for tap t of dz2[f][pos][co] * a1[f][ci][loc(pos, t)]:
+//       A = dz2 as [co x 4 frames], B = a1 as [4 frames x ci]; 100 (position, tap) pairs x 4 frame groups x 2 halves of co
+//       = 800 MFMAs per 16 frames (k_stem_bwd: 60 per frame = 960).
+//   (2) da1[f][ci] at each of the 49 a1 locations = sum over the (position, tap) pairs that touch it and over co of
+//       dz2[f][pos][co] * W2[co][ci][t] — chained into ONE accumulator per location (no scatter): 100 pairs x 8 groups of 4 co
+//       = 800 MFMAs (k_stem_bwd: 72 per frame = 1152).
+//   (3) dz1 = da1 * (a1 > 0) comes out of (2) as [frame = 4 q + r][ci = lane & 15] — which IS the A operand layout of an MFMA over
+//       frames {r, 4 + r, 8 + r, 12 + r}: dW1[ci][tap] += dz1^T x window(x)[frame][tap] is 4 MFMAs per location (196 per pass) whose
+//       B operand is one ds_read_b32 of the zero-bordered x tile per lane (lane & 15 = tap; column 9 is fed ones: db1).
+// 512 threads, one workgroup per CU: the pass's tiles (x 15.6 KB, a1 53 KB, dz2 35 KB) are shared by 8 waves — two per SIMD —
+// that each take one eighth of (1) (a 2x2 quadrant of positions x one half of co: 100 MFMAs) and one eighth of the 49 locations
+// of (2) + (3) (12 pairs each, the centre's 4 on top of one of them). Both tiles are laid out [..][frame][17]: read with the frame
+// on the lane's low bits or on its high bits, the 64 lanes of a ds_read_b32 fall into different banks either way.
+constexpr int kXB = 244;                        // x tile per frame: 15 rows x 16 (zero border all round) + 4: bank 52 f mod 64
+constexpr int kA1L = 16 * 17;                   // a1 tile: [49 locations][16 frames][17]
+constexpr int kDzP = 2 * 16 * 17 + 4;           // dz2 tile: [16 positions][2 halves of co][16 frames][17] (+4: the writer's banks)
+constexpr int kThreadsB16 = 512;
+struct LdsB16 { float x[kF * kXB]; float a1[49 * kA1L]; float dz[2][16 * kDzP]; float w2[kW2]; };   // 15.3 + 52.1 + 2 x 34.3 + 18 KB = 153.9 KB
+
+// which of the 8 waves owns a1 location (ih, iw) in steps (2) + (3): four rotationally symmetric 24-pair regions cut in two,
+// the centre (4 pairs) with role 4
+__host__ __device__ constexpr int bwd16_role_of(int ih, int iw)
+{
+    return (ih <= 2 && iw <= 3) ? (ih == 1 ? 0 : 1)
+         : (ih <= 3 && iw >= 4) ? (ih <= 1 ? 2 : 3)
+         : (ih >= 4 && iw >= 3) ? (ih == 5 ? 4 : 5)
+         : (ih >= 3 && iw <= 2) ? (ih <= 4 ? 6 : 7)
+         : 4;
+}
+
+template <int ROLE>
+__device__ __forceinline__ void bwd16_mfma_phase(const LdsB16 &s, const float *dzt, int c, int q, f32x4 (&dw2)[9], f32x4 &dw1)
+{
+    // ---- (1): quadrant (QA, QB) of the output positions x half H of the output channels
+    constexpr int QA = ROLE >> 2, QB = (ROLE >> 1) & 1, H = ROLE & 1;
+    {
+        const float *dzl = dzt + H * 272 + q * 17 + c;           // A[i = co][k = frame 4 kk + q]
+        const float *a1l = s.a1 + q * 17 + c;                    // B[k = frame 4 kk + q][j = ci]
+        float A[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) A[p][kk] = dzl[((2 * QA + (p >> 1)) * 4 + 2 * QB + (p & 1)) * kDzP + kk * 4 * 17];
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const int oh = 2 * QA + (p >> 1), ow = 2 * QB + (p & 1);
+                const int ih = 2 * oh - 1 + t / 3, iw = 2 * ow - 1 + t % 3;
+                if (ih < 0 || ih > 6 || iw < 0 || iw > 6) continue;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) dw2[t] = mfma(A[p][kk], a1l[(ih * 7 + iw) * kA1L + kk * 4 * 17], dw2[t]);
+            }
+    }
+    // ---- (2) + (3): this role's a1 locations
+    const float *dzf = dzt + c * 17 + q;                         // A[i = frame][k = co 4 kc + q]
+    const float *w2l = s.w2 + q * 144 + c * 9;                   // B[k = co 4 kc + q][j = ci] of tap t: native [co][ci][t] order,
+                                                                 // bank (16 q + 9 c) mod 64: conflict-free
+    const float *a1m = s.a1 + (4 * q) * 17 + c;                  // the mask: a1[loc][frame 4 q + r][ci = c]
+    const int tap = c < 9 ? c : 0;
+    const float *xw = s.x + (4 * q) * kXB + (tap / 3) * 16 + (tap % 3);     // B of (3): lane & 15 = tap, frame 4 q + r
+    // A location's tail (mask, then the 4 MFMAs of (3)) depends on its last MFMA of (2): it is issued one location late, behind
+    // the next location's MFMAs, so that the matrix pipe has work while the result comes back.
+    auto tail = [&](const f32x4 &d, int ih, int iw) {
+        const int loc = ih * 7 + iw;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float dz1 = a1m[loc * kA1L + r * 17] > 0.f ? d[r] : 0.f;
+            const float xv = xw[r * kXB + (2 * ih) * 16 + 2 * iw];
+            dw1 = mfma(dz1, c < 9 ? xv : (c == 9 ? 1.0f : 0.0f), dw1);
+        }
+    };
+    f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+    int pih = -1, piw = -1;
+#pragma unroll
+    for (int ih = 0; ih < 7; ih++)
+#pragma unroll
+        for (int iw = 0; iw < 7; iw++) {
+            if (bwd16_role_of(ih, iw) != ROLE) continue;
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    const int oh2 = ih + 1 - kh, ow2 = iw + 1 - kw;          // 2 oh, 2 ow
+                    if ((oh2 & 1) || (ow2 & 1) || oh2 < 0 || oh2 > 6 || ow2 < 0 || ow2 > 6) continue;
+                    const int pos = (oh2 >> 1) * 4 + (ow2 >> 1);
+#pragma unroll
+                    for (int kc = 0; kc < 8; kc++)
+                        d = mfma(dzf[pos * kDzP + (kc >> 2) * 272 + (kc & 3) * 4], w2l[kc * 4 * 144 + kh * 3 + kw], d);
+                }
+            if (pih >= 0) tail(dp, pih, piw);
+            dp = d; pih = ih; piw = iw;
+        }
+    tail(dp, pih, piw);
+}
+
+template <typename XT>
+__global__ __launch_bounds__(kThreadsB16) void k_stem_bwd16(const XT *__restrict__ x, const float *__restrict__ y,
+                                                            const float *__restrict__ dy, const float *__restrict__ w1,
+                                                            const float *__restrict__ b1, const float *__restrict__ w2,
+                                                            float *__restrict__ partial, long long M, long long xs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_b16[];
+    LdsB16 &s = *reinterpret_cast<LdsB16 *>(lds_b16);
+    const int tid = (int)threadIdx.x, l = tid & 63, wave = tid >> 6, c = l & 15, q = l >> 4;
+    const long long stride = (long long)gridDim.x * kF;
+    long long m0 = (long long)blockIdx.x * kF;
+    // the prefetch registers: 4 float4 of y and of dy of a pass (element idx = tid + 512 i: frame idx >> 7, 4 positions of one output
+    // channel), 6 elements of x (frame tid >> 5)
+    float4 yv[4], dv[4];
+    uint32_t xr[6];
+    auto load_yd = [&](long long mb) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + kThreadsB16 * i;
+            long long m = mb + (idx >> 7);
+            m = m < M ? m : M - 1;
+            yv[i] = stem_ldg4(y + m * 512 + (idx & 127) * 4);
+            dv[i] = stem_ldg4(dy + m * 512 + (idx & 127) * 4);
+        }
+    };
+    auto load_x16 = [&](long long mb) {
+        long long m = mb + (tid >> 5);
+        m = m < M ? m : M - 1;
+        const XT __attribute__((address_space(1))) *px = (const XT __attribute__((address_space(1))) *)(x + m * xs);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            int e = (tid & 31) + 32 * k;
+            e = e < 169 ? e : 168;
+            xr[k] = sizeof(XT) == 4 ? __float_as_uint((float)px[e]) : (uint32_t)px[e];
+        }
+    };
+    float gb2 = 0.f;                                // db2 of channel (tid >> 2) & 31, this thread's elements
+    auto write_x = [&]() {                          // the interior of the bordered x tile
+        float *xd = s.x + (tid >> 5) * kXB;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int e = (tid & 31) + 32 * k, row = (e * 79) >> 10;
+            if (e < 169) xd[(row + 1) * 16 + (e - row * 13) + 1] = sizeof(XT) == 4 ? __uint_as_float(xr[k]) : (float)xr[k];
+        }
+    };
+    auto write_dz = [&](float *dzt, long long mb) {   // dz2 = dy * (y > 0) of the pass at mb (zero past the last frame)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + kThreadsB16 * i, f = idx >> 7, co = (idx >> 2) & 31, k4 = idx & 3;
+            float4 z = relu_mask(yv[i], dv[i]);
+            if (mb + f >= M) z = make_float4(0.f, 0.f, 0.f, 0.f);
+            gb2 += (z.x + z.y) + (z.z + z.w);
+            float *d = dzt + (4 * k4) * kDzP + (co >> 4) * 272 + f * 17 + (co & 15);
+            d[0] = z.x; d[kDzP] = z.y; d[2 * kDzP] = z.z; d[3 * kDzP] = z.w;
+        }
+    };
+    load_yd(m0);
+    load_x16(m0);
+    for (int i = tid; i < kF * kXB; i += kThreadsB16) s.x[i] = 0.0f;      // the border stays zero: passes rewrite the interior only
+    // B operand of (2): W2 in LDS for the whole kernel (in 72 VGPRs it pushed the MFMA phase into scratch spills)
+    for (int i = tid; i < kW2; i += kThreadsB16) s.w2[i] = w2[i];
+    // conv1 (recomputed) on packed FMAs: lane = (frame l & 15, channels 2 wave and 2 wave + 1, output rows 2 q and 2 q + 1)
+    Conv1W cw;
+#pragma unroll
+    for (int k = 0; k < 9; k++) cw.w[k] = f32x2{w1[(2 * wave) * 9 + k], w1[(2 * wave + 1) * 9 + k]};
+    cw.b = f32x2{b1[2 * wave], b1[2 * wave + 1]};
+    f32x4 dw2[9], dw1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; t++) dw2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                // the x tile is zeroed
+    write_x();
+    write_dz(s.dz[0], m0);
+    load_yd(m0 + stride);
+    load_x16(m0 + stride);
+    lds_barrier();
+    // Per pass: conv1 | barrier | dz2 of the NEXT pass into the other buffer, then the MFMA phase | barrier | x of the next pass
+    // | barrier. (a1 and x are single: the MFMA phase reads both; dz2 is double, so that its 16 LDS writes per thread and the next
+    // pass's loads go out under the MFMAs.)
+    int buf = 0;
+    for (; m0 < M; m0 += stride, buf ^= 1) {
+        STEM_STAMP(0);
+        // ---- conv1 -> a1 tile [loc][frame][17]
+        {
+            const float *xf = s.x + c * kXB + (4 * q) * 16;         // padded input rows 4 q .. 4 q + 4
+            float *a1o = s.a1 + (2 * q * 7) * kA1L + c * 17 + 2 * wave;
+            float R[5][16];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const float4 *row = reinterpret_cast<const float4 *>(xf + j * 16);
+                const float4 a = row[0], b = row[1], cc = row[2], d = row[3];
+                const float t[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, cc.x, cc.y, cc.z, cc.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) R[j][jj] = t[jj];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                if (rr == 1 && q == 3) break;                       // output row 7 does not exist
+                f32x2 acc[7];
+#pragma unroll
+                for (int cc = 0; cc < 7; cc++) acc[cc] = cw.b;
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                    for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+                        for (int cc = 0; cc < 7; cc++) {
+                            const float xv = R[2 * rr + kh][2 * cc + kw];
+                            acc[cc] = __builtin_elementwise_fma(f32x2{xv, xv}, cw.w[kh * 3 + kw], acc[cc]);
+                        }
+#pragma unroll
+                for (int cc = 0; cc < 7; cc++) {
+                    a1o[(rr * 7 + cc) * kA1L] = fmaxf(acc[cc].x, 0.0f);
+                    a1o[(rr * 7 + cc) * kA1L + 1] = fmaxf(acc[cc].y, 0.0f);
+                }
+            }
+        }
+        lds_barrier();
+        STEM_STAMP(1);
+        // ---- the next pass's dz2 (its y / dy arrived during conv1), the loads of the pass after it, then the MFMA phase by role
+        write_dz(s.dz[buf ^ 1], m0 + stride);
+        load_yd(m0 + 2 * stride);
+        STEM_STAMP(2);
+        const float *dzt = s.dz[buf];
+        switch (wave) {
+        case 0: bwd16_mfma_phase<0>(s, dzt, c, q, dw2, dw1); break;
+        case 1: bwd16_mfma_phase<1>(s, dzt, c, q, dw2, dw1); break;
+        case 2: bwd16_mfma_phase<2>(s, dzt, c, q, dw2, dw1); break;
+        case 3: bwd16_mfma_phase<3>(s, dzt, c, q, dw2, dw1); break;
+        case 4: bwd16_mfma_phase<4>(s, dzt, c, q, dw2, dw1); break;
+        case 5: bwd16_mfma_phase<5>(s, dzt, c, q, dw2, dw1); break;
+        case 6: bwd16_mfma_phase<6>(s, dzt, c, q, dw2, dw1); break;
+        default: bwd16_mfma_phase<7>(s, dzt, c, q, dw2, dw1); break;
+        }
+#ifdef STEM_PROBE
+        if (l == 0 && blockIdx.x < 2048 / 2) g_stem_probe[(1024 + blockIdx.x) * 8 + wave] = wall_clock64();
+#endif
+        lds_barrier();
+        STEM_STAMP(3);
+        write_x();
+        load_x16(m0 + 2 * stride);
+        lds_barrier();
+    }
+    // ---- one record per workgroup; the waves add up in wave order (fixed order -> reproducible sums)
+    float *red = s.a1;                              // kPartial floats, zeroed
+    for (int i = tid; i < kPartial; i += kThreadsB16) red[i] = 0.0f;
+    float *red2 = s.dz[0];                          // db2: [32 channels][16 contributors]
+    red2[((tid >> 2) & 31) * 16 + (tid & 3) * 4 + (tid >> 7)] = gb2;
+    __syncthreads();
+    for (int wv = 0; wv < 8; wv++) {
+        if (wave == wv) {
+            const int h = wave & 1;
+#pragma unroll
+            for (int t = 0; t < 9; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[(16 * h + 4 * q + r) * 144 + c * 9 + t] += dw2[t][r];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (c < 9) red[kW2 + kC2 + (4 * q + r) * 9 + c] += dw1[r];
+                else if (c == 9) red[kW2 + kC2 + 144 + 4 * q + r] += dw1[r];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 32) {
+        float v = 0.f;
+        for (int k = 0; k < 16; k++) v += red2[tid * 16 + k];
+        red[kW2 + tid] = v;
+    }
+    __syncthreads();
+    float *rec = partial + (size_t)blockIdx.x * kPartial;
+    for (int i = tid; i < kPartial; i += kThreadsB16) rec[i] = red[i];
+}
+
 // Fixed-order reduction of the per-workgroup records: 16 record elements x 64 record slices per block.
 __global__ __launch_bounds__(1024) void k_stem_reduce(const float *__restrict__ partial, int nrec, float *__restrict__ dw1,
                                                       float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2)
@@ -790,6 +1065,12 @@ static int stem_forward2_impl(const XT *x0, long long x0_stride, const float *w1
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+static long long bwd16_min_frames()
+{
+    static const long long v = getenv("ATR_STEM_BWD16_MIN") ? atoll(getenv("ATR_STEM_BWD16_MIN")) : 16384;   // (crossover experiments)
+    return v;
+}
+
 template <typename XT>
 static int stem_backward_impl(const XT *x, long long x_stride, const float *y, const float *dy, const float *w1,
                               const float *b1, const float *w2, float *dw1, float *db1, float *dw2, float *db2,
@@ -797,10 +1078,25 @@ static int stem_backward_impl(const XT *x, long long x_stride, const float *y, c
 {
     if (!x || !y || !dy || !w1 || !b1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !workspace || M <= 0 || x_stride < 169)
         return -1;
-    const int grid = stem_grid(M, stem_bwd_blocks());
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((k_stem_bwd<XT>), dim3((unsigned)grid), dim3(kThreads), 0, st, x, y, dy, w1, b1, w2, workspace, M,
-                       x_stride);
+    int grid;
+    if (M >= bwd16_min_frames()) {      // 16 frames per workgroup pass, one workgroup per CU (never more records than stem_grid's)
+        static bool lds_set[2] = {false, false};
+        if (!lds_set[sizeof(XT) == 4]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stem_bwd16<XT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sizeof(LdsB16)) != hipSuccess)
+                return -2;
+            lds_set[sizeof(XT) == 4] = true;
+        }
+        const long long cap = stem_grid(1LL << 40, 1), need = (M + kF - 1) / kF;
+        grid = (int)(need < cap ? need : cap);
+        hipLaunchKernelGGL((k_stem_bwd16<XT>), dim3((unsigned)grid), dim3(kThreadsB16), sizeof(LdsB16), st, x, y, dy, w1, b1, w2,
+                           workspace, M, x_stride);
+    } else {
+        grid = stem_grid(M, stem_bwd_blocks());
+        hipLaunchKernelGGL((k_stem_bwd<XT>), dim3((unsigned)grid), dim3(kThreads), 0, st, x, y, dy, w1, b1, w2, workspace, M,
+                           x_stride);
+    }
     hipLaunchKernelGGL(k_stem_reduce, dim3((kPartial + 15) / 16), dim3(1024), 0, st, workspace, grid, dw1, db1, dw2, db2);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

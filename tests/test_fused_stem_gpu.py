@@ -14,7 +14,7 @@ def _ref(x, w1, b1, w2, b2):
     return F.relu(F.conv2d(a, w2, b2, stride=2, padding=1)).reshape(x.shape[0], -1)
 
 
-@pytest.mark.parametrize("M", [1, 3, 64, 1000, 12288])
+@pytest.mark.parametrize("M", [1, 3, 64, 1000, 12288, 16391])      # (from 16384 frames up: the 16-frames-per-pass kernels)
 def test_fused_stem_matches_conv2d(M):
     from active_tracking_rl_amd import fused
     torch.manual_seed(M)
@@ -421,6 +421,35 @@ def test_sixteen_frame_forward_equals_the_wave_per_frame_forward_bit_for_bit(M):
     fused.stem_into2(obs[:, 0], E(encs[0]), oa, obs[:M - 7, 1], E(encs[1]), ob)
     assert torch.equal(oa, chunked(obs[:, 0], encs[0]))
     assert torch.equal(ob, chunked(obs[:, 1], encs[1])[:M - 7])
+
+
+@pytest.mark.parametrize("M", [16384, 40007])
+def test_sixteen_frame_backward_equals_the_wave_per_frame_backward(M):
+    """From 16384 frames up atr_stem_backward* runs 16 frames per workgroup pass (k_stem_bwd16: frames on an MFMA dimension, border
+    products not issued, the conv1 filter gradient on the matrix cores too); below that one wave per frame (k_stem_bwd). Same
+    (x, y, dy) -> the same four gradients up to the order of the fp32 sums: the launch against the sum over chunks of 8000
+    frames, 2e-5 of the gradient's max (against F.conv2d's autograd the two differ by the same ReLU-mask flips of the forward:
+    that comparison is test_fused_stem_matches_conv2d's)."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(M)
+    dev = "cuda"
+    conv1 = torch.nn.Conv2d(1, 16, 3, 2, 1).to(dev)
+    conv2 = torch.nn.Conv2d(16, 32, 3, 2, 1).to(dev)
+    with torch.no_grad():
+        conv1.weight.mul_(2.0); conv2.weight.mul_(3.0); conv1.bias.normal_(0, 0.2); conv2.bias.normal_(0, 0.2)
+    obs = torch.tensor(np.random.RandomState(M).choice([0, 1, 2, 4], size=(M, 2, 13, 13)).astype(np.uint8), device=dev)
+    w1, b1, w2 = conv1.weight.detach().contiguous(), conv1.bias.detach(), conv2.weight.detach().contiguous()
+    shapes = (w1.shape, w2.shape)
+    for x in (obs[:, 1], obs[:, 0].float()):
+        y = fused.stem(x, conv1, conv2)
+        dy = torch.randn_like(y)
+        big = fused._stem_backward(fused.rows169(x), y, dy, w1, b1, w2, shapes)
+        parts = [fused._stem_backward(fused.rows169(x[i:i + 8000]), y[i:i + 8000], dy[i:i + 8000], w1, b1, w2, shapes)
+                 for i in range(0, M, 8000)]
+        for k, name in enumerate(("dw1", "db1", "dw2", "db2")):
+            want = torch.stack([pt[k].double() for pt in parts]).sum(0)
+            scale = float(want.abs().max()) + 1e-6
+            assert float((big[k].double() - want).abs().max()) <= 2e-5 * scale, (name, M)
 
 
 @pytest.mark.parametrize("N", [1, 130, 4096])
