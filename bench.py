@@ -523,8 +523,9 @@ def main():
 
     # ---- the policy-side hot kernels (the largest single kernels of the iteration): f32-MFMA roofline ------------
     # learner shape of the target's encoder: 2 frames x 4096 envs x 20 steps. ALGORITHMIC FLOPs = taps that read real
-    # pixels (conv1 16 x 361, conv2 32 x 16 x 100 MACs per frame; backward = 2x conv2 + conv1 recompute + dW1); the
-    # kernels issue the dense zero-padded products (16 x 49 x 9 and 32 x 16 x 144 MACs: 1.42x), reported alongside.
+    # pixels (conv1 16 x 361, conv2 32 x 16 x 100 MACs per frame; backward = 2x conv2 + conv1 recompute + dW1). The
+    # wave-per-frame kernels (launches below 16384 frames: the rollout's) issue the dense zero-padded products (16 x 49 x 9 and
+    # 32 x 16 x 144 MACs: 1.42x, `issued_over_algorithmic`); the 16-frame kernels measured here issue conv2's real products only.
     stem_roof = None
     try:
         from active_tracking_rl_amd import fused
@@ -535,23 +536,37 @@ def main():
         dys_ = torch.randn((Ms, 512), device=device)
         prm = [enc.conv1.weight.detach(), enc.conv1.bias.detach(), enc.conv2.weight.detach(), enc.conv2.bias.detach()]
 
-        def t_us(fn, reps=10):
-            fn(); fn()
+        def t_us(fn, launches=5, reps=4):
+            """microseconds per launch, the launches replayed from a hipGraph (how the learner issues them) with HIP events
+            around the replays; best of 3"""
+            fn()
             torch.cuda.synchronize(device)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(launches):
+                    fn()
+            g.replay()
             torch.cuda.synchronize(device)
-            return e0.elapsed_time(e1) * 1e3 / reps
+            best = None
+            for _ in range(3):
+                e0.record()
+                for _ in range(reps):
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize(device)
+                us = e0.elapsed_time(e1) * 1e3 / (reps * launches)
+                best = us if best is None else min(best, us)
+            del g
+            return best
+        w1c, w2c = prm[0].contiguous(), prm[2].contiguous()
         f_us = t_us(lambda: fused.stem_into(xs_, enc.conv1, enc.conv2, ys_))
-        b_us = t_us(lambda: fused._stem_backward(xs_, ys_, dys_, prm[0].contiguous(), prm[1], prm[2].contiguous(),
-                                                 (prm[0].shape, prm[2].shape)))
+        b_us = t_us(lambda: fused._stem_backward(xs_, ys_, dys_, w1c, prm[1], w2c, (prm[0].shape, prm[2].shape)))
         c1, c2, c1d, c2d = 16 * 361, 32 * 16 * 100, 16 * 49 * 9, 32 * 16 * 144
         f_tf = 2.0 * (c1 + c2) * Ms / (f_us * 1e-6) / 1e12
         b_tf = 2.0 * (2 * c2 + 2 * c1) * Ms / (b_us * 1e-6) / 1e12
         dense = float(c1d + c2d) / (c1 + c2)
-        stem_roof = {"bound": "mfma", "kernel": "atr::k_stem_fwd / atr::k_stem_bwd (v_mfma_f32_16x16x4_f32)",
+        stem_roof = {"bound": "mfma", "kernel": "atr::k_stem_fwd16 / atr::k_stem_bwd16 + k_stem_reduce (v_mfma_f32_16x16x4_f32; 16 frames "
+                                                  "per workgroup pass: the launch sizes from 16384 frames up since round 5)",
                      "frames": Ms, "fwd_us": f_us, "bwd_us": b_us,
                      "achieved": f_tf, "achieved_bwd": b_tf, "peak": 157.3, "unit": "TFLOP/s",
                      "frac": f_tf / 157.3, "frac_bwd": b_tf / 157.3, "issued_over_algorithmic": dense,

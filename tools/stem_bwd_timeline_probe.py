@@ -27,6 +27,7 @@ assert lib.atr_stem_probe_read(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
 t = buf.reshape(2048, 8).astype(np.int64)
 wg = 256
 a, w = t[:wg, :4], t[1024:1024 + wg]
+print("k_stem_bwd16, %d frames on 256 workgroups: the last pass of every workgroup, microseconds" % M)
 names = ["pass start", "conv1 done (barrier)", "next dz2 written, loads issued", "MFMA phase done (barrier)"]
 d = np.diff(a, axis=1) / 100.0
 for i in range(3):
