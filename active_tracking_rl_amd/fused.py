@@ -405,6 +405,32 @@ def _lt_key(g):
         g.workspace_bytes if g.workspace else 0)
 
 
+def _lt_family(key):
+    """The problem key without the output's batch stride. A product must not change with the PLACE its batches are written to
+    (the gate GEMM writes a [2, N, 512] scratch tensor or — since round 5 — slot t of the rollout's [2, T, N, 512] store: the
+    same products), but hipBLASLt's heuristic takes the stride into account and a timing run can crown another tile shape,
+    whose fp32 sums differ in the last bit: two runs of one seed then part ways at the first sampled action. So the kernel is
+    chosen per FAMILY: every output stride runs the choice recorded (or first timed) for the family."""
+    import re
+    return re.sub(r"_sc\d+", "", key)
+
+
+def _lt_family_choices():
+    """{family: (candidate index, solution index)}: of a family's records the one with the largest output stride (the rollout
+    store at the bench's rollout length — the default path)."""
+    fam = {}
+    import re
+    for k, v in lt_choices().items():
+        sc = int(re.search(r"_sc(\d+)", k).group(1)) if re.search(r"_sc(\d+)", k) else 0
+        f = _lt_family(k)
+        if f not in fam or sc > fam[f][0]:
+            fam[f] = (sc, v)
+    return {f: v for f, (sc, v) in fam.items()}
+
+
+_lt_family_first = {}       # families without a record: the choice the first problem of the family ended up with
+
+
 def lt_library():
     """{'version', 'git', 'header_version'} of the hipBLASLt build csrc/lt_gemm.cpp loaded (PyTorch's copy) and of the header it
     was compiled against."""
@@ -499,13 +525,19 @@ def linear_lt(a, w, out, bias=None, relu=False, workspace=None):
     g = _linear_args(a, w, out, bias, relu, workspace)
     L = lib()
     key = _lt_key(g)
-    if key not in _lt_seen:
+    fresh = key not in _lt_seen
+    if fresh:
         _lt_seen[key] = g
-        rec = lt_choices().get(key)
+        fam = _lt_family(key)
+        rec = _lt_family_choices().get(fam) or _lt_family_first.get(fam)
         if rec is not None:
             L.atr_linear_set_choice(C.byref(g), rec[0], rec[1])
     if L.atr_linear(C.byref(g), _stream(a)) != 0:
         raise RuntimeError("atr_linear failed: %s" % L.atr_lt_last_error().decode())
+    if fresh and rec is None:
+        info = _plan_info(g)
+        if info is not None and info["chosen"] >= 0 and info["solution"] >= 0:
+            _lt_family_first[fam] = (info["chosen"], info["solution"])
     return out
 
 

@@ -67,6 +67,28 @@ def test_linear_lt_batched_gate_gemm_matches_torch(N):
     assert torch.equal(out2, gates)
 
 
+@pytest.mark.parametrize("N", [1024, 4096, 1536])
+def test_gate_gemm_kernel_does_not_depend_on_where_its_batches_land(N):
+    """The gate GEMM writes a [2, N, 512] scratch tensor or slot t of a [2, T, N, 512] rollout store — the same products. The
+    kernel is chosen per problem FAMILY (fused._lt_family: the key without the output's batch stride), recorded or not (1536
+    rows: no record, the first problem of the family is timed and its siblings follow), so the outputs are equal bit for bit:
+    otherwise two runs of one seed part ways at the first sampled action (store_preacts on / off, another rollout length)."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(5)
+    store = torch.randn(2, 3, N, 384, device=DEV)
+    w_cat = (torch.randn(2, 512, 384, device=DEV) * 0.05).contiguous()
+    x = store[:, 1]
+    outs, sols = [], []
+    for T in (None, 20, 8):
+        dst = torch.empty(2, N, 512, device=DEV) if T is None else torch.empty(2, T, N, 512, device=DEV)[:, T // 2]
+        fused.linear_lt(x, w_cat, dst)
+        info = fused.linear_lt_info(x, w_cat, dst)
+        outs.append(dst.clone())
+        sols.append(info["solution"])
+    assert sols[0] >= 0 and sols[0] == sols[1] == sols[2], sols
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_relu_backward_and_embed_add_on_strided_features():
     from active_tracking_rl_amd import fused
     torch.manual_seed(5)
