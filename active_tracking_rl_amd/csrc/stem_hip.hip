@@ -998,19 +998,31 @@ static StemProblem make_problem(const void *x, long long x_stride, const float *
     return p;
 }
 
-// From 16384 frames per launch up the forward runs 16 frames per workgroup pass (k_stem_fwd16: no MFMA on border zeros; 0.66 of the
-// f32 MFMA peak at 163840 frames against 0.54 of k_stem_fwd). In isolation it wins from 3072 frames up (tools/stem_bench.py,
-// tools/stem_rollout_bench.py: 13.9 against 17.2 us for the rollout step's 2 x 4096 frames), but inside the iteration a launch
-// of that size is bounded by what surrounds its 14 us of work (tools/stem_timeline_probe.py: dispatch, and the write-back of
-// 16.8 MB of outputs at the kernel boundary: 24.5 against 24.9 us in rocprofv3's kernel trace), and beside the learner's kernels
-// under the pipelined schedule its 62 KB of LDS and 236 VGPRs are the worse neighbour (16.58 against 16.97 M env steps/s at
-// 4096 envs): the rollout's launches stay with a wave per frame. Same results bit for bit either way.
+// From 16384 frames per launch up the forward runs 16 frames per workgroup pass (k_stem_fwd16: no MFMA on border zeros; 0.65 of the
+// f32 MFMA peak at 163840 frames against 0.54 of k_stem_fwd); below that by use_fwd16()'s rule. Same results bit for bit either way.
 constexpr int kFwd16BlocksPerCu = 2;
 static long long fwd16_min_frames()
 {
     static const long long v = getenv("ATR_STEM_FWD16_MIN") ? atoll(getenv("ATR_STEM_FWD16_MIN")) : 16384;   // (crossover experiments)
     return v;
 }
+// Which forward kernel a launch of `passes` 16-frame passes (over all its problems) and M frames gets. From fwd16_min_frames()
+// up always the 16-frame kernel; below it only where the passes fill the 2-per-CU slots evenly — at most one pass per slot, or
+// rounds that are >= 85 % full — and there are enough frames (3072) for a pass per CU: 768 passes on 512 slots (the headline's
+// tracker-aware pair at 4096 envs: 4096 + 8192 frames) are two rounds for 1.5 rounds of work and tie with the wave-per-frame
+// kernel (24.1 against 24.6 us), 512 passes (4096 + 4096) win (15.8 against 19.3 us), 256 passes win (9.6 against 12.1 us;
+// configs[4]: 17.31 -> 17.65 M env steps/s). A third workgroup per CU would make 768 passes one round: built (byte x tile, 52 KB of
+// LDS) and dropped — under the 168-VGPR cap of three waves per SIMD the kernel spills (241 us at 163840 frames against 182).
+// ATR_STEM_FWD16_MIN set by hand switches the rule off (the A/B tools).
+static bool use_fwd16(long long M, long long passes)
+{
+    if (M >= fwd16_min_frames()) return true;
+    if (getenv("ATR_STEM_FWD16_MIN") || M < 3072) return false;
+    const long long slots = (long long)stem_grid(1LL << 40, kFwd16BlocksPerCu);
+    const long long rounds = (passes + slots - 1) / slots;
+    return rounds == 1 || passes * 100 >= rounds * slots * 85;
+}
+
 static int stem_grid16(long long M)
 {
     static const int bpc = getenv("ATR_STEM_FWD16_BLOCKS") ? atoi(getenv("ATR_STEM_FWD16_BLOCKS")) : kFwd16BlocksPerCu;   // (co-run experiments)
@@ -1026,7 +1038,7 @@ static int stem_forward_impl(const XT *x, long long x_stride, const float *w1, c
     if (M == 0) return 0;
     StemPair pr;
     pr.p[0] = pr.p[1] = make_problem(x, x_stride, w1, b1, w2, b2, y, M);
-    if (M >= fwd16_min_frames()) {
+    if (use_fwd16(M, (M + kF - 1) / kF)) {
         pr.split = stem_grid16(M);
         hipLaunchKernelGGL((k_stem_fwd16<XT>), dim3((unsigned)pr.split), dim3(kThreads), 0, (hipStream_t)stream, pr);
     } else {
@@ -1049,7 +1061,7 @@ static int stem_forward2_impl(const XT *x0, long long x0_stride, const float *w1
     pr.p[0] = make_problem(x0, x0_stride, w1_0, b1_0, w2_0, b2_0, y0, M0);
     pr.p[1] = make_problem(x1, x1_stride, w1_1, b1_1, w2_1, b2_1, y1, M1);
     // split the resident workgroups in proportion to the frame counts (every wave gets the same number of frames)
-    const bool f16 = M0 + M1 >= fwd16_min_frames();
+    const bool f16 = use_fwd16(M0 + M1, (M0 + kF - 1) / kF + (M1 + kF - 1) / kF);
     const int per = f16 ? kF : kWaves;
     const int total = f16 ? stem_grid16(M0 + M1) : stem_grid(M0 + M1, kFwdBlocksPerCu);
     int g0 = (int)(((long long)total * M0 + (M0 + M1) / 2) / (M0 + M1));

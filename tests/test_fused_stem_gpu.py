@@ -388,10 +388,11 @@ def test_u8_frames_give_the_float_results_bit_for_bit(M):
     assert torch.equal(out_u, out_f)
 
 
-@pytest.mark.parametrize("M", [16384, 16387, 20301])
+@pytest.mark.parametrize("M", [4099, 16384, 16387, 20301])
 def test_sixteen_frame_forward_equals_the_wave_per_frame_forward_bit_for_bit(M):
-    """From 16384 frames up atr_stem_forward* runs 16 frames per workgroup pass (k_stem_fwd16: frames on the MFMA rows, border
-    taps not issued); below that one wave per frame (k_stem_fwd). A frame's output must not depend on the launch it was part
+    """From 16384 frames up — and below that wherever the 16-frame passes fill the chip's workgroup slots evenly (4099 frames: 257
+    passes on 512 slots) — atr_stem_forward* runs 16 frames per workgroup pass (k_stem_fwd16: frames on the MFMA rows, border
+    taps not issued); otherwise one wave per frame (k_stem_fwd). A frame's output must not depend on the launch it was part
     of (the rollout evaluates 2 N frames per step, the recompute learner 20 x 2 N at once): the same frames in chunks of 1000
     give the same bits — floats, bytes, a strided view, a ragged last pass, and the two-problem launch."""
     from active_tracking_rl_amd import fused
