@@ -178,8 +178,10 @@ def test_gae_kernel_matches_the_reference_recursion():
         torch.testing.assert_close(gae[i], g_run, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("M0,M1", [(4096, 8192), (5, 3), (1, 700)])
+@pytest.mark.parametrize("M0,M1", [(4096, 8192), (5, 3), (1, 700), (4096, 4096), (3100, 5), (9, 8183), (2048, 4096)])
 def test_paired_stem_launch_equals_two_launches(M0, M1):
+    """(the last four: launches that take the 16-frames-per-pass kernel — passes that fill the workgroup slots evenly —, with a
+    one-pass problem on either side and ragged last passes)"""
     from active_tracking_rl_amd import fused
     from active_tracking_rl_amd.model import CNN_maze
     torch.manual_seed(M0 + M1)
