@@ -420,7 +420,8 @@ __device__ __forceinline__ uint32_t ram_reset(S &ts)
     uint32_t n = 1u + ts.bounded(8u); // randint(1,10) is evaluated before choice(4, n)  (navigator.py:91)
     return plan_random(ts, n);
 }
-__device__ __forceinline__ uint32_t ram_step(uint32_t &plan, Stream &ts)
+template <class S>
+__device__ __forceinline__ uint32_t ram_step(uint32_t &plan, S &ts)
 {
     uint32_t cur = plan_cur(plan), len = plan_len(plan);
     uint32_t action = plan_act(plan, cur);

@@ -85,6 +85,10 @@ struct DevState {
 enum : int { OP_STEP = 0, OP_RESET = 1, OP_OBSERVE = 2 };
 constexpr uint32_t kPoolEmpty = 0xffffffffu;
 constexpr int kNpStateWords = 640;           // 624 words of MT19937 state, the read position at [624], padding
+// ... of which two words carry per-env facts of a numpy-stream handle: [625] the squared distance of the env's last TERMINAL
+// step (info['distance'] of a step whose in-launch auto-reset has already replaced d2), [626] != 0: the env's target is the
+// reference's RamAgent, stepped from this stream by k_ram_np (t2d_np_attach on a handle with T2D_TGT_RAM envs)
+constexpr int kNpTermD2 = 625, kNpRamFlag = 626;
 // The reward is a pure function of the integer squared distance (<= 2 * 81^2) and the mode's w_p in {0, 1, -0.5}
 // (track_1v1.py:96-104,147-152): the float64 formula is evaluated once per handle into a table by the same
 // reward_f64 device code the exhaustive parity test checks against the oracle; the step kernel then replaces a
@@ -591,6 +595,7 @@ struct NpStream {
         return v;
     }
     __device__ __forceinline__ int randint(int low, int high) { return low + (int)upto((uint32_t)(high - 1 - low)); }
+    __device__ __forceinline__ uint32_t bounded(uint32_t top) { return upto(top); }   // (the name ram_reset / ram_step draw by)
     // permutation(n): arange(n) shuffled from the top (i = n - 1 .. 1: swap with a uniform j in [0, i])
     __device__ __forceinline__ void permutation(int n, uint16_t *perm)
     {
@@ -705,7 +710,12 @@ __device__ __forceinline__ void generate_episode_np(NpStream &rs, uint16_t *perm
 // The generator pass of a numpy-stream handle: ONE wave per env, its consumed slots refilled in episode order (the stream is
 // sequential: episode k + 1's draws follow episode k's).
 constexpr int kNpWaves = 2;
-__global__ __launch_bounds__(64 * kNpWaves) void k_gen_np(DevState s, uint32_t lo, uint32_t hi, int force)
+// inter (handles whose Ram targets draw from the stream BETWEEN resets, RamAgent.step navigator.py:77-88): nothing may be
+// generated ahead of time — the pass runs inside t2d_reset, BEFORE the reset launch, for exactly the envs that launch restarts
+// (mask; null = all), makes the one episode they are about to start and ends it with RamAgent.reset's draws (navigator.py:90-93,
+// after init_maze: track_1v1.py:134-144).
+__global__ __launch_bounds__(64 * kNpWaves) void k_gen_np(DevState s, uint32_t lo, uint32_t hi, int force, const uint8_t *mask,
+                                                          int inter)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tiles[kNpWaves][kTileWords];
     __shared__ uint32_t mts[kNpWaves][624];
@@ -717,9 +727,14 @@ __global__ __launch_bounds__(64 * kNpWaves) void k_gen_np(DevState s, uint32_t l
     const uint32_t cfg = s.cfg[e];
     const uint32_t cur = s.episode[e];
     const uint32_t req0 = s.gen_req[e], req1 = s.gen_req[(size_t)s.n + e];
-    const bool need0 = force || (req0 >= lo && req0 <= hi && req0 != 0u), need1 = force || (req1 >= lo && req1 <= hi && req1 != 0u);
+    bool need0 = force || (req0 >= lo && req0 <= hi && req0 != 0u), need1 = force || (req1 >= lo && req1 <= hi && req1 != 0u);
+    if (inter) {
+        const bool mine = force && (mask == nullptr || mask[e] != 0);
+        need0 = mine && ((cur + 1u) & 1u) == 0u; need1 = mine && ((cur + 1u) & 1u) == 1u;
+    }
     if (!need0 && !need1) return;
     uint32_t *mt_g = s.np_mt + (size_t)e * kNpStateWords;
+    const bool ram = inter && uni(mt_g[kNpRamFlag]) != 0u;
     NpStream rs;
     rs.mt = mts[wave]; rs.lane = lane;
     for (int i = lane; i < 624; i += 64) rs.mt[i] = mt_g[i];
@@ -734,16 +749,62 @@ __global__ __launch_bounds__(64 * kNpWaves) void k_gen_np(DevState s, uint32_t l
         const size_t so = (size_t)slot * s.n + e;
         uint32_t pos, goals, d2;
         generate_episode_np(rs, perms[wave], tiles[wave], lane, cfg, pos, goals, d2);
+        const uint32_t plan0 = ram ? ram_reset(rs) : 0u;        // RamAgent.reset(): randint(1, 10), then choice(4, n)
         wave_lds_sync();
         store_slot_map(s, so, tiles[wave], lane, cfg, pos);
         if (lane == 0) {
-            s.n_pos[so] = pos; s.n_goals[so] = goals; s.n_plan[so] = 0u; s.n_tctr[so] = 0u;
+            s.n_pos[so] = pos; s.n_goals[so] = goals; s.n_plan[so] = plan0; s.n_tctr[so] = 0u;
             s.n_navgoal[so] = goals >> 16; s.n_d2[so] = d2; s.gen_req[so] = 0u; s.n_nav2[so] = 0u;
         }
         wave_lds_sync();
     }
     for (int i = lane; i < 624; i += 64) mt_g[i] = rs.mt[i];
     if (lane == 0) mt_g[624] = (uint32_t)rs.pos;
+}
+
+// RamAgent.step() (navigator.py:77-88) for the Ram-target envs of a numpy-stream handle, BEFORE the step launch: the action
+// the env step will take for the target (track_1v1.py:80-82 overrides action[1]) goes to out[e] in the caller's action dtype;
+// every other env's entry is the caller's own. One wave per env: almost all of them read the plan word, emit the next planned
+// action and leave; the env whose plan runs out on this step brings its MT19937 state into LDS and draws — the coin, on heads
+// the action that OVERRIDES the one being returned and the run length, on tails a fresh length and plan — exactly the words
+// the reference's global stream would have handed RamAgent at this point of the env's life.
+__global__ __launch_bounds__(64 * kNpWaves) void k_ram_np(DevState s, const void *act_in, void *act_out, int adt)
+{
+    __shared__ uint32_t mts[kNpWaves][624];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int e = (int)blockIdx.x * kNpWaves + wave;
+    if (e >= s.n) return;
+    uint32_t *mt_g = s.np_mt + (size_t)e * kNpStateWords;
+    long long a = 0;
+    if (uni(mt_g[kNpRamFlag]) == 0u) {
+        if (act_in) a = adt == T2D_ACT_U8 ? (long long)reinterpret_cast<const uint8_t *>(act_in)[e]
+                      : (adt == T2D_ACT_I32 ? (long long)reinterpret_cast<const int32_t *>(act_in)[e]
+                                            : reinterpret_cast<const long long *>(act_in)[e]);
+    } else {
+        uint32_t plan = uni(s.plan[e]);
+        if (plan_cur(plan) + 1u >= plan_len(plan)) {              // the plan ends with this action: RamAgent draws now
+            NpStream rs;
+            rs.mt = mts[wave]; rs.lane = lane;
+            for (int i = lane; i < 624; i += 64) rs.mt[i] = mt_g[i];
+            rs.pos = (int)mt_g[624];
+            wave_lds_sync();
+            a = (long long)ram_step(plan, rs);
+            wave_lds_sync();
+            for (int i = lane; i < 624; i += 64) mt_g[i] = rs.mt[i];
+            if (lane == 0) mt_g[624] = (uint32_t)rs.pos;
+        } else {                                                   // ram_step's other branch: the next planned action
+            const uint32_t cur = plan_cur(plan);
+            a = (long long)plan_act(plan, cur);
+            plan = (plan & 0xf0ffffffu) | ((cur + 1u) << 24);
+        }
+        if (lane == 0) s.plan[e] = plan;
+    }
+    if (lane == 0) {
+        if (adt == T2D_ACT_U8) reinterpret_cast<uint8_t *>(act_out)[e] = (uint8_t)a;
+        else if (adt == T2D_ACT_I32) reinterpret_cast<int32_t *>(act_out)[e] = (int32_t)a;
+        else reinterpret_cast<long long *>(act_out)[e] = a;
+    }
 }
 
 // Grow the mazes the coming generator passes will ask for: for every Maze env the episodes current + 3 and current + 4 (the two
@@ -1050,6 +1111,7 @@ __global__ __launch_bounds__(256) void k_env(DevState s, const void *act0, const
             uint4 *dst = reinterpret_cast<uint4 *>(s.dirf + (size_t)e * kDirWords);
             dst[lane] = src[lane]; dst[lane + 64] = src[lane + 64];
         }
+        if (OP == OP_STEP && s.np_mt && lane == 0) s.np_mt[(size_t)e * kNpStateWords + kNpTermD2] = d2;   // the finished step's distance
         pos = s.n_pos[so]; plan = s.n_plan[so]; tctr = s.n_tctr[so]; navgoal = s.n_navgoal[so]; d2 = s.n_d2[so];
         if (NAV && lane == 0) { s.nav2[e] = s.n_nav2[so]; s.p_state[pq_state_index(s, episode, e)] = 0u; }   // the finished episode's queue is void
         cnt = (uint32_t)side_of_cfg(cfg) << 24;
@@ -1414,6 +1476,7 @@ struct Step2 {
                 reinterpret_cast<uint4 *>(s.maps + (size_t)(e0 + 1) * kTileWords)[lane] = sp_tile1;
             if (consume) {
                 switched = true;
+                if (s.np_mt && leader) s.np_mt[(size_t)e * kNpStateWords + kNpTermD2] = d2;   // (numpy-stream handles: info['distance'])
                 pos = sp_pos; plan = sp_plan; tctr = sp_tctr; d2 = sp_d2;
                 cnt = (uint32_t)side_of_cfg(cfg) << 24;
                 episode = sp_episode + 1u;
@@ -1934,6 +1997,10 @@ struct t2d_handle {
     // k_pregrow (Maze handles): forked launches run on pg_stream between a fork event on the caller's stream and a join the
     // next generator pass (or t2d_generator_join / t2d_flush) waits for; pg_auto: every generator pass forks one behind itself
     bool has_maze = false, pg_auto = false, pg_pending = false;
+    // t2d_np_attach on a handle with Ram targets: their draws interleave with the resets (np_inter), so episodes are generated
+    // inside t2d_reset and RamAgent.step runs as k_ram_np before every step launch, its actions in np_act ([N] of 8 bytes)
+    bool np_inter = false;
+    void *np_act = nullptr;
     hipStream_t pg_stream = nullptr;
     hipEvent_t ev_pg_fork = nullptr, ev_pg_join = nullptr;
 };
@@ -2106,6 +2173,7 @@ extern "C" int t2d_destroy(t2d_handle *h)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->coop_ctl) (void)hipFree(h->coop_ctl);
+    if (h->np_act) (void)hipFree(h->np_act);
     for (void *p : {(void *)s.g_maps, (void *)s.g_ep, (void *)s.pg_stats, (void *)s.np_mt})
         if (p) (void)hipFree(p);
     if (h->pg_stream) {
@@ -2120,10 +2188,13 @@ extern "C" int t2d_destroy(t2d_handle *h)
 static inline dim3 env_grid(int n) { return dim3((unsigned)((n + kWavesPerBlock - 1) / kWavesPerBlock)); }
 constexpr int kGenNavMaxEnvs = 2048;
 
-static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t lo, uint32_t hi, int force, bool prefetch = false)
+static void launch_gen(t2d_handle *h, hipStream_t st, uint32_t lo, uint32_t hi, int force, bool prefetch = false,
+                       const uint8_t *mask = nullptr)
 {
     if (h->s.np_mt) {                               // numpy-stream handle (t2d_np_attach): one wave per env, slots in episode order
-        hipLaunchKernelGGL(k_gen_np, dim3((unsigned)((h->s.n + kNpWaves - 1) / kNpWaves)), dim3(64 * kNpWaves), 0, st, h->s, lo, hi, force);
+        if (h->np_inter && !force) return;          // (interleaved streams: nothing is generated ahead of a reset)
+        hipLaunchKernelGGL(k_gen_np, dim3((unsigned)((h->s.n + kNpWaves - 1) / kNpWaves)), dim3(64 * kNpWaves), 0, st, h->s, lo, hi,
+                           force, mask, h->np_inter ? 1 : 0);
         return;
     }
     const dim3 grid = env_grid(2 * h->s.n);        // one wave per (slot, env)
@@ -2354,9 +2425,13 @@ extern "C" int t2d_np_attach(t2d_handle *h, const uint32_t *states_host)
 {
     if (!h || !states_host) return fail(T2D_ERR_INVALID, "t2d_np_attach: null argument");
     if (h->primed || h->reset_done) return fail(T2D_ERR_STATE, "t2d_np_attach: attach the streams before the first t2d_reset");
-    if (h->has_ram || h->has_navmode || h->has_rpfmode)
-        return fail(T2D_ERR_INVALID, "t2d_np_attach: scripted Ram / Nav / RPF targets draw from the stream between resets: those "
-                                     "stay on the host streams (environment.NumpyVecEnv); Adv / PZR / Far / Ext only");
+    if (h->has_navmode || h->has_rpfmode)
+        return fail(T2D_ERR_INVALID, "t2d_np_attach: scripted Nav / RPF targets plan with the reference's heap A* between resets: "
+                                     "those stay on the host streams (environment.NumpyVecEnv); Adv / PZR / Far / Ext / Ram only");
+    if (h->has_ram && h->s.auto_reset)
+        return fail(T2D_ERR_INVALID, "t2d_np_attach: a Ram target draws from the stream between resets, so its next episode cannot "
+                                     "be generated ahead of the in-launch auto-reset: create the handle with auto_reset = 0 and "
+                                     "restart finished envs with t2d_reset(mask = done)");
     DeviceGuard guard(h->device);
     const int n = h->s.n;
     std::vector<uint32_t> padded((size_t)n * kNpStateWords, 0u);
@@ -2364,8 +2439,37 @@ extern "C" int t2d_np_attach(t2d_handle *h, const uint32_t *states_host)
         if (states_host[(size_t)i * 625 + 624] > 624u) return fail(T2D_ERR_INVALID, "t2d_np_attach: env %d: read position > 624", i);
         std::memcpy(&padded[(size_t)i * kNpStateWords], states_host + (size_t)i * 625, 625 * sizeof(uint32_t));
     }
+    if (h->has_ram) {
+        // The Ram envs' target is stepped by k_ram_np from the env's own stream; to the step kernels their mode becomes "the
+        // target's action comes from outside" (T2D_TGT_EXT: w_p = 0 either way, track_1v1.py:147-152) and the Philox Ram code
+        // is not selected (has_ram off)
+        std::vector<uint32_t> cfg((size_t)n);
+        HIP_TRY(hipMemcpy(cfg.data(), h->s.cfg, cfg.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++)
+            if (((cfg[(size_t)i] >> 2) & 7u) == (uint32_t)TGT_RAM) {
+                cfg[(size_t)i] = (cfg[(size_t)i] & ~(7u << 2)) | ((uint32_t)T2D_TGT_EXT << 2);
+                padded[(size_t)i * kNpStateWords + kNpRamFlag] = 1u;
+            }
+        HIP_TRY(hipMemcpy(h->s.cfg, cfg.data(), cfg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!h->np_act) HIP_TRY(hipMalloc(&h->np_act, (size_t)n * 8));
+        h->np_inter = true; h->has_ram = false;
+    }
     if (!h->s.np_mt) HIP_TRY(hipMalloc((void **)&h->s.np_mt, padded.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(h->s.np_mt, padded.data(), padded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return T2D_OK;
+}
+
+extern "C" int t2d_np_terminal_d2(t2d_handle *h, int first, int count, uint32_t *d2_host, void *stream)
+{
+    if (!h || !d2_host) return fail(T2D_ERR_INVALID, "t2d_np_terminal_d2: null argument");
+    if (!h->s.np_mt) return fail(T2D_ERR_STATE, "t2d_np_terminal_d2: no numpy streams attached (t2d_np_attach)");
+    if (first < 0 || count < 0 || first + count > h->s.n) return fail(T2D_ERR_INVALID, "t2d_np_terminal_d2: range [%d, %d)", first, first + count);
+    if (count == 0) return T2D_OK;
+    DeviceGuard guard(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpy2DAsync(d2_host, sizeof(uint32_t), h->s.np_mt + (size_t)first * kNpStateWords + kNpTermD2,
+                             kNpStateWords * sizeof(uint32_t), sizeof(uint32_t), (size_t)count, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return T2D_OK;
 }
 
@@ -2380,6 +2484,15 @@ extern "C" int t2d_pregrow_stats(t2d_handle *h, uint32_t stats_host[4], void *st
     return T2D_OK;
 }
 
+// RamAgent.step() of the numpy-stream Ram envs, ahead of the step launch: the target's action of this step (track_1v1.py:80-82)
+// for them, the caller's for everybody else, in the handle's own buffer (the caller's dtype).
+static const void *np_ram_actions(t2d_handle *h, hipStream_t st, const void *a1, int adt)
+{
+    hipLaunchKernelGGL(k_ram_np, dim3((unsigned)((h->s.n + kNpWaves - 1) / kNpWaves)), dim3(64 * kNpWaves), 0, st, h->s, a1,
+                       h->np_act, adt);
+    return h->np_act;
+}
+
 template <bool RANDOM>
 static int step_impl(t2d_handle *h, hipStream_t st, const void *a0, const void *a1, int adt, float *obs, float *rew,
                      uint8_t *done, uint32_t slo, uint32_t shi, uint32_t sidx)
@@ -2388,6 +2501,10 @@ static int step_impl(t2d_handle *h, hipStream_t st, const void *a0, const void *
         int rc = window_begin(h, st);
         if (rc) return rc;
         h->phase++;
+    }
+    if (h->np_inter) {
+        if (RANDOM) return fail(T2D_ERR_INVALID, "random-action rollouts are not defined for numpy-stream Ram handles");
+        a1 = np_ram_actions(h, st, a1, adt);
     }
     launch_env<OP_STEP, RANDOM>(h, st, a0, a1, adt, nullptr, obs, rew, done, slo, shi, sidx, h->phase);
     HIP_TRY(hipGetLastError());
@@ -2402,12 +2519,15 @@ extern "C" int t2d_reset(t2d_handle *h, const uint8_t *mask_dev, float *obs_dev,
     hipStream_t st = (hipStream_t)stream;
     int rc = flush_impl(h, st);
     if (rc) return rc;
-    if (!h->primed) { // first use: generate episode 1 into every next slot
+    if (mask_dev != nullptr && !h->reset_done)
+        return fail(T2D_ERR_STATE, "t2d_reset: the first reset must cover every env (mask == NULL)");
+    if (h->np_inter) {   // numpy streams with Ram targets: the episode each restarted env is about to start is drawn NOW, from where
+        launch_gen(h, st, 0u, 0u, 1, false, mask_dev);      // its stream stands after the finished episode's step-time draws
+        h->primed = true;
+    } else if (!h->primed) { // first use: generate episode 1 into every next slot
         launch_gen(h, st, 0u, 0u, 1);
         h->primed = true;
     }
-    if (mask_dev != nullptr && !h->reset_done)
-        return fail(T2D_ERR_STATE, "t2d_reset: the first reset must cover every env (mask == NULL)");
     launch_env<OP_RESET, false>(h, st, nullptr, nullptr, 0, mask_dev, obs_dev, nullptr, nullptr, 0u, 0u, 0u, 1u);
     launch_gen(h, st, 1u, 1u, 0); // refill the consumed next slots, in order on the caller's stream
     HIP_TRY(hipGetLastError());
@@ -2446,6 +2566,7 @@ extern "C" int t2d_step_u8(t2d_handle *h, const void *act_tracker_dev, const voi
         if (rc) return rc;
         h->phase++;
     }
+    if (h->np_inter) act_target_dev = np_ram_actions(h, st, act_target_dev, act_dtype);
     launch_step2<false, false>(h, st, act_tracker_dev, act_target_dev, act_dtype, obs_u8_dev, true, rew_dev, done_dev, 0u,
                                0u, 0u, h->phase, 1);
     HIP_TRY(hipGetLastError());
@@ -2485,6 +2606,9 @@ extern "C" int atr_act_env_step(t2d_handle *h, const atr_act_step *args, void *o
         return T2D_OK;
     }
     if (!rew_dev || !done_dev || !obs_dev) return fail(T2D_ERR_INVALID, "atr_act_env_step: null env buffer");
+    if (h->np_inter)
+        return fail(T2D_ERR_INVALID, "atr_act_env_step: numpy-stream Ram handles take the target's action from k_ram_np before the "
+                                     "step launch (t2d_step / t2d_step_u8), not from the policy's draw inside this kernel");
     if (!use_step2(h))
         return fail(T2D_ERR_INVALID, "atr_act_env_step: exists for 'Partial' ids without the RPF target (the k_step2 family)");
     if (a.N != h->s.n) return fail(T2D_ERR_INVALID, "atr_act_env_step: policy batch %d != %d envs", a.N, h->s.n);
@@ -2525,6 +2649,7 @@ extern "C" int atr_coop_env_step(t2d_handle *h, const atr_act_step *act, const a
                                  float *rew_dev, uint8_t *done_dev, void *stream)
 {
     if (!h || !act || !coop) return fail(T2D_ERR_INVALID, "atr_coop_env_step: null argument");
+    if (h->np_inter) return fail(T2D_ERR_INVALID, "atr_coop_env_step: not for numpy-stream Ram handles (see atr_act_env_step)");
     atr_act_step a = *act;
     const atr_coop_step &k = *coop;
     const int N = h->s.n, G = k.workgroups, F = k.F, R = 128;
@@ -2631,6 +2756,7 @@ extern "C" int t2d_rollout_random(t2d_handle *h, int steps, uint64_t action_seed
     if (!h) return fail(T2D_ERR_INVALID, "t2d_rollout_random: null handle");
     if (!rew_dev || !done_dev || steps < 0) return fail(T2D_ERR_INVALID, "t2d_rollout_random: bad argument");
     if (!h->reset_done || (h->s.auto_reset && !h->primed)) return fail(T2D_ERR_STATE, "t2d_rollout_random: reset first");
+    if (h->np_inter) return fail(T2D_ERR_INVALID, "t2d_rollout_random: random-action rollouts are not defined for numpy-stream Ram handles");
     DeviceGuard guard(h->device);
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)h->s.n, obs_elems = h->s.obs_full ? (size_t)2 * h->s.obs_side * h->s.obs_side : (size_t)kObsPerEnv;

@@ -196,8 +196,11 @@ class NumpyVecEnv(object):
         """device_generators: the numpy-legacy streams live ON THE DEVICE (np_mode.attach_device_streams -> csrc k_gen_np: MT19937,
         numpy's doubles / bounded integers / whole Fisher-Yates permutations, the reference's map generators and samplers, one
         wavefront per env) and finished envs restart inside the step launch from episodes pre-generated out of their own stream:
-        no host round trip, same episodes. For ids whose target draws nothing itself (Adv, PZR, Far); scripted Ram / Nav / RPF
-        targets interleave their draws with the resets and stay on the host streams (device_generators=False)."""
+        no host round trip, same episodes. For ids whose target draws nothing itself (Adv, PZR, Far) — and, since round 6, the
+        scripted Ram target, whose draws interleave with the resets: such a handle runs without the in-launch auto-reset, step()
+        restarts finished envs with a masked reset that draws their next episode at that moment, and RamAgent.step() itself runs
+        on the device from the env's stream ahead of every step (csrc k_ram_np). Nav / RPF targets (the reference's heap A*
+        between resets) stay on the host streams (device_generators=False)."""
         from .np_mode import NpBatchSource
         n = len(seeds)
         ids = [env_ids] * n if isinstance(env_ids, str) else list(env_ids)
@@ -206,14 +209,17 @@ class NumpyVecEnv(object):
         assert len(set(x["obs_type"] for x in sp)) == 1, "one observation type per handle"
         self.num_envs, self.env_ids = n, ids
         self.device_generators = bool(device_generators)
+        self._interleaved = False
         if self.device_generators:
             from .np_mode import attach_device_streams
-            bad = sorted(set(x["target_mode"] for x in sp) - {"Adv", "PZR", "Far"})
+            bad = sorted(set(x["target_mode"] for x in sp) - {"Adv", "PZR", "Far", "Ram"})
             if bad:
-                raise ValueError("NumpyVecEnv(device_generators=True): target mode(s) %s draw from the stream between resets; "
+                raise ValueError("NumpyVecEnv(device_generators=True): target mode(s) %s plan with heap A* between resets; "
                                  "use the host streams (device_generators=False)" % ", ".join(bad))
             self.src = None
-            self.core = VecTrack2D(ids[0], num_envs=n, device=device, seed=int(seeds[0]), auto_reset=True,
+            # a Ram target's draws interleave with the resets: no episode can be made ahead of time, so no in-launch auto-reset
+            self._interleaved = any(x["target_mode"] == "Ram" for x in sp)
+            self.core = VecTrack2D(ids[0], num_envs=n, device=device, seed=int(seeds[0]), auto_reset=not self._interleaved,
                                    map_type_per_env=np.array([registry.MAP_CODE[x["map_type"]] for x in sp], np.uint8),
                                    target_mode_per_env=np.array([registry.TARGET_CODE[x["target_mode"]] for x in sp], np.uint8),
                                    level_per_env=np.array([x["level"] for x in sp], np.uint8), obs_type=sp[0]["obs_type"])
@@ -258,9 +264,15 @@ class NumpyVecEnv(object):
             ta = self.src.target_actions(self._scripted_idx)
             a1[torch.as_tensor(self._scripted_idx, device=dev)] = torch.as_tensor(ta, dtype=torch.int64, device=dev)
         obs, rew, done = self.core.step(a0, a1.contiguous())
-        if self.device_generators:             # (finished envs restarted inside the launch; info['distance'] of the step itself)
-            # (for an env that finished, d2 already belongs to its next episode: info['distance'] is the step's only while running)
-            return obs, rew, done, {"distance": np.sqrt(self.core.get_state()["d2"].astype(np.float64))}
+        if self.device_generators:
+            d2 = self.core.get_state()["d2"].astype(np.float64)
+            if self._interleaved:              # Ram targets: finished envs restart NOW, from where their stream stands
+                obs = self.core.reset(done, out=obs)       # (fresh first observations for them, everybody else's as they were)
+            else:                              # restarted inside the launch: d2 is the new episode's, the step's own was parked
+                fin = done.cpu().numpy() != 0
+                if fin.any():
+                    d2[fin] = self.core.terminal_d2().astype(np.float64)[fin]
+            return obs, rew, done, {"distance": np.sqrt(d2)}
         d2 = self.core.get_state()["d2"].astype(np.float64)
         fin = np.nonzero(done.cpu().numpy())[0]
         if len(fin):
@@ -370,8 +382,12 @@ def create_env(env_id, args, num_envs=None, device=None, env_id_base=0, obs_u8=N
             raise NotImplementedError("rng='numpy' with num_envs > 1 returns raw float32 observations (no frame stack / rescale)")
         # rng="numpy-device" / args.np_device: the streams on the device (t2d_np_attach) where the target mode allows it
         on_dev = rng == "numpy-device" or bool(getattr(args, "np_device", False))
-        return NumpyVecEnv(env_id, [int(seed) + int(env_id_base) + i for i in range(n)], device=device,
-                           device_generators=on_dev and registry.spec(env_id)["target_mode"] in ("Adv", "PZR", "Far"))
+        if on_dev and registry.spec(env_id)["target_mode"] not in ("Adv", "PZR", "Far", "Ram"):
+            import warnings
+            warnings.warn("rng='numpy-device': %s has a Nav / RPF target, whose heap A* between resets is host code — the streams "
+                          "of this batch stay on the host (NumpyVecEnv(device_generators=False))" % env_id)
+            on_dev = False
+        return NumpyVecEnv(env_id, [int(seed) + int(env_id_base) + i for i in range(n)], device=device, device_generators=on_dev)
     if n > 1:
         return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base, rescale=rescale,
                       obs_u8=obs_u8, inv=inv)

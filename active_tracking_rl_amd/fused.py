@@ -536,7 +536,9 @@ def linear_lt(a, w, out, bias=None, relu=False, workspace=None):
         raise RuntimeError("atr_linear failed: %s" % L.atr_lt_last_error().decode())
     if fresh and rec is None:
         info = _plan_info(g)
-        if info is not None and info["chosen"] >= 0 and info["solution"] >= 0:
+        # (only a TIMED choice is handed to the family's other strides: a first-usable plan made inside a stream capture is
+        # re-timed later and may change — its siblings would keep the untimed kernel and the family would split again)
+        if info is not None and info["chosen"] >= 0 and info["solution"] >= 0 and info["tuned"]:
             _lt_family_first[fam] = (info["chosen"], info["solution"])
     return out
 

@@ -652,7 +652,9 @@ class A3C_Dueling(nn.Module):
             c.f = [torch.empty((T, N, p.encoder.outdim), device=dev) for p in (p0, p1)]
         c.feat1 = torch.empty((T, N, p1.encoder.outdim), device=dev) if self.tat else None
         c.pre_all = None
-        if c.fh_all is not None and self.store_preacts and fused_lstm and not coop:
+        # (the activated-gates store may only be dropped when EVERY step of this rollout is certain to take the one-GEMM branch of
+        # _act_step — the MFMA actor step and the per-player fallback launches write acts[i])
+        if c.fh_all is not None and self.store_preacts and fused_lstm and not coop and self._env_fused_static(N, R):
             c.pre_all = torch.empty((2, T, N, 4 * R), device=dev)     # slot t = the gate GEMM's output of step t
             c.acts = None
         else:
@@ -688,6 +690,21 @@ class A3C_Dueling(nn.Module):
                 c.emb = fa.weight.t() + fa.bias                    # row a = fc_action_tracker(one_hot(a))
                 c.emb_ih = c.emb @ p1.lstm.weight_ih.t()           # ... projected through W_ih: [n_act, 4R]
         return c
+
+    def _mfma_step_static(self, n, R):
+        """The batch-size / shape half of _act_step's choice of the per-player MFMA actor step (csrc/actor_step_hip.hip)."""
+        from . import fused
+        p0, p1 = self.player0, self.player1
+        return bool(self.fused_actor_step and n >= self.mfma_step_min_rows and fused.actor_step_supported(p0.encoder.outdim, R)
+                    and p1.encoder.outdim == p0.encoder.outdim)
+
+    def _env_fused_static(self, n, R):
+        """What new_cache can know about _act_step's `env_fused` branch before the first step (ONE predicate for both: a cache
+        laid out for the one-GEMM step must never meet a step that takes another branch)."""
+        p0, p1 = self.player0, self.player1
+        return bool(not self._mfma_step_static(n, R) and self.fused_env_step and self.fused_sampling and R == 128
+                    and p0.actor.actor_linear.weight.shape == p1.actor.actor_linear.weight.shape
+                    and p0.actor.actor_linear.weight.shape[0] <= 8)
 
     def _coop_ok(self, N, Fd, R, dev):
         """Whether a rollout step of N envs takes the one-launch cooperative form (shape limits of atr_coop_env_step for the
@@ -783,14 +800,14 @@ class A3C_Dueling(nn.Module):
         # (only from 3072 rows up: one wave tile per SIMD of the chip needs 4096 rows; at 1024 rows its 22 us per call lose to
         # the library GEMMs + cell kernel, measured with tools/config_sweep.py)
         self.env_stepped = False
-        mfma_step = (self.fused_actor_step and n >= self.mfma_step_min_rows and actions is not None and self._sampler._ordinal is not None
-                     and fused.actor_step_supported(p0.encoder.outdim, R) and p1.encoder.outdim == p0.encoder.outdim)
-        env_fused = (not mfma_step and self.fused_env_step and R == 128 and f_pair is not None and actions is not None
+        mfma_step = (self._mfma_step_static(n, R) and actions is not None and self._sampler._ordinal is not None)
+        env_fused = (not mfma_step and self._env_fused_static(n, R) and f_pair is not None and actions is not None
                      and self._sampler._ordinal is not None and getattr(cache, "has_wih_t", False)
-                     and p0.actor.actor_linear.weight.shape == p1.actor.actor_linear.weight.shape
-                     and p0.actor.actor_linear.weight.shape[0] <= 8
                      and all(t.is_contiguous() for t in (c_prev[0], c_prev[1], h_out[0], h_out[1], c_out[0], c_out[1],
                                                          h_prev[0], h_prev[1]) + ((acts[0], acts[1]) if acts is not None else ())))
+        if not env_fused and acts is None:
+            raise RuntimeError("this rollout cache keeps the gate GEMM's output instead of the activated gates (store_preacts), "
+                               "which only the one-GEMM step fills; the step at hand takes another branch")
         # fh = (this step's [2, N, F + R] rows of the [features | k h_prev] store, the next step's): one gate GEMM, K = F + R
         cat_gemm = env_fused and fh is not None and getattr(cache, "gates", None) is not None
         pair_gemm = env_fused and not cat_gemm and n <= self.pair_gemm_max_rows and getattr(cache, "gates", None) is not None

@@ -9,7 +9,7 @@ from . import registry, vec_env
 
 NP_SYMBOLS = ("t2d_np_create", "t2d_np_destroy", "t2d_np_last_error", "t2d_np_seed", "t2d_np_reset",
               "t2d_np_target_action", "t2d_np_get_plan", "t2d_np_astar", "t2d_np_draw", "t2d_np_reset_many",
-              "t2d_np_target_actions", "t2d_np_mt_state", "t2d_np_attach")
+              "t2d_np_target_actions", "t2d_np_mt_state", "t2d_np_attach", "t2d_np_terminal_d2")
 _ready = False
 
 
@@ -163,7 +163,10 @@ def mt_states(seeds):
 def attach_device_streams(core, seeds):
     """Hand a vec_env.VecTrack2D one numpy-legacy stream per env (np.random.seed(seeds[i])): from now on its generator — reset()
     and the pre-generated episodes of the in-launch auto-reset — restates the reference's draws on the device (t2d_np_attach,
-    csrc/track2d_hip.hip k_gen_np). Before the first reset; Adv / PZR / Far (and host-driven Ext) targets only."""
+    csrc/track2d_hip.hip k_gen_np). Before the first reset. Adv / PZR / Far (and host-driven Ext) targets on any handle; Ram
+    targets (whose draws interleave with the resets: RamAgent, navigator.py:73-93) on handles created with auto_reset=False — the
+    episode of a restarted env is then drawn inside reset(mask) and RamAgent.step() runs on the device ahead of every step
+    (k_ram_np). Nav / RPF targets are refused (heap A* between resets: host streams)."""
     assert len(seeds) == core.num_envs
     st = np.ascontiguousarray(mt_states(seeds))
     rc = _lib().t2d_np_attach(core.h, _ptr(st))

@@ -230,7 +230,10 @@ class GraphedIteration(object):
         if iters <= 0:
             return
         tensors = self._optimizer_tensors()
-        saved = [t.clone() for t in tensors] if tensors is not None else None
+        if tensors is None:
+            raise RuntimeError("burn_in needs the flat-bucket optimizer (weights and optimizer state as a few tensors to restore); "
+                               "this optimizer has none: its updates would be KEPT")
+        saved = [t.clone() for t in tensors]
         n0 = self.player.n_steps
         for _ in range(int(iters)):
             self.run(mode)

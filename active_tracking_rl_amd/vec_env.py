@@ -102,6 +102,8 @@ def load_library():
     L.t2d_pregrow.argtypes = [vp, i32, vp]
     L.t2d_pregrow_stats.restype = i32
     L.t2d_pregrow_stats.argtypes = [vp, vp, vp]
+    L.t2d_np_terminal_d2.restype = i32
+    L.t2d_np_terminal_d2.argtypes = [vp, i32, i32, vp, vp]
     L.t2d_step_random.restype = i32
     L.t2d_step_random.argtypes = [vp, i32, u64, vp, vp, vp, vp]
     L.t2d_rollout_random.restype = i32
@@ -345,6 +347,14 @@ class VecTrack2D(object):
         _check(self.L.t2d_get_state(self.h, first, count, _np_ptr(pos), _np_ptr(goals), _np_ptr(c_far), _np_ptr(t),
                                     _np_ptr(ep), _np_ptr(side), _np_ptr(d2), self._stream()))
         return dict(pos=pos, goals=goals, c_far=c_far, t=t, episode=ep, side=side, d2=d2)
+
+    def terminal_d2(self, first=0, count=None):
+        """uint32 [count]: squared distance of each env's last TERMINAL step on a handle with numpy streams attached
+        (t2d_np_terminal_d2: after an in-launch auto-reset get_state()['d2'] is already the next episode's)."""
+        count = self.num_envs - first if count is None else count
+        d2 = np.zeros(count, np.uint32)
+        _check(self.L.t2d_np_terminal_d2(self.h, first, count, _np_ptr(d2), self._stream()))
+        return d2
 
     def get_maps(self, first=0, count=None):
         """u8 [count, 82, 82]; cells outside an env's side x side square are 0."""

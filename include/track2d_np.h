@@ -56,10 +56,25 @@ int t2d_np_mt_state(uint32_t seed, uint32_t out[625]);
  * Fisher-Yates permutations included — on one wavefront per env: episode k of env i is the k-th reset() of the reference
  * env after np.random.seed(seed_i), at batch scale, with no host in the loop. For target modes that draw nothing themselves
  * (Adv, PZR, Far; Ext = host-driven), any map type, 'Partial' or 'Full' observations; call it before the first t2d_reset.
- * Returns 0 or a T2D_ERR_* code (t2d_last_error). (Scripted Ram / Nav targets interleave their own draws with the resets:
- * they stay on the host streams, environment.NumpyVecEnv.) */
+ * Returns 0 or a T2D_ERR_* code (t2d_last_error).
+ *
+ * T2D_TGT_RAM envs (round 6; RamAgent, G/envs/navigator.py:73-93) are accepted on handles created with auto_reset = 0. A Ram
+ * target draws from the stream BETWEEN resets (the coin, the overriding action and the run length / the fresh plan, whenever
+ * its plan runs out: navigator.py:80-86), so its next episode cannot be generated ahead of time. For such a handle
+ *   - t2d_reset(mask) draws the episode of every env it restarts AT THAT MOMENT (init_maze, then RamAgent.reset's
+ *     randint(1, 10) + choice(4, n): track_1v1.py:134-144, navigator.py:90-93) — restart finished envs with mask = the step's
+ *     done flags, as the reference's worker loop does (train.py:73-74);
+ *   - t2d_step / t2d_step_u8 first run RamAgent.step() for every Ram env from its stream (csrc k_ram_np) and hand the env
+ *     step that action as the target's (track_1v1.py:80-82); the caller's target action is used for the other envs only;
+ *   - the policy-fused step (atr_act_env_step, atr_coop_env_step) and t2d_rollout_random refuse the handle.
+ * t2d_get_target reports the Ram plan as for the Philox generators. Nav / RPF targets (heap A* between resets) stay on the
+ * host streams, environment.NumpyVecEnv. */
 struct t2d_handle;
 int t2d_np_attach(struct t2d_handle *h, const uint32_t *states_host);
+/* info['distance']^2 of each env's last TERMINAL step (track_1v1.py:118) on a handle with attached streams: with the in-launch
+ * auto-reset the handle's d2 already belongs to the next episode when the caller sees done = 1. Entry i = env first + i; only
+ * meaningful for envs that have finished an episode. */
+int t2d_np_terminal_d2(struct t2d_handle *h, int first, int count, uint32_t *d2_host, void *stream);
 
 /* The two per-step / per-episode calls for MANY envs (a batch replayed against the reference: each env keeps its own stream,
  * so the calls are independent and are spread over `threads` host threads; 0 = one per hardware thread). envs[i] -> entry i of

@@ -140,7 +140,17 @@ if __name__ == '__main__':
             sched.tune_streams()
         else:
             sched = GraphedIteration(player, optimizer, args, mode=first_mode)
-        sched.burn_in(args.burn_in, first_mode)
+        if args.burn_in > 0 and args.load_model_dir is None:
+            # (not counted in n_steps or the logs: the updates are discarded, only the episode clocks of the shard move on)
+            sched.burn_in(args.burn_in, first_mode)
+            if rank == 0:
+                print("burn-in: %d iterations (%d env steps per rank) with their updates discarded"
+                      % (args.burn_in, args.burn_in * args.num_steps * player.num_envs), file=sys.stderr, flush=True)
+        elif args.burn_in > 0 and rank == 0:
+            print("burn-in skipped: resuming from --load-model-dir", file=sys.stderr, flush=True)
+    elif args.burn_in > 0 and rank == 0:
+        print("warning: --burn-in %d ignored with --no-graph (the eager loop has no rollback of its updates)" % args.burn_in,
+              file=sys.stderr, flush=True)
     step = sched.run if sched is not None else None
     drain = getattr(sched, "finish", lambda: None)          # pipelined: both streams joined before the host reads anything
     it = 0
@@ -164,6 +174,10 @@ if __name__ == '__main__':
         if args.log_every > 0 and it % args.log_every == 0:
             drain()
             torch.cuda.synchronize(device)
+            faults = player.env.core.faults() if hasattr(getattr(player.env, "core", None), "faults") else 0
+            if faults:        # sticky device fault word (include/track2d.h t2d_get_faults): bits 1-3 = the cooperative step's barriers
+                raise RuntimeError("env handle reports device faults 0x%x at iteration %d: the rollout state is not trustworthy "
+                                   "(ATR_COOP_STEP=0 selects the four-launch step)" % (faults, it))
             now = time.time()
             fps = (it - it_log) * args.num_steps * player.num_envs / max(now - t_log, 1e-9)
             log_train_scalars(writer, stats, train_modes[rank], fps, it * args.num_steps * player.num_envs, player.num_agents)

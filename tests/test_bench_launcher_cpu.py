@@ -24,6 +24,16 @@ def test_plain_command_self_launches_n_ranks():
     assert lines[0]["n_gpus"] == 2 and lines[0]["ranks"] == 2 and len(lines[0]["devices"]) == 2
 
 
+def test_plain_command_self_launches_eight_ranks():
+    """The driver's 8-GPU line in miniature: eight ranks over gloo, the communicator proven to have eight, devices gathered."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-check"],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["n_gpus"] == 8 and lines[0]["ranks"] == 8 and len(lines[0]["devices"]) == 8
+
+
 def test_refuses_a_rank_count_that_differs_from_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"],
                        env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)

@@ -80,11 +80,13 @@ def _worker(rank, world, port, out_dir):
         dist.all_gather(gathered, local)
         player.allreduce_grads(opt)
         assert torch.allclose(opt.bucket.grad, sum(gathered) / world, rtol=1e-6, atol=1e-8)
-        assert not torch.equal(gathered[0], gathered[1])           # ranks really saw different envs
+        for r in range(1, world):
+            assert not torch.equal(gathered[0], gathered[r])       # ranks really saw different envs
         opt.step()
         flats = [torch.zeros_like(opt.bucket.flat) for _ in range(world)]
         dist.all_gather(flats, opt.bucket.flat)
-        assert torch.equal(flats[0], flats[1]), "replicas diverged"
+        for r in range(1, world):
+            assert torch.equal(flats[0], flats[r]), "replicas diverged (rank %d)" % r
     if rank == 0:
         torch.save(opt.bucket.flat, os.path.join(out_dir, "flat.pt"))
     dist.barrier()
@@ -99,15 +101,17 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_gloo_update_matches_single_process():
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_rank_gloo_update_matches_single_process(world):
+    """world = 4 (round 6): env_id_base for ranks 2 and 3, a four-way mean, four replicas bit-identical after every update."""
     out_dir = tempfile.mkdtemp()
-    mp.spawn(_worker, args=(2, _free_port(), out_dir), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out_dir), nprocs=world, join=True)
     sharded = torch.load(os.path.join(out_dir, "flat.pt"))
     saved = torch.Tensor.multinomial
     try:
         _deterministic_sampling()
-        player, opt, args = _player(list(range(6)))
+        player, opt, args = _player(list(range(3 * world)))
         for it in range(2):
             rollout(player, args.num_steps)
             player.optimize(None, opt, player.model, args.train_mode, torch.device("cpu"))

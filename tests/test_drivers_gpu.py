@@ -302,6 +302,92 @@ def test_burn_in_moves_the_envs_and_nothing_else(schedule):
     player.env.close()
 
 
+def _transplant_rollout(src, dst, path="player", seen=None):
+    """Copy every tensor reachable from agent `src`'s rollout state (attributes, lists / tuples / dicts of tensors, the
+    RolloutCache) into the tensor at the same attribute path of agent `dst` — the static buffers its captured learner reads."""
+    from active_tracking_rl_amd.model import RolloutCache
+    seen = set() if seen is None else seen
+    n = 0
+    if torch.is_tensor(src):
+        assert torch.is_tensor(dst) and dst.shape == src.shape and dst.dtype == src.dtype, path
+        if dst.data_ptr() != src.data_ptr() and (dst.data_ptr(), dst.shape) not in seen:
+            seen.add((dst.data_ptr(), tuple(dst.shape)))
+            with torch.no_grad():
+                dst.copy_(src.detach())
+            n = 1
+        return n
+    if isinstance(src, (list, tuple)):
+        assert isinstance(dst, (list, tuple)) and len(dst) == len(src), path
+        return sum(_transplant_rollout(a, b, "%s[%d]" % (path, i), seen) for i, (a, b) in enumerate(zip(src, dst)))
+    if isinstance(src, dict):
+        return sum(_transplant_rollout(v, dst[k], "%s[%r]" % (path, k), seen) for k, v in src.items()
+                   if (torch.is_tensor(v) or isinstance(v, (list, tuple, dict, RolloutCache))) and k in dst)
+    if isinstance(src, RolloutCache):
+        assert isinstance(dst, RolloutCache), path
+        for k in list(src.__dict__):
+            if k in ("lazy", "consts", "boot"):       # (weight-derived constants; the bootstrap scratch is written before it is read)
+                continue
+            if k in dst.__dict__:
+                n += _transplant_rollout(src.__dict__[k], dst.__dict__[k], path + "." + k, seen)
+        return n
+    return 0
+
+
+@pytest.mark.parametrize("env_id,network,aux,n_envs,train_mode", [
+    ("Track2D-BlockPartialPZR-v0", "tat-maze-lstm", "reward", 512, -1),
+    ("Track2D-BlockPartialPZR-v0", "tat-maze-lstm", "reward", 512, 0),
+    ("Track2D-BlockPartialPZR-v0", "tat-maze-lstm", "reward", 512, 1),
+    ("Track2D-MazePartialNav-v0", "maze-lstm", "none", 1024, 0),
+    ("Track2D-BlockPartialAdv-v0", "maze-lstm", "none", 1024, -1),
+    ("Track2D-BlockPartialPZR-v0", "tat-maze-lstm", "reward", 1024, -1)])
+def test_the_two_schedules_learners_give_the_same_gradient_from_the_same_rollout(monkeypatch, env_id, network, aux, n_envs,
+                                                                                train_mode):
+    """GraphedIteration (synchronous) and PipelinedIteration differ in WHEN a gradient is applied, and must differ in nothing
+    else: their captured learners — the master agent's loss + backward inside the synchronous rollout graph, a replica agent's
+    learner graph on its own stores and flat weight buffer — are handed the SAME rollout (every store of the master's rollout
+    copied into the replica's static buffers, same weights, same draw-stream position for the bootstrap step) and must produce
+    the SAME gradient bucket bit for bit. (What round 5's learning tables could not say: whether the no-delay schedule's
+    weaker runs on configs[3] come from a defect in its learner — carry, bootstrap, select_params — or from the schedule.)
+    Both tat (the bootstrap draws a tracker action) and maze-lstm networks, every training mode, the pair-kernel (512 envs) and
+    one-GEMM (1024 envs) rollout stores. The pipelined learner's co-run dW form (another split-K plan) is switched off: it
+    changes the summation order by design."""
+    from active_tracking_rl_amd.train import GraphedIteration, PipelinedIteration, default_args, make_player
+    monkeypatch.setenv("ATR_PIPE_CORUN", "0")
+    dev = torch.device("cuda:0")
+    args = default_args(env=env_id, network=network, aux=aux, train_mode=train_mode, num_envs=n_envs, seed=19)
+    args.gpu_ids = [0]
+    player, opt = make_player(args, dev)
+    # the pipelined schedule first: its constructor warms up eagerly on the master (whose attributes would otherwise stop
+    # naming the synchronous graph's static buffers)
+    it_p = PipelinedIteration(player, opt, args, mode=train_mode, serial=True)
+    assert not it_p.corun
+    it_g = GraphedIteration(player, opt, args, mode=train_mode)
+    w0 = opt.bucket.flat.clone()
+    for b in it_p.buckets:
+        assert torch.equal(b.flat, w0)
+    rep = it_p.players[0]
+    rep.model._sampler.seed = player.model._sampler.seed           # the bootstrap step's draw: same Philox key ...
+    it_p._capture(train_mode, 0)                                    # (the seed is a kernel argument of the captured launches)
+    torch.cuda.synchronize()
+    opt.bucket.grad.zero_()
+    it_g.g_rolls[train_mode].replay()                               # rollout X + the synchronous learner -> opt.bucket.grad
+    torch.cuda.synchronize()
+    g_sync = opt.bucket.grad.clone()
+    assert torch.equal(opt.bucket.flat, w0) and torch.isfinite(g_sync).all() and float(g_sync.abs().sum()) > 0
+    moved = _transplant_rollout({k: v for k, v in vars(player).items() if k not in ("model", "env", "args")},
+                                {k: v for k, v in vars(rep).items() if k not in ("model", "env", "args")})
+    assert moved >= 8, moved
+    rep.model._sampler.counter.copy_(player.model._sampler.counter)   # ... and the same counter value
+    opt.bucket.grad.zero_()
+    it_p.buckets[0].grad.zero_()
+    it_p.graphs[(train_mode, 0)][1].replay()                        # the pipelined learner of replica 0 on the transplanted rollout
+    torch.cuda.synchronize()
+    assert torch.equal(it_p.buckets[0].grad, opt.bucket.grad)       # (the learner graph ends by handing its bucket to the optimizer's)
+    diff = (it_p.buckets[0].grad - g_sync).abs().max().item()
+    assert torch.equal(it_p.buckets[0].grad, g_sync), "gradient buckets differ: max |diff| %.3e" % diff
+    player.env.close()
+
+
 @pytest.mark.parametrize("train_mode", [-1, 0, 1])
 def test_keeping_the_gate_gemm_output_instead_of_the_activated_gates_changes_no_bit(train_mode):
     """One-GEMM rollout path, round 5: the rollout keeps the gate GEMM's OUTPUT per step (pre-activations without bias) and the
@@ -331,6 +417,36 @@ def test_keeping_the_gate_gemm_output_instead_of_the_activated_gates_changes_no_
         assert torch.equal(a, b)
     assert torch.isfinite(res[0][4]).all() and float(res[0][4].abs().sum()) > 0
     assert torch.equal(res[0][4], res[1][4])
+
+
+def test_mfma_actor_step_keeps_its_activated_gates_store_when_preacts_are_on():
+    """ATR_MFMA_MIN_ROWS <= N (bench.py --actor-step mfma) with the default store_preacts: _act_step takes the per-player MFMA
+    actor step, which writes acts[i] — new_cache must not have dropped that store for the one-GEMM step's pre-activation store
+    (one predicate, model._env_fused_static, decides both). The rollout and the cached learner run and agree with the
+    recompute learner."""
+    from active_tracking_rl_amd.train import default_args, make_player, rollout
+    args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=1024, num_steps=5, network="tat-maze-lstm", seed=13, train_mode=-1)
+    args.gpu_ids = [0]
+    player, opt = make_player(args, torch.device("cuda:0"), 0, 1)
+    m = player.model
+    m.fused_actor_step, m.mfma_step_min_rows = True, 768
+    assert m.store_preacts and not m._env_fused_static(1024, 128)
+    rollout(player, args.num_steps, fast=True)
+    c = player._cache
+    assert c is not None and c.acts is not None and c.pre_all is None
+    outs = []
+    for cached in (True, False):
+        player._cache = c if cached else None
+        torch.manual_seed(5)
+        m._sampler.counter.zero_()
+        m._sampler._last = None
+        loss, pl, vl, ent, pred = player.loss_recompute(args.train_mode)
+        player._cache = c
+        grads = torch.autograd.grad(loss, list(m.parameters()), allow_unused=True)
+        outs.append((loss.detach(), grads))
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-4, atol=1e-5)
+    _check_grads(outs[0][1], outs[1][1])
+    player.env.close()
 
 
 def test_bootstrap_values_and_rollout_bookkeeping_kernels():
@@ -806,6 +922,7 @@ def test_numpy_rng_batch_replays_all_reference_episodes_concurrently_in_one_hand
         for i, (e, t) in enumerate(cur):
             if e < len(eps[i]):
                 act[:, i] = eps[i][e]["act_in"][t]
+        act[1, is_ram] = 3 - act[1, is_ram]          # (a Ram env's recorded target action must NOT be what moves its target)
         obs, rew, done, info = env.step([act[0], act[1]])
         obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
         cut = np.zeros(n, bool)
@@ -840,18 +957,30 @@ def test_numpy_rng_batch_replays_all_reference_episodes_concurrently_in_one_hand
           % (steps, dt, steps / dt))
 
 
-def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_alone():
+@pytest.mark.parametrize("targets", ["unscripted", "ram"])
+def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_alone(targets):
     """NumpyVecEnv(device_generators=True): the numpy-legacy streams live on the DEVICE (t2d_np_attach -> k_gen_np: MT19937, numpy's
     doubles / bounded integers / whole Fisher-Yates permutations, init_maze, both map generators, sample_goal,
     sample_close_states, get_around restated draw for draw, one wavefront per env) and a finished env restarts inside the step
     launch from an episode pre-generated out of its own stream. Every multi-episode capture of episodes.npz whose target draws
     nothing itself (PZR / Adv / Far on Block / Maze / Empty maps, levels 0 / 1), four copies each, advanced in lock step from
     (env id, seed, recorded policy actions) ALONE — no host stream, no injection: every observation, reward and done flag of
-    every episode equals the reference's, the first observation of every following episode included."""
+    every episode equals the reference's, the first observation of every following episode included.
+    targets="ram" (round 6): the captures with the scripted Ram target (RamAgent, navigator.py:73-93: its coin / action / run
+    length draws come from the same stream BETWEEN the resets) next to two unscripted ones in ONE handle. Nothing can be
+    generated ahead of time there: the handle runs without the in-launch auto-reset, a finished env's next episode is drawn
+    inside the masked reset that follows its terminal step (init_maze, then RamAgent.reset), and RamAgent.step runs on the
+    device ahead of every step launch (k_ram_np) — the recorded TARGET actions are never fed in, the device's Ram target must
+    reproduce them from the seed for the observations to match."""
     from conftest import GOLDEN
     from active_tracking_rl_amd.environment import NumpyVecEnv
     g = np.load(os.path.join(GOLDEN, "episodes.npz"))
-    names = [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) in ("PZR", "Adv", "Far")] * 4
+    if targets == "ram":
+        names = [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) == "Ram"] * 4
+        names += [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) in ("PZR", "Adv")][:2]
+        assert sum(str(g[n + "/meta"][1]) == "Ram" for n in names) >= 8
+    else:
+        names = [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) in ("PZR", "Adv", "Far")] * 4
     ids, seeds, eps = [], [], []
     for name in names:
         mp, mode, lvl, seed, _ = [str(x) for x in g[name + "/meta"]]
@@ -860,10 +989,13 @@ def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_a
         eps.append([{k: g["%s/ep%d_%s" % (name, e, k)] for k in ("obs0", "act_in", "obs", "rew", "done", "pos")}
                     for e in range(int(g[name + "/n_eps"]))])
     n = len(names)
-    assert n >= 24 and len(set(i.split("Partial")[0] for i in ids)) == 3          # Block, Maze and Empty maps among them
-    with pytest.raises(ValueError, match="draw from the stream between resets"):
-        NumpyVecEnv(["Track2D-BlockPartialRam-v0"], [1], device_generators=True)
+    if targets == "unscripted":
+        assert n >= 24 and len(set(i.split("Partial")[0] for i in ids)) == 3          # Block, Maze and Empty maps among them
+    with pytest.raises(ValueError, match="heap A\\* between resets"):
+        NumpyVecEnv(["Track2D-BlockPartialNav-v0"], [1], device_generators=True)
     env = NumpyVecEnv(ids, seeds, device_generators=True)
+    assert env._interleaved == (targets == "ram") and bool(env.core.auto_reset) == (targets != "ram")
+    is_ram = np.array(["Ram" in i for i in ids])
     obs = env.reset().cpu().numpy()
     for i in range(n):
         assert np.array_equal(obs[i], eps[i][0]["obs0"].astype(np.float32)), (names[i], "first reset")
@@ -874,6 +1006,7 @@ def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_a
         for i, (e, t) in enumerate(cur):
             if e < len(eps[i]):
                 act[:, i] = eps[i][e]["act_in"][t]
+        act[1, is_ram] = 3 - act[1, is_ram]          # (a Ram env's recorded target action must NOT be what moves its target)
         obs, rew, done, info = env.step([act[0], act[1]])
         obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
         cut = np.zeros(n, bool)
@@ -884,9 +1017,9 @@ def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_a
             last = t == len(E["act_in"]) - 1
             assert bool(done[i]) == bool(E["done"][t]), (names[i], e, t, "done")
             assert np.array_equal(rew[i].astype(np.float64), E["rew"][t].astype(np.float32).astype(np.float64)), (names[i], e, t)
+            dr = E["pos"][t, 1] - E["pos"][t, 0]          # info['distance'] is the STEP's, also when the env restarted in the launch
+            assert abs(info["distance"][i] - float(np.sqrt(float((dr * dr).sum())))) < 1e-12, (names[i], e, t, "distance")
             if not done[i]:
-                dr = E["pos"][t, 1] - E["pos"][t, 0]
-                assert abs(info["distance"][i] - float(np.sqrt(float((dr * dr).sum())))) < 1e-12
                 assert np.array_equal(obs[i], E["obs"][t].astype(np.float32)), (names[i], e, t, "obs")
             elif e + 1 < len(eps[i]):             # finished: restarted inside the launch, from the env's own stream
                 assert last
@@ -903,7 +1036,7 @@ def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_a
                 assert np.array_equal(fresh[i], eps[i][cur[i][0]]["obs0"].astype(np.float32)), (names[i], cur[i][0], "obs0")
     assert env.core.faults() == 0
     env.close()
-    assert steps > 2000
+    assert steps > (2000 if targets == "unscripted" else 1000)
 
 
 def test_create_env_numpy_rng_batch_equals_single_numpy_envs():
