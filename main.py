@@ -112,11 +112,18 @@ if __name__ == '__main__':
     # (GPU_MAX_HW_QUEUES for the single-GPU pipelined schedule was decided before torch was imported: _wants_two_hw_queues)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(args.gpu_ids[0])))
+    # test hooks (as bench.py's BENCH_*): N ranks sharing ONE device over gloo exercise the multi-rank code path on a 1-GPU box
+    backend = os.environ.get("ATR_DIST_BACKEND", "nccl")
+    if os.environ.get("ATR_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     args.gpu_ids = [local_rank]
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
@@ -194,6 +201,18 @@ if __name__ == '__main__':
             break
     drain()
     torch.cuda.synchronize(device)
+    if world > 1:       # synchronous data parallel: every rank applied the same all-reduced gradients to the same start
+        flat = getattr(optimizer, "bucket", None)
+        if flat is not None:
+            ref = flat.flat.detach().clone()
+            dist.broadcast(ref, src=0)
+            same = torch.tensor([1 if torch.equal(ref, flat.flat) else 0], dtype=torch.int64, device=device)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            if rank == 0:
+                print("replicas bit-identical across %d ranks after %d iterations: %s" % (world, it, bool(same.item())),
+                      file=sys.stderr, flush=True)
+            if not bool(same.item()):
+                raise RuntimeError("rank %d: master weights differ from rank 0's after %d iterations" % (rank, it))
     writer.close()
     player.env.close()
     if world > 1:
