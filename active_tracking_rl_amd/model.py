@@ -629,8 +629,8 @@ class A3C_Dueling(nn.Module):
         same_f = p0.encoder.outdim == p1.encoder.outdim
         from . import fused as _fz
         coop = self._coop_ok(N, p0.encoder.outdim, R, dev) if (same_f and env_fused) else False
-        if (same_f and env_fused and self.cat_gate_gemm and (N >= self.cat_gemm_min_rows or coop) and self.fused_env_step
-                and self.fused_sampling and _fz.lt_available()
+        if (same_f and env_fused and self.cat_gate_gemm and (N >= self.cat_gemm_min_rows or coop) and self._env_fused_static(N, R)
+                and _fz.lt_available()
                 and R == 128 and p0.lstm.weight_ih.shape == p1.lstm.weight_ih.shape and p0.encoder.outdim % 4 == 0):
             # From cat_gemm_min_rows up the LSTMCell's two GEMMs are ONE product over rows [features | k h_prev] (K = F + R):
             # slot t of this store holds step t's fc features (written by the fc GEMM with row stride F + R) next to the
@@ -652,9 +652,10 @@ class A3C_Dueling(nn.Module):
             c.f = [torch.empty((T, N, p.encoder.outdim), device=dev) for p in (p0, p1)]
         c.feat1 = torch.empty((T, N, p1.encoder.outdim), device=dev) if self.tat else None
         c.pre_all = None
-        # (the activated-gates store may only be dropped when EVERY step of this rollout is certain to take the one-GEMM branch of
-        # _act_step — the MFMA actor step and the per-player fallback launches write acts[i])
-        if c.fh_all is not None and self.store_preacts and fused_lstm and not coop and self._env_fused_static(N, R):
+        # (the [features | k h] rows above — and with them this store in place of the activated gates — exist only when EVERY step
+        # of the rollout is certain to take the one-GEMM branch of _act_step (_env_fused_static): the MFMA actor step and the
+        # per-player fallback launches want contiguous feature rows and write acts[i])
+        if c.fh_all is not None and self.store_preacts and fused_lstm and not coop:
             c.pre_all = torch.empty((2, T, N, 4 * R), device=dev)     # slot t = the gate GEMM's output of step t
             c.acts = None
         else:

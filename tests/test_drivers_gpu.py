@@ -433,7 +433,7 @@ def test_mfma_actor_step_keeps_its_activated_gates_store_when_preacts_are_on():
     assert m.store_preacts and not m._env_fused_static(1024, 128)
     rollout(player, args.num_steps, fast=True)
     c = player._cache
-    assert c is not None and c.acts is not None and c.pre_all is None
+    assert c is not None and c.acts is not None and c.pre_all is None and c.fh_all is None
     outs = []
     for cached in (True, False):
         player._cache = c if cached else None
@@ -922,7 +922,6 @@ def test_numpy_rng_batch_replays_all_reference_episodes_concurrently_in_one_hand
         for i, (e, t) in enumerate(cur):
             if e < len(eps[i]):
                 act[:, i] = eps[i][e]["act_in"][t]
-        act[1, is_ram] = 3 - act[1, is_ram]          # (a Ram env's recorded target action must NOT be what moves its target)
         obs, rew, done, info = env.step([act[0], act[1]])
         obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
         cut = np.zeros(n, bool)
