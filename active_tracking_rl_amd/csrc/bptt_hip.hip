@@ -51,13 +51,18 @@ struct Bptt {
     float *dg;                 // + p * dg_ps + (t * N + n) * 4R : pre-activation gate gradients (out)
     long long dg_ps;
     float *dh0, *dc0;          // [P, N, R]: gradient into the rollout's initial hidden / cell state (out)
+    // PRE + emb only (nullable): per row tile of player emb_player, the column sums of dG over the tile's rows BY THE TRACKER'S
+    // ACTION of the row — [tiles][4][4R] (n_act == 4). S = their sum over the tiles is all the embedding needs of the backward
+    // pass: d fc_action_tracker = S W_ih, and the target's dW_ih = dG^T (f + E[a]) = dG^T f + S^T E (atr_embed_fold) — the
+    // learner then neither materialises f + E[a] nor gathers dL/df by action (two passes over [T N, F] each)
+    float *act_sums;
     int P, T, N;
 };
 
 template <bool PRE>
 __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
 {
-    extern __shared__ __attribute__((aligned(16))) float tileA[];      // [2][kBRows][kBLd] (+ PRE: the embedding table)
+    extern __shared__ __attribute__((aligned(16))) float tileA[];      // [2][kBRows][kBLd] (+ PRE: the embedding table, row actions)
     const int tid = (int)threadIdx.x, l = tid & 63, w = tid >> 6;
     const int col = l & 15, q = l >> 4;
     const int tiles = (a.N + kBRows - 1) / kBRows;
@@ -94,6 +99,10 @@ __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
         __syncthreads();
     }
     int ai[4] = {0, 0, 0, 0};
+    // column sums of dG by the row's tracker action: thread tid owns COLUMN tid of the [16 x 512] tile every step parks in LDS
+    const bool sums = PRE && with_emb && a.act_sums != nullptr;
+    float *actL = embL + (size_t)kMaxActions * kBK;       // [2][16][4]: one-hot of the tile rows' actions (zeros: no such row)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};          // dG_{t+1} W_hh for this thread's pairs (gradient arriving through h_t)
     float dcc[4] = {0.f, 0.f, 0.f, 0.f};       // dc_{t+1} f_{t+1}
     // staged inputs of one step (fetched one step ahead, under the MFMAs)
@@ -146,9 +155,27 @@ __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
                 __builtin_nontemporal_store(d_g, o + 2 * kBR); __builtin_nontemporal_store(d_o, o + 3 * kBR);  // GEMMs read dG later
             }
         }
+        if (sums && w == 0 && col == 0) {                  // (one lane per row group: rows 4 q + i of the tile)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int ra = ok[i] ? ai[i] : -1;
+                *reinterpret_cast<float4 *>(actL + ((t & 1) * kBRows + 4 * q + i) * 4) =
+                    make_float4(ra == 0 ? 1.f : 0.f, ra == 1 ? 1.f : 0.f, ra == 2 ? 1.f : 0.f, ra == 3 ? 1.f : 0.f);
+            }
+        }
         __syncthreads();                                   // the tile of step t is complete (the other buffer: step t + 1's
                                                            // reads finished before this step's writes began two barriers ago)
         if (t > 0) BPTT_FETCH(t - 1);                      // next step's inputs: in flight under the MFMAs
+        if (sums) {                                        // this thread's column of the tile, by action (VALU under the MFMAs)
+            const float *colp = At + tid;
+            const float *ar = actL + (t & 1) * kBRows * 4;
+#pragma unroll 4                                           // (fully unrolled, the 16 mask quads are hoisted: spills at 256 VGPRs)
+            for (int r = 0; r < kBRows; r++) {             // (fmaf(1, v, s) = s + v, fmaf(0, v, s) = s: exact either way)
+                const float v = colp[r * kBLd];
+                const float4 m = *reinterpret_cast<const float4 *>(ar + 4 * r);
+                s0 = fmaf(m.x, v, s0); s1 = fmaf(m.y, v, s1); s2 = fmaf(m.z, v, s2); s3 = fmaf(m.w, v, s3);
+            }
+        }
         // ---- dh_{t-1} contribution: acc = dG_t[rows, :] W_hh[:, units of this wave]
         acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -180,6 +207,10 @@ __global__ __launch_bounds__(512, 1) void k_lstm_bptt(Bptt a)
         acc += acc2;
     }
 #undef BPTT_FETCH
+    if (sums) {
+        float *o = a.act_sums + (size_t)rt * 4 * kBK + tid;
+        o[0] = s0; o[kBK] = s1; o[2 * kBK] = s2; o[3 * kBK] = s3;
+    }
     // ---- gradient into the rollout's initial state
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -196,7 +227,8 @@ using namespace atr;
 
 static int bptt_launch(const Bptt &a, bool pre, void *stream)
 {
-    const size_t lds = (size_t)2 * kBRows * kBLd * sizeof(float) + (pre ? (size_t)kMaxActions * kBK * sizeof(float) : 0);
+    const size_t lds = (size_t)2 * kBRows * kBLd * sizeof(float) +
+                       (pre ? (size_t)kMaxActions * kBK * sizeof(float) + 2 * kBRows * 4 * sizeof(float) : 0);
     static bool attr_set[2] = {false, false};
     if (!attr_set[pre ? 1 : 0]) {
         const void *fn = pre ? (const void *)k_lstm_bptt<true> : (const void *)k_lstm_bptt<false>;
@@ -222,16 +254,37 @@ extern "C" int atr_lstm_bptt(const float *dh0_heads, const float *dh1_heads, con
     a.c_ps = c_pstride; a.whh[0] = whh0; a.whh[1] = whh1; a.dg = dg; a.dg_ps = dg_pstride; a.dh0 = dh_init; a.dc0 = dc_init;
     a.P = P; a.T = T; a.N = N;
     a.bias[0] = a.bias[1] = nullptr; a.emb = nullptr; a.act = nullptr; a.act_ts = 0; a.emb_player = -1; a.n_act = 0;
+    a.act_sums = nullptr;
     return bptt_launch(a, false, stream);
 }
 
 // atr_lstm_bptt over a rollout that stored the gate GEMM's OUTPUT (pre-activations without bias) instead of the activated gates.
+extern "C" int atr_lstm_bptt_pre2(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *pre,
+                                  long long pre_pstride, const float *bias0, const float *bias1, const float *emb, int emb_player,
+                                  int n_act, const long long *act_tracker, long long act_tstride, const float *c_all,
+                                  long long c_pstride, const float *whh0, const float *whh1, float *dg, long long dg_pstride,
+                                  float *dh_init, float *dc_init, float *act_sums, int P, int T, int N, int R, void *stream);
+
 extern "C" int atr_lstm_bptt_pre(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *pre,
                                  long long pre_pstride, const float *bias0, const float *bias1, const float *emb, int emb_player,
                                  int n_act, const long long *act_tracker, long long act_tstride, const float *c_all,
                                  long long c_pstride, const float *whh0, const float *whh1, float *dg, long long dg_pstride,
                                  float *dh_init, float *dc_init, int P, int T, int N, int R, void *stream)
 {
+    return atr_lstm_bptt_pre2(dh0_heads, dh1_heads, keep, pre, pre_pstride, bias0, bias1, emb, emb_player, n_act, act_tracker,
+                              act_tstride, c_all, c_pstride, whh0, whh1, dg, dg_pstride, dh_init, dc_init, nullptr, P, T, N, R,
+                              stream);
+}
+
+extern "C" long long atr_lstm_bptt_act_sums_floats(int N) { return (long long)((N + kBRows - 1) / kBRows) * 4 * kBK; }
+
+extern "C" int atr_lstm_bptt_pre2(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *pre,
+                                  long long pre_pstride, const float *bias0, const float *bias1, const float *emb, int emb_player,
+                                  int n_act, const long long *act_tracker, long long act_tstride, const float *c_all,
+                                  long long c_pstride, const float *whh0, const float *whh1, float *dg, long long dg_pstride,
+                                  float *dh_init, float *dc_init, float *act_sums, int P, int T, int N, int R, void *stream)
+{
+    if (act_sums && (!emb || n_act != 4)) return -1;     // (the by-action sums are built for the four-move action table)
     if (!keep || !pre || !bias0 || !c_all || !whh0 || !dg || !dh_init || !dc_init || P < 1 || P > 2 || (P == 2 && (!whh1 || !bias1)) ||
         T < 1 || N < 1 || R != kBR)
         return -1;
@@ -242,5 +295,6 @@ extern "C" int atr_lstm_bptt_pre(const float *dh0_heads, const float *dh1_heads,
     a.P = P; a.T = T; a.N = N;
     a.bias[0] = bias0; a.bias[1] = bias1; a.emb = emb; a.act = act_tracker; a.act_ts = act_tstride;
     a.emb_player = emb ? emb_player : -1; a.n_act = emb ? n_act : 0;
+    a.act_sums = act_sums;
     return bptt_launch(a, true, stream);
 }

@@ -456,6 +456,112 @@ extern "C" int atr_embed_grad(const float *dout, const long long *actions, long 
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+// ---- the tracker-action embedding folded out of the learner's big tensors (round 6) -------------------------------------------
+// TAT.forward adds fc_action_tracker(one_hot(a_tracker)) = E[a] to the target's fc features before the LSTMCell (model.py:193-194
+// of the reference). With S[a][j] = the sum of dG[r][j] over the rows r whose tracker action is a (atr_lstm_bptt_pre2 makes it per
+// row tile, beside the recurrence), everything the embedding contributes to the backward pass is [4 x 512]-sized algebra:
+//     dW_ih  = dG^T (f + E[a])  = dG^T f  +  S^T E          (the grouped weight-gradient launch contracts the raw features)
+//     dE[a]  = sum over rows with action a of (dG W_ih)[r]  =  (S W_ih)[a];   d weight[c][a] = dE[a][c],  d bias[c] = sum_a dE[a][c]
+// k_sact_reduce: S from the tiles' partial sums (fixed order); k_embed_fold: blocks [0, J) add S^T E to dW_ih's rows, the blocks
+// after them make dE 64 columns at a time.
+// (both kernels are a handful of workgroups with short dependent chains: what they cost is load LATENCY, so every thread keeps
+// 8-16 independent loads in flight and the partial sums meet in LDS in a fixed order)
+__global__ __launch_bounds__(1024) void k_sact_reduce(const float *__restrict__ part, float *__restrict__ S, int tiles, int n)
+{
+    __shared__ float red[16][64];
+    const int lc = (int)(threadIdx.x & 63u), g = (int)(threadIdx.x >> 6);       // 64 columns x 16 tile groups
+    const int c = (int)blockIdx.x * 64 + lc;
+    float acc = 0.f;
+    if (c < n) {
+        int t = g;
+        for (; t + 7 * 16 < tiles; t += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = part[(size_t)(t + 16 * k) * n + c];
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc += v[k];
+        }
+        for (; t < tiles; t += 16) acc += part[(size_t)t * n + c];
+    }
+    red[g][lc] = acc;
+    __syncthreads();
+    if (g == 0 && c < n) {
+        float r = red[0][lc];
+#pragma unroll
+        for (int k = 1; k < 16; k++) r += red[k][lc];
+        S[c] = r;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_embed_fold(const float *__restrict__ S, const float *__restrict__ fa_w,
+                                                     const float *__restrict__ fa_b, const float *__restrict__ wih,
+                                                     float *__restrict__ dwih, float *__restrict__ dfa_w, float *__restrict__ dfa_b,
+                                                     int J, int C, int rows_per_block)
+{
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int nb_w = (J + rows_per_block - 1) / rows_per_block;
+    if (b < nb_w) {                                // dW_ih[j][:] += sum_a S[a][j] E[a][:],  E[a][c] = fa_w[c][a] + fa_b[c]
+        for (int idx = tid; idx < rows_per_block * C; idx += 1024) {
+            const int j = b * rows_per_block + idx / C, c = idx % C;
+            if (j >= J) break;
+            const float4 w = *reinterpret_cast<const float4 *>(fa_w + 4 * c);
+            const float bb = fa_b[c];
+            float *d = dwih + (size_t)j * C + c;
+            *d = *d + (((S[j] * (w.x + bb) + S[J + j] * (w.y + bb)) + S[2 * J + j] * (w.z + bb)) + S[3 * J + j] * (w.w + bb));
+        }
+        return;
+    }
+    // dE[:, c] for 64 columns: j in 16 interleaved groups (8 loads of W in flight per thread), summed in a fixed order
+    __shared__ float red[16][4][64];
+    const int lc = tid & 63, g = tid >> 6;
+    const int c = (b - nb_w) * 64 + lc;
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+    if (c < C) {
+        int j = g;
+        for (; j + 7 * 16 < J; j += 8 * 16) {
+            float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = wih[(size_t)(j + 16 * k) * C + c];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int jj = j + 16 * k;
+                e0 = fmaf(S[jj], w[k], e0); e1 = fmaf(S[J + jj], w[k], e1); e2 = fmaf(S[2 * J + jj], w[k], e2); e3 = fmaf(S[3 * J + jj], w[k], e3);
+            }
+        }
+        for (; j < J; j += 16) {
+            const float w = wih[(size_t)j * C + c];
+            e0 = fmaf(S[j], w, e0); e1 = fmaf(S[J + j], w, e1); e2 = fmaf(S[2 * J + j], w, e2); e3 = fmaf(S[3 * J + j], w, e3);
+        }
+    }
+    red[g][0][lc] = e0; red[g][1][lc] = e1; red[g][2][lc] = e2; red[g][3][lc] = e3;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float e[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            float r = red[0][a][lc];
+#pragma unroll
+            for (int k = 1; k < 16; k++) r += red[k][a][lc];
+            e[a] = r;
+        }
+        *reinterpret_cast<float4 *>(dfa_w + 4 * c) = make_float4(e[0], e[1], e[2], e[3]);
+        dfa_b[c] = ((e[0] + e[1]) + e[2]) + e[3];
+    }
+}
+
+extern "C" int atr_embed_fold(const float *act_sums, int tiles, const float *fa_w, const float *fa_b, const float *wih, float *dwih,
+                              float *dfa_w, float *dfa_b, float *S, int J, int C, void *stream)
+{
+    if (!act_sums || !fa_w || !fa_b || !wih || !dwih || !dfa_w || !dfa_b || !S || tiles < 1 || J < 4 || (J & 3) || C < 1) return 1;
+    if (((uintptr_t)fa_w | (uintptr_t)dfa_w) & 15u) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sact_reduce, dim3((unsigned)((4 * J + 63) / 64)), dim3(1024), 0, st, act_sums, S, tiles, 4 * J);
+    const int rpb = 4;                                    // dW_ih rows per workgroup of the first block range
+    hipLaunchKernelGGL(k_embed_fold, dim3((unsigned)((J + rpb - 1) / rpb + (C + 63) / 64)), dim3(1024), 0, st, S, fa_w, fa_b, wih,
+                       dwih, dfa_w, dfa_b, J, C, rpb);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 extern "C" int atr_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, float *max_exp_avg_sq,
                              double *state, float *scalars, double lr, double beta1, double beta2, double eps,
                              double weight_decay, int torch_eps, long long n, void *stream)

@@ -125,6 +125,13 @@ def lib():
         L.atr_embed_grad.argtypes = [vp, vp, ll, ll, ll, vp, vp, vp, ll, i32, i32, vp]
         L.atr_lstm_bptt.restype = i32
         L.atr_lstm_bptt.argtypes = [vp, vp, vp, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, i32, i32, i32, i32, vp]
+        L.atr_lstm_bptt_pre2.restype = i32
+        L.atr_lstm_bptt_pre2.argtypes = [vp, vp, vp, vp, ll, vp, vp, vp, i32, i32, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, vp,
+                                         i32, i32, i32, i32, vp]
+        L.atr_lstm_bptt_act_sums_floats.restype = ll
+        L.atr_lstm_bptt_act_sums_floats.argtypes = [i32]
+        L.atr_embed_fold.restype = i32
+        L.atr_embed_fold.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
         L.atr_lstm_bptt_pre.restype = i32
         L.atr_lstm_bptt_pre.argtypes = [vp, vp, vp, vp, ll, vp, vp, vp, i32, i32, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp,
                                         i32, i32, i32, i32, vp]
@@ -749,10 +756,15 @@ def _lstm_bptt(whh, keep, h_all, c_all, acts, dhs, whh_nn=None, want_dwhh=True, 
                 emb, act = emb.contiguous(), pre["act"]
                 assert act.dtype == torch.int64 and act.shape == (T, N) and act.stride(1) == 1
                 n_act, act_ts = emb.shape[0], act.stride(0)
-            rc = L.atr_lstm_bptt_pre(_pn(dh_c[0]), _pn(dh_c[1]) if P > 1 else None, _p(keep), _p(acts), acts.stride(0),
-                                     _p(bias[0]), _p(bias[1]) if P > 1 else None, _pn(emb), ep, n_act, _pn(act), act_ts,
-                                     _p(c_all), ps, _p(whh_nn[0]), _p(whh_nn[1]) if P > 1 else None, _p(dG), pa, _p(dhn),
-                                     _p(dcc), P, T, N, R, st)
+            sums = None
+            if pre.get("want_sums") and emb is not None and n_act == 4:
+                # per row tile of the embedding's player: column sums of dG by the row's tracker action (see embed_fold)
+                sums = torch.empty(L.atr_lstm_bptt_act_sums_floats(N), dtype=torch.float32, device=dev)
+            pre["act_sums"] = sums
+            rc = L.atr_lstm_bptt_pre2(_pn(dh_c[0]), _pn(dh_c[1]) if P > 1 else None, _p(keep), _p(acts), acts.stride(0),
+                                      _p(bias[0]), _p(bias[1]) if P > 1 else None, _pn(emb), ep, n_act, _pn(act), act_ts,
+                                      _p(c_all), ps, _p(whh_nn[0]), _p(whh_nn[1]) if P > 1 else None, _p(dG), pa, _p(dhn),
+                                      _p(dcc), _pn(sums), P, T, N, R, st)
         else:
             rc = L.atr_lstm_bptt(_pn(dh_c[0]), _pn(dh_c[1]) if P > 1 else None, _p(keep), _p(acts), pa, _p(c_all), ps,
                                  _p(whh_nn[0]), _p(whh_nn[1]) if P > 1 else None, _p(dG), pa, _p(dhn), _p(dcc), P, T, N, R, st)
@@ -798,8 +810,9 @@ class _LstmSeqCached(torch.autograd.Function):
         # ([P, R, 4R] transposed copy: only the per-step fallback recurrence reads it — the fused BPTT kernel takes weight_hh as is)
         fused_path = use_fused_bptt and h_all.shape[-1] == 128 and h_all.is_cuda
         whh = h_all.new_empty(0) if fused_path else torch.stack([w.t() for w in whh_l], 0).contiguous()
-        ctx.save_for_backward(keep.contiguous(), h_all, c_all, acts, whh, *feats, *wih, *whh_l, *fw[3 * P:5 * P])
+        ctx.save_for_backward(keep.contiguous(), h_all, c_all, acts, whh, *feats, *wih, *whh_l, *fw[3 * P:5 * P], *fw[5 * P:])
         ctx.P = P
+        ctx.fold = len(fw) == 5 * P + 2           # fc_action_tracker's weight and bias ride along: the embedding is folded
         need, ctx.hm, ctx.pre = need              # (lstm_sequence_cached packs the non-tensor arguments together)
         ctx.need = tuple(bool(x) for x in need) if need is not None else (True,) * P
         return tuple(h_all[p, 1:] for p in range(P))
@@ -811,6 +824,8 @@ class _LstmSeqCached(torch.autograd.Function):
         feats, wih = ctx.saved_tensors[5:5 + P], ctx.saved_tensors[5 + P:5 + 2 * P]
         whh_nn = ctx.saved_tensors[5 + 2 * P:5 + 3 * P]          # weight_hh [4R, R] as nn.LSTMCell holds it
         bih, bhh = ctx.saved_tensors[5 + 3 * P:5 + 4 * P], ctx.saved_tensors[5 + 4 * P:5 + 5 * P]
+        fa_w, fa_b = (ctx.saved_tensors[5 + 5 * P], ctx.saved_tensors[5 + 5 * P + 1]) if ctx.fold else (None, None)
+        dfa = (None, None)
         dfeat, dwih, db, dwhh_l = [None] * P, [None] * P, [None] * P, [None] * P
         db2 = None
         q = _deferred
@@ -828,10 +843,18 @@ class _LstmSeqCached(torch.autograd.Function):
             pre = None
             if ctx.pre is not None:          # (this group's slice of the stored pre-activations' side information)
                 pre = dict(ctx.pre, bias=list(ctx.pre["bias"][a:b]), emb_player=ctx.pre.get("emb_player", -1) - a)
+                pre["want_sums"] = ctx.fold and a <= ctx.pre.get("emb_player", -1) < b
             dG, _, _, dwhh = _lstm_bptt(whh[a:b], keep, h_all[a:b], c_all[a:b], acts[a:b], dhs[a:b], whh_nn=list(whh_nn[a:b]),
                                         want_dwhh=not defer, pre=pre)
+            fold_p = ctx.pre.get("emb_player", -1) if (ctx.fold and pre is not None and pre.get("want_sums")) else -1
+            if fold_p >= 0 and pre.get("act_sums") is None:
+                raise RuntimeError("folded tracker-action embedding: the BPTT launch did not return the by-action sums of dG")
             for i, p in enumerate(grp):
                 dfeat[p] = dG[i] @ wih[p]
+                if p == fold_p:
+                    # (feats[p] are the RAW fc features: dW_ih's product misses S^T E, added by embed_fold once the product is there)
+                    fold_args = (pre["act_sums"], fa_w, fa_b, wih[p])
+                    dfa = (torch.empty_like(fa_w), torch.empty_like(fa_b))
                 if defer:
                     # both products of this player contract dG: registered with the grouped launch. dW_hh^T = dG^T (k h):
                     # the mask on h_{t-1} is keep[t-1] = the keep array shifted by one step of N rows, applied to dG's rows
@@ -848,20 +871,46 @@ class _LstmSeqCached(torch.autograd.Function):
                         db[p] = dbi
                         db2 = db2 if db2 is not None else [None] * P
                         db2[p] = dbh
+                        if p == fold_p:          # (the slice is filled by the grouped launch at flush(): the fold follows it)
+                            q.after.append(lambda fa_=fold_args, dw_=dwih[p], out_=dfa: embed_fold(*fa_, dw_, *out_))
                         continue
                     if r1 is not None:         # (cannot happen for R = 128; keep the queue consistent if it ever does)
                         raise RuntimeError("grouped weight gradients: dW_hh could not join the group after dW_ih did")
                     kprev = torch.cat([torch.ones_like(keep[:1]), keep[:-1]], 0).reshape(T * N)
                     dwhh_l[p] = gemm_tn(h_all[p, :T].reshape(T * N, R), dG[i], row_scale=kprev).t()
                     dwih[p], db[p] = gemm_tn(dG[i], feats[p], colsum=True)
+                    if p == fold_p:
+                        dwih[p] = dwih[p].contiguous()
+                        embed_fold(*fold_args, dwih[p], *dfa)
                     continue
                 dwih[p], db[p] = gemm_tn(dG[i], feats[p], colsum=True)
+                if p == fold_p:
+                    dwih[p] = dwih[p].contiguous()
+                    embed_fold(*fold_args, dwih[p], *dfa)
                 dwhh_l[p] = dwhh[i].t()
+        if ctx.fold and ctx.pre is not None and ctx.need[ctx.pre.get("emb_player", 0)] and dfa[0] is None:
+            raise RuntimeError("folded tracker-action embedding: no group of the backward pass produced its gradients")
         db_hh = tuple(db2[p] if (db2 is not None and db2[p] is not None) else db[p] for p in range(P))
-        return (None, None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + db_hh
+        out = (None, None, None, None, None) + tuple(dfeat) + tuple(dwih) + tuple(dwhh_l) + tuple(db) + db_hh
+        return out + (tuple(dfa) if ctx.fold else ())
 
 
-def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts, need=None, hm=None, pre=None):
+@torch.no_grad()
+def embed_fold(act_sums, fa_w, fa_b, wih, dwih, dfa_w, dfa_b):
+    """The tracker-action embedding's share of the target's backward pass from the by-action column sums of dG (atr_embed_fold):
+    dwih [4R, C] += S^T E in place, dfa_w [C, 4] / dfa_b [C] = the gradients of fc_action_tracker. act_sums: what
+    atr_lstm_bptt_pre2 left per row tile."""
+    J, Cc = wih.shape
+    assert fa_w.shape == (Cc, 4) and fa_w.is_contiguous() and fa_b.is_contiguous() and wih.is_contiguous() and dwih.is_contiguous()
+    assert dwih.shape == (J, Cc) and act_sums.numel() % (4 * J) == 0
+    S = torch.empty((4, J), dtype=torch.float32, device=wih.device)
+    rc = lib().atr_embed_fold(_p(act_sums), act_sums.numel() // (4 * J), _p(fa_w), _p(fa_b), _p(wih), _p(dwih), _p(dfa_w), _p(dfa_b),
+                              _p(S), J, Cc, _stream(wih))
+    if rc != 0:
+        raise RuntimeError("atr_embed_fold failed (%d)" % rc)
+
+
+def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts, need=None, hm=None, pre=None, fold=None):
     """feats: per-player [T*N, F] (with grad); lstms: the nn.LSTMCells; stored activations from the rollout.
     need: per player, whether anything upstream of its hidden sequence is trained (None = all).
     hm: per player the MASKED previous hidden rows k_{t-1} h_{t-1} as [T*N, R] (row-strided views are fine) when the rollout
@@ -870,7 +919,20 @@ def lstm_sequence_cached(lstms, feats, keep, h_all, c_all, acts, need=None, hm=N
     P = len(lstms)
     args = list(feats) + [l.weight_ih for l in lstms] + [l.weight_hh for l in lstms] + \
         [l.bias_ih for l in lstms] + [l.bias_hh for l in lstms]
+    if fold is not None:     # fold = the tracker-aware player's fc_action_tracker: feats[pre['emb_player']] are then its RAW fc
+        args += [fold.weight, fold.bias]     # features (no f + E[a] materialised), the embedding's gradients come from this node
     return _LstmSeqCached.apply(keep, h_all, c_all, acts, (need, hm, pre), *args)
+
+
+def embed_fold_ok(pre, h_all, c_all, keep, fa):
+    """Whether lstm_sequence_cached can fold the tracker-action embedding (the fused BPTT launch over stored pre-activations,
+    the four-move action table, parameters as the kernels read them)."""
+    return bool(fold_embedding and pre is not None and pre.get("emb") is not None and use_fused_bptt and h_all.is_cuda
+                and h_all.shape[-1] == 128 and c_all.is_contiguous() and keep.is_contiguous()
+                and fa.weight.shape[1] == 4 and fa.weight.is_contiguous() and fa.weight.data_ptr() % 16 == 0)
+
+
+fold_embedding = __import__("os").environ.get("ATR_FOLD_EMBEDDING", "1") != "0"
 
 
 @torch.no_grad()
@@ -1356,6 +1418,7 @@ class DeferredWeightGrads(object):
         for prm, v in zip(bucket.params, bucket.grad_views()):
             self.views[prm.data_ptr()] = v
         self.problems, self.K, self.registered = [], None, set()
+        self.after = []           # launches that need the group's outputs in place (run at the end of flush(), in order)
 
     def view(self, prm):
         return self.views.get(prm.data_ptr()) if prm is not None else None
@@ -1409,6 +1472,9 @@ class DeferredWeightGrads(object):
         if rc != 0:
             raise RuntimeError("atr_gemm_tn_grouped failed (%d)" % rc)
         self.problems, self.K = [], None
+        for fn in self.after:
+            fn()
+        self.after = []
 
 
 class deferred_weight_grads(object):

@@ -944,12 +944,25 @@ class A3C_Dueling(nn.Module):
                 states_seq.reshape(T, N, -1, states_seq.shape[4], states_seq.shape[5], states_seq.shape[6])
                 if self.tat else states_seq[:, :, 1]]
         feats = []
+        # the rollout kept the gate GEMM's outputs: the BPTT kernel re-activates them (bias, the tracker-action embedding of
+        # the tracker-aware target, then the cell's own sigmoid / tanh: the values the rollout computed, bit for bit)
+        pre = None
+        if getattr(cache, "pre_all", None) is not None:
+            pre = dict(bias=[cache.bsum[0], cache.bsum[1]], emb=cache.emb_ih if self.tat else None, emb_player=1,
+                       act=actions_seq[:, :, 0])
+        fold = None
+        if self.tat and (need is None or need[1]) and fused.embed_fold_ok(pre, cache.h_all, cache.c_all, keep, p1.fc_action_tracker):
+            fold = p1.fc_action_tracker
         for i, p in enumerate((p0, p1)):
             enc = p.encoder
             y = fused.stem_cached(x_in[i], cache.y[i].view(-1, 512), enc.conv1, enc.conv2)
             f = fused.linear_relu_cached(y.view(T * N, -1), enc.fc, cache.f[i].view(T * N, -1))
             if i == 1 and self.tat:      # + fc_action_tracker(one_hot(a_tracker)) (model.py:193-194): a row gather
-                if p.fc_action_tracker.weight.shape[1] <= 8 and f.shape[1] % 4 == 0:
+                if fold is not None or (need is not None and not need[1]):
+                    pass         # (folded: the LSTM node contracts the raw features and makes the embedding's gradients from
+                                 #  the by-action column sums of dG — no f + E[a] tensor, no gather of dL/df by action; or
+                                 #  the target is not trained in this mode and nothing reads its features)
+                elif p.fc_action_tracker.weight.shape[1] <= 8 and f.shape[1] % 4 == 0:
                     # ([T, N] view of the tracker's column of the [T, players, N] action store: read in place)
                     f = fused.embed_add(f, p.fc_action_tracker, actions_seq[:, :, 0])
                 else:
@@ -962,15 +975,9 @@ class A3C_Dueling(nn.Module):
         if getattr(cache, "fh_all", None) is not None and getattr(cache, "hm_written", 0) >= T:
             Fd = cache.f_all.shape[-1]
             hm = [cache.fh_all[i, :T, :, Fd:].view(T * N, -1) for i in range(2)]
-        pre = None
-        acts = cache.acts
-        if getattr(cache, "pre_all", None) is not None:
-            # the rollout kept the gate GEMM's outputs: the BPTT kernel re-activates them (bias, the tracker-action embedding of
-            # the tracker-aware target, then the cell's own sigmoid / tanh: the values the rollout computed, bit for bit)
-            acts = cache.pre_all
-            pre = dict(bias=[cache.bsum[0], cache.bsum[1]], emb=cache.emb_ih if self.tat else None, emb_player=1,
-                       act=actions_seq[:, :, 0])
-        return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, acts, need, hm=hm, pre=pre)
+        acts = cache.pre_all if pre is not None else cache.acts
+        return fused.lstm_sequence_cached([p0.lstm, p1.lstm], feats, keep, cache.h_all, cache.c_all, acts, need, hm=hm, pre=pre,
+                                          fold=fold)
 
     def forward_sequence_cached(self, cache, states_seq, actions_seq, keep):
         """forward_sequence over a cached rollout: only the heads are evaluated forward; the backward pass is the

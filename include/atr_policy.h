@@ -269,6 +269,24 @@ int atr_lstm_bptt_pre(const float *dh0_heads, const float *dh1_heads, const floa
                       const long long *act_tracker, long long act_tstride, const float *c_all, long long c_pstride,
                       const float *whh0, const float *whh1, float *dg, long long dg_pstride, float *dh_init, float *dc_init,
                       int P, int T, int N, int R, void *stream);
+/* atr_lstm_bptt_pre with one more output (round 6): act_sums (nullable; n_act must be 4) — atr_lstm_bptt_act_sums_floats(N)
+ * floats, [row tiles of 16][4][4R]: per row tile of player emb_player, the column sums of dG over the tile's rows grouped by the
+ * tracker's action of the row (all T steps). Their sum over the tiles, S [4][4R], is everything the tracker-action embedding
+ * (TAT.forward, model.py:193-194) needs of the backward pass — see atr_embed_fold. */
+long long atr_lstm_bptt_act_sums_floats(int N);
+int atr_lstm_bptt_pre2(const float *dh0_heads, const float *dh1_heads, const float *keep, const float *pre, long long pre_pstride,
+                       const float *bias0, const float *bias1, const float *emb, int emb_player, int n_act,
+                       const long long *act_tracker, long long act_tstride, const float *c_all, long long c_pstride,
+                       const float *whh0, const float *whh1, float *dg, long long dg_pstride, float *dh_init, float *dc_init,
+                       float *act_sums, int P, int T, int N, int R, void *stream);
+/* The embedding's share of the target's backward pass from those sums, instead of two passes over [T N, C] tensors (the learner
+ * no longer materialises f + E[a] for the dW_ih product nor gathers dL/df by action): with S = sum over tiles of act_sums
+ * (fixed order; written to S [4][J], J = 4R) and E[a][c] = fa_w[c][a] + fa_b[c] (fc_action_tracker.weight [C, 4], .bias [C]):
+ *     dwih [J, C] += S^T E     (dwih already holds dG^T f, the product over the RAW fc features)
+ *     dfa_w [C, 4] = (S wih)^T,  dfa_b [C] = its row sums     (wih = the target's weight_ih [J, C])
+ * Returns 0 or a non-zero code. */
+int atr_embed_fold(const float *act_sums, int tiles, const float *fa_w, const float *fa_b, const float *wih, float *dwih,
+                   float *dfa_w, float *dfa_b, float *S, int J, int C, void *stream);
 /* fc_action_tracker(one_hot(a_tracker)) added to the target's features over all stored steps (TAT.forward, model.py:193-194 of
  * the reference): out[r][c] = f[r][c] + w[c][action of row r] + b[c], w = fc_action_tracker.weight [C, A] (A <= 8, C
  * multiple of 4), actions int64; the action of row r is actions[(r / act_n) * act_tstride + (r % act_n) * act_stride] — a flat

@@ -389,14 +389,16 @@ def test_the_two_schedules_learners_give_the_same_gradient_from_the_same_rollout
 
 
 @pytest.mark.parametrize("train_mode", [-1, 0, 1])
-def test_keeping_the_gate_gemm_output_instead_of_the_activated_gates_changes_no_bit(train_mode):
+def test_keeping_the_gate_gemm_output_instead_of_the_activated_gates_changes_no_bit(monkeypatch, train_mode):
     """One-GEMM rollout path, round 5: the rollout keeps the gate GEMM's OUTPUT per step (pre-activations without bias) and the
     learner's BPTT kernel re-activates it (atr_lstm_bptt_pre: ((pre + bias) + emb[a_tracker]) then the cell's own sigmoid / tanh) —
     against the round-4 form that stores the activated gates from k_act_step: same seeds, same rollout (observations, actions,
     LSTM states equal bit for bit), and the SAME GRADIENT bit for bit, for every training mode (mode 1: the tracker-aware
     target's embedding row alone in its group)."""
+    from active_tracking_rl_amd import fused
     from active_tracking_rl_amd.train import default_args, make_player, rollout
     res = []
+    monkeypatch.setattr(fused, "fold_embedding", False)     # (the folded embedding — pre-activation path only — re-associates dW_ih)
     for keep_pre in (True, False):
         args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=1024, num_steps=8, network="tat-maze-lstm", seed=23,
                             train_mode=train_mode)
@@ -417,6 +419,49 @@ def test_keeping_the_gate_gemm_output_instead_of_the_activated_gates_changes_no_
         assert torch.equal(a, b)
     assert torch.isfinite(res[0][4]).all() and float(res[0][4].abs().sum()) > 0
     assert torch.equal(res[0][4], res[1][4])
+
+
+@pytest.mark.parametrize("train_mode,n_envs,steps", [(-1, 1024, 8), (1, 1024, 8), (0, 1024, 8), (-1, 4096, 20)])
+def test_folded_tracker_action_embedding_gives_the_gradient_of_the_explicit_one(monkeypatch, train_mode, n_envs, steps):
+    """Round 6: on the one-GEMM rollout path the learner no longer materialises f + fc_action_tracker(one_hot(a_tracker)) for the
+    target's dW_ih product nor gathers dL/df by action for the embedding's gradient (two passes over [T N, 256] tensors each):
+    the BPTT launch also leaves the column sums of dG by the row's tracker action, S [4, 512], and atr_embed_fold makes
+    dW_ih += S^T E and d fc_action_tracker = S W_ih from them. Same rollout, fold on / off: every other gradient bit-identical,
+    the target's weight_ih and fc_action_tracker equal to summation-order round-off (checked against a float64 evaluation of
+    the same expressions from the explicit path's own dG is not needed: the explicit path IS the previous round's tested one)."""
+    from active_tracking_rl_amd import fused
+    from active_tracking_rl_amd.train import default_args, make_player, rollout
+    res = []
+    for fold in (True, False):
+        monkeypatch.setattr(fused, "fold_embedding", fold)
+        args = default_args(env="Track2D-BlockPartialPZR-v0", num_envs=n_envs, num_steps=steps, network="tat-maze-lstm", seed=29,
+                            train_mode=train_mode)
+        args.gpu_ids = [0]
+        player, opt = make_player(args, torch.device("cuda:0"), 0, 1)
+        player.model.pair_gemm_max_rows = 0
+        rollout(player, args.num_steps, fast=True)
+        assert player._cache.pre_all is not None
+        acts_buf = player._actions_buf.clone()
+        opt.bucket.grad.zero_()
+        player.compute_grads(opt, train_mode)
+        torch.cuda.synchronize()
+        named = {n: p.grad.clone() if p.grad is not None else None for n, p in player.model.named_parameters()}
+        res.append((acts_buf, opt.bucket.grad.clone(), named))
+        player.env.close()
+    assert torch.equal(res[0][0], res[1][0])                 # the same rollout
+    touched = ("player1.lstm.weight_ih", "player1.fc_action_tracker.weight", "player1.fc_action_tracker.bias")
+    for name, g_fold in res[0][2].items():
+        g_ref = res[1][2][name]
+        if g_ref is None or g_fold is None:
+            assert g_ref is None and g_fold is None, name
+            continue
+        if name in touched and train_mode != 0:
+            scale = float(g_ref.abs().max()) + 1e-12
+            assert float((g_fold - g_ref).abs().max()) <= 2e-5 * scale + 1e-9, (name, float((g_fold - g_ref).abs().max()), scale)
+            assert float(g_ref.abs().max()) > 0, name
+        else:
+            assert torch.equal(g_fold, g_ref), name
+    assert torch.isfinite(res[0][1]).all()
 
 
 def test_mfma_actor_step_keeps_its_activated_gates_store_when_preacts_are_on():
@@ -1096,8 +1141,29 @@ def test_create_env_numpy_device_streams_equal_the_host_streams():
             ends += int(dd.sum())
         assert ends > 24
         dev_env.close(); host_env.close()
-    # a scripted target falls back to the host streams
-    e = create_env("Track2D-BlockPartialRam-v0", mk(5), num_envs=4, rng="numpy-device")
+    # the scripted Ram target (round 6): its stream on the device too — RamAgent.step as k_ram_np, episodes drawn inside the masked
+    # reset — against the host streams (np_mode.cpp's RamAgent), over episode ends and many re-plans; info['distance'] included
+    for env_id in ("Track2D-BlockPartialRam-v0", "Track2D-MazePartialRam-v1"):
+        dev_env = create_env(env_id, mk(5), num_envs=24, rng="numpy-device")
+        host_env = create_env(env_id, mk(5), num_envs=24, rng="numpy")
+        assert dev_env.device_generators and dev_env._interleaved and not host_env.device_generators
+        assert torch.equal(dev_env.reset(), host_env.reset())
+        rs = np.random.RandomState(3)
+        ends = 0
+        for t in range(200):
+            a = rs.randint(0, 4, size=(2, 24))
+            od, rd, dd, idv = dev_env.step([a[0], a[1]])
+            oh, rh, dh, ih = host_env.step([a[0], a[1]])
+            assert torch.equal(dd, dh) and torch.equal(rd, rh) and torch.equal(od, oh), (env_id, t)
+            assert np.array_equal(idv["distance"], ih["distance"]), (env_id, t)
+            ends += int(dd.sum())
+        assert ends > 24
+        tg = dev_env.core.get_target()
+        assert (tg["len"] >= 1).all() and (tg["len"] <= 9).all() and (tg["cursor"] < tg["len"]).all()
+        dev_env.close(); host_env.close()
+    # a Nav target (heap A* between resets) falls back to the host streams, and says so
+    with pytest.warns(UserWarning, match="stay on the host"):
+        e = create_env("Track2D-BlockPartialNav-v0", mk(5), num_envs=4, rng="numpy-device")
     assert not e.device_generators
     e.close()
 
