@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libtrack2d_hip.so")
 SOURCES = ["track2d_hip.hip", "stem_hip.hip", "policy_hip.hip", "lstm_hip.hip", "heads_hip.hip", "gemm_tn_hip.hip",
-           "actor_step_hip.hip", "pair_gemm_hip.hip", "bptt_hip.hip", "driver_hip.hip", "np_mode.cpp", "lt_gemm.cpp"]
+           "actor_step_hip.hip", "pair_gemm_hip.hip", "bptt_hip.hip", "driver_hip.hip", "gate_cell_hip.hip", "np_mode.cpp", "lt_gemm.cpp"]
 HEADERS = ["t2d_device.h", os.path.join("..", "..", "include", "track2d.h"),
            os.path.join("..", "..", "include", "atr_policy.h"), "atr_sample.h", "atr_cell.h",
            os.path.join("..", "..", "include", "track2d_np.h")]

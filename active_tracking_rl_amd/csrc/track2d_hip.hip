@@ -1680,8 +1680,17 @@ __device__ __forceinline__ void act_pair(const DevState &s, const atr_act_step &
         return make_float4(__builtin_nontemporal_load(&q_->x), __builtin_nontemporal_load(&q_->y),
                            __builtin_nontemporal_load(&q_->z), __builtin_nontemporal_load(&q_->w));
     };
+    // a.ig[0] == NULL (round 6): the tracker's cell already ran — as the epilogue of the step's LSTMCell product (atr_gate_cell,
+    // csrc/gate_cell_hip.hip) — and h_out[0] / c_out[0] hold its fresh state: nothing of its gates is read here, its hidden row
+    // is (wave-uniform branch: the argument is the same for every lane of the launch)
+    const bool pre0 = a.ig[0] == nullptr;
+    float4 h0_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pre0) h0_pre = ld4(a.h_out[0] + (size_t)e * R + j);
 #pragma unroll
     for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int x = 0; x < NA; x++) aw[p][x] = ld4(a.actor_w[p] + x * R + j);
+        if (p == 0 && pre0) continue;
         const float *ig = a.ig[p] + (size_t)e * 4 * R + j;
 #pragma unroll
         for (int g = 0; g < 4; g++) pre[p][g] = ldnt(ig + g * R);
@@ -1695,8 +1704,6 @@ __device__ __forceinline__ void act_pair(const DevState &s, const atr_act_step &
             for (int g = 0; g < 4; g++) pre[p][g] = fma4(1.0f, ld4(a.bias[p] + g * R + j), pre[p][g]);
         }
         cp[p] = ld4(a.c_prev[p] + (size_t)e * R + j);
-#pragma unroll
-        for (int x = 0; x < NA; x++) aw[p][x] = ld4(a.actor_w[p] + x * R + j);
     }
     const unsigned long long ctr = *a.counter;
     if (STAGE_EMB) {
@@ -1717,9 +1724,11 @@ __device__ __forceinline__ void act_pair(const DevState &s, const atr_act_step &
 #pragma unroll
             for (int g = 0; g < 4; g++) pre[1][g] = fma4(1.0f, ld4(em + g * R), pre[1][g]);
         }
-        const CellOut o = cell4(pre[p][0], pre[p][1], pre[p][2], pre[p][3], cp[p], k);
+        CellOut o;
+        if (p == 0 && pre0) o.h = h0_pre;
+        else o = cell4(pre[p][0], pre[p][1], pre[p][2], pre[p][3], cp[p], k);
         hkeep[p] = o.h;
-        if (live) {
+        if (live && !(p == 0 && pre0)) {
             st4(a.h_out[p] + (size_t)e * R + j, o.h);
             st4(a.c_out[p] + (size_t)e * R + j, o.c);
             if (a.acts[p]) {   // read next by the learner, a whole rollout later: streamed past the caches
@@ -2582,8 +2591,10 @@ extern "C" int atr_act_env_step(t2d_handle *h, const atr_act_step *args, void *o
     if (!args) return fail(T2D_ERR_INVALID, "atr_act_env_step: null argument");
     const atr_act_step &a = *args;
     for (int p = 0; p < 2; p++)
-        if (!a.ig[p] || !a.c_prev[p] || !a.h_out[p] || !a.c_out[p] || !a.actor_w[p] || !a.actor_b[p])
+        if ((!a.ig[p] && p != 0) || !a.h_out[p] || !a.actor_w[p] || !a.actor_b[p] || (a.ig[p] && (!a.c_prev[p] || !a.c_out[p])))
             return fail(T2D_ERR_INVALID, "atr_act_env_step: null policy buffer (player %d)", p);
+    if (!a.ig[0] && (a.hg[0] || a.acts[0]))
+        return fail(T2D_ERR_INVALID, "atr_act_env_step: ig[0] == NULL (the tracker's cell ran in atr_gate_cell) excludes hg[0] / acts[0]");
     if (!a.actions_out || !a.counter || a.R != 128 || (a.A != 4 && a.A != 8))
         return fail(T2D_ERR_INVALID, "atr_act_env_step: needs R = 128, A = 4 or 8, actions_out, counter");
     if ((a.hm_out[0] != nullptr) != (a.hm_out[1] != nullptr) || (a.hm_out[0] && (a.hm_ld < a.R || (a.hm_ld & 3) ||

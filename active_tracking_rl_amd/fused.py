@@ -46,6 +46,13 @@ class LinearArgs(C.Structure):
                 ("relu", C.c_int), ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong)]
 
 
+class GateCellArgs(C.Structure):
+    """atr_gate_cell_args of include/atr_policy.h."""
+    _fields_ = [("a", C.c_void_p * 2), ("w", C.c_void_p * 2), ("bias", C.c_void_p * 2), ("pre", C.c_void_p * 2),
+                ("c_prev", C.c_void_p * 2), ("h_out", C.c_void_p * 2), ("c_out", C.c_void_p * 2), ("done_prev", C.c_void_p),
+                ("lda", C.c_longlong), ("cell", C.c_int * 2), ("N", C.c_int), ("K", C.c_int), ("R", C.c_int), ("probe", C.c_void_p)]
+
+
 class PairLinearArgs(C.Structure):
     """atr_pair_linear_args of include/atr_policy.h."""
     _fields_ = [("a1", C.c_void_p * 2), ("w1", C.c_void_p * 2), ("a2", C.c_void_p * 2), ("w2", C.c_void_p * 2),
@@ -125,6 +132,10 @@ def lib():
         L.atr_embed_grad.argtypes = [vp, vp, ll, ll, ll, vp, vp, vp, ll, i32, i32, vp]
         L.atr_lstm_bptt.restype = i32
         L.atr_lstm_bptt.argtypes = [vp, vp, vp, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, i32, i32, i32, i32, vp]
+        L.atr_gate_cell.restype = i32
+        L.atr_gate_cell.argtypes = [C.POINTER(GateCellArgs), vp]
+        L.atr_gate_cell_workgroups.restype = i32
+        L.atr_gate_cell_workgroups.argtypes = [i32]
         L.atr_lstm_bptt_pre2.restype = i32
         L.atr_lstm_bptt_pre2.argtypes = [vp, vp, vp, vp, ll, vp, vp, vp, i32, i32, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, vp,
                                          i32, i32, i32, i32, vp]
@@ -1034,15 +1045,18 @@ def act_env_step(env_core, ig, hg, biases, c_prev, done, h_out, c_out, acts, sam
     hm_out (with the env step only): per-player [N,R] views with a common row stride — they receive the fresh hidden rows
     zeroed where this step's done flag is set (what the next step's LSTMCell GEMM reads).
     Same results as lstm_cell_act_into x 2 + env.step. Only valid inside sampler.begin_block(); consumes two ordinals."""
-    N, R = c_prev[0].shape
+    N, R = h_out[0].shape
     assert sampler._ordinal is not None and actions_out.is_contiguous() and actions_out.shape == (2, N)
     a = ActStepArgs()
     for p in range(2):
         for t in (ig[p], c_prev[p], h_out[p], c_out[p]):
-            assert t.is_contiguous() and t.dtype == torch.float32
-        a.ig[p], a.hg[p] = ig[p].data_ptr(), (hg[p].data_ptr() if hg is not None and hg[p] is not None else None)
+            assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
+        # (ig[0] None: the tracker's cell already ran as the epilogue of the step's gate product, fused.gate_cell)
+        a.ig[p] = ig[p].data_ptr() if ig[p] is not None else None
+        a.hg[p] = hg[p].data_ptr() if hg is not None and hg[p] is not None else None
         a.bias[p] = biases[p].data_ptr() if biases is not None and biases[p] is not None else None
-        a.c_prev[p], a.h_out[p], a.c_out[p] = c_prev[p].data_ptr(), h_out[p].data_ptr(), c_out[p].data_ptr()
+        a.c_prev[p] = c_prev[p].data_ptr() if c_prev[p] is not None else None
+        a.h_out[p], a.c_out[p] = h_out[p].data_ptr(), (c_out[p].data_ptr() if c_out[p] is not None else None)
         a.acts[p] = acts[p].data_ptr() if acts is not None and acts[p] is not None else None
         assert hg is None or hg[p] is None or hg[p].is_contiguous()
         assert acts is None or acts[p] is None or acts[p].is_contiguous()
@@ -1059,15 +1073,41 @@ def act_env_step(env_core, ig, hg, biases, c_prev, done, h_out, c_out, acts, sam
         a.hm_out[0], a.hm_out[1], a.hm_ld = hm_out[0].data_ptr(), hm_out[1].data_ptr(), hm_out[0].stride(0)
     L = lib()
     if env_core is None:
-        rc = L.atr_act_env_step(None, C.byref(a), None, 0, None, None, _stream(ig[0]))
+        rc = L.atr_act_env_step(None, C.byref(a), None, 0, None, None, _stream(h_out[0]))
     else:
         obs, rew, done_out = env_out
         assert obs.is_contiguous() and rew.is_contiguous() and done_out.is_contiguous() and obs.dtype in (torch.uint8, torch.float32)
         rc = L.atr_act_env_step(env_core.h, C.byref(a), _p(obs), 1 if obs.dtype == torch.uint8 else 0, _p(rew), _p(done_out),
-                                _stream(ig[0]))
+                                _stream(h_out[0]))
     if rc != 0:
         raise RuntimeError("atr_act_env_step failed (%d): %s" % (rc, L.t2d_last_error().decode()))
     return actions_out
+
+
+@torch.no_grad()
+def gate_cell(fh, w_cat, biases, pre, c_prev, done, h_out, c_out, cell=(True, False), probe=None):
+    """The step's LSTMCell product with the cell as its epilogue (atr_gate_cell, csrc/gate_cell_hip.hip): fh [2, N, K] rows
+    [features | k h_prev] (a common row stride), w_cat [2, 4R, K] contiguous, pre [2, N, 4R] with contiguous [N, 4R] slabs
+    (receives the product without bias), and for players with cell[p]: c_prev / h_out / c_out per-player [N, R] contiguous, biases per-player [4R]."""
+    P, N, K = fh.shape
+    a = GateCellArgs()
+    assert P == 2 and fh.stride(2) == 1 and w_cat.is_contiguous() and w_cat.shape[0] == 2 and w_cat.shape[2] == K
+    assert pre is None or (pre.shape == (2, N, w_cat.shape[1]) and pre[0].is_contiguous() and pre[1].is_contiguous())
+    for p in range(2):
+        a.a[p], a.w[p] = fh[p].data_ptr(), w_cat[p].data_ptr()
+        a.pre[p] = pre[p].data_ptr() if pre is not None else None
+        a.cell[p] = 1 if cell[p] else 0
+        if cell[p]:
+            for t in (c_prev[p], h_out[p], c_out[p], biases[p]):
+                assert t.is_contiguous() and t.dtype == torch.float32
+            a.bias[p], a.c_prev[p] = biases[p].data_ptr(), c_prev[p].data_ptr()
+            a.h_out[p], a.c_out[p] = h_out[p].data_ptr(), c_out[p].data_ptr()
+    a.done_prev = done.data_ptr() if done is not None else None
+    a.lda, a.N, a.K, a.R = fh.stride(1), N, K, w_cat.shape[1] // 4
+    a.probe = probe.data_ptr() if probe is not None else None
+    rc = lib().atr_gate_cell(C.byref(a), _stream(fh))
+    if rc != 0:
+        raise RuntimeError("atr_gate_cell failed (%d)" % rc)
 
 
 _stream_cus = {}

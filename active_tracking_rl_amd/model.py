@@ -551,6 +551,11 @@ class A3C_Dueling(nn.Module):
     # is kept as an option: since k_act_step the GEMM pair + ONE fused cell/draw/env launch is faster at every batch size
     # measured (4096 rows: 6.15 vs 6.21 ms per iteration); ATR_MFMA_MIN_ROWS=3072 restores round 2's choice
     mfma_step_min_rows = int(__import__('os').environ.get('ATR_MFMA_MIN_ROWS', str(1 << 30)))
+    # the one-GEMM step's product as csrc/gate_cell_hip.hip (f32 MFMA, the tracker's cell in its epilogue) instead of the library
+    # product + both cells in k_act_step (round 6; ATR_GATE_CELL=1 turns it on — see DESIGN.md section 5 for where it stands)
+    gate_cell_kernel = __import__('os').environ.get('ATR_GATE_CELL', '0') != '0'
+    gate_cell_min_rows = int(__import__('os').environ.get('ATR_GATE_CELL_MIN_ROWS', '2048'))
+    gate_cell_seen = False
 
     @torch.no_grad()
     def begin_act(self):
@@ -868,8 +873,18 @@ class A3C_Dueling(nn.Module):
                 # (gates: this step's slot of the rollout's pre-activation store — kept for the learner instead of the activated
                 # gates — else the scratch tensor)
                 g = gates if gates is not None else cache.gates
-                fused.linear_lt(fh_t, cache.w_cat, g, workspace=self._lt_ws)
-                ig, hg_, bs = g, None, cache.bsum
+                if (self.gate_cell_kernel and gates is not None and acts is None and n >= self.gate_cell_min_rows and R == 128
+                        and Fd % 32 == 0):
+                    # the product as this build's own MFMA kernel with the TRACKER's cell as its epilogue (csrc/gate_cell_hip.hip):
+                    # the tracker's gates are written once for the learner and never read back by the rollout; the tracker-aware
+                    # target's cell still needs the tracker's draw, so it stays in k_act_step (ig[0] = None tells it so)
+                    fused.gate_cell(fh_t, cache.w_cat, cache.bsum, g, c_prev, done, h_out, c_out, cell=(True, False))
+                    ig = [None, g[1]]
+                    self.gate_cell_seen = True
+                else:
+                    fused.linear_lt(fh_t, cache.w_cat, g, workspace=self._lt_ws)
+                    ig = g
+                hg_, bs = None, cache.bsum
                 hm = [fh_next[0][:, Fd:], fh_next[1][:, Fd:]] if (fh_next is not None and env_out is not None) else None
             else:
                 hm = None

@@ -261,7 +261,7 @@ class GraphedIteration(object):
 
 _hip, _masked_streams = None, {}
 MODEL_SWITCHES = ("fused_sampling", "fused_actor_step", "fused_env_step", "pair_gemm_max_rows", "mfma_step_min_rows",
-                  "cat_gate_gemm", "cat_gemm_min_rows", "coop_step", "coop_max_rows")
+                  "cat_gate_gemm", "cat_gemm_min_rows", "coop_step", "coop_max_rows", "gate_cell_kernel", "gate_cell_min_rows")
 
 
 def device_cus(device):

@@ -129,6 +129,33 @@ typedef struct atr_act_step {
     float *hm_out[2];
     long long hm_ld;
 } atr_act_step;
+/* The step's LSTMCell product with the cell as its epilogue (round 6; csrc/gate_cell_hip.hip; f32 MFMA, gfx950): for both players
+ *     pre[p] = a[p] w[p]^T            a[p] [N, K] rows [fc features | k h_prev] (row stride lda), w[p] [4R, K] = [W_ih | W_hh]
+ * (model.py:116,137,165,196 of the reference: both GEMMs of nn.LSTMCell as one product, K = 256 + 128), written to pre[p] [N, 4R]
+ * WITHOUT the bias (nullable where cell[p] != 0), and for every player with cell[p] != 0 the cell itself in the kernel's epilogue
+ * — ((pre + bias[p])) -> i, f, g, o (csrc/atr_cell.h: the expressions atr_act_env_step evaluates), c' = f (k c_prev) + i g,
+ * h' = o tanh(c'), k = (done_prev == 0) — into h_out[p] / c_out[p] [N, R]: that player's gate tensor is then never read back by
+ * the rollout (atr_act_env_step is told so by ig[p] == NULL: it takes h_out[p] as the fresh hidden row). A player whose gates
+ * still lack a term when the product is done — the tracker-aware target: + fc_action_tracker(one_hot(a_tracker)), model.py:193-194,
+ * known only after the tracker's draw — keeps cell[p] = 0. R must be 128, K a multiple of 32, pointers 16-byte aligned.
+ * probe: NULL, or u64 [atr_gate_cell_workgroups(N)][4] clock stamps (start, main loop end, end, XCD). Returns 0, -1, -2. */
+typedef struct atr_gate_cell_args {
+    const float *a[2];
+    const float *w[2];
+    const float *bias[2];
+    float *pre[2];
+    const float *c_prev[2];
+    float *h_out[2];
+    float *c_out[2];
+    const unsigned char *done_prev;
+    long long lda;
+    int cell[2];
+    int N, K, R;
+    void *probe;
+} atr_gate_cell_args;
+int atr_gate_cell(const atr_gate_cell_args *args, void *stream);
+int atr_gate_cell_workgroups(int N);
+
 struct t2d_handle;
 /* env == NULL: the policy half alone (N rows; the learner's bootstrap step). Otherwise N must equal the handle's env count,
  * obs is u8 [N,2,13,13] (obs_is_u8 != 0; 4-byte aligned) or float32 [N,2,13,13], rew float32 [N,2], done u8 [N]; only for

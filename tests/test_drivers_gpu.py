@@ -464,6 +464,44 @@ def test_folded_tracker_action_embedding_gives_the_gradient_of_the_explicit_one(
     assert torch.isfinite(res[0][1]).all()
 
 
+@pytest.mark.parametrize("n", [4096, 1000, 130])
+def test_gate_product_with_cell_epilogue_against_plain_pytorch(n):
+    """atr_gate_cell (csrc/gate_cell_hip.hip): pre = [features | k h_prev] [W_ih | W_hh]^T for both players against torch.bmm
+    in float64 (2e-5 of the row norm bound), the cell epilogue against nn.LSTMCell fp32 semantics evaluated in float64 — gates
+    (i, f, g, o), c' = f (k c) + i g, h' = o tanh(c') — to 2e-5 (the hardware exp / rcp forms of csrc/atr_cell.h), ragged row
+    counts (rows past N are neither read beyond the last row nor written), and a player without the cell leaves h / c alone."""
+    from active_tracking_rl_amd import fused
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n)
+    R, Fd = 128, 256
+    K = Fd + R
+    fh_store = torch.randn(2, n, K + 32, device=dev) * 0.5           # (row stride > K: a column block of wider rows)
+    fh = fh_store[:, :, :K]
+    w = torch.randn(2, 4 * R, K, device=dev) * 0.05
+    bias = [torch.randn(4 * R, device=dev) * 0.1 for _ in range(2)]
+    c_prev = [torch.randn(n, R, device=dev) for _ in range(2)]
+    done = (torch.rand(n, device=dev) < 0.2).to(torch.uint8)
+    pre = torch.full((2, n, 4 * R), float("nan"), device=dev)
+    guard = torch.full((2, 4 * R), 5.0, device=dev)                   # (allocated right behind: rows past N must not land here)
+    h = [torch.full((n, R), float("nan"), device=dev) for _ in range(2)]
+    c = [torch.full((n, R), float("nan"), device=dev) for _ in range(2)]
+    fused.gate_cell(fh, w, bias, pre, c_prev, done, h, c, cell=(True, False))
+    torch.cuda.synchronize()
+    ref = torch.bmm(fh.double(), w.double().transpose(1, 2))
+    assert float((pre.double() - ref).abs().max()) < 2e-5
+    assert torch.isnan(h[1]).all() and torch.isnan(c[1]).all()       # player 1: product only
+    assert torch.equal(guard, torch.full_like(guard, 5.0))
+    g = pre[0].double() + bias[0].double()                            # (the cell consumes the kernel's own fp32 product)
+    i_, f_, g_, o_ = g[:, :R].sigmoid(), g[:, R:2 * R].sigmoid(), g[:, 2 * R:3 * R].tanh(), g[:, 3 * R:].sigmoid()
+    k = (done == 0).double().unsqueeze(1)
+    cn = f_ * (k * c_prev[0].double()) + i_ * g_
+    hn = o_ * cn.tanh()
+    assert float((c[0].double() - cn).abs().max()) < 2e-5 and float((h[0].double() - hn).abs().max()) < 2e-5
+    fused.gate_cell(fh, w, bias, pre, c_prev, done, h, c, cell=(True, True))
+    torch.cuda.synchronize()
+    assert not torch.isnan(h[1]).any() and not torch.isnan(c[1]).any()
+
+
 def test_mfma_actor_step_keeps_its_activated_gates_store_when_preacts_are_on():
     """ATR_MFMA_MIN_ROWS <= N (bench.py --actor-step mfma) with the default store_preacts: _act_step takes the per-player MFMA
     actor step, which writes acts[i] — new_cache must not have dropped that store for the one-GEMM step's pre-activation store

@@ -188,6 +188,26 @@ def test_cooperative_two_launch_step_matches_the_oracle(name):
         case.close()
 
 
+@pytest.mark.parametrize("name,schedule", [("pzr4096_rank7", "synchronous"), ("pzr4096_rank0", "pipelined"),
+                                           ("adv2048_mixed_rank7", "synchronous"), ("pzr1024_timelimit37", "pipelined"),
+                                           ("mazenav1024_rank7", "synchronous"), ("ram1024", "pipelined")])
+def test_gate_product_with_the_cell_in_its_epilogue_matches_the_oracle(name, schedule):
+    """Round 6: the one-GEMM step's LSTMCell product as this build's own MFMA kernel with the tracker's cell as its epilogue
+    (atr_gate_cell, csrc/gate_cell_hip.hip; ATR_GATE_CELL=1) and k_act_step told that the tracker's hidden row is already there
+    (ig[0] = NULL): the replayed timed region — synchronous and pipelined graphs, tat and maze-lstm pairs, Ram / Nav targets, a
+    37-step TimeLimit, the last rank's env ids — against the oracle, every observation / reward / done of every env."""
+    case, min_done = _case(name)
+    try:
+        m = case.player.model
+        m.gate_cell_kernel, m.gate_cell_min_rows = True, 1024
+        (_synchronous if schedule == "synchronous" else _pipelined)(case)
+        assert m.gate_cell_seen or schedule == "pipelined"       # (the pipelined schedule's replicas do the stepping)
+        assert case.env.core.faults() == 0
+        case.final(min_done)
+    finally:
+        case.close()
+
+
 def test_cooperative_step_on_its_own_half_of_the_cus_matches_the_oracle_512():
     """... and under the pipelined schedule on the CU-partitioned stream pair (the rollout's 128 CUs to itself: the only form of
     that schedule in which the cooperative step may run — train.PipelinedIteration._set_coop_grid)."""

@@ -30,18 +30,32 @@ ap.add_argument("--burn-in", type=int, default=0,
                      "restored): the env shard keeps advancing under the initial policy, so the envs' episode phases drift apart — "
                      "what PipelinedIteration.tune_streams() does as a side effect (2 passes x ~7 stream pairs x 10 iterations)")
 ap.add_argument("--no-tune", action="store_true", help="pipelined: skip tune_streams() (and with it its ~140 untrained iterations)")
+ap.add_argument("--trace-seeds", type=int, nargs="*", default=[],
+                help="for these seeds also print, every --trace-every iterations up to --trace-iters: the tracker's entropy per step, "
+                     "value loss, policy loss (the iteration's loss statistics), its action histogram over the rollout just made "
+                     "and its mean reward per step")
+ap.add_argument("--lr", type=float, default=None, help="learning rate (default: main.py's 1e-3)")
+ap.add_argument("--entropy", type=float, default=None, help="the tracker's entropy weight (default: main.py's 0.01)")
+ap.add_argument("--trace-iters", type=int, default=200)
+ap.add_argument("--trace-every", type=int, default=10)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 print("# %s  %d envs  %s  train-mode %d  %d iterations; mean tracker (target) reward per env step over the 100 iterations before "
       "each checkpoint" % (a.env, a.num_envs, a.network, a.train_mode, a.iters), flush=True)
 marks = list(range(a.every, a.iters + 1, a.every))
-print("# burn-in %d untrained iterations%s" % (a.burn_in, "; pipelined without tune_streams()" if a.no_tune else ""), flush=True)
+print("# burn-in %d untrained iterations%s%s%s" % (a.burn_in, "; pipelined without tune_streams()" if a.no_tune else "",
+                                                   "; lr %g" % a.lr if a.lr is not None else "",
+                                                   "; entropy weight %g" % a.entropy if a.entropy is not None else ""), flush=True)
 print("# schedule seed " + " ".join("@%d" % m for m in marks), flush=True)
 final = {}
 for sched in a.schedules:
     for seed in a.seeds:
         args = default_args(env=a.env, network=a.network, aux="reward" if "tat" in a.network else "none",
                             train_mode=a.train_mode, num_envs=a.num_envs, seed=seed)
+        if a.lr is not None:
+            args.lr = a.lr
+        if a.entropy is not None:
+            args.entropy = a.entropy
         player, opt = make_player(args, dev)
         pipelined = sched != "synchronous"
         if pipelined:
@@ -83,6 +97,17 @@ for sched in a.schedules:
                             rew_acc += src.reward.mean(0)
                 else:
                     rew_acc += player.reward.mean(0)
+            if seed in a.trace_seeds and i <= a.trace_iters and (i % a.trace_every == 0 or i <= 5):
+                if pipelined:
+                    it.finish()
+                torch.cuda.synchronize()
+                src = it.players[(it.i - 1) & 1] if pipelined else player
+                st = [x.detach().float().reshape(-1).tolist() for x in it.stats]        # policy, value, entropy [, aux]: per player
+                acts = src._actions_buf[:, 0].reshape(-1)
+                hist = torch.bincount(acts, minlength=4).float() / acts.numel()
+                print("trace %-17s seed %2d it %4d  entropy/step %.4f  value loss %.4f  policy loss %+.4f  tracker actions %s  reward/step %+.3f"
+                      % (sched, seed, i, st[2][0] / args.num_steps, st[1][0], st[0][0], " ".join("%.2f" % h for h in hist.tolist()),
+                         src.reward.mean(0)[0].item()), flush=True)
             if i in marks:
                 if pipelined:
                     it.finish()
