@@ -69,6 +69,7 @@ struct DevState {
     // wanted next (current + 3, current + 4) then always fall on dead ones — so the pass and k_pregrow need no ordering
     // between them beyond the tag's release / acquire: a pass that finds another tag grows the maze itself, as before.
     uint32_t *np_mt;    // [N][kNpStateWords] per-env MT19937 state (t2d_np_attach: the generator draws from numpy-legacy streams), else null
+    unsigned char *np_nav;  // [N][kNavBytes] Navigator plan + A* scratch (t2d_np_attach on a handle with Nav targets), else null
     uint32_t *g_maps;   // [4][N][256]
     uint32_t *g_ep;     // [4][N]
     uint32_t *pg_stats; // [4] pass: mazes taken from the pool, mazes grown inline; k_pregrow: mazes grown, entries left alone
@@ -88,7 +89,17 @@ constexpr int kNpStateWords = 640;           // 624 words of MT19937 state, the 
 // ... of which two words carry per-env facts of a numpy-stream handle: [625] the squared distance of the env's last TERMINAL
 // step (info['distance'] of a step whose in-launch auto-reset has already replaced d2), [626] != 0: the env's target is the
 // reference's RamAgent, stepped from this stream by k_ram_np (t2d_np_attach on a handle with T2D_TGT_RAM envs)
-constexpr int kNpTermD2 = 625, kNpRamFlag = 626;
+constexpr int kNpTermD2 = 625, kNpRamFlag = 626;     // [626]: 1 = RamAgent, 2 = Navigator (heap A*), stepped by k_tgt_np
+// ... and, Navigator envs: [627] plan length, [628] plan cursor (a_i), [629] nav goal (r | c << 8). The plan's actions and the
+// A* search's arrays live in a per-env scratch block (DevState::np_nav, t2d_np_attach):
+constexpr int kNpPlanLen = 627, kNpPlanCur = 628, kNpNavGoal = 629;
+constexpr int kNavPlanCap = 4096, kNavNodeCap = 32768, kNavHeapCap = 16384, kNavCells = 82 * 82;
+// per-env scratch layout (bytes): plan u8 [4096] | nodes u64 [32768] | heap f f64 [16384] | heap node u32 [16384] |
+// in_frontier i32 [6724 -> 6728] | explored u8 [6724 -> 6728]
+constexpr size_t kNavOffNodes = kNavPlanCap, kNavOffHf = kNavOffNodes + (size_t)kNavNodeCap * 8,
+                 kNavOffHn = kNavOffHf + (size_t)kNavHeapCap * 8, kNavOffInf = kNavOffHn + (size_t)kNavHeapCap * 4,
+                 kNavOffExp = kNavOffInf + (size_t)6728 * 4, kNavBytes = kNavOffExp + 6728;
+constexpr uint32_t kFaultNavOverflow = 16u;      // fault bit 4: the device A* ran out of node / heap / plan space
 // The reward is a pure function of the integer squared distance (<= 2 * 81^2) and the mode's w_p in {0, 1, -0.5}
 // (track_1v1.py:96-104,147-152): the float64 formula is evaluated once per handle into a table by the same
 // reward_f64 device code the exhaustive parity test checks against the oracle; the step kernel then replaces a
@@ -707,6 +718,192 @@ __device__ __forceinline__ void generate_episode_np(NpStream &rs, uint16_t *perm
     d2 = (uint32_t)(dr * dr + dc * dc);
 }
 
+// ---- the reference's Navigator on the device: AstarSolver (Astar_solver.py:42-173) with heapq's exact sift order -----------
+// What makes the reference's A* paths ITS paths are accidents of its implementation, all restated here (as in the host
+// restatement csrc/np_mode.cpp, which the 49 reference searches of tests/golden/astar.npz pin): heap entries [f, node] compared
+// like Python lists — by f = path cost + float64 Euclidean distance, ties by Node.__lt__ = smaller path cost (:30-32,55) —
+// heapq._siftdown / _siftup's exact order, children in action order 0..3 with a wall bump returning the parent's state
+// (skipped as explored, :138-145,170-171), and the INVERTED replace test (:146-147: a queued node that is CHEAPER than the
+// child is replaced by it, every match in array order re-sifted). One lane runs the search (it is a sequential algorithm on
+// a heap); nodes, heap and the two cell maps live in the env's scratch block in device memory.
+struct AstarNp {
+    unsigned long long *nodes;   // r (7) | c (7) << 7 | action (2) << 14 | cost (16) << 16 | prev (32) << 32
+    double *hf;
+    uint32_t *hn;
+    int32_t *inf;                // cell -> node index or -1 (Frontier.state_nodes)
+    uint8_t *expl;
+    int nn, hs, gr, gc;
+    bool overflow;
+    __device__ __forceinline__ static int n_r(unsigned long long v) { return (int)(v & 127u); }
+    __device__ __forceinline__ static int n_c(unsigned long long v) { return (int)((v >> 7) & 127u); }
+    __device__ __forceinline__ static int n_act(unsigned long long v) { return (int)((v >> 14) & 3u); }
+    __device__ __forceinline__ static int n_cost(unsigned long long v) { return (int)((v >> 16) & 0xffffu); }
+    __device__ __forceinline__ static uint32_t n_prev(unsigned long long v) { return (uint32_t)(v >> 32); }
+    __device__ __forceinline__ int add_node(int r, int c, int act, int cost, uint32_t prev)
+    {
+        if (nn >= kNavNodeCap) { overflow = true; return nn - 1; }
+        nodes[nn] = (unsigned long long)r | ((unsigned long long)c << 7) | ((unsigned long long)act << 14) |
+                    ((unsigned long long)cost << 16) | ((unsigned long long)prev << 32);
+        return nn++;
+    }
+    __device__ __forceinline__ double f_of(int n) const      // :151-153: norm of an int vector = sqrt of an exact dot product
+    {
+        const unsigned long long v = nodes[n];
+        const double dr = (double)(n_r(v) - gr), dc = (double)(n_c(v) - gc);
+        return (double)n_cost(v) + sqrt(dr * dr + dc * dc);
+    }
+    __device__ __forceinline__ bool less(double fa, uint32_t na, double fb, uint32_t nb) const
+    {
+        if (fa != fb) return fa < fb;
+        return n_cost(nodes[na]) < n_cost(nodes[nb]);
+    }
+    __device__ void sift_down(int start, int p)               // heapq._siftdown: towards the root
+    {
+        const double f = hf[p];
+        const uint32_t n = hn[p];
+        while (p > start) {
+            const int parent = (p - 1) >> 1;
+            if (!less(f, n, hf[parent], hn[parent])) break;
+            hf[p] = hf[parent]; hn[p] = hn[parent];
+            p = parent;
+        }
+        hf[p] = f; hn[p] = n;
+    }
+    __device__ void sift_up(int p)                            // heapq._siftup: to a leaf, then back
+    {
+        const int end = hs, start = p;
+        const double f = hf[p];
+        const uint32_t n = hn[p];
+        int child = 2 * p + 1;
+        while (child < end) {
+            const int right = child + 1;
+            if (right < end && !less(hf[child], hn[child], hf[right], hn[right])) child = right;
+            hf[p] = hf[child]; hn[p] = hn[child];
+            p = child;
+            child = 2 * p + 1;
+        }
+        hf[p] = f; hn[p] = n;
+        sift_down(start, p);
+    }
+    __device__ void push(int n)                               // Frontier.add
+    {
+        if (hs >= kNavHeapCap) { overflow = true; return; }
+        hf[hs] = f_of(n); hn[hs] = (uint32_t)n;
+        hs++;
+        sift_down(0, hs - 1);
+        const unsigned long long v = nodes[n];
+        inf[n_r(v) * 82 + n_c(v)] = n;
+    }
+    __device__ int pop()                                      // Frontier.pop
+    {
+        const double lf = hf[hs - 1];
+        const uint32_t ln = hn[hs - 1];
+        hs--;
+        uint32_t top = ln;
+        if (hs > 0) {
+            top = hn[0];
+            hf[0] = lf; hn[0] = ln;
+            sift_up(0);
+        }
+        const unsigned long long v = nodes[top];
+        inf[n_r(v) * 82 + n_c(v)] = -1;
+        return (int)top;
+    }
+    __device__ void replace(int n)                            // Frontier.replace: every match, in array order, re-sifted
+    {
+        const unsigned long long v = nodes[n];
+        const int r = n_r(v), c = n_c(v);
+        for (int i = 0; i < hs; i++) {
+            const unsigned long long u = nodes[hn[i]];
+            if (n_r(u) == r && n_c(u) == c) {
+                hf[i] = f_of(n); hn[i] = (uint32_t)n;
+                sift_down(0, i);
+                inf[r * 82 + c] = n;
+            }
+        }
+    }
+};
+
+// AstarSolver(start, [0,1,2,3], maze, goal).get_actions() by lane 0 of the wave; every lane gets the result: the plan's length
+// (0: start == goal), or -1 when there is no path. plan: the env's action list (u8 [kNavPlanCap]).
+__device__ int astar_np(const uint32_t *tile, unsigned char *scratch, uint32_t from, uint32_t goal, int lane, uint32_t *faults)
+{
+    unsigned char *plan = scratch;
+    int32_t *inf = reinterpret_cast<int32_t *>(scratch + kNavOffInf);
+    uint8_t *expl = scratch + kNavOffExp;
+    for (int i = lane; i < kNavCells; i += 64) { inf[i] = -1; expl[i] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wave_lds_sync();
+    int result = -1;
+    if (lane == 0) {
+        AstarNp a;
+        a.nodes = reinterpret_cast<unsigned long long *>(scratch + kNavOffNodes);
+        a.hf = reinterpret_cast<double *>(scratch + kNavOffHf);
+        a.hn = reinterpret_cast<uint32_t *>(scratch + kNavOffHn);
+        a.inf = inf; a.expl = expl; a.nn = 0; a.hs = 0; a.overflow = false;
+        a.gr = (int)(goal & 0xffu); a.gc = (int)((goal >> 8) & 0xffu);
+        a.push(a.add_node((int)(from & 0xffu), (int)((from >> 8) & 0xffu), 0, 0, 0xffffffffu));
+        int solution = -1;
+        while (a.hs > 0 && !a.overflow) {
+            const int n = a.pop();
+            const unsigned long long v = a.nodes[n];
+            const int r = AstarNp::n_r(v), c = AstarNp::n_c(v);
+            if (r == a.gr && c == a.gc) { solution = n; break; }
+            expl[r * 82 + c] = 1;
+            const int cost = AstarNp::n_cost(v) + 1;
+            for (int act = 0; act < 4; act++) {
+                int cr = r + (act == 0 ? -1 : (act == 1 ? 1 : 0)), cc = c + (act == 2 ? -1 : (act == 3 ? 1 : 0));
+                if (tile_bit(tile, cr, cc) != 0u) { cr = r; cc = c; }          // _next_state: a wall bump returns the same state
+                const int k = cr * 82 + cc;
+                const int q = inf[k];
+                if (!expl[k] && q < 0) {
+                    a.push(a.add_node(cr, cc, act, cost, (uint32_t)n));
+                } else if (q >= 0 && AstarNp::n_cost(a.nodes[q]) < cost) {
+                    a.replace(a.add_node(cr, cc, act, cost, (uint32_t)n));      // the reference's (inverted) test, :146-147
+                }
+            }
+        }
+        if (a.overflow) { atomicOr(faults, kFaultNavOverflow); solution = -1; }
+        if (solution >= 0) {
+            const int len = AstarNp::n_cost(a.nodes[solution]);       // unit step cost: the path's length
+            if (len > kNavPlanCap) { atomicOr(faults, kFaultNavOverflow); }
+            else {
+                result = len;
+                int i = len;
+                for (uint32_t n = (uint32_t)solution; AstarNp::n_prev(a.nodes[n]) != 0xffffffffu; n = AstarNp::n_prev(a.nodes[n]))
+                    plan[--i] = (unsigned char)AstarNp::n_act(a.nodes[n]);
+            }
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(result);
+}
+
+// The planning loop shared by Navigator.reset and Navigator.step (navigator.py:22-38,46-62): A* to the goal; no path, or an
+// empty one (the target stands on the goal) -> a fresh goal = sample_goal(1)[0] (a whole permutation of the free cells), up to
+// six failures, then plan B = ten random actions. Leaves the plan in the env's scratch, its length, cursor 0 and the goal in
+// the stream block's side words.
+__device__ void nav_plan_np(NpStream &rs, uint16_t *perm, const uint32_t *tile, int side, unsigned char *scratch, uint32_t *side_words,
+                            uint32_t from, uint32_t goal, int lane, uint32_t *faults)
+{
+    int count_res = 0, len;
+    for (;;) {
+        len = astar_np(tile, scratch, from, goal, lane, faults);
+        if (len > 0) break;
+        if (++count_res > 5) { len = -1; break; }
+        const FreeIndex fi = build_free_index(tile, side, lane);
+        rs.permutation(fi.total, perm);                          // choice(len, size=1, replace=False)
+        goal = select_free(tile, side, fi, uni((int)perm[0]), lane);
+    }
+    if (len < 0) {                                               // plan B: np.random.choice(all_actions, 10)
+        len = 10;
+        for (int i = 0; i < 10; i++) {
+            const uint32_t a = rs.bounded(3u);
+            if (lane == 0) scratch[i] = (unsigned char)a;
+        }
+    }
+    if (lane == 0) { side_words[kNpPlanLen] = (uint32_t)len; side_words[kNpPlanCur] = 0u; side_words[kNpNavGoal] = goal; }
+}
+
 // The generator pass of a numpy-stream handle: ONE wave per env, its consumed slots refilled in episode order (the stream is
 // sequential: episode k + 1's draws follow episode k's).
 constexpr int kNpWaves = 2;
@@ -734,7 +931,8 @@ __global__ __launch_bounds__(64 * kNpWaves) void k_gen_np(DevState s, uint32_t l
     }
     if (!need0 && !need1) return;
     uint32_t *mt_g = s.np_mt + (size_t)e * kNpStateWords;
-    const bool ram = inter && uni(mt_g[kNpRamFlag]) != 0u;
+    const uint32_t tflag = inter ? uni(mt_g[kNpRamFlag]) : 0u;
+    const bool ram = tflag == 1u, navig = tflag == 2u;
     NpStream rs;
     rs.mt = mts[wave]; rs.lane = lane;
     for (int i = lane; i < 624; i += 64) rs.mt[i] = mt_g[i];
@@ -750,6 +948,9 @@ __global__ __launch_bounds__(64 * kNpWaves) void k_gen_np(DevState s, uint32_t l
         uint32_t pos, goals, d2;
         generate_episode_np(rs, perms[wave], tiles[wave], lane, cfg, pos, goals, d2);
         const uint32_t plan0 = ram ? ram_reset(rs) : 0u;        // RamAgent.reset(): randint(1, 10), then choice(4, n)
+        if (navig)      // Navigator.reset(init_states[1], goal_states[1], maze_generator) (track_1v1.py:139-141, navigator.py:43-63)
+            nav_plan_np(rs, perms[wave], tiles[wave], side_of_cfg(cfg), s.np_nav + (size_t)e * kNavBytes, mt_g, pos >> 16, goals >> 16,
+                        lane, s.faults);
         wave_lds_sync();
         store_slot_map(s, so, tiles[wave], lane, cfg, pos);
         if (lane == 0) {
@@ -768,16 +969,46 @@ __global__ __launch_bounds__(64 * kNpWaves) void k_gen_np(DevState s, uint32_t l
 // action and leave; the env whose plan runs out on this step brings its MT19937 state into LDS and draws — the coin, on heads
 // the action that OVERRIDES the one being returned and the run length, on tails a fresh length and plan — exactly the words
 // the reference's global stream would have handed RamAgent at this point of the env's life.
+// Navigator envs (flag 2; Navigator.step, navigator.py:11-41): the next action of the plan; a plan that is used up is replaced
+// first — a fresh goal = sample_goal(1)[0] (a whole permutation of the free cells), then the planning loop from the target's
+// current cell on the env's map (heap A*, retries, plan B: nav_plan_np).
 __global__ __launch_bounds__(64 * kNpWaves) void k_ram_np(DevState s, const void *act_in, void *act_out, int adt)
 {
     __shared__ uint32_t mts[kNpWaves][624];
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[kNpWaves][kTileWords];
+    __shared__ uint16_t perms[kNpWaves][6400];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = uni((int)(threadIdx.x >> 6));
     const int e = (int)blockIdx.x * kNpWaves + wave;
     if (e >= s.n) return;
     uint32_t *mt_g = s.np_mt + (size_t)e * kNpStateWords;
     long long a = 0;
-    if (uni(mt_g[kNpRamFlag]) == 0u) {
+    const uint32_t tflag = uni(mt_g[kNpRamFlag]);
+    if (tflag == 2u) {
+        unsigned char *scratch = s.np_nav + (size_t)e * kNavBytes;
+        uint32_t cur = uni(mt_g[kNpPlanCur]);
+        if (cur >= uni(mt_g[kNpPlanLen])) {
+            NpStream rs;
+            rs.mt = mts[wave]; rs.lane = lane;
+            for (int i = lane; i < 624; i += 64) rs.mt[i] = mt_g[i];
+            rs.pos = (int)mt_g[624];
+            reinterpret_cast<uint4 *>(tiles[wave])[lane] = reinterpret_cast<const uint4 *>(s.maps + (size_t)e * kTileWords)[lane];
+            wave_lds_sync();
+            const int side = (int)(uni(s.cnt[e]) >> 24);
+            const FreeIndex fi = build_free_index(tiles[wave], side, lane);
+            rs.permutation(fi.total, perms[wave]);               // sample_goal(1): choice(len, size=1, replace=False)
+            const uint32_t goal = select_free(tiles[wave], side, fi, uni((int)perms[wave][0]), lane);
+            nav_plan_np(rs, perms[wave], tiles[wave], side, scratch, mt_g, uni(s.pos[e]) >> 16, goal, lane, s.faults);
+            wave_lds_sync();
+            for (int i = lane; i < 624; i += 64) mt_g[i] = rs.mt[i];
+            if (lane == 0) mt_g[624] = (uint32_t)rs.pos;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            wave_lds_sync();
+            cur = 0u;
+        }
+        a = (long long)scratch[cur];
+        if (lane == 0) mt_g[kNpPlanCur] = cur + 1u;
+    } else if (tflag == 0u) {
         if (act_in) a = adt == T2D_ACT_U8 ? (long long)reinterpret_cast<const uint8_t *>(act_in)[e]
                       : (adt == T2D_ACT_I32 ? (long long)reinterpret_cast<const int32_t *>(act_in)[e]
                                             : reinterpret_cast<const long long *>(act_in)[e]);
@@ -2183,7 +2414,7 @@ extern "C" int t2d_destroy(t2d_handle *h)
         if (p) (void)hipFree(p);
     if (h->coop_ctl) (void)hipFree(h->coop_ctl);
     if (h->np_act) (void)hipFree(h->np_act);
-    for (void *p : {(void *)s.g_maps, (void *)s.g_ep, (void *)s.pg_stats, (void *)s.np_mt})
+    for (void *p : {(void *)s.g_maps, (void *)s.g_ep, (void *)s.pg_stats, (void *)s.np_mt, (void *)s.np_nav})
         if (p) (void)hipFree(p);
     if (h->pg_stream) {
         (void)hipStreamSynchronize(h->pg_stream);
@@ -2434,13 +2665,13 @@ extern "C" int t2d_np_attach(t2d_handle *h, const uint32_t *states_host)
 {
     if (!h || !states_host) return fail(T2D_ERR_INVALID, "t2d_np_attach: null argument");
     if (h->primed || h->reset_done) return fail(T2D_ERR_STATE, "t2d_np_attach: attach the streams before the first t2d_reset");
-    if (h->has_navmode || h->has_rpfmode)
-        return fail(T2D_ERR_INVALID, "t2d_np_attach: scripted Nav / RPF targets plan with the reference's heap A* between resets: "
-                                     "those stay on the host streams (environment.NumpyVecEnv); Adv / PZR / Far / Ext / Ram only");
-    if (h->has_ram && h->s.auto_reset)
-        return fail(T2D_ERR_INVALID, "t2d_np_attach: a Ram target draws from the stream between resets, so its next episode cannot "
-                                     "be generated ahead of the in-launch auto-reset: create the handle with auto_reset = 0 and "
-                                     "restart finished envs with t2d_reset(mask = done)");
+    if (h->has_rpfmode)
+        return fail(T2D_ERR_INVALID, "t2d_np_attach: the RPF patrol target plans on a map that differs from the env's own: it stays on "
+                                     "the host streams (environment.NumpyVecEnv); Adv / PZR / Far / Ext / Ram / Nav only");
+    if ((h->has_ram || h->has_navmode) && h->s.auto_reset)
+        return fail(T2D_ERR_INVALID, "t2d_np_attach: a Ram / Nav target draws from the stream between resets, so its next episode "
+                                     "cannot be generated ahead of the in-launch auto-reset: create the handle with auto_reset = 0 "
+                                     "and restart finished envs with t2d_reset(mask = done)");
     DeviceGuard guard(h->device);
     const int n = h->s.n;
     std::vector<uint32_t> padded((size_t)n * kNpStateWords, 0u);
@@ -2448,23 +2679,74 @@ extern "C" int t2d_np_attach(t2d_handle *h, const uint32_t *states_host)
         if (states_host[(size_t)i * 625 + 624] > 624u) return fail(T2D_ERR_INVALID, "t2d_np_attach: env %d: read position > 624", i);
         std::memcpy(&padded[(size_t)i * kNpStateWords], states_host + (size_t)i * 625, 625 * sizeof(uint32_t));
     }
-    if (h->has_ram) {
-        // The Ram envs' target is stepped by k_ram_np from the env's own stream; to the step kernels their mode becomes "the
-        // target's action comes from outside" (T2D_TGT_EXT: w_p = 0 either way, track_1v1.py:147-152) and the Philox Ram code
-        // is not selected (has_ram off)
+    if (h->has_ram || h->has_navmode) {
+        // The Ram / Nav envs' target is stepped by k_ram_np from the env's own stream; to the step kernels their mode becomes "the
+        // target's action comes from outside" (T2D_TGT_EXT: w_p = 0 either way, track_1v1.py:147-152) and neither the Philox Ram
+        // code nor the BFS Navigator of the device generators is selected (has_ram / has_nav off)
         std::vector<uint32_t> cfg((size_t)n);
         HIP_TRY(hipMemcpy(cfg.data(), h->s.cfg, cfg.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; i++)
-            if (((cfg[(size_t)i] >> 2) & 7u) == (uint32_t)TGT_RAM) {
+        for (int i = 0; i < n; i++) {
+            const uint32_t tm = (cfg[(size_t)i] >> 2) & 7u;
+            if (tm == (uint32_t)TGT_RAM || tm == (uint32_t)TGT_NAV) {
                 cfg[(size_t)i] = (cfg[(size_t)i] & ~(7u << 2)) | ((uint32_t)T2D_TGT_EXT << 2);
-                padded[(size_t)i * kNpStateWords + kNpRamFlag] = 1u;
+                padded[(size_t)i * kNpStateWords + kNpRamFlag] = tm == (uint32_t)TGT_RAM ? 1u : 2u;
             }
+        }
         HIP_TRY(hipMemcpy(h->s.cfg, cfg.data(), cfg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         if (!h->np_act) HIP_TRY(hipMalloc(&h->np_act, (size_t)n * 8));
-        h->np_inter = true; h->has_ram = false;
+        if (h->has_navmode && !h->s.np_nav) HIP_TRY(hipMalloc((void **)&h->s.np_nav, (size_t)n * kNavBytes));
+        h->np_inter = true; h->has_ram = false; h->has_nav = false; h->has_navmode = false;
     }
     if (!h->s.np_mt) HIP_TRY(hipMalloc((void **)&h->s.np_mt, padded.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(h->s.np_mt, padded.data(), padded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return T2D_OK;
+}
+
+// The device A* alone on a caller's maze (one wave; for the known-answer tests against the reference's searches).
+__global__ __launch_bounds__(64) void k_astar_probe(const uint32_t *tile_g, unsigned char *scratch, uint32_t from, uint32_t goal,
+                                                    int *len_out, uint32_t *faults)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile[kTileWords];
+    const int lane = (int)threadIdx.x;
+    reinterpret_cast<uint4 *>(tile)[lane] = reinterpret_cast<const uint4 *>(tile_g)[lane];
+    wave_lds_sync();
+    const int len = astar_np(tile, scratch, from, goal, lane, faults);
+    if (lane == 0) *len_out = len;
+}
+
+extern "C" int t2d_np_astar_device(int device, const uint8_t *maze, int32_t side, const int32_t start[2], const int32_t goal[2],
+                                   int32_t *actions, int32_t max_len, int32_t *n, int32_t *solvable)
+{
+    if (!maze || !start || !goal || !actions || !n || !solvable || side < 3 || side > 82)
+        return fail(T2D_ERR_INVALID, "t2d_np_astar_device: bad argument");
+    DeviceGuard guard(device);
+    std::vector<uint32_t> tile((size_t)kTileWords, 0u);
+    for (int r = 0; r < side; r++)
+        for (int c = 0; c < side; c++)
+            if (maze[r * side + c]) tile[(size_t)(r * kRowWords + (c >> 5))] |= 1u << (c & 31);
+    uint32_t *d_tile = nullptr, *d_faults = nullptr;
+    unsigned char *d_scr = nullptr;
+    int *d_len = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_tile, kTileWords * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&d_scr, kNavBytes));
+    HIP_TRY(hipMalloc((void **)&d_len, sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&d_faults, sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(d_tile, tile.data(), kTileWords * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_faults, 0, sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_astar_probe, dim3(1), dim3(64), 0, nullptr, d_tile, d_scr, (uint32_t)start[0] | ((uint32_t)start[1] << 8),
+                       (uint32_t)goal[0] | ((uint32_t)goal[1] << 8), d_len, d_faults);
+    int len = -1;
+    uint32_t faults = 0;
+    hipError_t e1 = hipMemcpy(&len, d_len, sizeof(int), hipMemcpyDeviceToHost);
+    hipError_t e2 = hipMemcpy(&faults, d_faults, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    std::vector<unsigned char> plan((size_t)(len > 0 ? len : 0));
+    hipError_t e3 = len > 0 ? hipMemcpy(plan.data(), d_scr, (size_t)len, hipMemcpyDeviceToHost) : hipSuccess;
+    (void)hipFree(d_tile); (void)hipFree(d_scr); (void)hipFree(d_len); (void)hipFree(d_faults);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(T2D_ERR_HIP, "t2d_np_astar_device: copy back failed");
+    if (faults) return fail(T2D_ERR_STATE, "t2d_np_astar_device: the search ran out of node / heap / plan space (fault 0x%x)", faults);
+    *solvable = len >= 0 ? 1 : 0;
+    *n = len > 0 ? len : 0;
+    for (int i = 0; i < len && i < max_len; i++) actions[i] = plan[(size_t)i];
     return T2D_OK;
 }
 

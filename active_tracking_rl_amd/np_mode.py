@@ -9,7 +9,7 @@ from . import registry, vec_env
 
 NP_SYMBOLS = ("t2d_np_create", "t2d_np_destroy", "t2d_np_last_error", "t2d_np_seed", "t2d_np_reset",
               "t2d_np_target_action", "t2d_np_get_plan", "t2d_np_astar", "t2d_np_draw", "t2d_np_reset_many",
-              "t2d_np_target_actions", "t2d_np_mt_state", "t2d_np_attach", "t2d_np_terminal_d2")
+              "t2d_np_target_actions", "t2d_np_mt_state", "t2d_np_attach", "t2d_np_terminal_d2", "t2d_np_astar_device")
 _ready = False
 
 
@@ -37,6 +37,8 @@ def _lib():
         L.t2d_np_draw.argtypes = [vp, i32, u32, u32, vp]
         L.t2d_np_mt_state.restype = i32
         L.t2d_np_mt_state.argtypes = [u32, vp]
+        L.t2d_np_astar_device.restype = i32
+        L.t2d_np_astar_device.argtypes = [i32, vp, i32, vp, vp, vp, i32, vp, vp]
         L.t2d_np_attach.restype = i32
         L.t2d_np_attach.argtypes = [vp, vp]
         L.t2d_np_reset_many.restype = i32
@@ -166,12 +168,28 @@ def attach_device_streams(core, seeds):
     csrc/track2d_hip.hip k_gen_np). Before the first reset. Adv / PZR / Far (and host-driven Ext) targets on any handle; Ram
     targets (whose draws interleave with the resets: RamAgent, navigator.py:73-93) on handles created with auto_reset=False — the
     episode of a restarted env is then drawn inside reset(mask) and RamAgent.step() runs on the device ahead of every step
-    (k_ram_np). Nav / RPF targets are refused (heap A* between resets: host streams)."""
+    (k_ram_np), as does Navigator.step() for Nav targets, with the reference's heap A* restated on the device. RPF targets are
+    refused (host streams)."""
     assert len(seeds) == core.num_envs
     st = np.ascontiguousarray(mt_states(seeds))
     rc = _lib().t2d_np_attach(core.h, _ptr(st))
     if rc != 0:
         raise NpError("t2d_np_attach failed (%d): %s" % (rc, core.L.t2d_last_error().decode()))
+
+
+def astar_device(maze, start, goal, max_len=8192, device=0):
+    """astar() run by the device restatement (csrc/track2d_hip.hip astar_np): -> (solvable, actions int32 [n])."""
+    maze = np.ascontiguousarray(maze, np.uint8)
+    side = maze.shape[0]
+    assert maze.shape == (side, side)
+    st, gl = np.asarray(start, np.int32).reshape(2).copy(), np.asarray(goal, np.int32).reshape(2).copy()
+    acts = np.zeros(max_len, np.int32)
+    n, ok = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    rc = _lib().t2d_np_astar_device(int(device), _ptr(maze), side, _ptr(st), _ptr(gl), _ptr(acts), max_len, _ptr(n), _ptr(ok))
+    if rc != 0:
+        from . import vec_env
+        raise NpError("t2d_np_astar_device failed (%d): %s" % (rc, vec_env.load_library().t2d_last_error().decode()))
+    return bool(ok[0]), acts[:int(n[0])].copy()
 
 
 def astar(maze, start, goal, max_len=8192):

@@ -67,8 +67,16 @@ int t2d_np_mt_state(uint32_t seed, uint32_t out[625]);
  *   - t2d_step / t2d_step_u8 first run RamAgent.step() for every Ram env from its stream (csrc k_ram_np) and hand the env
  *     step that action as the target's (track_1v1.py:80-82); the caller's target action is used for the other envs only;
  *   - the policy-fused step (atr_act_env_step, atr_coop_env_step) and t2d_rollout_random refuse the handle.
- * t2d_get_target reports the Ram plan as for the Philox generators. Nav / RPF targets (heap A* between resets) stay on the
- * host streams, environment.NumpyVecEnv. */
+ * t2d_get_target reports the Ram plan as for the Philox generators.
+ * T2D_TGT_NAV envs (round 6; Navigator + AstarSolver, G/envs/navigator.py:5-70, G/envs/Astar_solver.py:42-173) likewise, under
+ * the same conditions: Navigator.reset's plan is made inside t2d_reset after init_maze, Navigator.step runs ahead of every
+ * step launch — when the plan is used up: sample_goal(1) (a whole permutation of the free cells), then the planning loop (A*,
+ * up to six failures with fresh goals, plan B = ten random actions). The search is the reference's, accident for accident:
+ * heap entries [f, node] compared like Python lists (f = path cost + float64 Euclidean distance, ties by the smaller path
+ * cost), heapq's exact sift order, children in action order with wall bumps skipped as explored, and the inverted replace
+ * test — one lane per search, its arrays in a per-env scratch block (fault bit 4 if a search outgrows it). So the device's
+ * Nav target walks the reference's own paths, not merely paths of the same length. The RPF patrol target (which plans on a map
+ * that differs from the env's own) stays on the host streams, environment.NumpyVecEnv. */
 struct t2d_handle;
 int t2d_np_attach(struct t2d_handle *h, const uint32_t *states_host);
 /* info['distance']^2 of each env's last TERMINAL step (track_1v1.py:118) on a handle with attached streams: with the in-launch
@@ -91,6 +99,11 @@ int t2d_np_get_plan(const t2d_np *e, int32_t *plan, int32_t max_len, int32_t *le
  * wall). *solvable = solution_node is not None; actions = get_actions() (caller buffer of max_len ints, *n = length). */
 int t2d_np_astar(const uint8_t *maze, int32_t side, const int32_t start[2], const int32_t goal[2], int32_t *actions,
                  int32_t max_len, int32_t *n, int32_t *solvable);
+
+/* t2d_np_astar's search run by the DEVICE code (csrc/track2d_hip.hip astar_np, one wavefront on GPU `device`): same arguments and
+ * results; for the known-answer tests that hold the HIP restatement to the reference's recorded searches. T2D_ERR_* codes. */
+int t2d_np_astar_device(int device, const uint8_t *maze, int32_t side, const int32_t start[2], const int32_t goal[2],
+                        int32_t *actions, int32_t max_len, int32_t *n, int32_t *solvable);
 
 /* Primitives of the stream, exposed for the known-answer tests against the installed numpy. */
 int t2d_np_draw(t2d_np *e, int kind, uint32_t arg, uint32_t count, double *out);

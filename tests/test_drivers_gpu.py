@@ -1039,6 +1039,25 @@ def test_numpy_rng_batch_replays_all_reference_episodes_concurrently_in_one_hand
           % (steps, dt, steps / dt))
 
 
+def test_device_astar_matches_the_reference_solver():
+    """The HIP restatement of AstarSolver (csrc/track2d_hip.hip astar_np: heapq's sift order, [f, node] list comparison, the
+    inverted replace test) on the 49 searches recorded from the reference (tests/golden/astar.npz): solvable or not, and the
+    action list itself — tie-breaks included, not just its length."""
+    from conftest import GOLDEN, unpack_maze
+    from active_tracking_rl_amd import np_mode
+    d = np.load(os.path.join(GOLDEN, "astar.npz"))
+    names = sorted(set(k.split("/")[0] for k in d.keys() if "/" in k))
+    assert len(names) >= 40
+    n_unsolvable = 0
+    for nme in names:
+        ok, acts = np_mode.astar_device(unpack_maze(d[nme + "/maze"], d[nme + "/side"]), d[nme + "/start"], d[nme + "/goal"])
+        assert ok == bool(d[nme + "/solvable"]), nme
+        n_unsolvable += not ok
+        if ok:
+            assert np.array_equal(acts, d[nme + "/actions"]), nme
+    assert n_unsolvable >= 1
+
+
 @pytest.mark.parametrize("targets", ["unscripted", "ram"])
 def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_alone(targets):
     """NumpyVecEnv(device_generators=True): the numpy-legacy streams live on the DEVICE (t2d_np_attach -> k_gen_np: MT19937, numpy's
@@ -1053,14 +1072,17 @@ def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_a
     generated ahead of time there: the handle runs without the in-launch auto-reset, a finished env's next episode is drawn
     inside the masked reset that follows its terminal step (init_maze, then RamAgent.reset), and RamAgent.step runs on the
     device ahead of every step launch (k_ram_np) — the recorded TARGET actions are never fed in, the device's Ram target must
-    reproduce them from the seed for the observations to match."""
+    reproduce them from the seed for the observations to match. The same handle holds the captures with the Nav target: the
+    reference's Navigator — goal draws (whole permutations of the free cells), the retry loop, plan B and AstarSolver with heapq's
+    exact sift order, list-comparison tie-breaks and its inverted replace test — runs on the device too (one lane per search),
+    and the device's target must walk the reference's own A* paths, not merely paths of the same length."""
     from conftest import GOLDEN
     from active_tracking_rl_amd.environment import NumpyVecEnv
     g = np.load(os.path.join(GOLDEN, "episodes.npz"))
     if targets == "ram":
-        names = [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) == "Ram"] * 4
+        names = [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) in ("Ram", "Nav")] * 4
         names += [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) in ("PZR", "Adv")][:2]
-        assert sum(str(g[n + "/meta"][1]) == "Ram" for n in names) >= 8
+        assert sum(str(g[n + "/meta"][1]) == "Ram" for n in names) >= 8 and sum(str(g[n + "/meta"][1]) == "Nav" for n in names) >= 8
     else:
         names = [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) in ("PZR", "Adv", "Far")] * 4
     ids, seeds, eps = [], [], []
@@ -1073,11 +1095,11 @@ def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_a
     n = len(names)
     if targets == "unscripted":
         assert n >= 24 and len(set(i.split("Partial")[0] for i in ids)) == 3          # Block, Maze and Empty maps among them
-    with pytest.raises(ValueError, match="heap A\\* between resets"):
-        NumpyVecEnv(["Track2D-BlockPartialNav-v0"], [1], device_generators=True)
+    with pytest.raises(ValueError, match="stay on the host streams"):
+        NumpyVecEnv(["Track2D-BlockPartialRPF-v0"], [1], device_generators=True)
     env = NumpyVecEnv(ids, seeds, device_generators=True)
     assert env._interleaved == (targets == "ram") and bool(env.core.auto_reset) == (targets != "ram")
-    is_ram = np.array(["Ram" in i for i in ids])
+    is_ram = np.array(["Ram" in i or "Nav" in i for i in ids])        # (scripted on the device: the recorded target action is not fed)
     obs = env.reset().cpu().numpy()
     for i in range(n):
         assert np.array_equal(obs[i], eps[i][0]["obs0"].astype(np.float32)), (names[i], "first reset")
@@ -1179,9 +1201,10 @@ def test_create_env_numpy_device_streams_equal_the_host_streams():
             ends += int(dd.sum())
         assert ends > 24
         dev_env.close(); host_env.close()
-    # the scripted Ram target (round 6): its stream on the device too — RamAgent.step as k_ram_np, episodes drawn inside the masked
-    # reset — against the host streams (np_mode.cpp's RamAgent), over episode ends and many re-plans; info['distance'] included
-    for env_id in ("Track2D-BlockPartialRam-v0", "Track2D-MazePartialRam-v1"):
+    # the scripted Ram and Nav targets (round 6): their streams on the device too — RamAgent.step / Navigator.step (heap A*) as k_ram_np,
+    # episodes drawn inside the masked reset — against the host streams (np_mode.cpp's RamAgent / Navigator / Astar), over episode ends
+    # and many re-plans; info['distance'] included
+    for env_id in ("Track2D-BlockPartialRam-v0", "Track2D-MazePartialRam-v1", "Track2D-MazePartialNav-v0", "Track2D-BlockPartialNav-v1"):
         dev_env = create_env(env_id, mk(5), num_envs=24, rng="numpy-device")
         host_env = create_env(env_id, mk(5), num_envs=24, rng="numpy")
         assert dev_env.device_generators and dev_env._interleaved and not host_env.device_generators
@@ -1196,12 +1219,14 @@ def test_create_env_numpy_device_streams_equal_the_host_streams():
             assert np.array_equal(idv["distance"], ih["distance"]), (env_id, t)
             ends += int(dd.sum())
         assert ends > 24
-        tg = dev_env.core.get_target()
-        assert (tg["len"] >= 1).all() and (tg["len"] <= 9).all() and (tg["cursor"] < tg["len"]).all()
+        if "Ram" in env_id:
+            tg = dev_env.core.get_target()
+            assert (tg["len"] >= 1).all() and (tg["len"] <= 9).all() and (tg["cursor"] < tg["len"]).all()
+        assert dev_env.core.faults() == 0
         dev_env.close(); host_env.close()
-    # a Nav target (heap A* between resets) falls back to the host streams, and says so
+    # the RPF patrol target falls back to the host streams, and says so
     with pytest.warns(UserWarning, match="stay on the host"):
-        e = create_env("Track2D-BlockPartialNav-v0", mk(5), num_envs=4, rng="numpy-device")
+        e = create_env("Track2D-BlockPartialRPF-v0", mk(5), num_envs=4, rng="numpy-device")
     assert not e.device_generators
     e.close()
 
