@@ -1,8 +1,8 @@
 #!/bin/bash
 # A round's evidence, regenerated under gpurun_out/<tag>/ on the GPU box (tools/publish_profiles_round.sh <tag> copies what is to
-# be judged to profiles/):   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/collect_profiles_round.sh r05'
+# be judged to profiles/):   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/collect_profiles_round.sh r06'
 # PMC passes are separate runs with no trace domains besides the counter collection (pool rule).
-TAG=${1:-r05}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
+TAG=${1:-r06}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 export PYTHONPATH=$R GPU_MAX_HW_QUEUES=2; cd /tmp; export TMPDIR=/tmp
 # --- the bench line (driver flags and defaults), and the same command under the profiler
 timeout 1200 python $R/bench.py > $O/bench.json 2> $O/bench.err
@@ -69,11 +69,19 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_pmc; (cd $R && ACT_BENCH_MODE=pre timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/p_pmc -- python tools/act_step_bench.py 4096 > /dev/null 2>&1)
   python $R/tools/summarize_prof.py pmc /tmp/p_pmc k_act_step > $O/act_step_pmc_${c}_4096.txt
 done
-# --- round 5: the two-launch (cooperative) rollout step — its phase timeline and the shard sizes with it on / off
-for n in 512 1024; do (cd $R && timeout 300 python tools/coop_step_timeline.py $n > $O/coop_step_timeline_$n.txt 2>&1); done
+# --- shard sizes (the coop-step timelines of round 5 are not regenerated: that kernel is experimental and unchanged)
 (cd $R && timeout 600 python tools/shard_sweep.py 512 1024 2048 4096 > $O/shard_sweep.txt 2>&1)
-(cd $R && ATR_COOP_STEP=1 timeout 600 python tools/shard_sweep.py 512 1024 > $O/shard_sweep_coop_step.txt 2>&1)
-(cd $R && timeout 120 scratch_exp/xcd_barrier > $O/xcd_barrier_microbench.txt 2>&1)
+# --- round 6: the gate product with the cell as its epilogue against the library product (timeline per workgroup), the same iteration
+# with it on / off and with the embedding fold on / off, the CU-partition curve one partition per process, the 8-rank runs on one GPU
+(cd $R && timeout 600 python tools/gate_cell_bench.py 4096 2048 1024 --timeline 2>&1 | grep -v amdgpu.ids > $O/gate_cell_bench.txt)
+bash $R/tools/prof_iter_ab.sh ATR_GATE_CELL $TAG > /dev/null 2>&1
+bash $R/tools/prof_iter_ab.sh ATR_FOLD_EMBEDDING $TAG > /dev/null 2>&1
+(cd $R && timeout 900 bash tools/cu_split_sweep.sh 512 0 64 96 112 128 144 160 192 > $O/cu_split_sweep_512.txt 2>&1)
+(cd $R && BENCH_SINGLE_DEVICE=1 BENCH_DIST_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline --no-shards 2> /dev/null | grep "^{" > $O/bench_selflaunch_8ranks_gloo_1gpu.json)
+(cd $R && ATR_DIST_BACKEND=gloo ATR_SINGLE_DEVICE=1 timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 \
+   main.py --shared-optimizer --split --train-mode -1 --env Track2D-BlockPartialPZR-v0 --num-envs 512 --max-step 50 --test-every 25 --log-every 10 \
+   --burn-in 10 --log-dir gpurun_out/$TAG/main8_logs/ 2>&1 | grep -v "socket.cpp\|amdgpu.ids\|^20.*: [a-z_]*:" > $O/main_py_8ranks_gloo_1gpu.txt)
+rm -rf $O/main8_logs
 # --- learning checks under the default (pipelined) schedule, and a main.py run with the evaluator's scalars
 (cd $R && timeout 600 python tools/learning_check.py --iters 1500 > $O/learning_check_ram_tracker.txt 2>&1)
 (cd $R && timeout 600 python tools/learning_check.py --env Track2D-BlockPartialPZR-v0 --network tat-maze-lstm --train-mode -1 --iters 1500 > $O/learning_check_pzr_dueling.txt 2>&1)
