@@ -129,7 +129,9 @@ typedef struct atr_act_step {
     float *hm_out[2];
     long long hm_ld;
 } atr_act_step;
-/* The step's LSTMCell product with the cell as its epilogue (round 6; csrc/gate_cell_hip.hip; f32 MFMA, gfx950): for both players
+/* OPT-IN (ATR_GATE_CELL=1; round 6) — parity-green, measured 3.5 us per launch slower than the library product at 4096 rows while
+ * saving 2.2 us in atr_act_env_step: DESIGN.md section 5 has the per-workgroup timeline.
+ * The step's LSTMCell product with the cell as its epilogue (csrc/gate_cell_hip.hip; f32 MFMA, gfx950): for both players
  *     pre[p] = a[p] w[p]^T            a[p] [N, K] rows [fc features | k h_prev] (row stride lda), w[p] [4R, K] = [W_ih | W_hh]
  * (model.py:116,137,165,196 of the reference: both GEMMs of nn.LSTMCell as one product, K = 256 + 128), written to pre[p] [N, 4R]
  * WITHOUT the bias (nullable where cell[p] != 0), and for every player with cell[p] != 0 the cell itself in the kernel's epilogue
@@ -163,7 +165,9 @@ struct t2d_handle;
 int atr_act_env_step(struct t2d_handle *env, const atr_act_step *args, void *obs, int obs_is_u8, float *rew,
                      unsigned char *done, void *stream);
 
-/* The small-shard rollout step after the stem as ONE launch (csrc/track2d_hip.hip: k_coop_step; csrc/coop_gemm.h) — what
+/* EXPERIMENTAL — off by default (ATR_COOP_STEP=1), measured SLOWER than the four-launch step it replaces (1.51 against 1.42 ms per
+ * synchronous iteration at 512 envs: profiles/EXPERIMENTS.md "The two-launch step"); kept built and parity-tested.
+ * The small-shard rollout step after the stem as ONE launch (csrc/track2d_hip.hip: k_coop_step; csrc/coop_gemm.h) — what
  * train.py:81-88 -> player_util.py:44-67 -> model.py:238-265 of the reference do between the conv stem and the next
  * observation: CNN_maze's fc + ReLU for both players (perception.py:81,90), both GEMMs of nn.LSTMCell for both players
  * (model.py:110,137,172,203) as one product over [features | k h_prev] rows, then atr_act_env_step's cells + heads + draws +
@@ -257,7 +261,10 @@ typedef struct atr_pair_linear_args {
 } atr_pair_linear_args;
 int atr_pair_linear(const atr_pair_linear_args *args, void *stream);
 
-/* The actor's whole LSTMCell step for ONE player as one f32-MFMA kernel (csrc/actor_step_hip.hip): both GEMMs of
+/* EXPERIMENTAL — off by default (ATR_MFMA_MIN_ROWS / bench.py --actor-step mfma select it): round 2's per-player fused GEMM + cell,
+ * 22 us per 4096-row call against 14.9 + 6 for the library product + k_act_step's share since round 3; superseded as an
+ * experiment by atr_gate_cell (both players, one launch, DMA-to-LDS operands). Kept built and tested.
+ * The actor's whole LSTMCell step for ONE player as one f32-MFMA kernel (csrc/actor_step_hip.hip): both GEMMs of
  * nn.LSTMCell (model.py:110,172 of the reference) and the cell, without materialising the gate pre-activations:
  *   gates = f W_ih^T + (k h_prev) W_hh^T + bias [+ emb[act_in[n]]],  k[n] = (done[n] == 0) (1 if done is NULL)
  *   c' = sigm(f) (k c_prev) + sigm(i) tanh(g),  h' = sigm(o) tanh(c')        (gate order i, f, g, o)
