@@ -92,7 +92,7 @@ constexpr int kNpStateWords = 640;           // 624 words of MT19937 state, the 
 constexpr int kNpTermD2 = 625, kNpRamFlag = 626;     // [626]: 1 = RamAgent, 2 = Navigator (heap A*), stepped by k_tgt_np
 // ... and, Navigator envs: [627] plan length, [628] plan cursor (a_i), [629] nav goal (r | c << 8). The plan's actions and the
 // A* search's arrays live in a per-env scratch block (DevState::np_nav, t2d_np_attach):
-constexpr int kNpPlanLen = 627, kNpPlanCur = 628, kNpNavGoal = 629;
+constexpr int kNpPlanLen = 627, kNpPlanCur = 628, kNpNavGoal = 629, kNpRpfVector = 630;     // ([626] = 3: the RPF patrol Navigator)
 constexpr int kNavPlanCap = 4096, kNavNodeCap = 32768, kNavHeapCap = 16384, kNavCells = 82 * 82;
 // per-env scratch layout (bytes): plan u8 [4096] | nodes u64 [32768] | heap f f64 [16384] | heap node u32 [16384] |
 // in_frontier i32 [6724 -> 6728] | explored u8 [6724 -> 6728]
@@ -630,8 +630,44 @@ __device__ __forceinline__ void tile_set(uint32_t *tile, int r, int c, int lane)
 }
 
 // One reset() of the reference env (track_1v1.py:134-168 -> init_maze :218-240) from the env's numpy stream.
+// The four patrol cells of the RPF ids (static_goals, generators.py:12-19): (s/6, s/6), (5s/6, s/6), (5s/6, 5s/6), (s/6, 5s/6) as r | c << 8.
+__device__ __forceinline__ uint32_t rpf_cand(int side, int k)
+{
+    const uint32_t lo = (uint32_t)(side / 6), hi = (uint32_t)(side * 5 / 6);
+    const uint32_t r = (k == 1 || k == 2) ? hi : lo, c = (k >= 2) ? hi : lo;
+    return r | (c << 8);
+}
+// Clear the patrol cells on the tile (the GENERATOR's map: track_1v1.py:233-236 copies the env's own map before static_goals frees
+// them); returns which of them were walls, for rpf_restore.
+__device__ __forceinline__ uint32_t rpf_clear(uint32_t *tile, int side, int lane)
+{
+    uint32_t saved = 0u;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t cd = rpf_cand(side, k);
+        saved |= tile_bit(tile, (int)(cd & 0xffu), (int)(cd >> 8)) << k;
+    }
+    wave_lds_sync();
+    if (lane == 0)
+        for (int k = 0; k < 4; k++) {
+            const uint32_t cd = rpf_cand(side, k);
+            tile[(cd & 0xffu) * kRowWords + ((cd >> 8) >> 5)] &= ~(1u << ((cd >> 8) & 31u));
+        }
+    wave_lds_sync();
+    return saved;
+}
+__device__ __forceinline__ void rpf_restore(uint32_t *tile, int side, uint32_t saved, int lane)
+{
+    wave_lds_sync();
+    for (int k = 0; k < 4; k++)
+        if ((saved >> k) & 1u) { const uint32_t cd = rpf_cand(side, k); tile_set(tile, (int)(cd & 0xffu), (int)(cd >> 8), lane); }
+    wave_lds_sync();
+}
+
+// rpf: the RPF ids — the tile is left as the GENERATOR's map (patrol cells freed: what the samplers and the Navigator see), `saved`
+// says which of them the env's own map keeps as walls; `vector` = the patrol index static_goals starts at 0 and sample_goal advances.
 __device__ __forceinline__ void generate_episode_np(NpStream &rs, uint16_t *perm, uint32_t *tile, int lane, uint32_t cfg,
-                                                    uint32_t &pos, uint32_t &goals, uint32_t &d2)
+                                                    uint32_t &pos, uint32_t &goals, uint32_t &d2, bool rpf = false,
+                                                    uint32_t *saved = nullptr, uint32_t *vector = nullptr)
 {
     const int map_type = cfg & 3, level = (cfg >> 5) & 15;
     const int side = side_of_cfg(cfg);
@@ -682,10 +718,13 @@ __device__ __forceinline__ void generate_episode_np(NpStream &rs, uint16_t *perm
         tile_border(tile, 82, lane);
         wave_lds_sync();
     }
+    uint32_t vec = 0u;
+    if (rpf) *saved = rpf_clear(tile, side, lane);
     const FreeIndex fi = build_free_index(tile, side, lane);
     const int n = fi.total;
     uint32_t g0, g1;
     auto sample_goal2 = [&]() {     // sample_goal(2): choice(len, 2, replace=False) = permutation(len)[:2]
+        if (rpf) { vec = (vec + 1u) & 3u; g0 = g1 = rpf_cand(side, (int)vec); return; }     // (static: no draw, generators.py:48-50)
         rs.permutation(n, perm);
         const int i0 = uni((int)perm[0]), i1 = uni((int)perm[1]);
         g0 = select_free(tile, side, fi, i0, lane);
@@ -694,8 +733,8 @@ __device__ __forceinline__ void generate_episode_np(NpStream &rs, uint16_t *perm
     sample_goal2();
     // sample_close_states(2, 1): choice(len, 2, replace=False) of which only the first is used, then get_around, then
     // sample_state(0) = choice(len, 0, replace=False) — still a whole permutation
-    rs.permutation(n, perm);
-    const uint32_t tr = select_free(tile, side, fi, uni((int)perm[0]), lane);
+    rs.permutation(n, perm);                                 // (drawn in the static case too, then ignored: generators.py:61,68)
+    const uint32_t tr = rpf ? rpf_cand(side, 0) : select_free(tile, side, fi, uni((int)perm[0]), lane);
     const int r = (int)(tr & 0xffu), c = (int)(tr >> 8);
     const int x0 = max(0, r - 1), x1 = min(side - 1, r + 1), y0 = max(0, c - 1), y1 = min(side - 1, c + 1);
     int m = 0;
@@ -716,6 +755,7 @@ __device__ __forceinline__ void generate_episode_np(NpStream &rs, uint16_t *perm
     goals = g0 | (g1 << 16);
     const int dr = (int)(tg & 0xffu) - r, dc = (int)(tg >> 8) - c;
     d2 = (uint32_t)(dr * dr + dc * dc);
+    if (rpf) *vector = vec;
 }
 
 // ---- the reference's Navigator on the device: AstarSolver (Astar_solver.py:42-173) with heapq's exact sift order -----------
@@ -883,17 +923,19 @@ __device__ int astar_np(const uint32_t *tile, unsigned char *scratch, uint32_t f
 // six failures, then plan B = ten random actions. Leaves the plan in the env's scratch, its length, cursor 0 and the goal in
 // the stream block's side words.
 __device__ void nav_plan_np(NpStream &rs, uint16_t *perm, const uint32_t *tile, int side, unsigned char *scratch, uint32_t *side_words,
-                            uint32_t from, uint32_t goal, int lane, uint32_t *faults)
+                            uint32_t from, uint32_t goal, int lane, uint32_t *faults, bool rpf = false, uint32_t vector = 0u)
 {
     int count_res = 0, len;
     for (;;) {
         len = astar_np(tile, scratch, from, goal, lane, faults);
         if (len > 0) break;
         if (++count_res > 5) { len = -1; break; }
+        if (rpf) { vector = (vector + 1u) & 3u; goal = rpf_cand(side, (int)vector); continue; }   // static sample_goal: the next patrol cell
         const FreeIndex fi = build_free_index(tile, side, lane);
         rs.permutation(fi.total, perm);                          // choice(len, size=1, replace=False)
         goal = select_free(tile, side, fi, uni((int)perm[0]), lane);
     }
+    if (rpf && lane == 0) side_words[kNpRpfVector] = vector;
     if (len < 0) {                                               // plan B: np.random.choice(all_actions, 10)
         len = 10;
         for (int i = 0; i < 10; i++) {
@@ -932,7 +974,7 @@ __global__ __launch_bounds__(64 * kNpWaves) void k_gen_np(DevState s, uint32_t l
     if (!need0 && !need1) return;
     uint32_t *mt_g = s.np_mt + (size_t)e * kNpStateWords;
     const uint32_t tflag = inter ? uni(mt_g[kNpRamFlag]) : 0u;
-    const bool ram = tflag == 1u, navig = tflag == 2u;
+    const bool ram = tflag == 1u, rpf = tflag == 3u, navig = tflag == 2u || rpf;
     NpStream rs;
     rs.mt = mts[wave]; rs.lane = lane;
     for (int i = lane; i < 624; i += 64) rs.mt[i] = mt_g[i];
@@ -946,11 +988,13 @@ __global__ __launch_bounds__(64 * kNpWaves) void k_gen_np(DevState s, uint32_t l
         if (!(slot == 0 ? need0 : need1)) continue;
         const size_t so = (size_t)slot * s.n + e;
         uint32_t pos, goals, d2;
-        generate_episode_np(rs, perms[wave], tiles[wave], lane, cfg, pos, goals, d2);
+        uint32_t rpf_saved = 0u, rpf_vec = 0u;
+        generate_episode_np(rs, perms[wave], tiles[wave], lane, cfg, pos, goals, d2, rpf, &rpf_saved, &rpf_vec);
         const uint32_t plan0 = ram ? ram_reset(rs) : 0u;        // RamAgent.reset(): randint(1, 10), then choice(4, n)
         if (navig)      // Navigator.reset(init_states[1], goal_states[1], maze_generator) (track_1v1.py:139-141, navigator.py:43-63)
             nav_plan_np(rs, perms[wave], tiles[wave], side_of_cfg(cfg), s.np_nav + (size_t)e * kNavBytes, mt_g, pos >> 16, goals >> 16,
-                        lane, s.faults);
+                        lane, s.faults, rpf, rpf_vec);
+        if (rpf) rpf_restore(tiles[wave], side_of_cfg(cfg), rpf_saved, lane);     // the ENV's map keeps its walls on the patrol cells
         wave_lds_sync();
         store_slot_map(s, so, tiles[wave], lane, cfg, pos);
         if (lane == 0) {
@@ -984,7 +1028,8 @@ __global__ __launch_bounds__(64 * kNpWaves) void k_ram_np(DevState s, const void
     uint32_t *mt_g = s.np_mt + (size_t)e * kNpStateWords;
     long long a = 0;
     const uint32_t tflag = uni(mt_g[kNpRamFlag]);
-    if (tflag == 2u) {
+    if (tflag >= 2u) {
+        const bool rpf = tflag == 3u;
         unsigned char *scratch = s.np_nav + (size_t)e * kNavBytes;
         uint32_t cur = uni(mt_g[kNpPlanCur]);
         if (cur >= uni(mt_g[kNpPlanLen])) {
@@ -995,10 +1040,17 @@ __global__ __launch_bounds__(64 * kNpWaves) void k_ram_np(DevState s, const void
             reinterpret_cast<uint4 *>(tiles[wave])[lane] = reinterpret_cast<const uint4 *>(s.maps + (size_t)e * kTileWords)[lane];
             wave_lds_sync();
             const int side = (int)(uni(s.cnt[e]) >> 24);
-            const FreeIndex fi = build_free_index(tiles[wave], side, lane);
-            rs.permutation(fi.total, perms[wave]);               // sample_goal(1): choice(len, size=1, replace=False)
-            const uint32_t goal = select_free(tiles[wave], side, fi, uni((int)perms[wave][0]), lane);
-            nav_plan_np(rs, perms[wave], tiles[wave], side, scratch, mt_g, uni(s.pos[e]) >> 16, goal, lane, s.faults);
+            uint32_t goal, vec = 0u;
+            if (rpf) {              // the patrol: plans are made on the generator's map, the next patrol cell is the goal (no draw)
+                (void)rpf_clear(tiles[wave], side, lane);
+                vec = (uni(mt_g[kNpRpfVector]) + 1u) & 3u;
+                goal = rpf_cand(side, (int)vec);
+            } else {
+                const FreeIndex fi = build_free_index(tiles[wave], side, lane);
+                rs.permutation(fi.total, perms[wave]);           // sample_goal(1): choice(len, size=1, replace=False)
+                goal = select_free(tiles[wave], side, fi, uni((int)perms[wave][0]), lane);
+            }
+            nav_plan_np(rs, perms[wave], tiles[wave], side, scratch, mt_g, uni(s.pos[e]) >> 16, goal, lane, s.faults, rpf, vec);
             wave_lds_sync();
             for (int i = lane; i < 624; i += 64) mt_g[i] = rs.mt[i];
             if (lane == 0) mt_g[624] = (uint32_t)rs.pos;
@@ -2665,11 +2717,8 @@ extern "C" int t2d_np_attach(t2d_handle *h, const uint32_t *states_host)
 {
     if (!h || !states_host) return fail(T2D_ERR_INVALID, "t2d_np_attach: null argument");
     if (h->primed || h->reset_done) return fail(T2D_ERR_STATE, "t2d_np_attach: attach the streams before the first t2d_reset");
-    if (h->has_rpfmode)
-        return fail(T2D_ERR_INVALID, "t2d_np_attach: the RPF patrol target plans on a map that differs from the env's own: it stays on "
-                                     "the host streams (environment.NumpyVecEnv); Adv / PZR / Far / Ext / Ram / Nav only");
-    if ((h->has_ram || h->has_navmode) && h->s.auto_reset)
-        return fail(T2D_ERR_INVALID, "t2d_np_attach: a Ram / Nav target draws from the stream between resets, so its next episode "
+    if ((h->has_ram || h->has_navmode || h->has_rpfmode) && h->s.auto_reset)
+        return fail(T2D_ERR_INVALID, "t2d_np_attach: a Ram / Nav / RPF target draws from the stream between resets, so its next episode "
                                      "cannot be generated ahead of the in-launch auto-reset: create the handle with auto_reset = 0 "
                                      "and restart finished envs with t2d_reset(mask = done)");
     DeviceGuard guard(h->device);
@@ -2679,7 +2728,7 @@ extern "C" int t2d_np_attach(t2d_handle *h, const uint32_t *states_host)
         if (states_host[(size_t)i * 625 + 624] > 624u) return fail(T2D_ERR_INVALID, "t2d_np_attach: env %d: read position > 624", i);
         std::memcpy(&padded[(size_t)i * kNpStateWords], states_host + (size_t)i * 625, 625 * sizeof(uint32_t));
     }
-    if (h->has_ram || h->has_navmode) {
+    if (h->has_ram || h->has_navmode || h->has_rpfmode) {
         // The Ram / Nav envs' target is stepped by k_ram_np from the env's own stream; to the step kernels their mode becomes "the
         // target's action comes from outside" (T2D_TGT_EXT: w_p = 0 either way, track_1v1.py:147-152) and neither the Philox Ram
         // code nor the BFS Navigator of the device generators is selected (has_ram / has_nav off)
@@ -2687,15 +2736,17 @@ extern "C" int t2d_np_attach(t2d_handle *h, const uint32_t *states_host)
         HIP_TRY(hipMemcpy(cfg.data(), h->s.cfg, cfg.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (int i = 0; i < n; i++) {
             const uint32_t tm = (cfg[(size_t)i] >> 2) & 7u;
-            if (tm == (uint32_t)TGT_RAM || tm == (uint32_t)TGT_NAV) {
+            if (tm == (uint32_t)TGT_RAM || tm == (uint32_t)TGT_NAV || tm == (uint32_t)TGT_RPF) {
                 cfg[(size_t)i] = (cfg[(size_t)i] & ~(7u << 2)) | ((uint32_t)T2D_TGT_EXT << 2);
-                padded[(size_t)i * kNpStateWords + kNpRamFlag] = tm == (uint32_t)TGT_RAM ? 1u : 2u;
+                padded[(size_t)i * kNpStateWords + kNpRamFlag] = tm == (uint32_t)TGT_RAM ? 1u : (tm == (uint32_t)TGT_NAV ? 2u : 3u);
             }
         }
         HIP_TRY(hipMemcpy(h->s.cfg, cfg.data(), cfg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         if (!h->np_act) HIP_TRY(hipMalloc(&h->np_act, (size_t)n * 8));
-        if (h->has_navmode && !h->s.np_nav) HIP_TRY(hipMalloc((void **)&h->s.np_nav, (size_t)n * kNavBytes));
-        h->np_inter = true; h->has_ram = false; h->has_nav = false; h->has_navmode = false;
+        if ((h->has_navmode || h->has_rpfmode) && !h->s.np_nav) HIP_TRY(hipMalloc((void **)&h->s.np_nav, (size_t)n * kNavBytes));
+        // (an RPF env's agents may stand on cells its own map keeps as walls: has_rpf stays, as for every handle with Ext envs)
+        h->has_rpf = h->has_rpf || h->has_rpfmode;
+        h->np_inter = true; h->has_ram = false; h->has_nav = false; h->has_navmode = false; h->has_rpfmode = false;
     }
     if (!h->s.np_mt) HIP_TRY(hipMalloc((void **)&h->s.np_mt, padded.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(h->s.np_mt, padded.data(), padded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

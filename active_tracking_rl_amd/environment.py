@@ -201,7 +201,8 @@ class NumpyVecEnv(object):
         restarts finished envs with a masked reset that draws their next episode at that moment, and RamAgent.step() itself runs
         on the device from the env's stream ahead of every step (csrc k_ram_np) — and the Nav target: Navigator.reset / .step with
         the reference's heap A* (heapq's sift order, list-comparison ties, the inverted replace test) restated on the device,
-        one lane per search. The RPF patrol target stays on the host streams (device_generators=False)."""
+        one lane per search — and the RPF patrol (the same Navigator planning on the generator's map, whose four patrol cells are
+        free, while the env's own map may keep them as walls: track_1v1.py:233-236)."""
         from .np_mode import NpBatchSource
         n = len(seeds)
         ids = [env_ids] * n if isinstance(env_ids, str) else list(env_ids)
@@ -213,13 +214,9 @@ class NumpyVecEnv(object):
         self._interleaved = False
         if self.device_generators:
             from .np_mode import attach_device_streams
-            bad = sorted(set(x["target_mode"] for x in sp) - {"Adv", "PZR", "Far", "Ram", "Nav"})
-            if bad:
-                raise ValueError("NumpyVecEnv(device_generators=True): target mode(s) %s (the patrol target plans on a map of its "
-                                 "own) stay on the host streams (device_generators=False)" % ", ".join(bad))
             self.src = None
-            # a Ram / Nav target's draws interleave with the resets: no episode can be made ahead of time, so no in-launch auto-reset
-            self._interleaved = any(x["target_mode"] in ("Ram", "Nav") for x in sp)
+            # a scripted target's draws interleave with the resets: no episode can be made ahead of time, so no in-launch auto-reset
+            self._interleaved = any(x["target_mode"] in ("Ram", "Nav", "RPF") for x in sp)
             self.core = VecTrack2D(ids[0], num_envs=n, device=device, seed=int(seeds[0]), auto_reset=not self._interleaved,
                                    map_type_per_env=np.array([registry.MAP_CODE[x["map_type"]] for x in sp], np.uint8),
                                    target_mode_per_env=np.array([registry.TARGET_CODE[x["target_mode"]] for x in sp], np.uint8),
@@ -383,11 +380,6 @@ def create_env(env_id, args, num_envs=None, device=None, env_id_base=0, obs_u8=N
             raise NotImplementedError("rng='numpy' with num_envs > 1 returns raw float32 observations (no frame stack / rescale)")
         # rng="numpy-device" / args.np_device: the streams on the device (t2d_np_attach) where the target mode allows it
         on_dev = rng == "numpy-device" or bool(getattr(args, "np_device", False))
-        if on_dev and registry.spec(env_id)["target_mode"] not in ("Adv", "PZR", "Far", "Ram", "Nav"):
-            import warnings
-            warnings.warn("rng='numpy-device': %s has the RPF patrol target, which plans on a map of its own — the streams of this "
-                          "batch stay on the host (NumpyVecEnv(device_generators=False))" % env_id)
-            on_dev = False
         return NumpyVecEnv(env_id, [int(seed) + int(env_id_base) + i for i in range(n)], device=device, device_generators=on_dev)
     if n > 1:
         return VecEnv(env_id, n, device=device, seed=seed, stack_frames=stack, env_id_base=env_id_base, rescale=rescale,

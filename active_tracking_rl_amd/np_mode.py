@@ -168,8 +168,7 @@ def attach_device_streams(core, seeds):
     csrc/track2d_hip.hip k_gen_np). Before the first reset. Adv / PZR / Far (and host-driven Ext) targets on any handle; Ram
     targets (whose draws interleave with the resets: RamAgent, navigator.py:73-93) on handles created with auto_reset=False — the
     episode of a restarted env is then drawn inside reset(mask) and RamAgent.step() runs on the device ahead of every step
-    (k_ram_np), as does Navigator.step() for Nav targets, with the reference's heap A* restated on the device. RPF targets are
-    refused (host streams)."""
+    (k_ram_np), as does Navigator.step() for Nav and RPF targets, with the reference's heap A* restated on the device."""
     assert len(seeds) == core.num_envs
     st = np.ascontiguousarray(mt_states(seeds))
     rc = _lib().t2d_np_attach(core.h, _ptr(st))

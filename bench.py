@@ -30,11 +30,11 @@ Extra objects on the same JSON line:
                is measured where it runs: a whole 20-step rollout of the player is captured into a hipGraph twice — as it is,
                and with the k_act_step launches left out — and replayed alternately with HIP events on the launch stream; the
                difference / 20 is the kernel's in-situ cost (`avg_launch_us`; rocprofv3's average for the kernel in a replayed
-               iteration, profiles/r05_iteration_kernel_stats.txt, rides along as `rocprof_in_iteration_us` and must agree).
+               iteration, profiles/r06_iteration_kernel_stats.txt, rides along as `rocprof_in_iteration_us` and must agree).
                `frac` = that figure / 8 TB/s. The same duration priced with EVERYTHING the fused kernel moves (gate
                pre-activations, cell / hidden state, activated gates parked for the learner) is reported under its own name,
                `policy_state_included`, never as `frac`. `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc
-               passes (profiles/r05_pmc_traffic.json). `other_variants`: the stand-alone step kernel (k_step2; what t2d_step /
+               passes (profiles/r06_pmc_traffic.json). `other_variants`: the stand-alone step kernel (k_step2; what t2d_step /
                t2d_step_u8 launch for callers that bring their own actions), measured alone in a 9-launch graph.
   env_only     the stand-alone step kernel driven with on-device random actions (no policy): launches/s -> env steps/s, per
                launch and in the persistent mode (t2d_rollout_random: up to 10 steps per launch).
@@ -577,7 +577,7 @@ def main():
         stem_roof = {"error": repr(ex)}
 
     traffic, traffic_src, traffic_u8, traffic_u8_src, traffic_act, traffic_act_src = None, None, None, None, None, None
-    for fname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+    for fname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
         try:   # HBM traffic of the same kernels from the committed rocprofv3 --pmc passes (cannot be taken inside this run)
             pm = json.load(open(os.path.join(ROOT, "profiles", fname)))
             if pm.get("n_envs") == n and traffic is None:
@@ -594,7 +594,7 @@ def main():
         except Exception:
             pass
     kernel_sum, rocprof_act_us = None, None
-    for fname in ("r05_iteration_kernel_stats.txt", "r04_iteration_kernel_stats.txt", "r03_iteration_kernel_stats.txt"):
+    for fname in ("r06_iteration_kernel_stats.txt", "r05_iteration_kernel_stats.txt", "r04_iteration_kernel_stats.txt", "r03_iteration_kernel_stats.txt"):
         try:   # one replayed iteration under rocprofv3 --kernel-trace --stats (tools/iter_profile.py), committed: the sum of its
             # kernel durations, and the in-iteration average of the env kernel the in-situ figure below must agree with
             tot_ms = its = None

@@ -75,8 +75,10 @@ int t2d_np_mt_state(uint32_t seed, uint32_t out[625]);
  * heap entries [f, node] compared like Python lists (f = path cost + float64 Euclidean distance, ties by the smaller path
  * cost), heapq's exact sift order, children in action order with wall bumps skipped as explored, and the inverted replace
  * test — one lane per search, its arrays in a per-env scratch block (fault bit 4 if a search outgrows it). So the device's
- * Nav target walks the reference's own paths, not merely paths of the same length. The RPF patrol target (which plans on a map
- * that differs from the env's own) stays on the host streams, environment.NumpyVecEnv. */
+ * Nav target walks the reference's own paths, not merely paths of the same length. T2D_TGT_RPF envs too: the same Navigator with
+ * static goals (generators.py:12-19,48-50,68: the patrol index advances instead of a draw, the tracker spawns on the first
+ * patrol cell) planning on the GENERATOR's map — the four patrol cells freed — while the handle's map, the env's own
+ * (track_1v1.py:233-236), keeps whatever walls they had: a planned step into such a wall bumps, exactly as in the reference. */
 struct t2d_handle;
 int t2d_np_attach(struct t2d_handle *h, const uint32_t *states_host);
 /* info['distance']^2 of each env's last TERMINAL step (track_1v1.py:118) on a handle with attached streams: with the in-launch

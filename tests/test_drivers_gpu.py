@@ -421,14 +421,16 @@ def test_keeping_the_gate_gemm_output_instead_of_the_activated_gates_changes_no_
     assert torch.equal(res[0][4], res[1][4])
 
 
-@pytest.mark.parametrize("train_mode,n_envs,steps", [(-1, 1024, 8), (1, 1024, 8), (0, 1024, 8), (-1, 4096, 20)])
+@pytest.mark.parametrize("train_mode,n_envs,steps", [(-1, 1024, 8), (1, 1024, 8), (0, 1024, 8), (-1, 4096, 20), (-1, 1024, 3)])
 def test_folded_tracker_action_embedding_gives_the_gradient_of_the_explicit_one(monkeypatch, train_mode, n_envs, steps):
     """Round 6: on the one-GEMM rollout path the learner no longer materialises f + fc_action_tracker(one_hot(a_tracker)) for the
     target's dW_ih product nor gathers dL/df by action for the embedding's gradient (two passes over [T N, 256] tensors each):
     the BPTT launch also leaves the column sums of dG by the row's tracker action, S [4, 512], and atr_embed_fold makes
     dW_ih += S^T E and d fc_action_tracker = S W_ih from them. Same rollout, fold on / off: every other gradient bit-identical,
     the target's weight_ih and fc_action_tracker equal to summation-order round-off (checked against a float64 evaluation of
-    the same expressions from the explicit path's own dG is not needed: the explicit path IS the previous round's tested one)."""
+    the same expressions from the explicit path's own dG is not needed: the explicit path IS the previous round's tested one).
+    (1024 envs x 3 steps = 3072 rows: below the grouped weight-gradient launch's threshold — the fold then follows the product on
+    the spot instead of as the group's post-flush hook.)"""
     from active_tracking_rl_amd import fused
     from active_tracking_rl_amd.train import default_args, make_player, rollout
     res = []
@@ -1078,28 +1080,35 @@ def test_device_side_numpy_streams_replay_the_reference_episodes_from_the_seed_a
     and the device's target must walk the reference's own A* paths, not merely paths of the same length."""
     from conftest import GOLDEN
     from active_tracking_rl_amd.environment import NumpyVecEnv
-    g = np.load(os.path.join(GOLDEN, "episodes.npz"))
+    g0 = np.load(os.path.join(GOLDEN, "episodes.npz"))
     if targets == "ram":
-        names = [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) in ("Ram", "Nav")] * 4
-        names += [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) in ("PZR", "Adv")][:2]
-        assert sum(str(g[n + "/meta"][1]) == "Ram" for n in names) >= 8 and sum(str(g[n + "/meta"][1]) == "Nav" for n in names) >= 8
+        grpf = np.load(os.path.join(GOLDEN, "episodes_rpf.npz"))
+        names = [(g0, str(n)) for n in g0["names"] if str(g0[str(n) + "/meta"][1]) in ("Ram", "Nav")] * 4
+        names += [(grpf, str(n)) for n in grpf["names"]] * 2          # the RPF patrol (plans on the generator's map, walks the env's)
+        names += [(g0, str(n)) for n in g0["names"] if str(g0[str(n) + "/meta"][1]) in ("PZR", "Adv")][:2]
+        modes = [str(gg[n + "/meta"][1]) for gg, n in names]
+        assert modes.count("Ram") >= 8 and modes.count("Nav") >= 8 and modes.count("RPF") >= 8
     else:
-        names = [str(n) for n in g["names"] if str(g[str(n) + "/meta"][1]) in ("PZR", "Adv", "Far")] * 4
+        names = [(g0, str(n)) for n in g0["names"] if str(g0[str(n) + "/meta"][1]) in ("PZR", "Adv", "Far")] * 4
     ids, seeds, eps = [], [], []
-    for name in names:
+    for g, name in names:
         mp, mode, lvl, seed, _ = [str(x) for x in g[name + "/meta"]]
         ids.append("Track2D-%sPartial%s-v%s" % (mp, mode, lvl))
         seeds.append(int(seed))
         eps.append([{k: g["%s/ep%d_%s" % (name, e, k)] for k in ("obs0", "act_in", "obs", "rew", "done", "pos")}
                     for e in range(int(g[name + "/n_eps"]))])
+        for E in eps[-1]:      # (the RPF captures step on THROUGH done — the raw env never resets itself; a batch env restarts a finished
+            dn = np.nonzero(E["done"])[0]          # env at once, so an episode is the capture up to its first done. The patrol draws
+            if len(dn) and dn[0] + 1 < len(E["done"]):     # nothing at step time: the next capture's reset follows in the stream.)
+                for k in ("act_in", "obs", "rew", "done", "pos"):
+                    E[k] = E[k][:dn[0] + 1]
     n = len(names)
     if targets == "unscripted":
         assert n >= 24 and len(set(i.split("Partial")[0] for i in ids)) == 3          # Block, Maze and Empty maps among them
-    with pytest.raises(ValueError, match="stay on the host streams"):
-        NumpyVecEnv(["Track2D-BlockPartialRPF-v0"], [1], device_generators=True)
+    names = [n for _, n in names]
     env = NumpyVecEnv(ids, seeds, device_generators=True)
     assert env._interleaved == (targets == "ram") and bool(env.core.auto_reset) == (targets != "ram")
-    is_ram = np.array(["Ram" in i or "Nav" in i for i in ids])        # (scripted on the device: the recorded target action is not fed)
+    is_ram = np.array([any(m in i for m in ("Ram", "Nav", "RPF")) for i in ids])    # (scripted on the device: the recorded target action is not fed)
     obs = env.reset().cpu().numpy()
     for i in range(n):
         assert np.array_equal(obs[i], eps[i][0]["obs0"].astype(np.float32)), (names[i], "first reset")
@@ -1204,7 +1213,8 @@ def test_create_env_numpy_device_streams_equal_the_host_streams():
     # the scripted Ram and Nav targets (round 6): their streams on the device too — RamAgent.step / Navigator.step (heap A*) as k_ram_np,
     # episodes drawn inside the masked reset — against the host streams (np_mode.cpp's RamAgent / Navigator / Astar), over episode ends
     # and many re-plans; info['distance'] included
-    for env_id in ("Track2D-BlockPartialRam-v0", "Track2D-MazePartialRam-v1", "Track2D-MazePartialNav-v0", "Track2D-BlockPartialNav-v1"):
+    for env_id in ("Track2D-BlockPartialRam-v0", "Track2D-MazePartialRam-v1", "Track2D-MazePartialNav-v0", "Track2D-BlockPartialNav-v1",
+                   "Track2D-BlockPartialRPF-v0", "Track2D-MazePartialRPF-v1"):
         dev_env = create_env(env_id, mk(5), num_envs=24, rng="numpy-device")
         host_env = create_env(env_id, mk(5), num_envs=24, rng="numpy")
         assert dev_env.device_generators and dev_env._interleaved and not host_env.device_generators
@@ -1224,11 +1234,6 @@ def test_create_env_numpy_device_streams_equal_the_host_streams():
             assert (tg["len"] >= 1).all() and (tg["len"] <= 9).all() and (tg["cursor"] < tg["len"]).all()
         assert dev_env.core.faults() == 0
         dev_env.close(); host_env.close()
-    # the RPF patrol target falls back to the host streams, and says so
-    with pytest.warns(UserWarning, match="stay on the host"):
-        e = create_env("Track2D-BlockPartialRPF-v0", mk(5), num_envs=4, rng="numpy-device")
-    assert not e.device_generators
-    e.close()
 
 
 def test_max_grad_norm_is_applied_inside_the_captured_update_graphs():
