@@ -28,7 +28,7 @@ prof_iter iteration_kernel_stats_config3 Track2D-MazePartialNav-v0 1024 maze-lst
 (cd $R && (echo "== wave per frame (k_stem_fwd, k_stem_bwd: ATR_STEM_FWD16_MIN / ATR_STEM_BWD16_MIN out of reach)"; ATR_STEM_FWD16_MIN=100000000 ATR_STEM_BWD16_MIN=100000000 timeout 300 python tools/stem_bench.py 8192 81920 163840 2>&1 | grep -v amdgpu.ids) >> $O/stem_bench.txt)
 (cd $R && (echo "== rollout-shaped launches, wave per frame (the default below 16384 frames)"; timeout 300 python tools/stem_rollout_bench.py 2>&1 | grep -v amdgpu.ids; echo "== rollout-shaped launches, 16 frames per pass forced (ATR_STEM_FWD16_MIN=2048)"; ATR_STEM_FWD16_MIN=2048 timeout 300 python tools/stem_rollout_bench.py 2>&1 | grep -v amdgpu.ids) > $O/stem_rollout_bench.txt)
 (cd $R/active_tracking_rl_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -ldl -DSTEM_PROBE \
-    -o $R/scratch_exp/libstemprobe.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
+    -o $R/scratch_exp/libstemprobe.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip gate_cell_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
 (cd $R && (ATR_STEM_FWD16_MIN=2048 T2D_LIB_PATH=$R/scratch_exp/libstemprobe.so timeout 300 python tools/stem_timeline_probe.py 4096 2>&1 | grep -v amdgpu.ids; echo; T2D_LIB_PATH=$R/scratch_exp/libstemprobe.so timeout 300 python tools/stem_bwd_timeline_probe.py 81920 2>&1 | grep -v amdgpu.ids) > $O/stem_timelines.txt)
 (cd $R && timeout 300 python tools/act_step_bench.py > $O/act_step_bench.txt 2>&1)
 (cd $R && ACT_BENCH_MODE=one timeout 300 python tools/act_step_bench.py 512 1024 2048 4096 >> $O/act_step_bench.txt 2>&1)
@@ -36,7 +36,7 @@ prof_iter iteration_kernel_stats_config3 Track2D-MazePartialNav-v0 1024 maze-lst
 # --- the learner's grouped weight-gradient GEMM alone, and its per-workgroup timeline (probe build -DATR_TN_PROBE=1, compiled here)
 (cd $R && timeout 300 python tools/gemm_group_bench.py 512 1024 2048 4096 > $O/gemm_group_bench.txt 2>&1)
 mkdir -p $R/scratch_exp; (cd $R/active_tracking_rl_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -ldl -Wno-unused-result -DATR_TN_PROBE=1 \
-    -o $R/scratch_exp/libtnprobe.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
+    -o $R/scratch_exp/libtnprobe.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip gate_cell_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
 [ -f $R/scratch_exp/libtnprobe.so ] && (cd $R && T2D_LIB_PATH=scratch_exp/libtnprobe.so timeout 300 python tools/gemm_tn_timeline.py 4096 1536 > $O/gemm_tn_timeline.txt 2>&1)
 # --- multi-rank settings under a 1-rank RCCL group
 (cd $R && bash tools/multirank_probe.sh > /dev/null 2>&1; cp gpurun_out/r04_multirank_1gpu.txt $O/multirank_1gpu.txt 2>/dev/null)
@@ -53,7 +53,7 @@ rm -rf /tmp/p_it; ITER_PROFILE_SCHEDULE=pipelined timeout 300 rocprofv3 --kernel
 python $R/tools/summarize_prof.py stats /tmp/p_it 200 > $O/iteration_kernel_stats_config3_pipelined.txt
 # (the probe build of the library, -DT2D_EXP=9, compiled here from the sources of this very tree)
 mkdir -p $R/scratch_exp; (cd $R/active_tracking_rl_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -ldl -Wno-unused-result -DT2D_EXP=9 \
-    -o $R/scratch_exp/libexp9.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
+    -o $R/scratch_exp/libexp9.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip gate_cell_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
 [ -f $R/scratch_exp/libexp9.so ] && (cd $R && T2D_LIB_PATH=scratch_exp/libexp9.so timeout 300 python tools/gen_nav_timeline_probe.py > $O/generator_nav_timeline.txt 2>&1)
 # --- env-only: the stand-alone step kernel at every size (rocprofv3 stats)
 for n in 4096 65536 262144 1048576; do
