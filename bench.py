@@ -684,6 +684,10 @@ def main():
                                "(policy fwd + HIP env step + loss/backward + grad all-reduce + SharedAdam)"
                                % (a.env, n, world, a.network),
                    "global_envs": n_total, "rollout": T, "hipgraph": graphed,
+                   "episode_source": "device Philox generators (the reference's sequential algorithms on a counter-based bit source: "
+                                     "bit-exact against the oracle's PHILOX mode, distribution-exact against the reference); the "
+                                     "reference's own numpy-stream episodes also run on the device, draw for draw, for every target "
+                                     "mode (t2d_np_attach: a parity mode, not the timed path)",
                    "obs": "u8 (t2d_step_u8 -> atr_stem_*_u8)" if getattr(player.env, "obs_u8", False) else "f32",
                    "gemm_algos": {"torch": "TunableOp picks from tunableop_gfx950.csv" if tuned else "library default",
                                   "hipblaslt_direct": _lt_status()}, "parallelism": "dp%d (env shards, 1 grad all-reduce/update)" % world},

@@ -24,6 +24,9 @@ CASES = [
      dict(env="Track2D-BlockPartialAdv-v0", num_envs=2048, network="maze-lstm", aux="none", train_mode=-1), "mixed"),
 ]
 dev = torch.device("cuda:0")
+print("# episodes of these runs come from the device's Philox generators: the scripted Ram target's plans agree with the reference's in "
+      "distribution and the Nav target's paths in LENGTH (BFS field), not draw for draw — the draw-for-draw device mode (t2d_np_attach: "
+      "RamAgent, Navigator + heap A*) is the parity tool, tests/test_drivers_gpu.py", flush=True)
 import sys
 only = [int(x) for x in sys.argv[1:]]              # e.g. `config_sweep.py 3 4`: just those configurations
 for ci, (name, over, special) in enumerate(CASES):
