@@ -181,7 +181,7 @@ struct StemProblem {
 };
 // Up to two independent problems per launch (the rollout's tracker and target encoders: different weights, same
 // step): workgroups [0, split) work on p[0], the rest on p[1], so the chip is filled by one launch.
-struct StemPair { StemProblem p[2]; int split; };
+struct StemPair { StemProblem p[2]; int split, cus; };
 
 template <typename XT>
 __global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_stem_fwd(StemPair pr)
 // version split the output into 2x2 quadrants, stored 8-byte pieces, and spent 40 % of its time on them); a1 of the 16 frames
 // lies in LDS frame-innermost ([ci][ih][iw][frame]: the A operand of lane (frame = l & 15, k = l >> 4) is one conflict-free
 // ds_read_b32 at an immediate offset), un-bordered.
-// conv1 is one lane per (frame, channel) on plain f32 FMAs, border taps skipped at compile time too.
+// conv1 is one lane per (frame, channel pair, half of the positions) on packed f32 FMAs, border taps skipped at compile time too.
 // Every frame's arithmetic is the one of k_stem_fwd in the same order (taps ascending, channel groups inside; products with
 // border zeros left out change no sum), so the two kernels agree bit for bit — a frame's result does not depend on the launch
 // size it was part of.
@@ -316,18 +316,26 @@ __device__ __forceinline__ void load_row13(const float *xf, int ir, float (&t)[1
     t[0] = r0.x; t[1] = r0.y; t[2] = r0.z; t[3] = r0.w; t[4] = r1.x; t[5] = r1.y; t[6] = r1.z; t[7] = r1.w;
     t[8] = r2.x; t[9] = r2.y; t[10] = r2.z; t[11] = r2.w; t[12] = r3;
 }
-__device__ __forceinline__ void conv1_lane(const float *xf, float *a1o, const float (&w)[9], float b)
+// On packed FMAs (v_pk_fma_f32: both halves are plain f32 FMAs): a lane takes TWO channels of its frame and half of the 49 output
+// positions (RH 0: rows 0-2 and row 3's columns 0-3 = 25; RH 1: row 3's columns 4-6 and rows 4-6 = 24; RH is wave-uniform) —
+// 193 / 187 packed FMAs; one channel and all 49 positions per lane were 380 plain ones. It matters because conv1 runs beside the
+// CU's other workgroup's conv2, and VALU and MFMA issue on a SIMD add up (rollout launch 20.5 -> 19.8 us, 163840 frames 182 -> 175 us).
+template <int RH>
+__device__ __forceinline__ void conv1_lane2(const float *xf, float *o0, float *o1, const f32x2 (&w)[9], f32x2 b)
 {
+    constexpr int r_lo = RH ? 3 : 0, r_hi = RH ? 6 : 3;
     float R[3][13], Nx[2][13];
-    load_row13(xf, 0, R[1]);
-    load_row13(xf, 1, R[2]);
+    if (2 * r_lo - 1 >= 0) load_row13(xf, 2 * r_lo - 1, R[0]);
+    load_row13(xf, 2 * r_lo, R[1]);
+    load_row13(xf, 2 * r_lo + 1, R[2]);
 #pragma unroll
-    for (int r = 0; r < 7; r++) {
-        if (r < 6) {
+    for (int r = r_lo; r <= r_hi; r++) {
+        if (r < r_hi) {
             load_row13(xf, 2 * r + 2, Nx[0]);
             if (2 * r + 3 <= 12) load_row13(xf, 2 * r + 3, Nx[1]);
         }
-        float acc[7];                               // the row's 7 outputs advance together: 7 independent FMA chains
+        const int c_lo = (r == 3 && RH) ? 4 : 0, c_hi = (r == 3 && !RH) ? 3 : 6;
+        f32x2 acc[7];
 #pragma unroll
         for (int c = 0; c < 7; c++) acc[c] = b;
 #pragma unroll
@@ -338,12 +346,16 @@ __device__ __forceinline__ void conv1_lane(const float *xf, float *a1o, const fl
 #pragma unroll
                 for (int c = 0; c < 7; c++) {
                     const int ic = 2 * c - 1 + kw;
-                    if (ic < 0 || ic > 12) continue;
-                    acc[c] = fmaf(R[kh][ic], w[kh * 3 + kw], acc[c]);
+                    if (c < c_lo || c > c_hi || ic < 0 || ic > 12) continue;
+                    acc[c] = __builtin_elementwise_fma(f32x2{R[kh][ic], R[kh][ic]}, w[kh * 3 + kw], acc[c]);
                 }
         }
 #pragma unroll
-        for (int c = 0; c < 7; c++) a1o[(r * 7 + c) * kF] = fmaxf(acc[c], 0.0f);
+        for (int c = 0; c < 7; c++) {
+            if (c < c_lo || c > c_hi) continue;
+            o0[(r * 7 + c) * kF] = fmaxf(acc[c].x, 0.0f);
+            o1[(r * 7 + c) * kF] = fmaxf(acc[c].y, 0.0f);
+        }
 #pragma unroll
         for (int j = 0; j < 13; j++) { R[0][j] = R[2][j]; R[1][j] = Nx[0][j]; R[2][j] = Nx[1][j]; }
     }
@@ -372,6 +384,8 @@ __device__ __forceinline__ void conv2_rows(const float *ap, const float (&Wh)[36
 #ifdef STEM_PROBE        // probe build only (tools/stem_timeline_probe.py): wall-clock stamps of wave 0 at the phase boundaries
 __device__ unsigned long long g_stem_probe[2048 * 8];
 #define STEM_STAMP(i) do { if (tid == 0 && blockIdx.x < 2048) g_stem_probe[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_stem_probe2[2048 * 4];     // k_stem_fwd16: [0] HW_ID | XCC_ID << 32, [1] / [2] first pass: conv1 / conv2 done
+#define STEM_STAMP2(i) do { if (tid == 0 && blockIdx.x < 2048) g_stem_probe2[blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
 #else
 #define STEM_STAMP(i) do { } while (0)
 #endif
@@ -382,36 +396,76 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_fwd16(StemPair pr)
     __shared__ __attribute__((aligned(16))) LdsF16 s;
     const int tid = (int)threadIdx.x, l = tid & 63, wave = tid >> 6;
     STEM_STAMP(0);
-    const bool second = (int)blockIdx.x >= pr.split;
+#ifdef STEM_PROBE
+    if (tid == 0 && blockIdx.x < 2048) {
+        g_stem_probe[blockIdx.x * 8 + 6] = 0ull;
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_stem_probe2[blockIdx.x * 4] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+#endif
+    // Which passes a workgroup takes. When the grid is two workgroups per CU, workgroups u and u + cus share CU u (dispatch order,
+    // checked with HW_ID stamps), and where both want the same SIMD the OLDER one (u) issues first (measured: its pass takes 6.5 us
+    // beside the younger one's 10; s_setprio did not change that). The passes rarely divide by the workgroups, so: (1) the problems
+    // split the workgroups in CU order (v = 2 u + half: a CU's two workgroups are neighbours), (2) within a problem the older halves
+    // come first in the block numbering — the low block numbers are the ones that get the extra pass. The headline's 4096 + 8192
+    // frames = 768 passes on 512 workgroups: every CU gets three, two of them on its older workgroup, and the CU's tail is the
+    // younger one finishing its only pass, not a lone workgroup with a whole pass to go (24.4 -> 20.5 us per launch).
+    bool second;
+    int blk, nblk;
+    {
+        const int i = (int)blockIdx.x, G = (int)gridDim.x, C = pr.cus;
+        if (G == 2 * C) {
+            const int half = i >= C ? 1 : 0, u = i - half * C, v = 2 * u + half, sp = pr.split;
+            const int ne0 = (sp + 1) >> 1, no0 = sp >> 1;           // problem 0's older / younger workgroups
+            second = v >= sp;
+            if (!second) { blk = half ? ne0 + u : u; nblk = sp; }
+            else { blk = half ? (C - ne0) + (u - no0) : u - ne0; nblk = G - sp; }
+        } else {
+            second = i >= pr.split;
+            blk = second ? i - pr.split : i;
+            nblk = second ? G - pr.split : pr.split;
+        }
+    }
     const StemProblem &pb = pr.p[second ? 1 : 0];
     const XT *__restrict__ x = reinterpret_cast<const XT *>(pb.x);
     const float *__restrict__ w1 = pb.w1, *__restrict__ b1 = pb.b1, *__restrict__ w2 = pb.w2, *__restrict__ b2 = pb.b2;
     float *__restrict__ y = pb.y;
     const long long M = pb.M, xs = pb.xs;
-    const int blk = second ? (int)blockIdx.x - pr.split : (int)blockIdx.x;
-    const int nblk = second ? (int)gridDim.x - pr.split : pr.split;
     const long long stride = (long long)nblk * kF;
     long long m0 = (long long)blk * kF;
     XTile xv = load_xtile(x, m0, M, xs, tid);
     const int c = l & 15, q = l >> 4;
     // wave = (output row pair qa, output channel half h): 50 real (position, tap) pairs x 4 channel groups = 200 MFMAs each
     const int qa = wave >> 1, h = wave & 1;
+    // Prologue: every global load of the workgroup (first frames, conv2 weights, conv1 weights, biases) is in flight before the
+    // first is waited for — one memory latency — and the barrier behind the weights' LDS copy orders LDS only.
+    typedef const float __attribute__((address_space(1))) *gfloats;
+    float wv[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) wv[k] = ((gfloats)w2)[tid + kThreads * k];
+    const float bias = ((gfloats)b2)[16 * h + c];
+    // conv1: this lane's two channels (ch, ch + 4: q <-> ch mod 4 keeps the a1 writes conflict-free) and its half of the positions
+    const int ch = 8 * (wave & 1) + q, rh = wave >> 1;
+    f32x2 cw[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) cw[k] = f32x2{((gfloats)w1)[ch * 9 + k], ((gfloats)w1)[(ch + 4) * 9 + k]};
+    const f32x2 cb = f32x2{((gfloats)b1)[ch], ((gfloats)b1)[ch + 4]};
     float Wh[36];
     {
         float *wst = s.a1;                          // (see k_stem_fwd: the conv2 weights pass through LDS, rows padded to 145)
-        stage_w2(wst, w2, tid);
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 18; k++) {
+            const int i = tid + kThreads * k;
+            wst[(i / 144) * 145 + (i % 144)] = wv[k];
+        }
+        lds_barrier();
 #pragma unroll
         for (int t = 0; t < 9; t++)
 #pragma unroll
             for (int cq = 0; cq < 4; cq++) Wh[t * 4 + cq] = wst[(16 * h + c) * 145 + (4 * cq + q) * 9 + t];
     }
-    const float bias = b2[16 * h + c];
-    const int ch = 4 * wave + q;                    // conv1: this lane's channel (q <-> ch mod 4: conflict-free a1 writes)
-    float cw[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) cw[k] = w1[ch * 9 + k];
-    const float cb = b1[ch];
     store_xtile<XT>(s.x, xv, tid);
     xv = load_xtile(x, m0 + stride, M, xs, tid);
     const float *xf = s.x + c * kXF;
@@ -420,9 +474,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_fwd16(StemPair pr)
     lds_barrier();
     STEM_STAMP(1);
     for (; m0 < M; m0 += stride) {
-        conv1_lane(xf, a1o, cw, cb);
+        if (rh == 0) conv1_lane2<0>(xf, a1o, a1o + 4 * 49 * kF, cw, cb);
+        else conv1_lane2<1>(xf, a1o, a1o + 4 * 49 * kF, cw, cb);
         lds_barrier();                            // a1 complete; the x tile is free
         STEM_STAMP(2);
+#ifdef STEM_PROBE
+        if (m0 == (long long)blk * kF) STEM_STAMP2(1);
+#endif
         store_xtile<XT>(s.x, xv, tid);
         xv = load_xtile(x, m0 + 2 * stride, M, xs, tid);
         f32x4 acc[8];
@@ -434,6 +492,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_fwd16(StemPair pr)
         // per instruction). So the 16 frames' outputs meet in LDS (over a1, which conv2 is done with) and leave as whole rows.
         lds_barrier();                              // a1 is free (and the next x tile complete)
         STEM_STAMP(3);
+#ifdef STEM_PROBE
+        if (m0 == (long long)blk * kF) STEM_STAMP2(2);
+#endif
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             float4 *yt = reinterpret_cast<float4 *>(s.a1 + (4 * q + r) * kYF + (16 * h + c) * kYC + 8 * qa);
@@ -443,16 +504,37 @@ __global__ __launch_bounds__(kThreads, 2) void k_stem_fwd16(StemPair pr)
                                 fmaxf(acc[7][r] + bias, 0.f));
         }
         lds_barrier();
+        // (plain stores: streamed past the L2 — nontemporal — the launch itself is 1-2 us shorter, but the GEMM that reads y
+        // next pays more than that: measured +25..65 us per 20-step iteration)
+        // Thread tid takes 16-byte piece tid & 3 of channel (tid >> 2) & 31 of frames (tid >> 7) + 2 i: all eight pieces are read
+        // from LDS before the first leaves, and the stores go out relative to ONE uniform base (the pass's first row of y) with a
+        // 32-bit lane offset — written frame by frame with 64-bit addresses and a bounds test each, the eight stores were eight
+        // dependent LDS round trips and cost 32 address registers.
+        {
+            const unsigned fo = (unsigned)(tid >> 7), co = (unsigned)((tid >> 2) & 31), k = (unsigned)(tid & 3);
+            const float *yt = s.a1 + fo * kYF + co * kYC + 4 * k;
+            float4 v[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int idx = tid + kThreads * i, f = idx >> 7, co = (idx >> 2) & 31, k = idx & 3;
-            const float4 v = *reinterpret_cast<const float4 *>(s.a1 + f * kYF + co * kYC + 4 * k);
-            // (plain stores: streamed past the L2 — nontemporal — the launch itself is 1-2 us shorter, but the GEMM that reads y
-            // next pays more than that: measured +25..65 us per 20-step iteration)
-            if (m0 + f < M) *reinterpret_cast<float4 *>(y + (m0 + f) * 512 + co * 16 + 4 * k) = v;
+            for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const float4 *>(yt + 2 * i * kYF);
+            float *yb = y + m0 * 512;                                // uniform
+            const unsigned o = fo * 512u + co * 16u + 4u * k;
+            const long long left = M - m0;
+            if (left >= kF) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) *reinterpret_cast<float4 *>(yb + (o + 1024u * i)) = v[i];
+            } else {
+                const unsigned nv = (unsigned)left;
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (fo + 2u * i < nv) *reinterpret_cast<float4 *>(yb + (o + 1024u * i)) = v[i];
+            }
         }
         lds_barrier();                              // the output tile has left a1
         STEM_STAMP(4);
+#ifdef STEM_PROBE
+        if (m0 == (long long)blk * kF) STEM_STAMP(7);      // (the end of the workgroup's FIRST pass; slot 6: its pass count)
+        if (tid == 0 && blockIdx.x < 2048) g_stem_probe[blockIdx.x * 8 + 6] += 1ull;
+#endif
     }
 #ifdef STEM_PROBE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1007,20 +1089,20 @@ static long long fwd16_min_frames()
     return v;
 }
 // Which forward kernel a launch of `passes` 16-frame passes (over all its problems) and M frames gets. From fwd16_min_frames()
-// up always the 16-frame kernel; below it only where the passes fill the 2-per-CU slots evenly — at most one pass per slot, or
-// rounds that are >= 85 % full — and there are enough frames (3072) for a pass per CU: 768 passes on 512 slots (the headline's
-// tracker-aware pair at 4096 envs: 4096 + 8192 frames) are two rounds for 1.5 rounds of work and tie with the wave-per-frame
-// kernel (24.1 against 24.6 us), 512 passes (4096 + 4096) win (15.8 against 19.3 us), 256 passes win (9.6 against 12.1 us;
-// configs[4]: 17.31 -> 17.65 M env steps/s). A third workgroup per CU would make 768 passes one round: built (byte x tile, 52 KB of
-// LDS) and dropped — under the 168-VGPR cap of three waves per SIMD the kernel spills (241 us at 163840 frames against 182).
-// ATR_STEM_FWD16_MIN set by hand switches the rule off (the A/B tools).
+// up always the 16-frame kernel; below it only where there are enough frames (3072) for a pass per CU and the passes load the CUs
+// evenly — at most one pass per workgroup slot, or CU rounds that are >= 85 % full (k_stem_fwd16 hands a CU's passes to its two
+// workgroups itself). 768 passes (the headline's tracker-aware pair at 4096 envs: 4096 + 8192 frames) are exactly three per CU:
+// 19.8 us against the wave-per-frame kernel's 24.4 (round 5, before the CU-aware assignment: a tie at 24.1); 512 passes
+// (4096 + 4096) 15.6 against 15.5 (19.3 in round 5's measurement), 384 passes 14.2 / 14.2, 192 passes 8.9 / 9.1. A third workgroup
+// per CU would make 768 passes one round: built (byte x tile, 52 KB of LDS) and dropped — under the 168-VGPR cap of three waves per
+// SIMD the kernel spills (241 us at 163840 frames against 182). ATR_STEM_FWD16_MIN set by hand switches the rule off (the A/B tools).
 static bool use_fwd16(long long M, long long passes)
 {
     if (M >= fwd16_min_frames()) return true;
     if (getenv("ATR_STEM_FWD16_MIN") || M < 3072) return false;
-    const long long slots = (long long)stem_grid(1LL << 40, kFwd16BlocksPerCu);
-    const long long rounds = (passes + slots - 1) / slots;
-    return rounds == 1 || passes * 100 >= rounds * slots * 85;
+    const long long cus = (long long)stem_grid(1LL << 40, 1), slots = cus * kFwd16BlocksPerCu;
+    const long long rounds = (passes + cus - 1) / cus;
+    return passes <= slots || passes * 100 >= rounds * cus * 85;
 }
 
 static int stem_grid16(long long M)
@@ -1037,6 +1119,7 @@ static int stem_forward_impl(const XT *x, long long x_stride, const float *w1, c
     if (!x || !w1 || !b1 || !w2 || !b2 || !y || M < 0 || x_stride < 169) return -1;
     if (M == 0) return 0;
     StemPair pr;
+    pr.cus = stem_grid(1LL << 40, 1);
     pr.p[0] = pr.p[1] = make_problem(x, x_stride, w1, b1, w2, b2, y, M);
     if (use_fwd16(M, (M + kF - 1) / kF)) {
         pr.split = stem_grid16(M);
@@ -1058,6 +1141,7 @@ static int stem_forward2_impl(const XT *x0, long long x0_stride, const float *w1
         !w2_1 || !b2_1 || !y1 || M1 <= 0 || x1_stride < 169)
         return -1;
     StemPair pr;
+    pr.cus = stem_grid(1LL << 40, 1);
     pr.p[0] = make_problem(x0, x0_stride, w1_0, b1_0, w2_0, b2_0, y0, M0);
     pr.p[1] = make_problem(x1, x1_stride, w1_1, b1_1, w2_1, b2_1, y1, M1);
     // split the resident workgroups in proportion to the frame counts (every wave gets the same number of frames)
@@ -1156,5 +1240,9 @@ extern "C" int atr_stem_backward_u8(const unsigned char *x, long long x_stride, 
 extern "C" int atr_stem_probe_read(unsigned long long *host, int n)
 {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(atr::g_stem_probe), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+extern "C" int atr_stem_probe2_read(unsigned long long *host, int n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(atr::g_stem_probe2), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -26,10 +26,12 @@ prof_iter iteration_kernel_stats_config3 Track2D-MazePartialNav-v0 1024 maze-lst
 # either forward kernel, and the phase timelines of the 16-frame kernels (probe build)
 (cd $R && timeout 300 python tools/stem_bench.py 2>&1 | grep -v amdgpu.ids > $O/stem_bench.txt)
 (cd $R && (echo "== wave per frame (k_stem_fwd, k_stem_bwd: ATR_STEM_FWD16_MIN / ATR_STEM_BWD16_MIN out of reach)"; ATR_STEM_FWD16_MIN=100000000 ATR_STEM_BWD16_MIN=100000000 timeout 300 python tools/stem_bench.py 8192 81920 163840 2>&1 | grep -v amdgpu.ids) >> $O/stem_bench.txt)
-(cd $R && (echo "== rollout-shaped launches, wave per frame (the default below 16384 frames)"; timeout 300 python tools/stem_rollout_bench.py 2>&1 | grep -v amdgpu.ids; echo "== rollout-shaped launches, 16 frames per pass forced (ATR_STEM_FWD16_MIN=2048)"; ATR_STEM_FWD16_MIN=2048 timeout 300 python tools/stem_rollout_bench.py 2>&1 | grep -v amdgpu.ids) > $O/stem_rollout_bench.txt)
+(cd $R && (echo "== rollout-shaped launches, the default rule (use_fwd16 in csrc/stem_hip.hip: 16 frames per pass from 3072 frames up where the passes load the CUs evenly)"; timeout 300 python tools/stem_rollout_bench.py 2>&1 | grep -v amdgpu.ids; echo "== wave per frame everywhere below 16384 frames (ATR_STEM_FWD16_MIN=16384)"; ATR_STEM_FWD16_MIN=16384 timeout 300 python tools/stem_rollout_bench.py 2>&1 | grep -v amdgpu.ids; echo "== 16 frames per pass forced (ATR_STEM_FWD16_MIN=2048)"; ATR_STEM_FWD16_MIN=2048 timeout 300 python tools/stem_rollout_bench.py 2>&1 | grep -v amdgpu.ids) > $O/stem_rollout_bench.txt)
 (cd $R/active_tracking_rl_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -ldl -DSTEM_PROBE \
     -o $R/scratch_exp/libstemprobe.so track2d_hip.hip stem_hip.hip policy_hip.hip lstm_hip.hip heads_hip.hip gemm_tn_hip.hip actor_step_hip.hip pair_gemm_hip.hip bptt_hip.hip driver_hip.hip gate_cell_hip.hip np_mode.cpp lt_gemm.cpp > /dev/null 2>&1)
-(cd $R && (ATR_STEM_FWD16_MIN=2048 T2D_LIB_PATH=$R/scratch_exp/libstemprobe.so timeout 300 python tools/stem_timeline_probe.py 4096 2>&1 | grep -v amdgpu.ids; echo; T2D_LIB_PATH=$R/scratch_exp/libstemprobe.so timeout 300 python tools/stem_bwd_timeline_probe.py 81920 2>&1 | grep -v amdgpu.ids) > $O/stem_timelines.txt)
+(cd $R && (ATR_STEM_FWD16_MIN=2048 T2D_LIB_PATH=$R/scratch_exp/libstemprobe.so timeout 300 python tools/stem_timeline_probe.py 4096 2>&1 | grep -v amdgpu.ids; echo; echo "== the headline rollout launch (4096 + 8192 frames), per workgroup"; ATR_STEM_FWD16_MIN=2048 T2D_LIB_PATH=$R/scratch_exp/libstemprobe.so timeout 300 python tools/stem_tat_timeline.py 4096 2>&1 | grep -v amdgpu.ids; echo; T2D_LIB_PATH=$R/scratch_exp/libstemprobe.so timeout 300 python tools/stem_bwd_timeline_probe.py 81920 2>&1 | grep -v amdgpu.ids) > $O/stem_timelines.txt)
+# --- round 6: is the f32 MFMA's k-sum the ascending fmaf chain? (what the stems' bit-identity between kernels rests on)
+(cd $R/tools/microbench && hipcc --offload-arch=gfx950 -O2 -ffp-contract=off mfma_order.hip -o $R/scratch_exp/mfma_order > /dev/null 2>&1; timeout 60 $R/scratch_exp/mfma_order > $O/mfma_order_microbench.txt 2>&1)
 (cd $R && timeout 300 python tools/act_step_bench.py > $O/act_step_bench.txt 2>&1)
 (cd $R && ACT_BENCH_MODE=one timeout 300 python tools/act_step_bench.py 512 1024 2048 4096 >> $O/act_step_bench.txt 2>&1)
 (cd $R && ACT_BENCH_MODE=pre timeout 300 python tools/act_step_bench.py 512 1024 2048 4096 >> $O/act_step_bench.txt 2>&1)

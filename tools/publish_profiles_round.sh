@@ -8,7 +8,7 @@ for f in bench_kernel_stats iteration_kernel_stats iteration_kernel_stats_shard2
          nav_env_only_1024 nav_env_only_8192 nav_kernel_stats_1024 nav_kernel_stats_8192 generator_nav_timeline \
          learning_check_ram_tracker learning_check_pzr_dueling learning_check_nav_tracker main_py_logger main_py_scalars_tail \
          main_py_test_scalars_tail coop_step_timeline_512 coop_step_timeline_1024 shard_sweep shard_sweep_coop_step nav_env_only_1024_pregrow nav_kernel_stats_1024_pregrow \
-         iteration_kernel_stats_config3_pipelined xcd_barrier_microbench stem_bench stem_rollout_bench stem_timelines pytest_gpu \
+         iteration_kernel_stats_config3_pipelined xcd_barrier_microbench stem_bench stem_rollout_bench stem_timelines mfma_order_microbench pytest_gpu \
          gate_cell_bench cu_split_sweep_512 main_py_8ranks_gloo_1gpu iteration_kernel_stats_ATR_GATE_CELL_0 iteration_kernel_stats_ATR_GATE_CELL_1 \
          iteration_kernel_stats_ATR_FOLD_EMBEDDING_0 iteration_kernel_stats_ATR_FOLD_EMBEDDING_1; do
   [ -s $O/$f.txt ] && cp $O/$f.txt $P/${TAG}_$f.txt
