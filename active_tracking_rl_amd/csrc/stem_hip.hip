@@ -386,8 +386,11 @@ __device__ unsigned long long g_stem_probe[2048 * 8];
 #define STEM_STAMP(i) do { if (tid == 0 && blockIdx.x < 2048) g_stem_probe[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 __device__ unsigned long long g_stem_probe2[2048 * 4];     // k_stem_fwd16: [0] HW_ID | XCC_ID << 32, [1] / [2] first pass: conv1 / conv2 done
 #define STEM_STAMP2(i) do { if (tid == 0 && blockIdx.x < 2048) g_stem_probe2[blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+// k_stem_bwd16: per wave, inside the MFMA phase: [0] start, [1] (1) issued, [2] dz2 written, [3] last MFMA issued (s_memtime: shader clock)
+#define BWD16_WAVE_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_stem_probe2[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STEM_STAMP(i) do { } while (0)
+#define BWD16_WAVE_STAMP(i) do { } while (0)
 #endif
 
 template <typename XT>
@@ -774,6 +777,11 @@ struct LdsB16 { float x[kF * kXB]; float a1[49 * kA1L]; float dz[2][16 * kDzP]; 
 // the centre (4 pairs) with role 4
 __host__ __device__ constexpr int bwd16_role_of(int ih, int iw)
 {
+    // (three locations change hands so that the four SIMDs — waves w and w + 4 share one — carry 252 / 244 / 252 / 248 of the 996
+    // MFMAs of (2) + (3) instead of 260 / 256 / 240 / 240)
+    if (ih == 5 && iw == 6) return 7;
+    if (ih == 6 && iw == 0) return 4;
+    if (ih == 0 && iw == 0) return 6;
     return (ih <= 2 && iw <= 3) ? (ih == 1 ? 0 : 1)
          : (ih <= 3 && iw >= 4) ? (ih <= 1 ? 2 : 3)
          : (ih >= 4 && iw >= 3) ? (ih == 5 ? 4 : 5)
@@ -781,11 +789,12 @@ __host__ __device__ constexpr int bwd16_role_of(int ih, int iw)
          : 4;
 }
 
-template <int ROLE>
-__device__ __forceinline__ void bwd16_mfma_phase(const LdsB16 &s, const float *dzt, int c, int q, f32x4 (&dw2)[9], f32x4 &dw1)
+template <int ROLE, typename Mid>
+__device__ __forceinline__ void bwd16_mfma_phase(const LdsB16 &s, const float *dzt, int c, int q, f32x4 (&dw2)[9], f32x4 &dw1, Mid &&mid)
 {
     // ---- (1): quadrant (QA, QB) of the output positions x half H of the output channels
     constexpr int QA = ROLE >> 2, QB = (ROLE >> 1) & 1, H = ROLE & 1;
+    BWD16_WAVE_STAMP(0);
     {
         const float *dzl = dzt + H * 272 + q * 17 + c;           // A[i = co][k = frame 4 kk + q]
         const float *a1l = s.a1 + q * 17 + c;                    // B[k = frame 4 kk + q][j = ci]
@@ -805,6 +814,11 @@ __device__ __forceinline__ void bwd16_mfma_phase(const LdsB16 &s, const float *d
                 for (int kk = 0; kk < 4; kk++) dw2[t] = mfma(A[p][kk], a1l[(ih * 7 + iw) * kA1L + kk * 4 * 17], dw2[t]);
             }
     }
+    // (the next pass's dz2 tile is written HERE, between the wave's two MFMA streams: at the head of the phase all eight waves would
+    // be writing at once with the matrix pipe idle)
+    BWD16_WAVE_STAMP(1);
+    mid();
+    BWD16_WAVE_STAMP(2);
     // ---- (2) + (3): this role's a1 locations
     const float *dzf = dzt + c * 17 + q;                         // A[i = frame][k = co 4 kc + q]
     const float *w2l = s.w2 + q * 144 + c * 9;                   // B[k = co 4 kc + q][j = ci] of tap t: native [co][ci][t] order,
@@ -846,6 +860,7 @@ __device__ __forceinline__ void bwd16_mfma_phase(const LdsB16 &s, const float *d
             dp = d; pih = ih; piw = iw;
         }
     tail(dp, pih, piw);
+    BWD16_WAVE_STAMP(3);
 }
 
 template <typename XT>
@@ -967,19 +982,21 @@ __global__ __launch_bounds__(kThreadsB16) void k_stem_bwd16(const XT *__restrict
         lds_barrier();
         STEM_STAMP(1);
         // ---- the next pass's dz2 (its y / dy arrived during conv1), the loads of the pass after it, then the MFMA phase by role
-        write_dz(s.dz[buf ^ 1], m0 + stride);
-        load_yd(m0 + 2 * stride);
         STEM_STAMP(2);
         const float *dzt = s.dz[buf];
+        auto mid = [&]() {
+            write_dz(s.dz[buf ^ 1], m0 + stride);
+            load_yd(m0 + 2 * stride);
+        };
         switch (wave) {
-        case 0: bwd16_mfma_phase<0>(s, dzt, c, q, dw2, dw1); break;
-        case 1: bwd16_mfma_phase<1>(s, dzt, c, q, dw2, dw1); break;
-        case 2: bwd16_mfma_phase<2>(s, dzt, c, q, dw2, dw1); break;
-        case 3: bwd16_mfma_phase<3>(s, dzt, c, q, dw2, dw1); break;
-        case 4: bwd16_mfma_phase<4>(s, dzt, c, q, dw2, dw1); break;
-        case 5: bwd16_mfma_phase<5>(s, dzt, c, q, dw2, dw1); break;
-        case 6: bwd16_mfma_phase<6>(s, dzt, c, q, dw2, dw1); break;
-        default: bwd16_mfma_phase<7>(s, dzt, c, q, dw2, dw1); break;
+        case 0: bwd16_mfma_phase<0>(s, dzt, c, q, dw2, dw1, mid); break;
+        case 1: bwd16_mfma_phase<1>(s, dzt, c, q, dw2, dw1, mid); break;
+        case 2: bwd16_mfma_phase<2>(s, dzt, c, q, dw2, dw1, mid); break;
+        case 3: bwd16_mfma_phase<3>(s, dzt, c, q, dw2, dw1, mid); break;
+        case 4: bwd16_mfma_phase<4>(s, dzt, c, q, dw2, dw1, mid); break;
+        case 5: bwd16_mfma_phase<5>(s, dzt, c, q, dw2, dw1, mid); break;
+        case 6: bwd16_mfma_phase<6>(s, dzt, c, q, dw2, dw1, mid); break;
+        default: bwd16_mfma_phase<7>(s, dzt, c, q, dw2, dw1, mid); break;
         }
 #ifdef STEM_PROBE
         if (l == 0 && blockIdx.x < 2048 / 2) g_stem_probe[(1024 + blockIdx.x) * 8 + wave] = wall_clock64();

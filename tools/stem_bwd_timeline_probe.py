@@ -1,7 +1,8 @@
 """Phase timeline of k_stem_bwd16's LAST pass per workgroup (probe build: hipcc -DSTEM_PROBE, loaded through T2D_LIB_PATH): wave 0
 stamps the 100 MHz wall clock at the pass's start, after conv1's barrier, after the next pass's dz2 tile is written and the loads
 of the pass after it are issued, after the MFMA phase's barrier; every wave stamps the end of its own MFMA phase (the roles'
-balance).   T2D_LIB_PATH=... python tools/stem_bwd_timeline_probe.py [M]"""
+balance) and, in SHADER-clock counts (s_memtime), its progress inside the phase: products (1) issued, the next pass's dz2 tile written,
+last MFMA issued — whose ratio to the wall clock is the clock the chip actually runs this kernel at.   T2D_LIB_PATH=... python tools/stem_bwd_timeline_probe.py [M]"""
 import ctypes as C
 import sys
 
@@ -34,3 +35,17 @@ for i in range(3):
     print("  %-26s -> %-26s median %6.2f us (min %.2f max %.2f)" % (names[i], names[i + 1], np.median(d[:, i]), d[:, i].min(), d[:, i].max()))
 rel = (w - a[:, 1:2]) / 100.0
 print("  per role, MFMA phase (conv1's barrier -> the wave's last MFMA issued), median us: " + " ".join("%.2f" % np.median(rel[:, k]) for k in range(8)))
+b2 = np.zeros(2048 * 4, dtype=np.uint64)
+if hasattr(lib, "atr_stem_probe2_read") and lib.atr_stem_probe2_read(b2.ctypes.data_as(C.c_void_p), b2.size) == 0:
+    # per wave, inside the MFMA phase, in SHADER-clock counts (s_memtime): start, products (1) issued, next dz2 written, last MFMA issued
+    sc = b2.reshape(256, 8, 4).astype(np.int64)
+    ok = sc[:, 0, 0] > 0
+    sc = sc[ok]
+    cyc = sc - sc[:, :, :1]
+    # the shader clock during the phase: counts of wave 0 over the same interval on the 100 MHz wall clock (phase start stamp -> its last MFMA)
+    wall_us = (w[ok, 0] - a[ok, 2]) / 100.0
+    ghz = np.median(cyc[:, 0, 3] / (wall_us * 1e3))
+    print("  shader clock during the MFMA phase (s_memtime counts / wall time of wave 0): %.2f GHz (nominal 2.4: the f32 MFMA peak at this clock is %.1f TFLOP/s)" % (ghz, 157.3 * ghz / 2.4))
+    print("  per wave, shader cycles since its own start of the MFMA phase (medians over %d workgroups; 32 cycles per MFMA at full rate):" % len(sc))
+    for k, name in ((1, "(1) issued"), (2, "next dz2 written"), (3, "last MFMA issued")):
+        print("    %-18s %s" % (name, " ".join("%6.0f" % np.median(cyc[:, r, k]) for r in range(8))))
