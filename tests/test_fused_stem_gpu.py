@@ -426,6 +426,36 @@ def test_sixteen_frame_forward_equals_the_wave_per_frame_forward_bit_for_bit(M):
     assert torch.equal(ob, chunked(obs[:, 1], encs[1])[:M - 7])
 
 
+@pytest.mark.parametrize("M0,M1", [(4096, 8192), (5000, 11003), (8190, 4090), (1531, 1541), (3072, 9216)])
+def test_paired_sixteen_frame_launch_hands_every_pass_to_exactly_one_workgroup(M0, M1):
+    """The two-problem launch of k_stem_fwd16 assigns its passes CU by CU when the grid is two workgroups per CU (problems split over
+    v = 2 u + half, the older half of every CU first in each problem's block numbering: csrc/stem_hip.hip): the headline's rollout
+    shape (4096 + 8192 frames: an ODD split, 171 + 341 workgroups), uneven and ragged problems, the larger problem first, a launch
+    below one pass per slot, and 768 passes on an even split — every frame of both outputs equals the frame evaluated in a
+    1000-frame launch of its own (wave per frame), bit for bit; rows past the problems' ends are not written."""
+    from active_tracking_rl_amd import fused
+    torch.manual_seed(M0 + M1)
+    dev = "cuda"
+
+    class E:
+        def __init__(self):
+            self.conv1 = torch.nn.Conv2d(1, 16, 3, 2, 1).to(dev)
+            self.conv2 = torch.nn.Conv2d(16, 32, 3, 2, 1).to(dev)
+            with torch.no_grad():
+                self.conv1.weight.mul_(2.0); self.conv2.weight.mul_(3.0); self.conv1.bias.normal_(0, 0.2); self.conv2.bias.normal_(0, 0.2)
+    encs = [E(), E()]
+    rs = np.random.RandomState(M0)
+    x0 = torch.tensor(rs.choice([0, 1, 2, 4], size=(M0, 169)).astype(np.uint8), device=dev)
+    x1 = torch.tensor(rs.choice([0, 1, 2, 4], size=(M1, 169)).astype(np.uint8), device=dev)
+    o0 = torch.full((M0 + 3, 512), -7.0, device=dev)
+    o1 = torch.full((M1 + 3, 512), -7.0, device=dev)
+    fused.stem_into2(x0, encs[0], o0[:M0], x1, encs[1], o1[:M1])
+    for x, e, o, M in ((x0, encs[0], o0, M0), (x1, encs[1], o1, M1)):
+        ref = torch.cat([fused.stem(x[i:i + 1000], e.conv1, e.conv2) for i in range(0, M, 1000)])
+        assert torch.equal(o[:M], ref)
+        assert bool((o[M:] == -7.0).all())
+
+
 @pytest.mark.parametrize("M", [16384, 40007])
 def test_sixteen_frame_backward_equals_the_wave_per_frame_backward(M):
     """From 16384 frames up atr_stem_backward* runs 16 frames per workgroup pass (k_stem_bwd16: frames on an MFMA dimension, border
